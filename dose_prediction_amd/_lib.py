@@ -1,0 +1,71 @@
+"""ctypes binding of libdose_hip.so (the C ABI declared in include/dose_hip.h).
+
+The prototypes are parsed from the header itself, so the Python side can never drift from the C ABI.
+The product path has NO CPU fallback: if the shared library is missing, importing any op raises.
+"""
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+HEADER = os.path.join(_ROOT, "include", "dose_hip.h")
+LIB_PATH = os.path.join(_HERE, "libdose_hip.so")
+
+_CTYPES = {
+    "int": ctypes.c_int, "int64_t": ctypes.c_int64, "float": ctypes.c_float, "int32_t": ctypes.c_int32,
+}
+
+
+def parse_header(path=HEADER):
+    """Return {name: (restype, [argtypes], [argnames])} for every prototype in the header."""
+    src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"//[^\n]*", "", src)
+    protos = {}
+    for m in re.finditer(r"(const\s+char\s*\*|int)\s+(dp_\w+)\s*\(([^)]*)\)\s*;", src):
+        ret, name, args = m.group(1), m.group(2), m.group(3).strip()
+        restype = ctypes.c_char_p if "char" in ret else ctypes.c_int
+        argtypes, argnames = [], []
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                argnames.append(re.split(r"[\s\*]+", a)[-1])
+                if "*" in a:
+                    argtypes.append(ctypes.c_void_p)
+                else:
+                    argtypes.append(_CTYPES[a.replace("const", "").split()[0]])
+        protos[name] = (restype, argtypes, argnames)
+    return protos
+
+
+PROTOS = parse_header()
+_lib = None
+
+
+class DoseHipError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DoseHipError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback for the HIP path.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes, _) in PROTOS.items():
+            fn = getattr(L, name)          # AttributeError if the .so does not export a declared symbol
+            fn.restype, fn.argtypes = restype, argtypes
+        _lib = L
+    return _lib
+
+
+def call(name, *args):
+    """Call an int-returning entry point; raise DoseHipError(dp_last_error()) on a non-zero status."""
+    L = lib()
+    rc = getattr(L, name)(*args)
+    if rc != 0:
+        raise DoseHipError(f"{name} failed (rc={rc}): {L.dp_last_error().decode()}")
+    return rc

@@ -1,0 +1,128 @@
+// Shared device/host helpers for libdose_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/dose_hip.h"
+
+typedef unsigned short bf16_t;   // raw bf16 bits
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+typedef short v4s __attribute__((ext_vector_type(4)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+
+void dp_set_error(const char* fmt, ...);
+#define DP_FAIL(...) do { dp_set_error(__VA_ARGS__); return 1; } while (0)
+#define DP_CHECK_LAUNCH(name) do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { \
+    dp_set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); return 2; } } while (0)
+
+// Dispatch on the storage dtype: CALL is a statement using the type alias T.
+#define DP_DISPATCH(dtype, ...) do { if ((dtype) == DP_F32) { typedef float T; __VA_ARGS__; } \
+    else if ((dtype) == DP_BF16) { typedef bf16_t T; __VA_ARGS__; } \
+    else { DP_FAIL("bad dtype %d", (int)(dtype)); } } while (0)
+
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {   // round-to-nearest-even, NaN preserved (plain cast -> v_cvt_pk_bf16_f32)
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(bf16_t, b);
+}
+__device__ __forceinline__ float ld_f(const float* p) { return *p; }
+__device__ __forceinline__ float ld_f(const bf16_t* p) { return bf2f(*p); }
+__device__ __forceinline__ void st_f(float* p, float v) { *p = v; }
+__device__ __forceinline__ void st_f(bf16_t* p, float v) { *p = f2bf(v); }
+
+// 8 consecutive elements of T as a register fragment.
+template <typename T> struct Frag8;
+template <> struct Frag8<float> { float v[8]; };
+template <> struct Frag8<bf16_t> { v4u u; };   // 8 x bf16 in 4 dwords
+
+template <typename T> __device__ __forceinline__ Frag8<T> frag_zero();
+template <> __device__ __forceinline__ Frag8<float> frag_zero<float>() { Frag8<float> f; for (int i = 0; i < 8; i++) f.v[i] = 0.f; return f; }
+template <> __device__ __forceinline__ Frag8<bf16_t> frag_zero<bf16_t>() { Frag8<bf16_t> f; f.u = (v4u){0, 0, 0, 0}; return f; }
+
+// Guarded load of up to 8 consecutive elements (nvalid in [0,8]); vector path when full and 16B/32B aligned.
+__device__ __forceinline__ Frag8<float> frag_load(const float* p, int nvalid) {
+  Frag8<float> f;
+  if (nvalid >= 8 && ((uintptr_t)p & 15) == 0) {
+    v4f a = *(const v4f*)p, b = *(const v4f*)(p + 4);
+    f.v[0] = a[0]; f.v[1] = a[1]; f.v[2] = a[2]; f.v[3] = a[3]; f.v[4] = b[0]; f.v[5] = b[1]; f.v[6] = b[2]; f.v[7] = b[3];
+  } else {
+    for (int i = 0; i < 8; i++) f.v[i] = (i < nvalid) ? p[i] : 0.f;
+  }
+  return f;
+}
+__device__ __forceinline__ Frag8<bf16_t> frag_load(const bf16_t* p, int nvalid) {
+  Frag8<bf16_t> f;
+  if (nvalid >= 8 && ((uintptr_t)p & 15) == 0) {
+    f.u = *(const v4u*)p;
+  } else {
+    unsigned w[4] = {0, 0, 0, 0};
+    for (int i = 0; i < 8; i++) if (i < nvalid) w[i >> 1] |= ((unsigned)p[i]) << ((i & 1) * 16);
+    f.u = (v4u){w[0], w[1], w[2], w[3]};
+  }
+  return f;
+}
+// LDS store/load of a fragment (pointer must be 16B aligned for bf16, 16B for float halves)
+__device__ __forceinline__ void frag_st_lds(float* p, const Frag8<float>& f) {
+  *(v4f*)p = (v4f){f.v[0], f.v[1], f.v[2], f.v[3]};
+  *(v4f*)(p + 4) = (v4f){f.v[4], f.v[5], f.v[6], f.v[7]};
+}
+__device__ __forceinline__ void frag_st_lds(bf16_t* p, const Frag8<bf16_t>& f) { *(v4u*)p = f.u; }
+__device__ __forceinline__ Frag8<float> frag_ld_lds(const float* p) {
+  Frag8<float> f; v4f a = *(const v4f*)p, b = *(const v4f*)(p + 4);
+  f.v[0] = a[0]; f.v[1] = a[1]; f.v[2] = a[2]; f.v[3] = a[3]; f.v[4] = b[0]; f.v[5] = b[1]; f.v[6] = b[2]; f.v[7] = b[3];
+  return f;
+}
+__device__ __forceinline__ Frag8<bf16_t> frag_ld_lds(const bf16_t* p) { Frag8<bf16_t> f; f.u = *(const v4u*)p; return f; }
+
+// One K=32 MFMA step on 16x16 tiles: acc += A(16x32) * B(32x16).  Lane l holds, for row/col (l&15), the 8
+// k-values 8*(l>>4)+j.  bf16: one v_mfma_f32_16x16x32_bf16.  f32: 8 x v_mfma_f32_16x16x4_f32 (step j uses
+// element j of every lane's fragment => k = 8q+j for q=0..3; exact fp32 FMA chain).  Verified by tools/mfma_probe.hip.
+__device__ __forceinline__ v4f mma16(const Frag8<bf16_t>& a, const Frag8<bf16_t>& b, v4f c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, a.u), __builtin_bit_cast(v8bf, b.u), c, 0, 0, 0);
+}
+__device__ __forceinline__ v4f mma16(const Frag8<float>& a, const Frag8<float>& b, v4f c) {
+#pragma unroll
+  for (int j = 0; j < 8; j++) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[j], b.v[j], c, 0, 0, 0);
+  return c;
+}
+
+// wave (64-lane) reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// activations (forward value and derivative w.r.t. the pre-activation z)
+__device__ __forceinline__ float act_fwd(float z, int act) {
+  switch (act) {
+    case DP_ACT_RELU: return z > 0.f ? z : 0.f;
+    case DP_ACT_LRELU: return z >= 0.f ? z : 0.01f * z;
+    case DP_ACT_MISH: { float sp = z > 20.f ? z : log1pf(expf(z)); return z * tanhf(sp); }
+    case DP_ACT_GELU: return 0.5f * z * (1.f + erff(z * 0.70710678118654752f));
+    default: return z;
+  }
+}
+__device__ __forceinline__ float act_bwd(float z, int act) {
+  switch (act) {
+    case DP_ACT_RELU: return z > 0.f ? 1.f : 0.f;
+    case DP_ACT_LRELU: return z >= 0.f ? 1.f : 0.01f;
+    case DP_ACT_MISH: {
+      float sp = z > 20.f ? z : log1pf(expf(z));
+      float t = tanhf(sp);
+      float sg = 1.f / (1.f + expf(-z));
+      return t + z * (1.f - t * t) * sg;
+    }
+    case DP_ACT_GELU: return 0.5f * (1.f + erff(z * 0.70710678118654752f)) + z * 0.3989422804014327f * expf(-0.5f * z * z);
+    default: return 1.f;
+  }
+}
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+static inline int roundup8(int c) { return (c + 7) & ~7; }

@@ -1,0 +1,320 @@
+// Data-movement and elementwise kernels (HBM-bound; 16-byte vector accesses wherever rows allow).
+#include "common.h"
+#include <stdarg.h>
+#include <string.h>
+
+// ------------------------------------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+void dp_set_error(const char* fmt, ...) {
+  va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+}
+extern "C" const char* dp_last_error(void) { return g_err; }
+extern "C" int dp_version(void) { return 100; }
+
+#define STREAM ((hipStream_t)stream)
+static inline int grid_for(int64_t work, int block, int cap = 256 * 16) {
+  int64_t g = (work + block - 1) / block;
+  if (g < 1) g = 1;
+  return (int)(g > cap ? cap : g);
+}
+
+template <typename T> __device__ __forceinline__ void frag_store(T* p, const Frag8<T>& f, int nvalid);
+template <> __device__ __forceinline__ void frag_store<float>(float* p, const Frag8<float>& f, int nvalid) {
+  if (nvalid >= 8 && ((uintptr_t)p & 15) == 0) {
+    *(v4f*)p = (v4f){f.v[0], f.v[1], f.v[2], f.v[3]}; *(v4f*)(p + 4) = (v4f){f.v[4], f.v[5], f.v[6], f.v[7]};
+  } else { for (int i = 0; i < 8; i++) if (i < nvalid) p[i] = f.v[i]; }
+}
+template <> __device__ __forceinline__ void frag_store<bf16_t>(bf16_t* p, const Frag8<bf16_t>& f, int nvalid) {
+  if (nvalid >= 8 && ((uintptr_t)p & 15) == 0) { *(v4u*)p = f.u; }
+  else { for (int i = 0; i < 8; i++) if (i < nvalid) p[i] = (bf16_t)((f.u[i >> 1] >> ((i & 1) * 16)) & 0xffff); }
+}
+__device__ __forceinline__ void frag_unpack(const Frag8<float>& f, float* o) { for (int i = 0; i < 8; i++) o[i] = f.v[i]; }
+__device__ __forceinline__ void frag_unpack(const Frag8<bf16_t>& f, float* o) {
+  for (int i = 0; i < 4; i++) { o[2 * i] = __uint_as_float(f.u[i] << 16); o[2 * i + 1] = __uint_as_float(f.u[i] & 0xffff0000u); }
+}
+__device__ __forceinline__ void frag_pack(Frag8<float>& f, const float* o) { for (int i = 0; i < 8; i++) f.v[i] = o[i]; }
+__device__ __forceinline__ void frag_pack(Frag8<bf16_t>& f, const float* o) {
+  for (int i = 0; i < 4; i++) f.u[i] = (unsigned)f2bf(o[2 * i]) | ((unsigned)f2bf(o[2 * i + 1]) << 16);
+}
+
+// ------------------------------------------------------------------------------------------------ layout
+template <typename T>
+__global__ void k_ncdhw_to_ndhwc(const float* __restrict__ src, T* __restrict__ dst, int N, int C, int64_t V, int ld, int cpad) {
+  int64_t total = (int64_t)N * V;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t n = i / V, v = i - n * V;
+    T* d = dst + i * ld;
+    const float* s = src + n * C * V + v;
+    for (int c = 0; c < cpad; c++) st_f(d + c, c < C ? s[(int64_t)c * V] : 0.f);
+  }
+}
+template <typename T>
+__global__ void k_ndhwc_to_ncdhw(const T* __restrict__ src, float* __restrict__ dst, int N, int C, int64_t V, int ld, int acc) {
+  int64_t total = (int64_t)N * V;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t n = i / V, v = i - n * V;
+    const T* s = src + i * ld;
+    float* d = dst + n * C * V + v;
+    for (int c = 0; c < C; c++) { float x = ld_f(s + c); if (acc) d[(int64_t)c * V] += x; else d[(int64_t)c * V] = x; }
+  }
+}
+extern "C" int dp_ncdhw_to_ndhwc(const float* src, void* dst, int N, int C, int64_t V, int ld, int cpad, int dtype, void* stream) {
+  if (cpad < C || ld < cpad) DP_FAIL("ncdhw_to_ndhwc: need C <= cpad <= ld");
+  DP_DISPATCH(dtype, hipLaunchKernelGGL(k_ncdhw_to_ndhwc<T>, dim3(grid_for(N * V, 256)), dim3(256), 0, STREAM, src, (T*)dst, N, C, V, ld, cpad));
+  DP_CHECK_LAUNCH("ncdhw_to_ndhwc"); return 0;
+}
+extern "C" int dp_ndhwc_to_ncdhw(const void* src, float* dst, int N, int C, int64_t V, int ld, int accumulate, int dtype, void* stream) {
+  DP_DISPATCH(dtype, hipLaunchKernelGGL(k_ndhwc_to_ncdhw<T>, dim3(grid_for(N * V, 256)), dim3(256), 0, STREAM, (const T*)src, dst, N, C, V, ld, accumulate));
+  DP_CHECK_LAUNCH("ndhwc_to_ncdhw"); return 0;
+}
+
+template <typename T>
+__global__ void k_copy_rows(const T* __restrict__ src, int lds, T* __restrict__ dst, int ldd, int64_t rows, int C) {
+  int cg8 = (C + 7) >> 3;
+  int64_t total = rows * cg8;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = i / cg8; int cg = (int)(i - r * cg8); int nv = min(8, C - cg * 8);
+    Frag8<T> f = frag_load(src + r * lds + cg * 8, nv);
+    frag_store<T>(dst + r * ldd + cg * 8, f, nv);
+  }
+}
+extern "C" int dp_copy_rows(const void* src, int lds, void* dst, int ldd, int64_t rows, int C, int dtype, void* stream) {
+  DP_DISPATCH(dtype, hipLaunchKernelGGL(k_copy_rows<T>, dim3(grid_for(rows * ((C + 7) / 8), 256)), dim3(256), 0, STREAM, (const T*)src, lds, (T*)dst, ldd, rows, C));
+  DP_CHECK_LAUNCH("copy_rows"); return 0;
+}
+
+template <typename S, typename D>
+__global__ void k_cast(const S* __restrict__ s, D* __restrict__ d, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) st_f(d + i, ld_f(s + i));
+}
+extern "C" int dp_cast(const void* src, int sdt, void* dst, int ddt, int64_t n, void* stream) {
+  dim3 g(grid_for(n, 256)), b(256);
+  if (sdt == DP_F32 && ddt == DP_BF16) hipLaunchKernelGGL((k_cast<float, bf16_t>), g, b, 0, STREAM, (const float*)src, (bf16_t*)dst, n);
+  else if (sdt == DP_BF16 && ddt == DP_F32) hipLaunchKernelGGL((k_cast<bf16_t, float>), g, b, 0, STREAM, (const bf16_t*)src, (float*)dst, n);
+  else if (sdt == DP_F32 && ddt == DP_F32) hipLaunchKernelGGL((k_cast<float, float>), g, b, 0, STREAM, (const float*)src, (float*)dst, n);
+  else if (sdt == DP_BF16 && ddt == DP_BF16) hipLaunchKernelGGL((k_cast<bf16_t, bf16_t>), g, b, 0, STREAM, (const bf16_t*)src, (bf16_t*)dst, n);
+  else DP_FAIL("cast: bad dtypes");
+  DP_CHECK_LAUNCH("cast"); return 0;
+}
+__global__ void k_fill(float* p, float v, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+extern "C" int dp_fill_f32(float* p, float v, int64_t n, void* stream) {
+  hipLaunchKernelGGL(k_fill, dim3(grid_for(n, 256)), dim3(256), 0, STREAM, p, v, n); DP_CHECK_LAUNCH("fill"); return 0;
+}
+
+// patchify: one thread per (b, token, p1, p2, p3): C contiguous elements on both sides.
+template <typename T, bool INV>
+__global__ void k_patchify(const T* __restrict__ x, T* __restrict__ out, int B, int S0, int S1, int S2, int C, int ld, int p) {
+  int f0 = S0 / p, f1 = S1 / p, f2 = S2 / p;
+  int64_t ntok = (int64_t)f0 * f1 * f2, p3n = (int64_t)p * p * p;
+  int64_t total = (int64_t)B * ntok * p3n;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t pp = i % p3n, bt = i / p3n; int64_t tok = bt % ntok, b = bt / ntok;
+    int p3 = (int)(pp % p), p2 = (int)((pp / p) % p), p1 = (int)(pp / ((int64_t)p * p));
+    int t2 = (int)(tok % f2), t1 = (int)((tok / f2) % f1), t0 = (int)(tok / ((int64_t)f2 * f1));
+    int64_t vox = (((int64_t)b * S0 + t0 * p + p1) * S1 + t1 * p + p2) * S2 + t2 * p + p3;
+    const T* a = x + vox * ld; T* o = out + i * C;   // i == ((b*ntok+tok)*p3n + pp)
+    if (!INV) { for (int c = 0; c < C; c++) o[c] = a[c]; }
+    else { T* aw = const_cast<T*>(a); for (int c = 0; c < C; c++) aw[c] = o[c]; }
+  }
+}
+extern "C" int dp_patchify(const void* x, void* out, int B, int S0, int S1, int S2, int C, int ld, int p, int dtype, void* stream) {
+  if (S0 % p || S1 % p || S2 % p) DP_FAIL("patchify: size not divisible by patch");
+  int64_t total = (int64_t)B * S0 * S1 * S2;
+  DP_DISPATCH(dtype, hipLaunchKernelGGL((k_patchify<T, false>), dim3(grid_for(total, 256)), dim3(256), 0, STREAM, (const T*)x, (T*)out, B, S0, S1, S2, C, ld, p));
+  DP_CHECK_LAUNCH("patchify"); return 0;
+}
+extern "C" int dp_unpatchify(const void* gout, void* gx, int B, int S0, int S1, int S2, int C, int ld, int p, int dtype, void* stream) {
+  if (S0 % p || S1 % p || S2 % p) DP_FAIL("unpatchify: size not divisible by patch");
+  int64_t total = (int64_t)B * S0 * S1 * S2;
+  DP_DISPATCH(dtype, hipLaunchKernelGGL((k_patchify<T, true>), dim3(grid_for(total, 256)), dim3(256), 0, STREAM, (const T*)gx, (T*)const_cast<void*>(gout), B, S0, S1, S2, C, ld, p));
+  DP_CHECK_LAUNCH("unpatchify"); return 0;
+}
+
+// pixel shuffle (2x2x2): src [V][8][C] <-> dst NDHWC(2D,2H,2W) pitch ldd
+template <typename T, bool INV>
+__global__ void k_pixel_shuffle2(const T* __restrict__ src, int lds, T* __restrict__ dst, int ldd, int N, int D, int H, int W, int C) {
+  int cg8 = (C + 7) >> 3;
+  int64_t V = (int64_t)N * D * H * W, total = V * 8 * cg8;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int cg = (int)(i % cg8); int64_t r = i / cg8; int abc = (int)(r & 7); int64_t v = r >> 3;
+    int w = (int)(v % W), h = (int)((v / W) % H), d = (int)((v / ((int64_t)W * H)) % D); int64_t n = v / ((int64_t)W * H * D);
+    int a = abc >> 2, b = (abc >> 1) & 1, c = abc & 1;
+    int64_t ov = ((n * 2 * D + 2 * d + a) * 2 * H + 2 * h + b) * 2 * W + 2 * w + c;
+    int nv = min(8, C - cg * 8);
+    if (!INV) {  // src compact [v][abc][C] -> dst big (pitch ldd)
+      Frag8<T> f = frag_load(src + (v * 8 + abc) * C + cg * 8, nv);
+      frag_store<T>(dst + ov * ldd + cg * 8, f, nv);
+    } else {     // src big (pitch lds) -> dst compact
+      Frag8<T> f = frag_load(src + ov * lds + cg * 8, nv);
+      frag_store<T>(dst + (v * 8 + abc) * C + cg * 8, f, nv);
+    }
+  }
+}
+extern "C" int dp_pixel_shuffle2(const void* src, void* dst, int N, int D, int H, int W, int C, int ldd, int dtype, void* stream) {
+  int64_t total = (int64_t)N * D * H * W * 8 * ((C + 7) / 8);
+  DP_DISPATCH(dtype, hipLaunchKernelGGL((k_pixel_shuffle2<T, false>), dim3(grid_for(total, 256)), dim3(256), 0, STREAM, (const T*)src, 0, (T*)dst, ldd, N, D, H, W, C));
+  DP_CHECK_LAUNCH("pixel_shuffle2"); return 0;
+}
+extern "C" int dp_pixel_unshuffle2(const void* src, int lds, void* dst, int N, int D, int H, int W, int C, int dtype, void* stream) {
+  int64_t total = (int64_t)N * D * H * W * 8 * ((C + 7) / 8);
+  DP_DISPATCH(dtype, hipLaunchKernelGGL((k_pixel_shuffle2<T, true>), dim3(grid_for(total, 256)), dim3(256), 0, STREAM, (const T*)src, lds, (T*)dst, 0, N, D, H, W, C));
+  DP_CHECK_LAUNCH("pixel_unshuffle2"); return 0;
+}
+
+// trilinear x2, align_corners=True: src = dst * (in-1)/(out-1) (computed in fp32 like ATen's area_pixel_compute_scale)
+__device__ __forceinline__ void tri_coord(int o, int n_in, int& i0, int& i1, float& f) {
+  if (n_in == 1) { i0 = i1 = 0; f = 0.f; return; }
+  float scale = (float)(n_in - 1) / (float)(2 * n_in - 1);
+  float s = scale * (float)o;
+  i0 = (int)s; if (i0 > n_in - 1) i0 = n_in - 1;
+  i1 = i0 + 1 < n_in ? i0 + 1 : n_in - 1;
+  f = s - (float)i0;
+}
+template <typename T>
+__global__ void k_trilinear_fwd(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, int N, int D, int H, int W, int C) {
+  int cg8 = (C + 7) >> 3;
+  int64_t OV = (int64_t)N * 8 * D * H * W, total = OV * cg8;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int cg = (int)(i % cg8); int64_t ov = i / cg8;
+    int ow = (int)(ov % (2 * W)), oh = (int)((ov / (2 * W)) % (2 * H)), od = (int)((ov / ((int64_t)4 * W * H)) % (2 * D));
+    int64_t n = ov / ((int64_t)8 * W * H * D);
+    int d0, d1, h0, h1, w0, w1; float fd, fh, fw;
+    tri_coord(od, D, d0, d1, fd); tri_coord(oh, H, h0, h1, fh); tri_coord(ow, W, w0, w1, fw);
+    int nv = min(8, C - cg * 8);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      int dd = (k & 4) ? d1 : d0, hh = (k & 2) ? h1 : h0, ww = (k & 1) ? w1 : w0;
+      float wgt = ((k & 4) ? fd : 1.f - fd) * ((k & 2) ? fh : 1.f - fh) * ((k & 1) ? fw : 1.f - fw);
+      float t[8];
+      frag_unpack(frag_load(x + (((n * D + dd) * H + hh) * W + ww) * ldx + cg * 8, nv), t);
+      for (int j = 0; j < 8; j++) acc[j] += wgt * t[j];
+    }
+    Frag8<T> f; frag_pack(f, acc);
+    frag_store<T>(y + ov * ldy + cg * 8, f, nv);
+  }
+}
+template <typename T>
+__global__ void k_trilinear_bwd(const T* __restrict__ gy, int ldgy, float* __restrict__ gx, int N, int D, int H, int W, int C) {
+  int64_t OV = (int64_t)N * 8 * D * H * W, total = OV * C;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int c = (int)(i % C); int64_t ov = i / C;
+    int ow = (int)(ov % (2 * W)), oh = (int)((ov / (2 * W)) % (2 * H)), od = (int)((ov / ((int64_t)4 * W * H)) % (2 * D));
+    int64_t n = ov / ((int64_t)8 * W * H * D);
+    int d0, d1, h0, h1, w0, w1; float fd, fh, fw;
+    tri_coord(od, D, d0, d1, fd); tri_coord(oh, H, h0, h1, fh); tri_coord(ow, W, w0, w1, fw);
+    float g = ld_f(gy + ov * ldgy + c);
+    for (int k = 0; k < 8; k++) {
+      int dd = (k & 4) ? d1 : d0, hh = (k & 2) ? h1 : h0, ww = (k & 1) ? w1 : w0;
+      float wgt = ((k & 4) ? fd : 1.f - fd) * ((k & 2) ? fh : 1.f - fh) * ((k & 1) ? fw : 1.f - fw);
+      if (wgt != 0.f) atomicAdd(gx + (((n * D + dd) * H + hh) * W + ww) * C + c, wgt * g);
+    }
+  }
+}
+extern "C" int dp_trilinear_up2_fwd(const void* x, int ldx, void* y, int ldy, int N, int D, int H, int W, int C, int dtype, void* stream) {
+  int64_t total = (int64_t)N * 8 * D * H * W * ((C + 7) / 8);
+  DP_DISPATCH(dtype, hipLaunchKernelGGL(k_trilinear_fwd<T>, dim3(grid_for(total, 256)), dim3(256), 0, STREAM, (const T*)x, ldx, (T*)y, ldy, N, D, H, W, C));
+  DP_CHECK_LAUNCH("trilinear_fwd"); return 0;
+}
+extern "C" int dp_trilinear_up2_bwd(const void* gy, int ldgy, float* gx, int N, int D, int H, int W, int C, int dtype, void* stream) {
+  int64_t total = (int64_t)N * 8 * D * H * W * C;
+  DP_DISPATCH(dtype, hipLaunchKernelGGL(k_trilinear_bwd<T>, dim3(grid_for(total, 256)), dim3(256), 0, STREAM, (const T*)gy, ldgy, gx, N, D, H, W, C));
+  DP_CHECK_LAUNCH("trilinear_bwd"); return 0;
+}
+
+// batched transpose through a 32x33 LDS tile
+template <typename T>
+__global__ void k_transpose(const T* __restrict__ src, int64_t lds, int64_t sb0, int64_t sb1, T* __restrict__ dst, int64_t ldd,
+                            int64_t db0, int64_t db1, int rows, int cols, int nb1) {
+  __shared__ float tile[32][33];
+  int b = blockIdx.z, b0 = b / nb1, b1 = b % nb1;
+  const T* s = src + b0 * sb0 + b1 * sb1; T* d = dst + b0 * db0 + b1 * db1;
+  int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: 32 x 8
+  for (int j = ty; j < 32; j += 8) { int r = r0 + j, c = c0 + tx; tile[j][tx] = (r < rows && c < cols) ? ld_f(s + (int64_t)r * lds + c) : 0.f; }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) { int c = c0 + j, r = r0 + tx; if (r < rows && c < cols) st_f(d + (int64_t)c * ldd + r, tile[tx][j]); }
+}
+extern "C" int dp_transpose(const void* src, int64_t lds, int64_t sb0, int64_t sb1, void* dst, int64_t ldd, int64_t db0, int64_t db1,
+                            int rows, int cols, int nb0, int nb1, int dtype, void* stream) {
+  dim3 g(cdiv(cols, 32), cdiv(rows, 32), nb0 * nb1);
+  if (g.y > 65535 || g.z > 65535) DP_FAIL("transpose: grid too large");
+  DP_DISPATCH(dtype, hipLaunchKernelGGL(k_transpose<T>, g, dim3(256), 0, STREAM, (const T*)src, lds, sb0, sb1, (T*)dst, ldd, db0, db1, rows, cols, nb1));
+  DP_CHECK_LAUNCH("transpose"); return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ elementwise
+template <typename T>
+__global__ void k_add(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y, int64_t n, int64_t period) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    st_f(y + i, ld_f(a + i) + ld_f(b + (i % period)));
+}
+extern "C" int dp_add(const void* a, const void* b, void* y, int64_t n, int64_t period, int dtype, void* stream) {
+  DP_DISPATCH(dtype, hipLaunchKernelGGL(k_add<T>, dim3(grid_for(n, 256)), dim3(256), 0, STREAM, (const T*)a, (const T*)b, (T*)y, n, period));
+  DP_CHECK_LAUNCH("add"); return 0;
+}
+template <typename T, bool BWD>
+__global__ void k_gelu(const T* __restrict__ x, const T* __restrict__ gy, T* __restrict__ out, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float z = ld_f(x + i);
+    st_f(out + i, BWD ? ld_f(gy + i) * act_bwd(z, DP_ACT_GELU) : act_fwd(z, DP_ACT_GELU));
+  }
+}
+extern "C" int dp_gelu_fwd(const void* x, void* y, int64_t n, int dtype, void* stream) {
+  DP_DISPATCH(dtype, hipLaunchKernelGGL((k_gelu<T, false>), dim3(grid_for(n, 256)), dim3(256), 0, STREAM, (const T*)x, (const T*)nullptr, (T*)y, n));
+  DP_CHECK_LAUNCH("gelu_fwd"); return 0;
+}
+extern "C" int dp_gelu_bwd(const void* x, const void* gy, void* gx, int64_t n, int dtype, void* stream) {
+  DP_DISPATCH(dtype, hipLaunchKernelGGL((k_gelu<T, true>), dim3(grid_for(n, 256)), dim3(256), 0, STREAM, (const T*)x, (const T*)gy, (T*)gx, n));
+  DP_CHECK_LAUNCH("gelu_bwd"); return 0;
+}
+
+// softmax over rows: one wave per row (4 rows per 256-thread block)
+template <typename T>
+__global__ void k_softmax_fwd(const T* __restrict__ s, T* __restrict__ p, int64_t rows, int cols, float scale) {
+  int lane = threadIdx.x & 63; int64_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const T* a = s + row * cols; T* o = p + row * cols;
+  float m = -INFINITY;
+  for (int c = lane; c < cols; c += 64) m = fmaxf(m, ld_f(a + c) * scale);
+  m = wave_max(m);
+  float sum = 0.f;
+  for (int c = lane; c < cols; c += 64) sum += expf(ld_f(a + c) * scale - m);
+  sum = wave_sum(sum);
+  float inv = 1.f / sum;
+  for (int c = lane; c < cols; c += 64) st_f(o + c, expf(ld_f(a + c) * scale - m) * inv);
+}
+template <typename T>
+__global__ void k_softmax_bwd(const T* __restrict__ p, const T* __restrict__ gp, T* __restrict__ gs, int64_t rows, int cols, float scale) {
+  int lane = threadIdx.x & 63; int64_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const T* a = p + row * cols; const T* g = gp + row * cols; T* o = gs + row * cols;
+  float dot = 0.f;
+  for (int c = lane; c < cols; c += 64) dot += ld_f(a + c) * ld_f(g + c);
+  dot = wave_sum(dot);
+  for (int c = lane; c < cols; c += 64) { float pv = ld_f(a + c); st_f(o + c, scale * pv * (ld_f(g + c) - dot)); }
+}
+extern "C" int dp_softmax_fwd(const void* s, void* p, int64_t rows, int cols, float scale, int dtype, void* stream) {
+  DP_DISPATCH(dtype, hipLaunchKernelGGL(k_softmax_fwd<T>, dim3(cdiv(rows, 4)), dim3(256), 0, STREAM, (const T*)s, (T*)p, rows, cols, scale));
+  DP_CHECK_LAUNCH("softmax_fwd"); return 0;
+}
+extern "C" int dp_softmax_bwd(const void* p, const void* gp, void* gs, int64_t rows, int cols, float scale, int dtype, void* stream) {
+  DP_DISPATCH(dtype, hipLaunchKernelGGL(k_softmax_bwd<T>, dim3(cdiv(rows, 4)), dim3(256), 0, STREAM, (const T*)p, (const T*)gp, (T*)gs, rows, cols, scale));
+  DP_CHECK_LAUNCH("softmax_bwd"); return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ cascade glue
+template <typename T>
+__global__ void k_argmax_onehot(const T* __restrict__ lg, int ld, T* __restrict__ out, int ldo, int choff, int32_t* labels, int64_t rows, int C) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < rows; i += (int64_t)gridDim.x * blockDim.x) {
+    const T* a = lg + i * ld; float best = ld_f(a); int bi = 0;
+    for (int c = 1; c < C; c++) { float v = ld_f(a + c); if (v > best) { best = v; bi = c; } }
+    if (labels) labels[i] = bi;
+    if (out) for (int c = 1; c < C; c++) st_f(out + i * ldo + choff + c - 1, c == bi ? 1.f : 0.f);
+  }
+}
+extern "C" int dp_argmax_onehot(const void* logits, int ld, void* out, int ldo, int choff, int32_t* labels, int64_t rows, int C, int dtype, void* stream) {
+  DP_DISPATCH(dtype, hipLaunchKernelGGL(k_argmax_onehot<T>, dim3(grid_for(rows, 256)), dim3(256), 0, STREAM, (const T*)logits, ld, (T*)out, ldo, choff, labels, rows, C));
+  DP_CHECK_LAUNCH("argmax_onehot"); return 0;
+}

@@ -1,0 +1,298 @@
+// Normalisation kernels: InstanceNorm3d / BatchNorm3d (two-phase: per-block partial sums -> fp64 finalize ->
+// fused normalise + affine + residual + activation) with their backward, and LayerNorm rows.
+// All are HBM-bound row streams over NDHWC voxel rows: each thread owns one 8-channel (16 B bf16) chunk of a row,
+// keeps its per-channel constants in registers and walks the block's voxel range.
+#include "common.h"
+
+#define STREAM ((hipStream_t)stream)
+#define ROWS_PER_BLOCK 2048
+#define NT 256
+
+template <typename T> __device__ __forceinline__ void unpack8(const T* p, int nv, float* o);
+template <> __device__ __forceinline__ void unpack8<float>(const float* p, int nv, float* o) {
+  Frag8<float> f = frag_load(p, nv); for (int i = 0; i < 8; i++) o[i] = f.v[i];
+}
+template <> __device__ __forceinline__ void unpack8<bf16_t>(const bf16_t* p, int nv, float* o) {
+  Frag8<bf16_t> f = frag_load(p, nv);
+  for (int i = 0; i < 4; i++) { o[2 * i] = __uint_as_float(f.u[i] << 16); o[2 * i + 1] = __uint_as_float(f.u[i] & 0xffff0000u); }
+}
+__device__ __forceinline__ void pack8(float* p, int nv, const float* o) {
+  if (nv >= 8 && ((uintptr_t)p & 15) == 0) { *(v4f*)p = (v4f){o[0], o[1], o[2], o[3]}; *(v4f*)(p + 4) = (v4f){o[4], o[5], o[6], o[7]}; }
+  else for (int i = 0; i < 8; i++) if (i < nv) p[i] = o[i];
+}
+__device__ __forceinline__ void pack8(bf16_t* p, int nv, const float* o) {
+  if (nv >= 8 && ((uintptr_t)p & 15) == 0) {
+    v4u u; for (int i = 0; i < 4; i++) u[i] = (unsigned)f2bf(o[2 * i]) | ((unsigned)f2bf(o[2 * i + 1]) << 16);
+    *(v4u*)p = u;
+  } else for (int i = 0; i < 8; i++) if (i < nv) p[i] = f2bf(o[i]);
+}
+
+extern "C" int dp_stats_nblk(int64_t V) { return (int)((V + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK); }
+
+// Common geometry: block b of sample n covers voxels [b*RPB, min(V,(b+1)*RPB)); thread t owns chunk cg = t % cg8 and
+// rows r0 + k*rpi.  (cg8 = chunks per row, rpi = rows per iteration = NT / cg8.)
+struct RowGeom { int cg8, rpi, cg, r0, nv; bool active; };
+__device__ __forceinline__ RowGeom row_geom(int C) {
+  RowGeom g; g.cg8 = (C + 7) >> 3; g.rpi = NT / g.cg8; if (g.rpi < 1) g.rpi = 1;
+  g.cg = threadIdx.x % g.cg8; g.r0 = threadIdx.x / g.cg8; g.active = g.r0 < g.rpi; g.nv = min(8, C - g.cg * 8);
+  return g;
+}
+
+// Deterministic block reduction of per-thread 16 partials (acc[0..7], acc2[0..7]) over the threads that share a chunk.
+// red: LDS float [NT][16].  Result written by threads c < 2*C... to part[(2)][C].
+__device__ __forceinline__ void block_reduce_store(float* red, const float* a1, const float* a2, const RowGeom& g, int C, float* part) {
+  for (int i = 0; i < 8; i++) { red[threadIdx.x * 16 + i] = g.active ? a1[i] : 0.f; red[threadIdx.x * 16 + 8 + i] = g.active ? a2[i] : 0.f; }
+  __syncthreads();
+  for (int o = threadIdx.x; o < 2 * C; o += NT) {
+    int which = o / C, c = o - which * C, cg = c >> 3, j = c & 7;
+    float s = 0.f;
+    for (int r = 0; r < g.rpi; r++) s += red[(r * g.cg8 + cg) * 16 + which * 8 + j];
+    part[which * C + c] = s;
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(NT) k_stats_partial(const T* __restrict__ x, int ld, int64_t V, int C, float* __restrict__ part, int nblk) {
+  __shared__ float red[NT * 16];
+  if (C > 8 * NT) return;
+  int b = blockIdx.x, n = blockIdx.y;
+  RowGeom g = row_geom(C);
+  int64_t v0 = (int64_t)b * ROWS_PER_BLOCK, v1 = min(V, v0 + ROWS_PER_BLOCK);
+  float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (g.active) for (int64_t v = v0 + g.r0; v < v1; v += g.rpi) {
+    float t[8]; unpack8<T>(x + ((int64_t)n * V + v) * ld + g.cg * 8, g.nv, t);
+    for (int i = 0; i < 8; i++) { s1[i] += t[i]; s2[i] += t[i] * t[i]; }
+  }
+  block_reduce_store(red, s1, s2, g, C, part + ((int64_t)n * nblk + b) * 2 * C);
+}
+extern "C" int dp_stats_partial(const void* x, int ld, int N, int64_t V, int C, float* part, int dtype, void* stream) {
+  if (C > 8 * NT) DP_FAIL("stats: C too large");
+  int nblk = dp_stats_nblk(V);
+  DP_DISPATCH(dtype, hipLaunchKernelGGL(k_stats_partial<T>, dim3(nblk, N), dim3(NT), 0, STREAM, (const T*)x, ld, V, C, part, nblk));
+  DP_CHECK_LAUNCH("stats_partial"); return 0;
+}
+
+__global__ void k_stats_finalize(const float* __restrict__ part, int N, int nblk, int C, int64_t V, int batch_mode, float eps,
+                                 float* mean, float* rstd, float* rmean, float* rvar, float momentum) {
+  int groups = batch_mode ? 1 : N;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= groups * C) return;
+  int gidx = i / C, c = i - gidx * C;
+  double s1 = 0, s2 = 0;
+  int n0 = batch_mode ? 0 : gidx, n1 = batch_mode ? N : gidx + 1;
+  for (int n = n0; n < n1; n++) for (int b = 0; b < nblk; b++) {
+    const float* p = part + ((int64_t)n * nblk + b) * 2 * C;
+    s1 += p[c]; s2 += p[C + c];
+  }
+  double cnt = (double)V * (n1 - n0);
+  double m = s1 / cnt, var = s2 / cnt - m * m;
+  if (var < 0) var = 0;
+  mean[i] = (float)m; rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+  if (rmean && batch_mode) {
+    double unb = cnt > 1 ? var * cnt / (cnt - 1) : var;
+    rmean[c] = (float)((1.0 - momentum) * rmean[c] + momentum * m);
+    rvar[c] = (float)((1.0 - momentum) * rvar[c] + momentum * unb);
+  }
+}
+extern "C" int dp_stats_finalize(const float* part, int N, int nblk, int C, int64_t V, int batch_mode, float eps, float* mean, float* rstd,
+                                 float* running_mean, float* running_var, float momentum, void* stream) {
+  int total = (batch_mode ? 1 : N) * C;
+  hipLaunchKernelGGL(k_stats_finalize, dim3(cdiv(total, 128)), dim3(128), 0, STREAM, part, N, nblk, C, V, batch_mode, eps, mean, rstd, running_mean, running_var, momentum);
+  DP_CHECK_LAUNCH("stats_finalize"); return 0;
+}
+
+// ---------------------------------------------------------------------------- fused normalise + affine + residual + act
+struct NormConst { float m[8], r[8], ga[8], be[8]; };
+__device__ __forceinline__ NormConst load_consts(const float* mean, const float* rstd, int sidx, const float* gamma, const float* beta, int c0, int nv) {
+  NormConst k;
+  for (int i = 0; i < 8; i++) {
+    bool ok = i < nv;
+    k.m[i] = (ok && mean) ? mean[sidx + c0 + i] : 0.f; k.r[i] = (ok && rstd) ? rstd[sidx + c0 + i] : 1.f;
+    k.ga[i] = (ok && gamma) ? gamma[c0 + i] : 1.f; k.be[i] = (ok && beta) ? beta[c0 + i] : 0.f;
+  }
+  return k;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(NT) k_norm_act_fwd(const T* __restrict__ x, int ldx, const float* mean, const float* rstd, int ssn,
+                                                     const float* gamma, const float* beta, const T* __restrict__ res, int ldr, int act,
+                                                     T* __restrict__ y, int ldy, int64_t V, int C) {
+  int b = blockIdx.x, n = blockIdx.y;
+  RowGeom g = row_geom(C);
+  if (!g.active) return;
+  NormConst k = load_consts(mean, rstd, n * ssn, gamma, beta, g.cg * 8, g.nv);
+  int64_t v0 = (int64_t)b * ROWS_PER_BLOCK, v1 = min(V, v0 + ROWS_PER_BLOCK);
+  for (int64_t v = v0 + g.r0; v < v1; v += g.rpi) {
+    int64_t row = (int64_t)n * V + v;
+    float t[8], rr[8];
+    unpack8<T>(x + row * ldx + g.cg * 8, g.nv, t);
+    if (res) unpack8<T>(res + row * ldr + g.cg * 8, g.nv, rr);
+    for (int i = 0; i < 8; i++) {
+      float z = (t[i] - k.m[i]) * k.r[i] * k.ga[i] + k.be[i];
+      if (res) z += rr[i];
+      t[i] = act_fwd(z, act);
+    }
+    pack8(y + row * ldy + g.cg * 8, g.nv, t);
+  }
+}
+extern "C" int dp_norm_act_fwd(const void* x, int ldx, const float* mean, const float* rstd, int ssn, const float* gamma, const float* beta,
+                               const void* res, int ldr, int act, void* y, int ldy, int N, int64_t V, int C, int dtype, void* stream) {
+  if (C > 8 * NT) DP_FAIL("norm_act_fwd: C too large");
+  DP_DISPATCH(dtype, hipLaunchKernelGGL(k_norm_act_fwd<T>, dim3(dp_stats_nblk(V), N), dim3(NT), 0, STREAM, (const T*)x, ldx, mean, rstd, ssn,
+                                        gamma, beta, (const T*)res, ldr, act, (T*)y, ldy, V, C));
+  DP_CHECK_LAUNCH("norm_act_fwd"); return 0;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(NT) k_norm_act_bwd_partial(const T* __restrict__ x, int ldx, const T* __restrict__ gy, int ldgy, const float* mean,
+                                                             const float* rstd, int ssn, const float* gamma, const float* beta,
+                                                             const T* __restrict__ res, int ldr, int act, int64_t V, int C,
+                                                             float* __restrict__ part, int nblk) {
+  __shared__ float red[NT * 16];
+  int b = blockIdx.x, n = blockIdx.y;
+  RowGeom g = row_geom(C);
+  NormConst k = load_consts(mean, rstd, n * ssn, gamma, beta, g.cg * 8, g.active ? g.nv : 0);
+  int64_t v0 = (int64_t)b * ROWS_PER_BLOCK, v1 = min(V, v0 + ROWS_PER_BLOCK);
+  float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (g.active) for (int64_t v = v0 + g.r0; v < v1; v += g.rpi) {
+    int64_t row = (int64_t)n * V + v;
+    float t[8], d[8], rr[8];
+    unpack8<T>(x + row * ldx + g.cg * 8, g.nv, t);
+    unpack8<T>(gy + row * ldgy + g.cg * 8, g.nv, d);
+    if (res) unpack8<T>(res + row * ldr + g.cg * 8, g.nv, rr);
+    for (int i = 0; i < 8; i++) {
+      float xh = (t[i] - k.m[i]) * k.r[i];
+      float z = xh * k.ga[i] + k.be[i]; if (res) z += rr[i];
+      float gg = d[i] * act_bwd(z, act);
+      s1[i] += gg; s2[i] += gg * xh;
+    }
+  }
+  block_reduce_store(red, s1, s2, g, C, part + ((int64_t)n * nblk + b) * 2 * C);
+}
+extern "C" int dp_norm_act_bwd_partial(const void* x, int ldx, const void* gy, int ldgy, const float* mean, const float* rstd, int ssn,
+                                       const float* gamma, const float* beta, const void* res, int ldr, int act, int N, int64_t V, int C,
+                                       float* part, int dtype, void* stream) {
+  if (C > 8 * NT) DP_FAIL("norm_act_bwd_partial: C too large");
+  int nblk = dp_stats_nblk(V);
+  DP_DISPATCH(dtype, hipLaunchKernelGGL(k_norm_act_bwd_partial<T>, dim3(nblk, N), dim3(NT), 0, STREAM, (const T*)x, ldx, (const T*)gy, ldgy, mean, rstd, ssn,
+                                        gamma, beta, (const T*)res, ldr, act, V, C, part, nblk));
+  DP_CHECK_LAUNCH("norm_act_bwd_partial"); return 0;
+}
+
+__global__ void k_norm_bwd_finalize(const float* __restrict__ part, int N, int nblk, int C, int batch_mode, float* s1, float* s2, float* dgamma, float* dbeta) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double t1 = 0, t2 = 0;
+  for (int n = 0; n < N; n++) {
+    double a1 = 0, a2 = 0;
+    for (int b = 0; b < nblk; b++) { const float* p = part + ((int64_t)n * nblk + b) * 2 * C; a1 += p[c]; a2 += p[C + c]; }
+    if (!batch_mode) { s1[n * C + c] = (float)a1; s2[n * C + c] = (float)a2; }
+    t1 += a1; t2 += a2;
+  }
+  if (batch_mode) { s1[c] = (float)t1; s2[c] = (float)t2; }
+  if (dgamma) dgamma[c] += (float)t2;
+  if (dbeta) dbeta[c] += (float)t1;
+}
+extern "C" int dp_norm_bwd_finalize(const float* part, int N, int nblk, int C, int batch_mode, float* s1, float* s2, float* dgamma, float* dbeta, void* stream) {
+  hipLaunchKernelGGL(k_norm_bwd_finalize, dim3(cdiv(C, 128)), dim3(128), 0, STREAM, part, N, nblk, C, batch_mode, s1, s2, dgamma, dbeta);
+  DP_CHECK_LAUNCH("norm_bwd_finalize"); return 0;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(NT) k_norm_act_bwd_apply(const T* __restrict__ x, int ldx, const T* __restrict__ gy, int ldgy, const float* mean,
+                                                           const float* rstd, int ssn, const float* gamma, const float* beta,
+                                                           const T* __restrict__ res, int ldr, int act, const float* s1, const float* s2,
+                                                           float inv_count, int use_stats, T* __restrict__ gx, int ldgx, T* __restrict__ gres, int ldgres,
+                                                           int64_t V, int C) {
+  int b = blockIdx.x, n = blockIdx.y;
+  RowGeom g = row_geom(C);
+  if (!g.active) return;
+  NormConst k = load_consts(mean, rstd, n * ssn, gamma, beta, g.cg * 8, g.nv);
+  float a1[8], a2[8];
+  for (int i = 0; i < 8; i++) {
+    bool ok = use_stats && i < g.nv;
+    a1[i] = ok ? s1[n * ssn + g.cg * 8 + i] * inv_count : 0.f;
+    a2[i] = ok ? s2[n * ssn + g.cg * 8 + i] * inv_count : 0.f;
+  }
+  int64_t v0 = (int64_t)b * ROWS_PER_BLOCK, v1 = min(V, v0 + ROWS_PER_BLOCK);
+  for (int64_t v = v0 + g.r0; v < v1; v += g.rpi) {
+    int64_t row = (int64_t)n * V + v;
+    float t[8], d[8], rr[8], gg[8];
+    unpack8<T>(x + row * ldx + g.cg * 8, g.nv, t);
+    unpack8<T>(gy + row * ldgy + g.cg * 8, g.nv, d);
+    if (res) unpack8<T>(res + row * ldr + g.cg * 8, g.nv, rr);
+    for (int i = 0; i < 8; i++) {
+      float xh = (t[i] - k.m[i]) * k.r[i];
+      float z = xh * k.ga[i] + k.be[i]; if (res) z += rr[i];
+      gg[i] = d[i] * act_bwd(z, act);
+      t[i] = k.ga[i] * k.r[i] * (gg[i] - a1[i] - xh * a2[i]);
+    }
+    if (gx) pack8(gx + row * ldgx + g.cg * 8, g.nv, t);
+    if (gres) pack8(gres + row * ldgres + g.cg * 8, g.nv, gg);
+  }
+}
+extern "C" int dp_norm_act_bwd_apply(const void* x, int ldx, const void* gy, int ldgy, const float* mean, const float* rstd, int ssn,
+                                     const float* gamma, const float* beta, const void* res, int ldr, int act, const float* s1, const float* s2,
+                                     float inv_count, int use_stats, void* gx, int ldgx, void* gres, int ldgres, int N, int64_t V, int C,
+                                     int dtype, void* stream) {
+  if (C > 8 * NT) DP_FAIL("norm_act_bwd_apply: C too large");
+  DP_DISPATCH(dtype, hipLaunchKernelGGL(k_norm_act_bwd_apply<T>, dim3(dp_stats_nblk(V), N), dim3(NT), 0, STREAM, (const T*)x, ldx, (const T*)gy, ldgy, mean, rstd,
+                                        ssn, gamma, beta, (const T*)res, ldr, act, s1, s2, inv_count, use_stats, (T*)gx, ldgx, (T*)gres, ldgres, V, C));
+  DP_CHECK_LAUNCH("norm_act_bwd_apply"); return 0;
+}
+
+// ---------------------------------------------------------------------------- LayerNorm: one wave per row
+template <typename T>
+__global__ void k_layernorm_fwd(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, T* __restrict__ y,
+                                float* __restrict__ mean, float* __restrict__ rstd, int64_t rows, int C, float eps) {
+  int lane = threadIdx.x & 63; int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const T* a = x + row * C; T* o = y + row * C;
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s += ld_f(a + c);
+  float m = wave_sum(s) / C;
+  float v = 0.f;
+  for (int c = lane; c < C; c += 64) { float d = ld_f(a + c) - m; v += d * d; }
+  float r = rsqrtf(wave_sum(v) / C + eps);
+  if (lane == 0) { mean[row] = m; rstd[row] = r; }
+  for (int c = lane; c < C; c += 64) st_f(o + c, (ld_f(a + c) - m) * r * gamma[c] + beta[c]);
+}
+template <typename T>
+__global__ void k_layernorm_bwd(const T* __restrict__ x, const T* __restrict__ gy, const float* __restrict__ gamma, const float* __restrict__ mean,
+                                const float* __restrict__ rstd, T* __restrict__ gx, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                int64_t rows, int C, int rows_per_block) {
+  // block = 4 waves; each wave walks rows_per_block/4 rows; per-column partial sums of dgamma/dbeta kept per lane,
+  // then one atomicAdd per (block, column).
+  extern __shared__ float sm[];            // [2][C]
+  for (int c = threadIdx.x; c < 2 * C; c += blockDim.x) sm[c] = 0.f;
+  __syncthreads();
+  int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int64_t rbeg = (int64_t)blockIdx.x * rows_per_block, rend = min(rows, rbeg + rows_per_block);
+  for (int64_t row = rbeg + wv; row < rend; row += 4) {
+    const T* a = x + row * C; const T* g = gy + row * C; T* o = gx + row * C;
+    float m = mean[row], r = rstd[row];
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = lane; c < C; c += 64) { float xh = (ld_f(a + c) - m) * r, dg = ld_f(g + c) * gamma[c]; s1 += dg; s2 += dg * xh; }
+    s1 = wave_sum(s1) / C; s2 = wave_sum(s2) / C;
+    for (int c = lane; c < C; c += 64) {
+      float xh = (ld_f(a + c) - m) * r, d = ld_f(g + c);
+      st_f(o + c, r * (d * gamma[c] - s1 - xh * s2));
+      atomicAdd(&sm[c], d * xh); atomicAdd(&sm[C + c], d);
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) { atomicAdd(dgamma + c, sm[c]); atomicAdd(dbeta + c, sm[C + c]); }
+}
+extern "C" int dp_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int64_t rows, int C,
+                                float eps, int dtype, void* stream) {
+  DP_DISPATCH(dtype, hipLaunchKernelGGL(k_layernorm_fwd<T>, dim3(cdiv(rows, 4)), dim3(256), 0, STREAM, (const T*)x, gamma, beta, (T*)y, mean, rstd, rows, C, eps));
+  DP_CHECK_LAUNCH("layernorm_fwd"); return 0;
+}
+extern "C" int dp_layernorm_bwd(const void* x, const void* gy, const float* gamma, const float* mean, const float* rstd, void* gx, float* dgamma,
+                                float* dbeta, int64_t rows, int C, int dtype, void* stream) {
+  int rpb = 16;
+  if ((size_t)2 * C * sizeof(float) > 64 * 1024) DP_FAIL("layernorm_bwd: C too large");
+  DP_DISPATCH(dtype, hipLaunchKernelGGL(k_layernorm_bwd<T>, dim3(cdiv(rows, rpb)), dim3(256), 2 * C * sizeof(float), STREAM, (const T*)x, (const T*)gy, gamma,
+                                        mean, rstd, (T*)gx, dgamma, dbeta, rows, C, rpb));
+  DP_CHECK_LAUNCH("layernorm_bwd"); return 0;
+}

@@ -1,0 +1,156 @@
+"""DOSE-PYFER on the HIP path.  Mirrors DosePrediction/Models/Networks/dose_pyfer.py: class names, constructor
+signatures, ValueErrors, state_dict keys and forward I/O ([output_A, [out128, out64, out32, out16]], NCDHW fp32)."""
+from typing import Sequence, Tuple, Union
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..blocks import ViT, UnetrBasicBlock, UnetrPrUpBlock, UnetrUpBlock
+from .base_blocks import ModifiedUnetrUpBlock
+from .c3d import BaseUNet, to_ndhwc, from_ndhwc
+
+
+def ensure_tuple_rep(v, n):
+    return tuple(v) if isinstance(v, (tuple, list)) else (v,) * n
+
+
+class ViTEncoder(nn.Module):
+    """dose_pyfer.ViTEncoder (22-144)."""
+
+    def __init__(self, in_channels: int, img_size: Union[Sequence[int], int], feature_size: int = 16, hidden_size: int = 768,
+                 mlp_dim: int = 3072, num_heads: int = 12, num_layers: int = 12, pos_embed: str = "conv",
+                 norm_name: Union[Tuple, str] = "instance", conv_block: bool = True, res_block: bool = True,
+                 dropout_rate: float = 0.0, spatial_dims: int = 3) -> None:
+        super().__init__()
+        if not (0 <= dropout_rate <= 1):
+            raise ValueError("dropout_rate should be between 0 and 1.")
+        if hidden_size % num_heads != 0:
+            raise ValueError("hidden_size should be divisible by num_heads.")
+        self.num_layers = num_layers
+        img_size = ensure_tuple_rep(img_size, spatial_dims)
+        self.patch_size = ensure_tuple_rep(16, spatial_dims)
+        self.feat_size = tuple(img_d // p_d for img_d, p_d in zip(img_size, self.patch_size))
+        self.hidden_size = hidden_size
+        self.classification = False
+        self.vit = ViT(in_channels=in_channels, img_size=img_size, patch_size=self.patch_size, hidden_size=hidden_size,
+                       mlp_dim=mlp_dim, num_layers=self.num_layers, num_heads=num_heads, pos_embed=pos_embed,
+                       classification=self.classification, dropout_rate=dropout_rate, spatial_dims=spatial_dims)
+        self.skip1 = UnetrBasicBlock(spatial_dims, in_channels, feature_size, kernel_size=3, stride=1, norm_name=norm_name,
+                                     res_block=res_block)
+        self.skip2 = UnetrPrUpBlock(spatial_dims, hidden_size, feature_size * 2, num_layer=2, kernel_size=3, stride=1,
+                                    upsample_kernel_size=2, norm_name=norm_name, conv_block=conv_block, res_block=res_block)
+        self.skip3 = UnetrPrUpBlock(spatial_dims, hidden_size, feature_size * 4, num_layer=1, kernel_size=3, stride=1,
+                                    upsample_kernel_size=2, norm_name=norm_name, conv_block=conv_block, res_block=res_block)
+        self.skip4 = UnetrPrUpBlock(spatial_dims, hidden_size, feature_size * 8, num_layer=0, kernel_size=3, stride=1,
+                                    upsample_kernel_size=2, norm_name=norm_name, conv_block=conv_block, res_block=res_block)
+        self.proj_axes = (0, spatial_dims + 1) + tuple(d + 1 for d in range(spatial_dims))
+        self.proj_view_shape = list(self.feat_size) + [self.hidden_size]
+
+    def proj_feat(self, x):
+        """[B, N, hidden] -> feature map.  In NDHWC the reference's view+permute+contiguous (118-122) is a free view."""
+        return x.view([x.size(0)] + self.proj_view_shape)
+
+    def forward(self, x_in):
+        i = self.num_layers // 4
+        z12, hidden_states_out = self.vit(x_in)
+        out_encoder_1 = self.skip1(x_in)
+        out_encoder_2 = self.skip2(self.proj_feat(hidden_states_out[i]))
+        out_encoder_3 = self.skip3(self.proj_feat(hidden_states_out[i * 2]))
+        out_encoder_4 = self.skip4(self.proj_feat(hidden_states_out[i * 3]))
+        out_encoder_5 = self.proj_feat(z12)
+        return [out_encoder_1, out_encoder_2, out_encoder_3, out_encoder_4, out_encoder_5]
+
+
+class PyMSCDecoder(nn.Module):
+    """dose_pyfer.PyMSCDecoder (150-239)."""
+
+    def __init__(self, feature_size: int = 16, hidden_size: int = 768, norm_name: Union[Tuple, str] = "instance",
+                 spatial_dims: int = 3, mode_multi: bool = False, act="relu", multiS_conv=True) -> None:
+        super().__init__()
+        chans = [(hidden_size, feature_size * 8), (feature_size * 8, feature_size * 4), (feature_size * 4, feature_size * 2),
+                 (feature_size * 2, feature_size)]
+        for lvl, (cin, cout) in zip((4, 3, 2, 1), chans):
+            if mode_multi:
+                blk = ModifiedUnetrUpBlock(spatial_dims=spatial_dims, in_channels=cin, out_channels=cout, upsample_kernel_size=2,
+                                           act=act, multiS_conv=multiS_conv)
+            else:
+                blk = UnetrUpBlock(spatial_dims=spatial_dims, in_channels=cin, out_channels=cout, upsample_kernel_size=2,
+                                   kernel_size=3, norm_name=norm_name)
+            setattr(self, f"decoder{lvl}", blk)
+
+    def forward(self, out_encoder):
+        e1, e2, e3, e4, e5 = out_encoder
+        dec4 = self.decoder4(e5, e4)
+        dec3 = self.decoder3(dec4, e3)
+        dec2 = self.decoder2(dec3, e2)
+        dec1 = self.decoder1(dec2, e1)
+        return [dec1, dec2, dec3, dec4]
+
+
+class MainSubsetModel(nn.Module):
+    """dose_pyfer.MainSubsetModel (245-319): ViT encoder + pyramid multi-scale decoder + 4 deep-supervision heads.
+    ``self.out`` exists (state_dict) but is never used in forward, exactly as in the reference (301-305, 311-319)."""
+
+    def __init__(self, in_ch, out_ch, img_size, feature_size: int = 16, hidden_size: int = 768, mlp_dim: int = 3072,
+                 num_heads: int = 12, num_layers: int = 12, conv_block: bool = True, res_block: bool = True,
+                 dropout_rate: float = 0.0, mode_multi_dec=False, act="relu", multiS_conv=True):
+        super().__init__()
+        self.encoder = ViTEncoder(in_channels=in_ch, img_size=img_size, feature_size=feature_size, hidden_size=hidden_size,
+                                  mlp_dim=mlp_dim, num_heads=num_heads, num_layers=num_layers, pos_embed="perceptron",
+                                  norm_name="instance", res_block=res_block, conv_block=conv_block, dropout_rate=dropout_rate)
+        self.decoder = PyMSCDecoder(feature_size=feature_size, hidden_size=hidden_size, mode_multi=mode_multi_dec, act=act,
+                                    multiS_conv=multiS_conv)
+
+        def to_out(in_feature):
+            return nn.Sequential(nn.Conv3d(in_feature, out_ch, kernel_size=1, padding=0, bias=True))
+
+        self.dose_convertors = nn.ModuleList([to_out(feature_size)])
+        for i in range(1, 4):
+            self.dose_convertors.append(to_out(int(feature_size * np.power(2, i))))
+        self.out = nn.Sequential(nn.Conv3d(feature_size, out_ch, kernel_size=1, padding=0, bias=True))
+
+    def update_config(self, config_hparam):
+        self.encoder.hidden_size = config_hparam["hidden_size"]
+        self.encoder.num_layers = config_hparam["hidden_size"]
+
+    def forward_ndhwc(self, x):
+        out_decoders = self.decoder(self.encoder(x))
+        return [ops.conv3d(d, conv[0].weight, conv[0].bias) for d, conv in zip(out_decoders, self.dose_convertors)]
+
+    def forward(self, x):
+        return [from_ndhwc(o) for o in self.forward_ndhwc(to_ndhwc(x))]
+
+
+class Model(nn.Module):
+    """dose_pyfer.Model (325-360): net_A (C3D U-Net) -> cat(out_A, x) -> net_B; returns [output_A, out_net_B]."""
+
+    def __init__(self, in_ch, out_ch, list_ch_A, feature_size=16, img_size=(128, 128, 128), num_layers=8, num_heads=6,
+                 act="mish", mode_multi_dec=True, multiS_conv=True):
+        super().__init__()
+        self.net_A = BaseUNet(in_ch, list_ch_A)
+        self.net_B = MainSubsetModel(in_ch=in_ch + list_ch_A[1], out_ch=out_ch, feature_size=feature_size, img_size=img_size,
+                                     num_layers=num_layers, num_heads=num_heads, act=act, mode_multi_dec=mode_multi_dec,
+                                     multiS_conv=multiS_conv)
+        self.conv_out_A = nn.Conv3d(list_ch_A[1], out_ch, kernel_size=1, padding=0, bias=True)
+
+    def forward(self, x):
+        xh = to_ndhwc(x)
+        out_net_A = self.net_A.forward_ndhwc(xh)
+        out_net_B = self.net_B.forward_ndhwc(ops.cat((out_net_A, xh)))
+        output_A = ops.conv3d(out_net_A, self.conv_out_A.weight, self.conv_out_A.bias)
+        return [from_ndhwc(output_A), [from_ndhwc(o) for o in out_net_B]]
+
+
+def create_pretrained_unet(ckpt_file, in_ch, out_ch, list_ch_A, feature_size, img_size, num_layers=8, num_heads=6, act="mish",
+                           mode_multi_dec=True, multiS_conv=True):
+    """dose_pyfer.create_pretrained_unet (363-407): load by key intersection, strict=False."""
+    pretrain = torch.load(ckpt_file, map_location="cpu")
+    net = Model(in_ch, out_ch, list_ch_A, feature_size=feature_size, img_size=img_size, num_layers=num_layers,
+                num_heads=num_heads, act=act, mode_multi_dec=mode_multi_dec, multiS_conv=multiS_conv)
+    net_dict = net.state_dict()
+    inside = tuple({k for k in pretrain["network_state_dict"] if k in net_dict.keys()})
+    pretrain["network_state_dict"] = {k: v for k, v in pretrain["network_state_dict"].items() if k in net_dict.keys()}
+    net.load_state_dict(pretrain["network_state_dict"], strict=False)
+    return net, inside

@@ -1,0 +1,780 @@
+"""torch.autograd.Function wrappers over the C ABI (include/dose_hip.h).
+
+Tensor conventions inside the HIP path
+  * activations: 5-D ``[N, D, H, W, C]`` (NDHWC), last stride 1; a tensor may be a channel slice of a
+    wider buffer (row pitch ``ld`` = stride of W).  dtype float32 (parity mode) or bfloat16 (bench mode).
+  * token matrices: 2-D/3-D ``[..., rows, C]`` contiguous.
+  * parameters stay fp32 ``nn.Parameter``s in the reference's own shapes (state_dict compatible); kernels
+    consume packed copies cached per (parameter version, dtype).  Weight gradients are produced in fp32.
+PyTorch only provides device memory, the current stream and autograd bookkeeping here.
+"""
+import math
+
+import torch
+
+from . import _lib
+
+ACT = {None: 0, "none": 0, "relu": 1, "lrelu": 2, "mish": 3, "gelu": 4}
+_DT = {torch.float32: 0, torch.bfloat16: 1}
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _dt(t):
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError(f"HIP path supports float32/bfloat16 activations, got {t.dtype}")
+
+
+def _chk_dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.DoseHipError("dose_prediction_amd ops need CUDA/HIP tensors (there is no CPU fallback)")
+
+
+def rows_ld(t):
+    """(rows, C, ld) of an activation / matrix whose rows are uniformly pitched."""
+    C = t.shape[-1]
+    if t.stride(-1) != 1 and C > 1:
+        raise ValueError("last dim must be contiguous")
+    if t.dim() == 1:
+        return 1, C, C
+    ld = t.stride(-2) if t.shape[-2] > 1 else max(C, t.stride(-2))
+    rows = 1
+    exp = ld
+    for d in range(t.dim() - 2, -1, -1):
+        if t.shape[d] > 1 and t.stride(d) != exp:
+            raise ValueError(f"tensor is not a uniformly pitched row matrix: shape {tuple(t.shape)} strides {t.stride()}")
+        exp *= t.shape[d]
+        rows *= t.shape[d]
+    return rows, C, ld
+
+
+def as_rows(t):
+    """Return a tensor satisfying rows_ld (copying if needed)."""
+    try:
+        rows_ld(t)
+        return t
+    except ValueError:
+        return t.contiguous()
+
+
+def new_act(like, shape, dtype=None):
+    return torch.empty(shape, dtype=dtype or like.dtype, device=like.device)
+
+
+# ------------------------------------------------------------------------------------------------ packed-weight cache
+class _PackCache:
+    """Packed (kernel-layout) copies of a parameter, stored ON the parameter object so that their lifetime is the
+    parameter's; an entry is rebuilt when the parameter's version counter, storage or device changed
+    (optimizer.step(), load_state_dict(), .to())."""
+
+    def get(self, w, key, builder):
+        store = w.__dict__.setdefault("_dp_packs", {})
+        ent = store.get(key)
+        tag = (w._version, w.data_ptr(), w.device)
+        if ent is None or ent[0] != tag:
+            ent = (tag, builder())
+            store[key] = ent
+        return ent[1]
+
+
+_packs = _PackCache()
+
+
+def _pack_conv(w, mode, dtype):
+    """torch [Cout,Cin,k,k,k] fp32 -> packed T (see dp_pack_conv_weight)."""
+    def build():
+        cout, cin = w.shape[0], w.shape[1]
+        taps = w[0, 0].numel()
+        rows, inner = (cout, cin) if mode == 0 else (cin, cout)
+        dst = torch.empty((rows, taps, (inner + 7) // 8 * 8), dtype=dtype, device=w.device)
+        wc = w.detach().contiguous()
+        _lib.call("dp_pack_conv_weight", _p(wc), _p(dst), cout, cin, taps, mode, _DT[dtype], _stream())
+        return dst
+    return _packs.get(w, ("conv", mode, dtype), build)
+
+
+def _pack_tconv(w, transposed, dtype):
+    """ConvTranspose3d weight [Cin,Cout,2,2,2] -> [(abc,co)][CinP] (fwd) or [Cin][(abc,co)P] (data grad)."""
+    def build():
+        cin, cout = w.shape[0], w.shape[1]
+        m = w.detach().permute(2, 3, 4, 1, 0).reshape(8 * cout, cin)      # [(abc,co), ci]
+        if transposed:
+            m = m.t()
+        m = m.contiguous()
+        pad = (-m.shape[1]) % 8
+        dst = torch.zeros((m.shape[0], m.shape[1] + pad), dtype=dtype, device=w.device)
+        tmp = torch.empty(m.shape, dtype=dtype, device=w.device)
+        _lib.call("dp_cast", _p(m), 0, _p(tmp), _DT[dtype], m.numel(), _stream())
+        _lib.call("dp_copy_rows", _p(tmp), m.shape[1], _p(dst), dst.shape[1], m.shape[0], m.shape[1], _DT[dtype], _stream())
+        return dst
+    return _packs.get(w, ("tconv", transposed, dtype), build)
+
+
+def _pack_mat(w, transposed, dtype):
+    """Linear weight [out,in] fp32 -> T [out][inP] or (transposed) [in][outP]."""
+    def build():
+        m = w.detach()
+        m = (m.t() if transposed else m).contiguous()
+        pad = (-m.shape[1]) % 8
+        if pad == 0 and dtype == torch.float32:
+            return m
+        dst = torch.zeros((m.shape[0], m.shape[1] + pad), dtype=dtype, device=w.device)
+        tmp = torch.empty(m.shape, dtype=dtype, device=w.device)
+        _lib.call("dp_cast", _p(m), 0, _p(tmp), _DT[dtype], m.numel(), _stream())
+        _lib.call("dp_copy_rows", _p(tmp), m.shape[1], _p(dst), dst.shape[1], m.shape[0], m.shape[1], _DT[dtype], _stream())
+        return dst
+    return _packs.get(w, ("mat", transposed, dtype), build)
+
+
+def _cast_vec(v, dtype):
+    if v is None or v.dtype == dtype:
+        return v
+    out = torch.empty(v.shape, dtype=dtype, device=v.device)
+    vc = v.detach().contiguous()
+    _lib.call("dp_cast", _p(vc), _DT[vc.dtype], _p(out), _DT[dtype], vc.numel(), _stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ raw helpers
+def gemm_nt(A, B, out, bias=None, alpha=1.0, M=None, N=None, K=None, batch=(1, 1), sa=(0, 0), sb=(0, 0), sc=(0, 0),
+            lda=None, ldb=None, ldc=None, splitk=1):
+    """out[m][n] = alpha * sum_k A[m][k] B[n][k] (+bias).  A, B share dtype; out dtype float32 => fp32 output."""
+    out_f32 = 1 if (out.dtype == torch.float32 and A.dtype != torch.float32) or splitk > 1 else 0
+    if splitk > 1 and out.dtype != torch.float32:
+        raise ValueError("split-K needs an fp32 output")
+    _lib.call("dp_gemm_nt", _p(A), lda, sa[0], sa[1], _p(B), ldb, sb[0], sb[1], _p(out), ldc, sc[0], sc[1], _p(bias),
+              M, N, K, batch[0], batch[1], float(alpha), out_f32, splitk, _dt(A), _stream())
+
+
+def colsum_into(gy2d_rows, ld, rows, C, db, dtype_code):
+    """db[c] += sum_rows gy[row][c]  (stats partial + finalize; no torch arithmetic)."""
+    L = _lib.lib()
+    nblk = L.dp_stats_nblk(rows)
+    part = torch.empty((nblk, 2, C), dtype=torch.float32, device=db.device)
+    s = torch.empty((2, C), dtype=torch.float32, device=db.device)
+    _lib.call("dp_stats_partial", gy2d_rows, ld, 1, rows, C, _p(part), dtype_code, _stream())
+    _lib.call("dp_norm_bwd_finalize", _p(part), 1, nblk, C, 1, _p(s[0]), _p(s[1]), 0, _p(db), _stream())
+
+
+def wgrad(x, ldx, gy, ldgy, dw, geom, cin, cout, k, stride, pad, dil, shift, choff, s_co, s_ci, s_tap, dtype_code):
+    N, Di, Hi, Wi, Do, Ho, Wo = geom
+    _lib.call("dp_conv3d_wgrad", _p(x), ldx, _p(gy), ldgy, _p(dw), N, Di, Hi, Wi, Do, Ho, Wo, cin, cout, k, stride, pad, dil,
+              shift, choff, s_co, s_ci, s_tap, dtype_code, _stream())
+
+
+# ------------------------------------------------------------------------------------------------ layout
+class ToNDHWC(torch.autograd.Function):
+    """NCDHW fp32 (the trainer's tensors, network_trainer.py:230) -> NDHWC T, channels zero-padded to cpad."""
+
+    @staticmethod
+    def forward(ctx, x, cpad, dtype):
+        _chk_dev(x)
+        x = x.contiguous().float()
+        N, C = x.shape[:2]
+        sp = tuple(x.shape[2:])
+        V = sp[0] * sp[1] * sp[2]
+        y = torch.empty((N,) + sp + (cpad,), dtype=dtype, device=x.device)
+        _lib.call("dp_ncdhw_to_ndhwc", _p(x), _p(y), N, C, V, cpad, cpad, _DT[dtype], _stream())
+        ctx.C = C
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        gy = as_rows(gy)
+        rows, cp, ld = rows_ld(gy)
+        N = gy.shape[0]
+        sp = tuple(gy.shape[1:4])
+        gx = torch.empty((N, ctx.C) + sp, dtype=torch.float32, device=gy.device)
+        _lib.call("dp_ndhwc_to_ncdhw", _p(gy), _p(gx), N, ctx.C, rows // N, ld, 0, _dt(gy), _stream())
+        return gx, None, None
+
+
+class FromNDHWC(torch.autograd.Function):
+    """NDHWC T -> NCDHW fp32 (what the loss / trainer consume)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _chk_dev(x)
+        x = as_rows(x)
+        rows, C, ld = rows_ld(x)
+        N = x.shape[0]
+        sp = tuple(x.shape[1:4])
+        y = torch.empty((N, C) + sp, dtype=torch.float32, device=x.device)
+        _lib.call("dp_ndhwc_to_ncdhw", _p(x), _p(y), N, C, rows // N, ld, 0, _dt(x), _stream())
+        ctx.dtype = x.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        gy = gy.contiguous().float()
+        N, C = gy.shape[:2]
+        sp = tuple(gy.shape[2:])
+        gx = torch.empty((N,) + sp + (C,), dtype=ctx.dtype, device=gy.device)
+        _lib.call("dp_ncdhw_to_ndhwc", _p(gy), _p(gx), N, C, sp[0] * sp[1] * sp[2], C, C, _DT[ctx.dtype], _stream())
+        return gx
+
+
+class Cat(torch.autograd.Function):
+    """torch.cat(dim=channels) by strided row copies; backward hands out channel-slice views."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        xs = [as_rows(x) for x in xs]
+        cs = [x.shape[-1] for x in xs]
+        out = torch.empty(tuple(xs[0].shape[:-1]) + (sum(cs),), dtype=xs[0].dtype, device=xs[0].device)
+        off = 0
+        for x, c in zip(xs, cs):
+            rows, _, ld = rows_ld(x)
+            _lib.call("dp_copy_rows", _p(x), ld, out.data_ptr() + off * out.element_size(), out.shape[-1], rows, c, _dt(x), _stream())
+            off += c
+        ctx.cs = cs
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        outs, off = [], 0
+        for c in ctx.cs:
+            outs.append(g[..., off:off + c])
+            off += c
+        return tuple(outs)
+
+
+def cat(xs):
+    return Cat.apply(*xs)
+
+
+# ------------------------------------------------------------------------------------------------ convolution
+class Conv3d(torch.autograd.Function):
+    """nn.Conv3d forward / data-gradient / weight-gradient (c3d.py:16, blocks_MDUNet.py:68,102,146)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, dil):
+        _chk_dev(x, weight)
+        x = as_rows(x)
+        rows, cx, ldx = rows_ld(x)
+        N, Di, Hi, Wi = x.shape[:4]
+        cout, cin, k = weight.shape[0], weight.shape[1], weight.shape[2]
+        if cx < cin:
+            raise ValueError(f"conv3d: input has {cx} channels, weight expects {cin}")
+        Do, Ho, Wo = [(s + 2 * pad - dil * (k - 1) - 1) // stride + 1 for s in (Di, Hi, Wi)]
+        y = torch.empty((N, Do, Ho, Wo, cout), dtype=x.dtype, device=x.device)
+        wp = _pack_conv(weight, 0, x.dtype)
+        b32 = None if bias is None else bias.detach()
+        if k == 1 and stride == 1 and pad == 0:
+            gemm_nt(x, wp, y, bias=b32, M=rows, N=cout, K=cin, lda=ldx, ldb=wp.shape[-1], ldc=cout)
+        else:
+            _lib.call("dp_conv3d", _p(x), ldx, _p(wp), _p(b32), _p(y), cout, N, Di, Hi, Wi, Do, Ho, Wo, cin, cout,
+                      k, stride, pad, dil, 0, _dt(x), _stream())
+        ctx.save_for_backward(x, weight)
+        ctx.cfg = (stride, pad, dil, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        stride, pad, dil, has_bias = ctx.cfg
+        gy = as_rows(gy)
+        grows, cout, ldg = rows_ld(gy)
+        rows, cx, ldx = rows_ld(x)
+        N, Di, Hi, Wi = x.shape[:4]
+        Do, Ho, Wo = gy.shape[1:4]
+        cin, k = weight.shape[1], weight.shape[2]
+        dtc = _dt(x)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty((N, Di, Hi, Wi, cx), dtype=x.dtype, device=x.device)
+            if cx > cin:
+                gx.zero_()
+            if k == 1 and stride == 1 and pad == 0:
+                wt = _pack_conv(weight, 1, x.dtype)          # [Cin][1][CoutP]
+                gemm_nt(gy, wt, gx, M=grows, N=cin, K=cout, lda=ldg, ldb=wt.shape[-1], ldc=cx)
+            elif stride == 1:
+                wt = _pack_conv(weight, 2, x.dtype)          # transposed + flipped: data gradient as a forward conv
+                _lib.call("dp_conv3d", _p(gy), ldg, _p(wt), 0, _p(gx), cx, N, Do, Ho, Wo, Di, Hi, Wi, cout, cin,
+                          k, 1, dil * (k - 1) - pad, dil, 0, dtc, _stream())
+            else:
+                wt = _pack_conv(weight, 1, x.dtype)
+                _lib.call("dp_conv3d", _p(gy), ldg, _p(wt), 0, _p(gx), cx, N, Do, Ho, Wo, Di, Hi, Wi, cout, cin,
+                          k, stride, pad, dil, 1, dtc, _stream())
+        if ctx.needs_input_grad[1]:
+            gw = torch.zeros(weight.shape, dtype=torch.float32, device=x.device)
+            taps = k * k * k
+            wgrad(x, ldx, gy, ldg, gw, (N, Di, Hi, Wi, Do, Ho, Wo), cin, cout, k, stride, pad, dil, 1, 0,
+                  cin * taps, taps, 1, dtc)
+        if has_bias and ctx.needs_input_grad[2]:
+            gb = torch.zeros((cout,), dtype=torch.float32, device=x.device)
+            colsum_into(_p(gy), ldg, grows, cout, gb, dtc)
+        return gx, gw, gb, None, None, None
+
+
+def conv3d(x, weight, bias=None, stride=1, pad=0, dil=1):
+    return Conv3d.apply(x, weight, bias, stride, pad, dil)
+
+
+class ConvTranspose2x(torch.autograd.Function):
+    """nn.ConvTranspose3d(kernel 2, stride 2, bias=False) (base_blocks.py:118-127; MONAI UnetrPrUpBlock):
+    GEMM [voxels x Cin] x [Cin x 8 Cout] then a 2x2x2 pixel shuffle."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        _chk_dev(x, weight)
+        x = as_rows(x)
+        rows, cx, ldx = rows_ld(x)
+        N, D, H, W = x.shape[:4]
+        cin, cout = weight.shape[0], weight.shape[1]
+        wp = _pack_tconv(weight, False, x.dtype)
+        tmp = torch.empty((rows, 8 * cout), dtype=x.dtype, device=x.device)
+        gemm_nt(x, wp, tmp, M=rows, N=8 * cout, K=cin, lda=ldx, ldb=wp.shape[-1], ldc=8 * cout)
+        y = torch.empty((N, 2 * D, 2 * H, 2 * W, cout), dtype=x.dtype, device=x.device)
+        _lib.call("dp_pixel_shuffle2", _p(tmp), _p(y), N, D, H, W, cout, cout, _dt(x), _stream())
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gy = as_rows(gy)
+        _, cout, ldg = rows_ld(gy)
+        rows, cx, ldx = rows_ld(x)
+        N, D, H, W = x.shape[:4]
+        cin = weight.shape[0]
+        dtc = _dt(x)
+        gu = torch.empty((rows, 8 * cout), dtype=x.dtype, device=x.device)
+        _lib.call("dp_pixel_unshuffle2", _p(gy), ldg, _p(gu), N, D, H, W, cout, dtc, _stream())
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            wt = _pack_tconv(weight, True, x.dtype)          # [Cin][(abc,co)P]
+            gx = torch.empty((N, D, H, W, cx), dtype=x.dtype, device=x.device)
+            if cx > cin:
+                gx.zero_()
+            gemm_nt(gu, wt, gx, M=rows, N=cin, K=8 * cout, lda=8 * cout, ldb=wt.shape[-1], ldc=cx)
+        if ctx.needs_input_grad[1]:
+            gw = torch.zeros(weight.shape, dtype=torch.float32, device=x.device)   # [Cin][Cout][8]
+            # "tap" = abc selects the gy column block abc*Cout; x is not shifted
+            wgrad(x, ldx, gu, 8 * cout, gw, (1, 1, 1, rows, 1, 1, rows), cin, cout, 2, 1, 0, 1, 0, cout, 8, cout * 8, 1, dtc)
+        return gx, gw
+
+
+def conv_transpose2x(x, weight):
+    return ConvTranspose2x.apply(x, weight)
+
+
+class Linear(torch.autograd.Function):
+    """nn.Linear on token rows (MONAI ViT blocks; patch embedding uses splitk)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, splitk):
+        _chk_dev(x, weight)
+        x = as_rows(x)
+        rows, K, ldx = rows_ld(x)
+        nout = weight.shape[0]
+        wp = _pack_mat(weight, False, x.dtype)
+        y = torch.empty(tuple(x.shape[:-1]) + (nout,), dtype=x.dtype, device=x.device)
+        b32 = None if bias is None else bias.detach()
+        if splitk > 1:
+            acc = torch.zeros((rows, nout), dtype=torch.float32, device=x.device)
+            gemm_nt(x, wp, acc, bias=b32, M=rows, N=nout, K=K, lda=ldx, ldb=wp.shape[-1], ldc=nout, splitk=splitk)
+            if x.dtype == torch.float32:
+                y = acc.view(y.shape)
+            else:
+                _lib.call("dp_cast", _p(acc), 0, _p(y), _dt(x), acc.numel(), _stream())
+        else:
+            gemm_nt(x, wp, y, bias=b32, M=rows, N=nout, K=K, lda=ldx, ldb=wp.shape[-1], ldc=nout)
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gy = as_rows(gy)
+        rows, K, ldx = rows_ld(x)
+        _, nout, ldg = rows_ld(gy)
+        dtc = _dt(x)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            wt = _pack_mat(weight, True, x.dtype)            # [in][outP]
+            gx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+            gemm_nt(gy, wt, gx, M=rows, N=K, K=nout, lda=ldg, ldb=wt.shape[-1], ldc=K)
+        if ctx.needs_input_grad[1]:
+            gw = torch.zeros(weight.shape, dtype=torch.float32, device=x.device)
+            wgrad(x, ldx, gy, ldg, gw, (1, 1, 1, rows, 1, 1, rows), K, nout, 1, 1, 0, 1, 0, 0, K, 1, 0, dtc)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = torch.zeros((nout,), dtype=torch.float32, device=x.device)
+            colsum_into(_p(gy), ldg, rows, nout, gb, dtc)
+        return gx, gw, gb, None
+
+
+def linear(x, weight, bias=None, splitk=1):
+    return Linear.apply(x, weight, bias, splitk)
+
+
+# ------------------------------------------------------------------------------------------------ normalisation
+class NormAct(torch.autograd.Function):
+    """InstanceNorm3d / BatchNorm3d (+affine) (+residual) + activation, fused.
+    kind: 'instance' | 'batch'.  For 'batch', running buffers are updated in place when training."""
+
+    @staticmethod
+    def forward(ctx, x, kind, gamma, beta, running_mean, running_var, training, res, act, eps, momentum):
+        _chk_dev(x)
+        x = as_rows(x)
+        rows, C, ldx = rows_ld(x)
+        N = x.shape[0]
+        V = rows // N
+        L = _lib.lib()
+        dtc = _dt(x)
+        dev = x.device
+        use_batch_stats = kind == "instance" or training
+        if use_batch_stats:
+            nblk = L.dp_stats_nblk(V)
+            part = torch.empty((N, nblk, 2, C), dtype=torch.float32, device=dev)
+            groups = N if kind == "instance" else 1
+            mean = torch.empty((groups, C), dtype=torch.float32, device=dev)
+            rstd = torch.empty((groups, C), dtype=torch.float32, device=dev)
+            _lib.call("dp_stats_partial", _p(x), ldx, N, V, C, _p(part), dtc, _stream())
+            upd = kind == "batch" and training and running_mean is not None
+            _lib.call("dp_stats_finalize", _p(part), N, nblk, C, V, 1 if kind == "batch" else 0, float(eps), _p(mean), _p(rstd),
+                      _p(running_mean) if upd else 0, _p(running_var) if upd else 0, float(momentum), _stream())
+        else:   # eval-mode batch norm: running statistics
+            mean = running_mean.detach().reshape(1, C).float()
+            rstd = torch.empty((1, C), dtype=torch.float32, device=dev)
+            zero_part = torch.zeros((1, 1, 2, C), dtype=torch.float32, device=dev)
+            # rstd = 1/sqrt(var+eps) through the finalize kernel: feed sums s1=0, s2=var (count 1)
+            zero_part[0, 0, 1].copy_(running_var.detach())
+            dummy = torch.empty((1, C), dtype=torch.float32, device=dev)
+            _lib.call("dp_stats_finalize", _p(zero_part), 1, 1, C, 1, 1, float(eps), _p(dummy), _p(rstd), 0, 0, 0.0, _stream())
+        ssn = C if kind == "instance" else 0
+        g32 = None if gamma is None else gamma.detach()
+        b32 = None if beta is None else beta.detach()
+        if res is not None:
+            res = as_rows(res)
+            ldr = rows_ld(res)[2]
+        else:
+            ldr = 0
+        y = torch.empty(x.shape, dtype=x.dtype, device=dev)
+        _lib.call("dp_norm_act_fwd", _p(x), ldx, _p(mean), _p(rstd), ssn, _p(g32), _p(b32), _p(res), ldr, ACT[act],
+                  _p(y), C, N, V, C, dtc, _stream())
+        ctx.save_for_backward(x, mean, rstd, gamma, beta, res)
+        ctx.cfg = (kind, act, use_batch_stats, ssn)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, mean, rstd, gamma, beta, res = ctx.saved_tensors
+        kind, act, use_stats, ssn = ctx.cfg
+        gy = as_rows(gy)
+        rows, C, ldx = rows_ld(x)
+        ldg = rows_ld(gy)[2]
+        N = x.shape[0]
+        V = rows // N
+        L = _lib.lib()
+        dtc = _dt(x)
+        dev = x.device
+        ldr = rows_ld(res)[2] if res is not None else 0
+        g32 = None if gamma is None else gamma.detach()
+        b32 = None if beta is None else beta.detach()
+        nblk = L.dp_stats_nblk(V)
+        part = torch.empty((N, nblk, 2, C), dtype=torch.float32, device=dev)
+        groups = N if kind == "instance" else 1
+        s1 = torch.empty((groups, C), dtype=torch.float32, device=dev)
+        s2 = torch.empty((groups, C), dtype=torch.float32, device=dev)
+        need_gb = gamma is not None and (ctx.needs_input_grad[2] or ctx.needs_input_grad[3])
+        dgamma = torch.zeros((C,), dtype=torch.float32, device=dev) if need_gb else None
+        dbeta = torch.zeros((C,), dtype=torch.float32, device=dev) if need_gb else None
+        if use_stats or need_gb:
+            _lib.call("dp_norm_act_bwd_partial", _p(x), ldx, _p(gy), ldg, _p(mean), _p(rstd), ssn, _p(g32), _p(b32), _p(res), ldr,
+                      ACT[act], N, V, C, _p(part), dtc, _stream())
+            _lib.call("dp_norm_bwd_finalize", _p(part), N, nblk, C, 0 if kind == "instance" else 1, _p(s1), _p(s2),
+                      _p(dgamma), _p(dbeta), _stream())
+        gx = gres = None
+        need_x = ctx.needs_input_grad[0]
+        need_res = res is not None and ctx.needs_input_grad[7]
+        if need_x or need_res:
+            gx = torch.empty(x.shape, dtype=x.dtype, device=dev) if need_x else None
+            gres = torch.empty(x.shape, dtype=x.dtype, device=dev) if need_res else None
+            cnt = V if kind == "instance" else N * V
+            _lib.call("dp_norm_act_bwd_apply", _p(x), ldx, _p(gy), ldg, _p(mean), _p(rstd), ssn, _p(g32), _p(b32), _p(res), ldr,
+                      ACT[act], _p(s1), _p(s2), 1.0 / cnt, 1 if use_stats else 0, _p(gx), C, _p(gres), C, N, V, C, dtc, _stream())
+        return gx, None, dgamma, dbeta, None, None, None, gres, None, None, None
+
+
+def norm_act(x, kind, gamma=None, beta=None, running_mean=None, running_var=None, training=True, res=None, act=None,
+             eps=1e-5, momentum=0.1):
+    return NormAct.apply(x, kind, gamma, beta, running_mean, running_var, training, res, act, eps, momentum)
+
+
+class LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        _chk_dev(x)
+        x = x.contiguous()
+        C = x.shape[-1]
+        rows = x.numel() // C
+        y = torch.empty_like(x)
+        mean = torch.empty((rows,), dtype=torch.float32, device=x.device)
+        rstd = torch.empty((rows,), dtype=torch.float32, device=x.device)
+        _lib.call("dp_layernorm_fwd", _p(x), _p(gamma.detach()), _p(beta.detach()), _p(y), _p(mean), _p(rstd), rows, C, float(eps),
+                  _dt(x), _stream())
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        gy = gy.contiguous()
+        C = x.shape[-1]
+        rows = x.numel() // C
+        gx = torch.empty_like(x)
+        dg = torch.zeros((C,), dtype=torch.float32, device=x.device)
+        db = torch.zeros((C,), dtype=torch.float32, device=x.device)
+        _lib.call("dp_layernorm_bwd", _p(x), _p(gy), _p(gamma.detach()), _p(mean), _p(rstd), _p(gx), _p(dg), _p(db), rows, C,
+                  _dt(x), _stream())
+        return gx, dg, db, None
+
+
+def layer_norm(x, gamma, beta, eps=1e-5):
+    return LayerNorm.apply(x, gamma, beta, eps)
+
+
+# ------------------------------------------------------------------------------------------------ elementwise
+class Add(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = a.contiguous(), b.contiguous()
+        y = torch.empty_like(a)
+        _lib.call("dp_add", _p(a), _p(b), _p(y), a.numel(), a.numel(), _dt(a), _stream())
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+def add(a, b):
+    return Add.apply(a, b)
+
+
+class AddBroadcast(torch.autograd.Function):
+    """x[B, ...] + p[1, ...] with p an fp32 parameter (position embeddings)."""
+
+    @staticmethod
+    def forward(ctx, x, p):
+        x = x.contiguous()
+        pc = _cast_vec(p.detach().contiguous(), x.dtype)
+        y = torch.empty_like(x)
+        _lib.call("dp_add", _p(x), _p(pc), _p(y), x.numel(), pc.numel(), _dt(x), _stream())
+        ctx.pshape = p.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        gp = None
+        if ctx.needs_input_grad[1]:
+            per = 1
+            for s in ctx.pshape:
+                per *= s
+            B = g.numel() // per
+            gp = torch.zeros((per,), dtype=torch.float32, device=g.device)
+            # sum over the batch with the column-sum reduction: rows = B, "channels" = per  (chunked to <= 2048 cols)
+            g2 = g.view(B, per)
+            step = 2048
+            for c0 in range(0, per, step):
+                c1 = min(per, c0 + step)
+                colsum_into(g2.data_ptr() + c0 * g.element_size(), per, B, c1 - c0, gp[c0:c1], _dt(g))
+            gp = gp.view(ctx.pshape)
+        return g, gp
+
+
+def add_broadcast(x, p):
+    return AddBroadcast.apply(x, p)
+
+
+class Gelu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        _lib.call("dp_gelu_fwd", _p(x), _p(y), x.numel(), _dt(x), _stream())
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        g = g.contiguous()
+        gx = torch.empty_like(x)
+        _lib.call("dp_gelu_bwd", _p(x), _p(g), _p(gx), x.numel(), _dt(x), _stream())
+        return gx
+
+
+def gelu(x):
+    return Gelu.apply(x)
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def _transpose(src, lds, sb, dst, ldd, db, rows, cols, nb, dtc):
+    _lib.call("dp_transpose", src, lds, sb[0], sb[1], dst, ldd, db[0], db[1], rows, cols, nb[0], nb[1], dtc, _stream())
+
+
+class Attention(torch.autograd.Function):
+    """softmax(q k^T d^-1/2) v of MONAI SABlock on a packed qkv tensor [B, N, 3*H] laid out "(qkv l d)".
+    Returns [B, N, H] with heads merged "(l d)".  v1: MFMA GEMMs + row softmax (scores materialised, N <= ~1k)."""
+
+    @staticmethod
+    def forward(ctx, qkv, heads):
+        _chk_dev(qkv)
+        qkv = qkv.contiguous()
+        B, N, H3 = qkv.shape
+        H = H3 // 3
+        d = H // heads
+        es = qkv.element_size()
+        dtc = _dt(qkv)
+        dev = qkv.device
+        scale = d ** -0.5
+        base = qkv.data_ptr()
+        qp, kp, vp = base, base + H * es, base + 2 * H * es
+        S = torch.empty((B, heads, N, N), dtype=qkv.dtype, device=dev)
+        bat, sq = (B, heads), (N * H3, d)
+        _lib.call("dp_gemm_nt", qp, H3, sq[0], sq[1], kp, H3, sq[0], sq[1], _p(S), N, heads * N * N, N * N, 0, N, N, d, B, heads,
+                  1.0, 0, 1, dtc, _stream())
+        _lib.call("dp_softmax_fwd", _p(S), _p(S), B * heads * N, N, float(scale), dtc, _stream())
+        Vt = torch.empty((B, heads, d, N), dtype=qkv.dtype, device=dev)
+        _transpose(vp, H3, sq, _p(Vt), N, (heads * d * N, d * N), N, d, bat, dtc)
+        O = torch.empty((B, N, H), dtype=qkv.dtype, device=dev)
+        _lib.call("dp_gemm_nt", _p(S), N, heads * N * N, N * N, _p(Vt), N, heads * d * N, d * N, _p(O), H, N * H, d, 0, N, d, N,
+                  B, heads, 1.0, 0, 1, dtc, _stream())
+        ctx.save_for_backward(qkv, S)
+        ctx.heads = heads
+        return O
+
+    @staticmethod
+    def backward(ctx, gO):
+        qkv, P = ctx.saved_tensors
+        heads = ctx.heads
+        gO = gO.contiguous()
+        B, N, H3 = qkv.shape
+        H = H3 // 3
+        d = H // heads
+        es = qkv.element_size()
+        dtc = _dt(qkv)
+        dev = qkv.device
+        scale = d ** -0.5
+        base = qkv.data_ptr()
+        qp, kp, vp = base, base + H * es, base + 2 * H * es
+        bat, sq = (B, heads), (N * H3, d)
+        sP = (heads * N * N, N * N)
+        gqkv = torch.empty_like(qkv)
+        gb = gqkv.data_ptr()
+        gqp, gkp, gvp = gb, gb + H * es, gb + 2 * H * es
+        # dP[q][key] = sum_d dO[q][d] V[key][d]
+        dP = torch.empty_like(P)
+        _lib.call("dp_gemm_nt", _p(gO), H, N * H, d, vp, H3, sq[0], sq[1], _p(dP), N, sP[0], sP[1], 0, N, N, d, B, heads,
+                  1.0, 0, 1, dtc, _stream())
+        # dV[key][d] = sum_q P[q][key] dO[q][d]  -> A = P^T [key][q], B = dO^T [d][q]
+        Pt = torch.empty_like(P)
+        _transpose(_p(P), N, sP, _p(Pt), N, sP, N, N, bat, dtc)
+        gOt = torch.empty((B, heads, d, N), dtype=qkv.dtype, device=dev)
+        sT = (heads * d * N, d * N)
+        _transpose(_p(gO), H, (N * H, d), _p(gOt), N, sT, N, d, bat, dtc)
+        _lib.call("dp_gemm_nt", _p(Pt), N, sP[0], sP[1], _p(gOt), N, sT[0], sT[1], gvp, H3, sq[0], sq[1], 0, N, d, N, B, heads,
+                  1.0, 0, 1, dtc, _stream())
+        # dS = scale * P * (dP - rowsum(dP*P))
+        _lib.call("dp_softmax_bwd", _p(P), _p(dP), _p(dP), B * heads * N, N, float(scale), dtc, _stream())
+        # dQ[q][d] = sum_key dS[q][key] K[key][d] -> B = K^T [d][key]
+        Kt = torch.empty((B, heads, d, N), dtype=qkv.dtype, device=dev)
+        _transpose(kp, H3, sq, _p(Kt), N, sT, N, d, bat, dtc)
+        _lib.call("dp_gemm_nt", _p(dP), N, sP[0], sP[1], _p(Kt), N, sT[0], sT[1], gqp, H3, sq[0], sq[1], 0, N, d, N, B, heads,
+                  1.0, 0, 1, dtc, _stream())
+        # dK[key][d] = sum_q dS[q][key] Q[q][d] -> A = dS^T, B = Q^T
+        _transpose(_p(dP), N, sP, _p(Pt), N, sP, N, N, bat, dtc)
+        Qt = Kt
+        _transpose(qp, H3, sq, _p(Qt), N, sT, N, d, bat, dtc)
+        _lib.call("dp_gemm_nt", _p(Pt), N, sP[0], sP[1], _p(Qt), N, sT[0], sT[1], gkp, H3, sq[0], sq[1], 0, N, d, N, B, heads,
+                  1.0, 0, 1, dtc, _stream())
+        return gqkv, None
+
+
+def attention(qkv, heads):
+    return Attention.apply(qkv, heads)
+
+
+# ------------------------------------------------------------------------------------------------ misc
+class Patchify(torch.autograd.Function):
+    """einops "b c (h p1)(w p2)(d p3) -> b (h w d)(p1 p2 p3 c)" on an NDHWC tensor (first C channels)."""
+
+    @staticmethod
+    def forward(ctx, x, C, p):
+        x = as_rows(x)
+        _, cx, ld = rows_ld(x)
+        B, S0, S1, S2 = x.shape[:4]
+        ntok = (S0 // p) * (S1 // p) * (S2 // p)
+        out = torch.empty((B, ntok, p * p * p * C), dtype=x.dtype, device=x.device)
+        _lib.call("dp_patchify", _p(x), _p(out), B, S0, S1, S2, C, ld, p, _dt(x), _stream())
+        ctx.cfg = (tuple(x.shape), C, p)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        shape, C, p = ctx.cfg
+        g = g.contiguous()
+        gx = torch.zeros(shape, dtype=g.dtype, device=g.device) if shape[-1] > C else torch.empty(shape, dtype=g.dtype, device=g.device)
+        _lib.call("dp_unpatchify", _p(g), _p(gx), shape[0], shape[1], shape[2], shape[3], C, shape[-1], p, _dt(g), _stream())
+        return gx, None, None
+
+
+def patchify(x, C, p=16):
+    return Patchify.apply(x, C, p)
+
+
+class TrilinearUp2(torch.autograd.Function):
+    """F.interpolate(scale_factor=2, mode='trilinear', align_corners=True) (c3d.py:36)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = as_rows(x)
+        _, C, ld = rows_ld(x)
+        N, D, H, W = x.shape[:4]
+        y = torch.empty((N, 2 * D, 2 * H, 2 * W, C), dtype=x.dtype, device=x.device)
+        _lib.call("dp_trilinear_up2_fwd", _p(x), ld, _p(y), C, N, D, H, W, C, _dt(x), _stream())
+        ctx.shape = tuple(x.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g = as_rows(g)
+        _, C, ldg = rows_ld(g)
+        N, D, H, W, _ = ctx.shape
+        acc = torch.zeros(ctx.shape, dtype=torch.float32, device=g.device)
+        _lib.call("dp_trilinear_up2_bwd", _p(g), ldg, _p(acc), N, D, H, W, C, _dt(g), _stream())
+        if g.dtype == torch.float32:
+            return acc
+        gx = torch.empty(ctx.shape, dtype=g.dtype, device=g.device)
+        _lib.call("dp_cast", _p(acc), 0, _p(gx), _dt(g), acc.numel(), _stream())
+        return gx
+
+
+def trilinear_up2(x):
+    return TrilinearUp2.apply(x)
+
+
+def argmax_onehot(logits, out=None, choff=0, labels=False):
+    """Cascade glue (train_light_linked_model.py:157-167): arg-max over channels -> one-hot of classes 1..C-1 written
+    into channels [choff, choff+C-1) of ``out`` (NDHWC); optionally also the int32 label volume."""
+    logits = as_rows(logits)
+    rows, C, ld = rows_ld(logits)
+    lab = torch.empty(tuple(logits.shape[:-1]), dtype=torch.int32, device=logits.device) if labels else None
+    ldo = 0
+    if out is not None:
+        ldo = rows_ld(out)[2]
+    _lib.call("dp_argmax_onehot", _p(logits), ld, _p(out), ldo, choff, _p(lab), rows, C, _dt(logits), _stream())
+    return lab

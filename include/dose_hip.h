@@ -1,0 +1,150 @@
+/* dose_hip.h -- C ABI of libdose_hip.so, the MI355X (gfx950) kernel library behind the
+ * DOSE-PYFER / OAR-TRANSEG nn.Module surface.
+ *
+ * The reference (GhTara/Dose_Prediction) has no FFI: its hot path is the chain of torch ops issued
+ * by the nn.Modules in DosePrediction/Models/Networks/{dose_pyfer,c3d}.py,
+ * OARSegmentation/Models/Nets/{base_blocks,blocks_MDUNet}.py and the MONAI blocks they import.
+ * Every entry point below replaces one torch op (forward or a backward piece) on that path; the
+ * "replaces:" line cites the reference call site.  dose_prediction_amd/ops.py binds these with
+ * ctypes; INTEGRATION.md shows the binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain pointers are DEVICE pointers; `stream` is a hipStream_t passed as void*.
+ *   - activations are NDHWC ("voxel rows"): element (n,d,h,w,c) at ((n*D+d)*H+h)*W+w)*ld + c, where
+ *     `ld` >= C is the row pitch in elements (so a tensor may be a channel slice of a wider buffer).
+ *   - dtype: DP_F32 (0) or DP_BF16 (1) selects the storage type T of activations / packed weights.
+ *     Accumulation and statistics are always fp32 (fp64 in the tiny finalize kernels).
+ *     DP_F32 uses v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain) -- the parity mode;
+ *     DP_BF16 uses v_mfma_f32_16x16x32_bf16 -- the benchmark mode.
+ *   - every function returns 0 on success, non-zero on error; dp_last_error() gives the message.
+ *   - no function allocates, frees or synchronises: workspaces are caller-provided.
+ */
+#ifndef DOSE_HIP_H
+#define DOSE_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { DP_F32 = 0, DP_BF16 = 1 };
+enum { DP_ACT_NONE = 0, DP_ACT_RELU = 1, DP_ACT_LRELU = 2, DP_ACT_MISH = 3, DP_ACT_GELU = 4 };
+
+const char* dp_last_error(void);
+int dp_version(void);
+
+/* ---- layout / data movement ---------------------------------------------------------------- */
+/* replaces: the implicit NCDHW layout of every torch op; entry `input_.to(device)` network_trainer.py:188.
+ * src fp32 [N][C][V] -> dst T [N][V][ld] (channels >= C up to cpad zero-filled). */
+int dp_ncdhw_to_ndhwc(const float* src, void* dst, int N, int C, int64_t V, int ld, int cpad, int dtype, void* stream);
+/* dst fp32 [N][C][V] <- src T [N][V][ld] (first C channels). accumulate!=0: dst += . */
+int dp_ndhwc_to_ncdhw(const void* src, float* dst, int N, int C, int64_t V, int ld, int accumulate, int dtype, void* stream);
+/* replaces: torch.cat(dim=1) (c3d.py:103-113, dose_pyfer.py:357, base_blocks.py:139, blocks_MDUNet.py:154):
+ * copy rows x C channels from src (pitch lds) into dst (pitch ldd). */
+int dp_copy_rows(const void* src, int lds, void* dst, int ldd, int64_t rows, int C, int dtype, void* stream);
+/* fp32 <-> T conversion of a flat array (weights, small vectors). */
+int dp_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream);
+/* replaces: einops Rearrange "b c (h p1)(w p2)(d p3) -> b (h w d)(p1 p2 p3 c)" in MONAI
+ * PatchEmbeddingBlock (call site dose_pyfer.py:55-67).  x NDHWC pitch ld -> out [B][ntok][p^3*C]. */
+int dp_patchify(const void* x, void* out, int B, int S0, int S1, int S2, int C, int ld, int p, int dtype, void* stream);
+int dp_unpatchify(const void* gout, void* gx, int B, int S0, int S1, int S2, int C, int ld, int p, int dtype, void* stream);
+/* replaces: the scatter half of nn.ConvTranspose3d(k2,s2) (base_blocks.py:118-127): src [N*D*H*W][8*C]
+ * (column = ((a*2+b)*2+c)*C + co) -> dst NDHWC at (2d+a,2h+b,2w+c), pitch ldd.  unshuffle = inverse gather. */
+int dp_pixel_shuffle2(const void* src, void* dst, int N, int D, int H, int W, int C, int ldd, int dtype, void* stream);
+int dp_pixel_unshuffle2(const void* src, int lds, void* dst, int N, int D, int H, int W, int C, int dtype, void* stream);
+/* replaces: F.interpolate(scale_factor=2, mode='trilinear', align_corners=True) c3d.py:36 (+ its backward). */
+int dp_trilinear_up2_fwd(const void* x, int ldx, void* y, int ldy, int N, int D, int H, int W, int C, int dtype, void* stream);
+int dp_trilinear_up2_bwd(const void* gy, int ldgy, float* gx_f32, int N, int D, int H, int W, int C, int dtype, void* stream);
+/* batched 2-D transpose: dst[b][c][r] = src[b][r][c]; two batch levels with independent strides. */
+int dp_transpose(const void* src, int64_t lds, int64_t sb0, int64_t sb1, void* dst, int64_t ldd, int64_t db0, int64_t db1,
+                 int rows, int cols, int nb0, int nb1, int dtype, void* stream);
+
+/* ---- elementwise ----------------------------------------------------------------------------- */
+/* y = a + b (b broadcast with period `period` elements; period==n for plain add).
+ * replaces: residual adds in MONAI TransformerBlock, `x + position_embeddings`. */
+int dp_add(const void* a, const void* b, void* y, int64_t n, int64_t period, int dtype, void* stream);
+/* replaces: nn.GELU in MONAI MLPBlock; bwd: gx = gy * gelu'(x). */
+int dp_gelu_fwd(const void* x, void* y, int64_t n, int dtype, void* stream);
+int dp_gelu_bwd(const void* x, const void* gy, void* gx, int64_t n, int dtype, void* stream);
+/* replaces: softmax(q k^T * scale) in MONAI SABlock (rows of length `cols`); in place allowed.
+ * bwd: gs = scale * p * (gp - sum(gp*p)). */
+int dp_softmax_fwd(const void* s, void* p, int64_t rows, int cols, float scale, int dtype, void* stream);
+int dp_softmax_bwd(const void* p, const void* gp, void* gs, int64_t rows, int cols, float scale, int dtype, void* stream);
+/* fp32 helpers for gradient buffers */
+int dp_fill_f32(float* p, float v, int64_t n, void* stream);
+
+/* ---- normalisation --------------------------------------------------------------------------- */
+/* replaces: the reductions of nn.InstanceNorm3d / nn.BatchNorm3d (c3d.py:17, blocks_MDUNet.py:69,103).
+ * Pass 1: per-block partial sums of x and x^2 per channel.  part: float [N][nblk][2][C]; returns nblk via
+ * dp_stats_nblk(V).  */
+int dp_stats_nblk(int64_t V);
+int dp_stats_partial(const void* x, int ld, int N, int64_t V, int C, float* part, int dtype, void* stream);
+/* Pass 2 (fp64 combine): mean/rstd per (n,c) [instance: groups==N] or per c [batch: groups==1, written
+ * to row 0].  If running_mean != NULL (batch, training): running = (1-m)*running + m*stat (unbiased var). */
+int dp_stats_finalize(const float* part, int N, int nblk, int C, int64_t V, int batch_mode, float eps,
+                      float* mean, float* rstd, float* running_mean, float* running_var, float momentum, void* stream);
+/* y = act( (x-mean)*rstd*gamma + beta + res ).  stat_stride_n = C for instance stats, 0 for batch/eval stats.
+ * gamma/beta/res may be NULL.  replaces: norm + activation (+ residual add of MONAI UnetResBlock). */
+int dp_norm_act_fwd(const void* x, int ldx, const float* mean, const float* rstd, int stat_stride_n,
+                    const float* gamma, const float* beta, const void* res, int ldr, int act,
+                    void* y, int ldy, int N, int64_t V, int C, int dtype, void* stream);
+/* backward pass 1: g = gy*act'(z); partials of sum(g) and sum(g*xhat): part float [N][nblk][2][C]. */
+int dp_norm_act_bwd_partial(const void* x, int ldx, const void* gy, int ldgy, const float* mean, const float* rstd,
+                            int stat_stride_n, const float* gamma, const float* beta, const void* res, int ldr, int act,
+                            int N, int64_t V, int C, float* part, int dtype, void* stream);
+/* combine partials: s1,s2 float [groups][C] (groups = N instance, 1 batch); dgamma/dbeta (+=) if non-NULL. */
+int dp_norm_bwd_finalize(const float* part, int N, int nblk, int C, int batch_mode, float* s1, float* s2,
+                         float* dgamma, float* dbeta, void* stream);
+/* backward pass 2: gx = gamma*rstd*(g - s1/M - xhat*s2/M) (use_stats) or gamma*rstd*g (eval BN);
+ * gres = g (if non-NULL). M = count per statistics group. */
+int dp_norm_act_bwd_apply(const void* x, int ldx, const void* gy, int ldgy, const float* mean, const float* rstd,
+                          int stat_stride_n, const float* gamma, const float* beta, const void* res, int ldr, int act,
+                          const float* s1, const float* s2, float inv_count, int use_stats,
+                          void* gx, int ldgx, void* gres, int ldgres, int N, int64_t V, int C, int dtype, void* stream);
+/* replaces: nn.LayerNorm(hidden) in MONAI TransformerBlock / ViT.norm.  rows x C, one wave per row. */
+int dp_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                     int64_t rows, int C, float eps, int dtype, void* stream);
+int dp_layernorm_bwd(const void* x, const void* gy, const float* gamma, const float* mean, const float* rstd,
+                     void* gx, float* dgamma, float* dbeta, int64_t rows, int C, int dtype, void* stream);
+
+/* ---- matrix products (MFMA) ------------------------------------------------------------------- */
+/* C[b0][b1][m][n] = alpha * sum_k A[..][m][k] * B[..][n][k] (+ bias[n]) ; "NT" GEMM, both operands k-contiguous.
+ * replaces: nn.Linear (MONAI ViT), 1x1x1 nn.Conv3d (blocks_MDUNet.py:146, dose_pyfer.py:292,353), the GEMM half of
+ * ConvTranspose3d k2s2, einsum QK^T / PV (MONAI SABlock).
+ * out_f32: C is float (else T).  splitk>1 requires out_f32 and atomically ACCUMULATES into C (caller zero-fills). */
+int dp_gemm_nt(const void* A, int64_t lda, int64_t sa0, int64_t sa1, const void* B, int64_t ldb, int64_t sb0, int64_t sb1,
+               void* C, int64_t ldc, int64_t sc0, int64_t sc1, const float* bias, int M, int N, int K, int nb0, int nb1,
+               float alpha, int out_f32, int splitk, int dtype, void* stream);
+
+/* ---- convolution ------------------------------------------------------------------------------ */
+/* weight packing: torch fp32 [Cout][Cin][k^3] -> T [Cout][k^3][CinP] (mode 0, forward),
+ * -> T [Cin][k^3][CoutP] (mode 1: transposed, for data-gradient "gather" form),
+ * -> T [Cin][k^3 flipped][CoutP] (mode 2: transposed + spatially flipped: stride-1 data gradient as a forward conv).
+ * CinP/CoutP = channel count rounded up to 8 (zero filled). */
+int dp_pack_conv_weight(const float* w, void* dst, int Cout, int Cin, int taps, int mode, int dtype, void* stream);
+/* replaces: nn.Conv3d k in {3,7} (any k), stride, padding, dilation (c3d.py:16, blocks_MDUNet.py:68,102,163,178).
+ * Implicit GEMM on MFMA.  mode 0: y[v] = sum_tap,ci x[v*stride - pad + tap*dil][ci] * wp[co][tap][ci] (+bias)
+ * mode 1 (data gradient of a strided conv): y[v] = sum over taps with (v + pad - tap*dil) % stride == 0 of
+ *         x[(v + pad - tap*dil)/stride][ci] * wp[co][tap][ci].
+ * x: [N][Di][Hi][Wi][ldx] (Cin channels), y: [N][Do][Ho][Wo][ldy] (Cout channels). CinP = roundup8(Cin). */
+int dp_conv3d(const void* x, int ldx, const void* wp, const float* bias, void* y, int ldy,
+              int N, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int Cin, int Cout,
+              int k, int stride, int pad, int dil, int mode, int dtype, void* stream);
+/* weight gradient (fp32, ACCUMULATES): for every tap t, co, ci:
+ *   dw[co*s_co + ci*s_ci + t*s_tap] += sum_v gy[v][co + t*gy_tap_choff] * x[shift ? v*stride - pad + t*dil : v][ci]
+ * replaces: autograd's conv/linear/conv-transpose weight gradients.  (v ranges over the gy voxels.) */
+int dp_conv3d_wgrad(const void* x, int ldx, const void* gy, int ldgy, float* dw,
+                    int N, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int Cin, int Cout,
+                    int k, int stride, int pad, int dil, int shift, int gy_tap_choff,
+                    int64_t s_co, int64_t s_ci, int64_t s_tap, int dtype, void* stream);
+
+/* ---- cascade glue ----------------------------------------------------------------------------- */
+/* replaces: AsDiscrete(argmax=True, to_onehot=True) + channel concat (train_light_linked_model.py:157-167):
+ * logits NDHWC [rows][ld] (C classes) -> one-hot of the arg-max (first max wins, as torch.argmax) for classes
+ * 1..C-1 written to out[rows][ldo] channels [choff, choff+C-1); also writes the label (int32) if labels!=NULL. */
+int dp_argmax_onehot(const void* logits, int ld, void* out, int ldo, int choff, int32_t* labels, int64_t rows, int C,
+                     int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,297 @@
+"""GPU parity of every HIP op (forward + backward, through the C ABI) against the CPU oracle leaf ops.
+
+fp32 mode: exact-fp32 MFMA -> tolerance 2e-5 (relative L2) / 1e-4 (max-abs relative to max|ref|).
+bf16 mode: inputs are rounded to bf16 FIRST and the oracle is evaluated (in fp64) on the rounded inputs, so the only
+differences are fp32 accumulation order and the final rounding of outputs to bf16 (2^-9): tolerance 6e-3 rel-L2.
+"""
+import math
+
+import pytest
+import torch
+
+import oracle
+from helpers import rel_l2, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float32: (2e-5, 1e-4), torch.bfloat16: (6e-3, 2e-2)}
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g) * scale
+
+
+def q(t, dtype):
+    """Quantise a CPU fp32 tensor to the compute dtype's grid (identity for fp32)."""
+    return t.to(dtype).float()
+
+
+def ndhwc(t):   # NCDHW -> NDHWC
+    return t.permute(0, 2, 3, 4, 1).contiguous()
+
+
+def ncdhw(t):
+    return t.permute(0, 4, 1, 2, 3).contiguous()
+
+
+def check(name, got, ref, dtype, scale=1.0):
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    assert torch.isfinite(got).all(), name
+    tl2, tmax = TOL[dtype]
+    e2, em = rel_l2(got, ref), rel_err(got, ref)
+    assert e2 < tl2 * scale and em < tmax * scale, f"{name}: rel_l2={e2:.3e} rel_max={em:.3e} ({dtype})"
+
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [
+    # (N, Cin, Cout, D, H, W, k, stride, pad, dil, bias)
+    (2, 16, 16, 6, 10, 20, 3, 1, 1, 1, True),
+    (1, 9, 16, 8, 8, 8, 3, 1, 1, 1, True),
+    (1, 25, 16, 5, 7, 9, 3, 1, 1, 1, False),
+    (2, 32, 16, 9, 8, 17, 7, 1, 3, 1, True),
+    (1, 16, 32, 8, 8, 8, 3, 2, 1, 1, True),
+    (1, 8, 4, 12, 12, 12, 3, 1, 2, 2, True),
+    (1, 8, 4, 12, 12, 12, 3, 1, 3, 3, True),
+    (1, 32, 16, 6, 6, 6, 1, 1, 0, 1, True),
+    (2, 16, 1, 4, 6, 8, 1, 1, 0, 1, True),
+    (1, 64, 64, 6, 6, 6, 3, 1, 1, 1, False),
+    (1, 128, 80, 4, 4, 4, 7, 1, 3, 1, True),
+    (1, 4, 4, 5, 5, 5, 7, 1, 3, 1, True),
+])
+def test_conv3d(cfg, dtype):
+    from dose_prediction_amd import ops
+    dev = _dev()
+    N, Cin, Cout, D, H, W, k, s, p, dl, has_b = cfg
+    x = q(rnd((N, Cin, D, H, W), 1), dtype)
+    w = q(rnd((Cout, Cin, k, k, k), 2, (Cin * k ** 3) ** -0.5), dtype)
+    b = rnd((Cout,), 3, 0.1) if has_b else None
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    br = b.double().requires_grad_(True) if has_b else None
+    yr = oracle.conv3d(xr, wr, br, s, p, dl)
+    r = q(rnd(yr.shape, 4), dtype)
+    (yr * r.double()).sum().backward()
+    xh = ndhwc(x).to(dev, dtype).requires_grad_(True)
+    wh = w.to(dev).requires_grad_(True)
+    bh = b.to(dev).requires_grad_(True) if has_b else None
+    yh = ops.conv3d(xh, wh, bh, s, p, dl)
+    yh.backward(ndhwc(r).to(dev, dtype))
+    check("y", ncdhw(yh), yr, dtype)
+    check("gx", ncdhw(xh.grad), xr.grad, dtype)
+    check("gw", wh.grad, wr.grad, dtype)
+    if has_b:
+        check("gb", bh.grad, br.grad, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv3d_channel_slice_and_padding(dtype):
+    """Input is a channel slice of a wider buffer (pitch > C) with extra zero-padded channels."""
+    from dose_prediction_amd import ops
+    dev = _dev()
+    x = q(rnd((1, 9, 6, 6, 6), 1), dtype)
+    w = q(rnd((8, 9, 3, 3, 3), 2, 0.1), dtype)
+    yr = oracle.conv3d(x.double(), w.double(), None, 1, 1, 1)
+    buf = torch.zeros((1, 6, 6, 6, 40), dtype=dtype, device=dev)
+    buf[..., 8:17] = ndhwc(x).to(dev, dtype)
+    yh = ops.conv3d(buf[..., 8:24], w.to(dev), None, 1, 1, 1)     # 16 channels visible, 9 used
+    check("y", ncdhw(yh), yr, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [(2, 48, 8, 2, 1, 1), (1, 32, 16, 4, 4, 4), (1, 768, 128, 2, 2, 2), (1, 6, 3, 3, 3, 3)])
+def test_conv_transpose(cfg, dtype):
+    from dose_prediction_amd import ops
+    dev = _dev()
+    N, Cin, Cout, D, H, W = cfg
+    x = q(rnd((N, Cin, D, H, W), 1), dtype)
+    w = q(rnd((Cin, Cout, 2, 2, 2), 2, Cin ** -0.5), dtype)
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    yr = oracle.conv_transpose3d_k2s2(xr, wr)
+    r = q(rnd(yr.shape, 3), dtype)
+    (yr * r.double()).sum().backward()
+    xh, wh = ndhwc(x).to(dev, dtype).requires_grad_(True), w.to(dev).requires_grad_(True)
+    yh = ops.conv_transpose2x(xh, wh)
+    yh.backward(ndhwc(r).to(dev, dtype))
+    check("y", ncdhw(yh), yr, dtype)
+    check("gx", ncdhw(xh.grad), xr.grad, dtype)
+    check("gw", wh.grad, wr.grad, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("kind,affine,act,res,training", [
+    ("instance", True, "relu", False, True), ("instance", False, "mish", False, True), ("instance", False, "lrelu", True, True),
+    ("instance", False, None, False, True), ("batch", True, "relu", False, True), ("batch", True, "relu", False, False)])
+def test_norm_act(kind, affine, act, res, training, dtype):
+    from dose_prediction_amd import ops
+    dev = _dev()
+    N, C, D, H, W = 2, 16, 7, 9, 40        # V = 2520 > one stats block
+    x = q(rnd((N, C, D, H, W), 1) * 1.5 + 0.3, dtype)
+    gam = (1 + 0.2 * rnd((C,), 2)) if affine else None
+    bet = 0.1 * rnd((C,), 3) if affine else None
+    rs = q(rnd((N, C, D, H, W), 4), dtype) if res else None
+    rm, rv = 0.1 * rnd((C,), 5), rnd((C,), 6).abs() + 0.5
+    xr = x.double().requires_grad_(True)
+    gr = gam.double().requires_grad_(True) if affine else None
+    br = bet.double().requires_grad_(True) if affine else None
+    rr = rs.double().requires_grad_(True) if res else None
+    if kind == "instance":
+        yr = oracle.instance_norm(xr, gr, br)
+        new_rm = new_rv = None
+    else:
+        yr, new_rm, new_rv = oracle.batch_norm(xr, gr, br, rm.double(), rv.double(), training)
+    if res:
+        yr = yr + rr
+    yr = oracle.activation(yr, act)
+    r = q(rnd(yr.shape, 7), dtype)
+    (yr * r.double()).sum().backward()
+    xh = ndhwc(x).to(dev, dtype).requires_grad_(True)
+    gh = gam.to(dev).requires_grad_(True) if affine else None
+    bh = bet.to(dev).requires_grad_(True) if affine else None
+    rh = ndhwc(rs).to(dev, dtype).requires_grad_(True) if res else None
+    rmh, rvh = rm.to(dev), rv.to(dev)
+    yh = ops.norm_act(xh, kind, gh, bh, rmh, rvh, training, rh, act)
+    yh.backward(ndhwc(r).to(dev, dtype))
+    check("y", ncdhw(yh), yr, dtype)
+    check("gx", ncdhw(xh.grad), xr.grad, dtype, scale=2.0)
+    if affine:
+        check("ggamma", gh.grad, gr.grad, dtype)
+        check("gbeta", bh.grad, br.grad, dtype)
+    if res:
+        check("gres", ncdhw(rh.grad), rr.grad, dtype)
+    if kind == "batch" and training:
+        check("running_mean", rmh, new_rm, torch.float32)
+        check("running_var", rvh, new_rv, torch.float32)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [(300, 768, 96, True), (64, 48, 144, False), (17, 96, 48, True), (1024, 1000, 64, True)])
+def test_linear(cfg, dtype):
+    from dose_prediction_amd import ops
+    dev = _dev()
+    rows, K, Nout, has_b = cfg
+    x = q(rnd((2, rows // 2 if rows % 2 == 0 else rows, K), 1), dtype)
+    w = q(rnd((Nout, K), 2, K ** -0.5), dtype)
+    b = 0.1 * rnd((Nout,), 3) if has_b else None
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    br = b.double().requires_grad_(True) if has_b else None
+    yr = oracle.linear(xr, wr, br)
+    r = q(rnd(yr.shape, 4), dtype)
+    (yr * r.double()).sum().backward()
+    for splitk in (1, 3):
+        xh, wh = x.to(dev, dtype).requires_grad_(True), w.to(dev).requires_grad_(True)
+        bh = b.to(dev).requires_grad_(True) if has_b else None
+        yh = ops.linear(xh, wh, bh, splitk)
+        yh.backward(r.to(dev, dtype))
+        check("y", yh, yr, dtype)
+        check("gx", xh.grad, xr.grad, dtype)
+        check("gw", wh.grad, wr.grad, dtype)
+        if has_b:
+            check("gb", bh.grad, br.grad, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_layernorm_gelu_add(dtype):
+    from dose_prediction_amd import ops
+    dev = _dev()
+    x = q(rnd((2, 37, 768), 1) * 2 + 0.5, dtype)
+    g, b = 1 + 0.2 * rnd((768,), 2), 0.1 * rnd((768,), 3)
+    xr, gr, br = x.double().requires_grad_(True), g.double().requires_grad_(True), b.double().requires_grad_(True)
+    yr = oracle.gelu(oracle.layer_norm(xr, gr, br)) + xr
+    r = q(rnd(yr.shape, 4), dtype)
+    (yr * r.double()).sum().backward()
+    xh, gh, bh = x.to(dev, dtype).requires_grad_(True), g.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    yh = ops.add(ops.gelu(ops.layer_norm(xh, gh, bh)), xh)
+    yh.backward(r.to(dev, dtype))
+    check("y", yh, yr, dtype, scale=2.0)
+    check("gx", xh.grad, xr.grad, dtype, scale=2.0)
+    check("ggamma", gh.grad, gr.grad, dtype, scale=2.0)
+    check("gbeta", bh.grad, br.grad, dtype, scale=2.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [(2, 64, 6, 128), (1, 512, 12, 64), (2, 8, 6, 8), (1, 144, 12, 4)])
+def test_attention(cfg, dtype):
+    from dose_prediction_amd import ops
+    dev = _dev()
+    B, N, heads, d = cfg
+    H = heads * d
+    x = q(rnd((B, N, H), 1), dtype)
+    wqkv = q(rnd((3 * H, H), 2, H ** -0.5), dtype)
+    wo, bo = q(rnd((H, H), 3, H ** -0.5), dtype), 0.1 * rnd((H,), 4)
+    xr, wr, wor, bor = (t.double().requires_grad_(True) for t in (x, wqkv, wo, bo))
+    yr = oracle.attention(xr, wr, wor, bor, heads)
+    r = q(rnd(yr.shape, 5), dtype)
+    (yr * r.double()).sum().backward()
+    xh = x.to(dev, dtype).requires_grad_(True)
+    wh, woh, boh = (t.to(dev).requires_grad_(True) for t in (wqkv, wo, bo))
+    yh = ops.linear(ops.attention(ops.linear(xh, wh), heads), woh, boh)
+    yh.backward(r.to(dev, dtype))
+    s = 3.0 if dtype == torch.bfloat16 else 1.0     # intermediate qkv / P / O roundings in bf16
+    check("y", yh, yr, dtype, scale=s)
+    check("gx", xh.grad, xr.grad, dtype, scale=s)
+    check("gwqkv", wh.grad, wr.grad, dtype, scale=s)
+    check("gwo", woh.grad, wor.grad, dtype, scale=s)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_patchify_posemb(dtype):
+    from dose_prediction_amd import ops
+    dev = _dev()
+    x = q(rnd((2, 5, 32, 16, 16), 1), dtype)
+    pos = 0.1 * rnd((1, 2, 5 * 4096), 2)
+    xr, pr = x.double().requires_grad_(True), pos.double().requires_grad_(True)
+    yr = oracle.patchify(xr) + pr
+    r = q(rnd(yr.shape, 3), dtype)
+    (yr * r.double()).sum().backward()
+    xp = torch.zeros((2, 32, 16, 16, 8), dtype=dtype)
+    xp[..., :5] = ndhwc(x).to(dtype)
+    xh, ph = xp.to(dev).requires_grad_(True), pos.to(dev).requires_grad_(True)
+    yh = ops.add_broadcast(ops.patchify(xh, 5, 16), ph)
+    yh.backward(r.to(dev, dtype))
+    check("y", yh, yr, dtype)
+    check("gx", ncdhw(xh.grad[..., :5]), xr.grad, dtype)
+    check("gpos", ph.grad, pr.grad, dtype)
+    assert xh.grad[..., 5:].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_trilinear_cat_layout(dtype):
+    from dose_prediction_amd import ops
+    dev = _dev()
+    x = q(rnd((2, 12, 3, 4, 5), 1), dtype)
+    s = q(rnd((2, 4, 6, 8, 10), 2), dtype)
+    xr, sr = x.double().requires_grad_(True), s.double().requires_grad_(True)
+    yr = torch.cat((oracle.trilinear_up2(xr), sr), dim=1)
+    r = rnd(yr.shape, 3)
+    (yr * r.double()).sum().backward()
+    xh, sh = x.to(dev).requires_grad_(True), s.to(dev).requires_grad_(True)
+    a = ops.ToNDHWC.apply(xh, 16, dtype)[..., :12]
+    b = ops.ToNDHWC.apply(sh, 8, dtype)[..., :4]
+    yh = ops.FromNDHWC.apply(ops.cat((ops.trilinear_up2(a), b)))
+    yh.backward(r.to(dev))
+    check("y", yh, yr, dtype)
+    check("gx", xh.grad, xr.grad, dtype)
+    check("gs", sh.grad, sr.grad, dtype)
+
+
+def test_argmax_onehot():
+    from dose_prediction_amd import ops
+    dev = _dev()
+    lg = rnd((2, 5, 6, 7, 8), 1)
+    lg[0, 0, 0, 0, :] = 0.5          # a tie: torch.argmax takes the first maximum
+    ref = torch.nn.functional.one_hot(lg.argmax(-1), 8)[..., 1:].float()
+    out = torch.zeros((2, 5, 6, 7, 16), device=dev)
+    lab = ops.argmax_onehot(lg.to(dev), out, choff=1, labels=True)
+    assert torch.equal(out[..., 1:8].cpu(), ref)
+    assert torch.equal(lab.cpu().long(), lg.argmax(-1))
+    assert out[..., 0].abs().max().item() == 0 and out[..., 8:].abs().max().item() == 0
