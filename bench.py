@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py -- DOSE-PYFER forward+backward throughput on MI355X (BASELINE.json configs[1]: dose-only path, 128^3 bf16,
+batch 2 per GPU), one process per GPU, RCCL gradient all-reduce for N > 1.
+
+A "step" = NetworkTrainer.forward/backward semantics (network_trainer.py:185-213): optimizer.zero_grad() ->
+network(input) -> GenLoss (train_light_pyfer.py:131) -> loss.backward() -> optimizer.step(), with net_A frozen
+(train_light_pyfer.py:85-88).  Inputs are synthetic (dose_prediction_amd/synth.py), resident in HBM before timing.
+
+Prints ONE JSON line on rank 0 (see the task contract) with `roofline` (dominant kernel = the 7x7x7 implicit-GEMM
+convolution, timed live with HIP events on the launch stream) and `cpu_baseline` (the CPU oracle on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md chip table
+PEAK_F32_TFLOPS = 157.3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--size", type=int, nargs="+", default=[128])
+    ap.add_argument("--batch", type=int, default=2, help="volumes per GPU")
+    ap.add_argument("--model", default="pyfer", choices=["pyfer", "transeg"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-optimizer", action="store_true")
+    ap.add_argument("--cpu-size", type=int, default=64)
+    return ap.parse_args()
+
+
+def build_model(args, shape, dev):
+    import dose_prediction_amd
+    from dose_prediction_amd.models import dose_pyfer, oar_transeg
+    dose_prediction_amd.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+    torch.manual_seed(4321)
+    if args.model == "pyfer":
+        # hyper-parameters: DosePrediction/Train/train_light_pyfer.py:73-83
+        net = dose_pyfer.Model(in_ch=9, out_ch=1, list_ch_A=[-1, 16, 32, 64, 128, 256], feature_size=16, img_size=shape,
+                               num_layers=8, num_heads=6, act="mish", mode_multi_dec=True, multiS_conv=True)
+        for n, p in net.named_parameters():           # frozen net_A: train_light_pyfer.py:85-88
+            if "net_A" in n or "conv_out_A" in n:
+                p.requires_grad = False
+    else:
+        net = oar_transeg.Model(in_channels=1, out_channels=8, img_size=shape, feature_size=16, hidden_size=768, mlp_dim=3072,
+                                num_heads=12, pos_embed="perceptron", norm_name="instance", res_block=True, conv_block=True)
+    return net.to(dev).train()
+
+
+def conv_flops(args_):
+    # dp_conv3d(x, ldx, wp, bias, y, ldy, N, Di,Hi,Wi, Do,Ho,Wo, Cin, Cout, k, stride, pad, dil, mode, dtype, stream)
+    N, Do, Ho, Wo, Cin, Cout, k = args_[6], args_[10], args_[11], args_[12], args_[13], args_[14], args_[15]
+    return 2.0 * N * Do * Ho * Wo * Cin * Cout * k ** 3, k
+
+
+def wgrad_flops(args_):
+    # dp_conv3d_wgrad(x, ldx, gy, ldgy, dw, N, Di,Hi,Wi, Do,Ho,Wo, Cin, Cout, k, ...)
+    N, Do, Ho, Wo, Cin, Cout, k = args_[5], args_[9], args_[10], args_[11], args_[12], args_[13], args_[14]
+    return 2.0 * N * Do * Ho * Wo * Cin * Cout * k ** 3, k
+
+
+def summarize_profile(records, steps):
+    groups = {}
+    for name, a, e0, e1 in records:
+        ms = e0.elapsed_time(e1)
+        if name == "dp_conv3d":
+            fl, k = conv_flops(a)
+            key = f"conv{k}x{k}x{k}_igemm"
+        elif name == "dp_conv3d_wgrad":
+            fl, k = wgrad_flops(a)
+            key = f"wgrad{k}x{k}x{k}"
+        else:
+            M, N, K, nb0, nb1 = a[13], a[14], a[15], a[16], a[17]
+            fl, key = 2.0 * M * N * K * nb0 * nb1, "gemm_nt"
+        g = groups.setdefault(key, [0.0, 0.0, 0])
+        g[0] += fl
+        g[1] += ms
+        g[2] += 1
+    out = {}
+    for key, (fl, ms, n) in groups.items():
+        out[key] = {"launches_per_step": n / steps, "avg_launch_ms": ms / n, "ms_per_step": ms / steps,
+                    "tflops": fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0}
+    return out
+
+
+def cpu_baseline(args):
+    """The CPU oracle (fp32 PyTorch-eager restatement, pinned to the reference by tests/golden) timed on the host cores:
+    one forward+backward of the same network/loss at cpu_size^3, batch 1, reported in 128^3-volume equivalents."""
+    import oracle
+    from dose_prediction_amd import synth
+    from dose_prediction_amd.models import dose_pyfer
+    cores = os.cpu_count() or 1
+    threads = min(cores, 128)
+    torch.set_num_threads(threads)
+    S = args.cpu_size
+    shape = (S, S, S)
+    torch.manual_seed(4321)
+    net = dose_pyfer.Model(in_ch=9, out_ch=1, list_ch_A=[-1, 16, 32, 64, 128, 256], feature_size=16, img_size=shape,
+                           num_layers=8, num_heads=6, act="mish")
+    sd = {}
+    for k, v in net.state_dict().items():
+        v = v.detach().clone()
+        if v.dtype.is_floating_point and "running" not in k and not (k.startswith("net_A") or k.startswith("conv_out_A")):
+            v.requires_grad_(True)
+        sd[k] = v
+    x = synth.dose_input(1, shape)
+    gt = synth.dose_target(1, shape)
+    t0 = time.time()
+    out = oracle.dose_pyfer(sd, x, num_layers=8, num_heads=6, act="mish", training=True)
+    loss = oracle.gen_loss(out, gt, 10, 1, casecade=True, freez=True)
+    loss.backward()
+    dt = time.time() - t0
+    scale = (S / 128.0) ** 3
+    return {"value": scale / dt, "unit": "128^3-equivalent volumes/s (fwd+bwd)", "cores": threads, "kind": "port",
+            "sample": f"1 step (forward + GenLoss + backward, net_A frozen) of the fp32 CPU oracle on one {S}^3 volume: "
+                      f"{dt:.2f} s with {threads} torch threads on {cores} host cores; scaled by voxel count ({scale:.4f})",
+            "seconds": dt}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback for the HIP path)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    shape = tuple(args.size * 3) if len(args.size) == 1 else tuple(args.size)
+    from dose_prediction_amd import synth, losses, _lib
+    from dose_prediction_amd.ddp import attach_gradient_allreduce
+    net = build_model(args, shape, dev)
+    if world > 1:
+        attach_gradient_allreduce(net, bucket_mb=32.0)
+    params = [p for p in net.parameters() if p.requires_grad]
+    opt = None if args.no_optimizer else torch.optim.Adam(params, lr=1e-4, weight_decay=3e-5, betas=(0.9, 0.999), eps=1e-8,
+                                                          amsgrad=True)   # network_trainer.py:120-125
+    B = args.batch
+    if args.model == "pyfer":
+        x = synth.dose_input(B, shape, seed=1234 + rank).to(dev)
+        gt = synth.dose_target(B, shape, seed=5678 + rank).to(dev)
+    else:
+        x = synth.ct_input(B, shape, seed=1234 + rank).to(dev)
+        gt = torch.randint(0, 8, (B,) + shape, generator=torch.Generator().manual_seed(5678 + rank)).to(dev)
+
+    def step():
+        if opt is not None:
+            opt.zero_grad(set_to_none=True)
+        else:
+            for p in params:
+                p.grad = None
+        out = net(x)
+        if args.model == "pyfer":
+            loss = losses.gen_loss(out, gt, 10.0, 1.0, casecade=True, freez=True)
+        else:
+            loss = torch.nn.functional.cross_entropy(out, gt)
+        loss.backward()
+        if opt is not None:
+            opt.step()
+        return loss
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    _lib.PROFILE = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    sync()
+    dt = time.perf_counter() - t0
+    records, _lib.PROFILE = _lib.PROFILE, None
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    final_loss = float(loss)
+    if rank == 0:
+        prof = summarize_profile(records, args.steps)
+        peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
+        dom = prof.get("conv7x7x7_igemm", {"tflops": 0.0, "avg_launch_ms": 0.0, "launches_per_step": 0})
+        res = {
+            "metric": "128^3 CT volumes/sec (fwd+bwd)", "value": world * B * args.steps / dt, "unit": "volumes/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": ("DOSE-PYFER dose-only path (BASELINE.json configs[1])" if args.model == "pyfer"
+                                    else "OAR-TRANSEG segmentation path (BASELINE.json configs[2])"),
+                       "volume": list(shape), "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
+                       "net_A_frozen": args.model == "pyfer", "optimizer_step_in_timed_region": opt is not None,
+                       "final_loss": final_loss},
+            "roofline": {"bound": "mfma", "kernel": "conv3d 7x7x7 implicit GEMM (forward + data-gradient launches)",
+                         "achieved": dom["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": dom["tflops"] / peak,
+                         "traffic": None, "avg_launch_ms": dom["avg_launch_ms"], "launches_per_step": dom["launches_per_step"]},
+            "kernels": prof,
+        }
+        if not args.no_cpu_baseline:
+            try:
+                res["cpu_baseline"] = cpu_baseline(args)
+            except Exception as e:   # the GPU numbers stay valid if the host leg fails
+                res["cpu_baseline"] = {"value": None, "unit": "volumes/s", "cores": os.cpu_count(), "kind": "port",
+                                       "sample": f"failed: {e!r}"}
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

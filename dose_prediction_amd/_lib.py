@@ -62,10 +62,25 @@ def lib():
     return _lib
 
 
+# Optional per-launch timing (bench.py): when PROFILE is a list and ``name`` is in PROFILE_NAMES, every call is bracketed by
+# HIP events recorded on the stream the kernel is launched on (torch's current stream) and appended as
+# (name, args, start_event, end_event).
+PROFILE = None
+PROFILE_NAMES = ("dp_conv3d", "dp_conv3d_wgrad", "dp_gemm_nt")
+
+
 def call(name, *args):
     """Call an int-returning entry point; raise DoseHipError(dp_last_error()) on a non-zero status."""
     L = lib()
-    rc = getattr(L, name)(*args)
+    if PROFILE is not None and name in PROFILE_NAMES:
+        import torch
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = getattr(L, name)(*args)
+        e1.record()
+        PROFILE.append((name, args, e0, e1))
+    else:
+        rc = getattr(L, name)(*args)
     if rc != 0:
         raise DoseHipError(f"{name} failed (rc={rc}): {L.dp_last_error().decode()}")
     return rc
