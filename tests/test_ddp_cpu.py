@@ -1,0 +1,82 @@
+"""CPU (gloo, world_size 2): the bucketed gradient all-reduce averages gradients across ranks, tolerates parameters that
+receive no gradient, broadcasts rank 0's parameters/buffers, and leaves state_dict keys untouched."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class Net(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.a = nn.Linear(8, 300)
+        self.bn = nn.BatchNorm1d(300)
+        self.b = nn.Linear(300, 2000)      # larger than one (tiny) bucket -> chunked bucket of its own
+        self.unused = nn.Linear(4, 4)      # never used in forward (like MainSubsetModel.out)
+        self.frozen = nn.Linear(8, 8)
+        for p in self.frozen.parameters():
+            p.requires_grad = False
+
+    def forward(self, x):
+        return self.b(torch.relu(self.bn(self.a(self.frozen(x))))).sum()
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dose_prediction_amd.ddp import attach_gradient_allreduce
+    torch.manual_seed(100 + rank)          # different initial weights per rank: the broadcast must fix that
+    net = Net()
+    keys_before = list(net.state_dict().keys())
+    attach_gradient_allreduce(net, bucket_mb=0.002)
+    assert list(net.state_dict().keys()) == keys_before
+    w0 = net.a.weight.detach().clone()
+    res = {"w0": w0}
+    for step in range(2):                  # two steps: bucket state must reset
+        net.zero_grad(set_to_none=True)
+        x = torch.randn(5, 8, generator=torch.Generator().manual_seed(7 + rank + 10 * step))
+        net(x).backward()
+        res[f"g{step}"] = {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+        res[f"x{step}"] = x
+    res["sd"] = {k: v.clone() for k, v in net.state_dict().items()}
+    out[rank] = res
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_gloo():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    r0, r1 = out[0], out[1]
+    assert torch.equal(r0["w0"], r1["w0"])                      # broadcast
+    torch.manual_seed(100)
+    ref = Net()
+    for step in range(2):
+        gs = []
+        for r in (r0, r1):
+            m = Net()
+            m.load_state_dict(ref.state_dict())
+            if step == 1:
+                m.train()
+                m(r["x0"])                                      # replay step 0 to advance the BN running stats identically
+                m.zero_grad()
+            m(r[f"x{step}"]).backward()
+            gs.append({k: p.grad for k, p in m.named_parameters() if p.grad is not None})
+        for k in gs[0]:
+            avg = 0.5 * (gs[0][k] + gs[1][k])
+            assert torch.allclose(r0[f"g{step}"][k], avg, rtol=1e-5, atol=1e-6), (step, k)
+            assert torch.equal(r0[f"g{step}"][k], r1[f"g{step}"][k])
+        assert "unused.weight" not in r0[f"g{step}"] and "frozen.weight" not in r0[f"g{step}"]
