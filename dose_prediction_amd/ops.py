@@ -102,6 +102,29 @@ def _pack_conv(w, mode, dtype):
     return _packs.get(w, ("conv", mode, dtype), build)
 
 
+USE_TILED = True
+
+
+def _tiled_elems(cin, cout, k, stride, pad, dil, W):
+    if not USE_TILED:
+        return 0
+    return _lib.lib().dp_conv3d_tiled_weight_elems(cin, cout, k, stride, pad, dil, W)
+
+
+def _pack_conv_tiled(w, tf, dtype, elems):
+    """Weights for the LDS-tiled conv kernel (tf=1: transposed+flipped, i.e. the data-gradient convolution)."""
+    def build():
+        cout, cin, k = w.shape[0], w.shape[1], w.shape[2]
+        dst = torch.empty((elems,), dtype=dtype, device=w.device)
+        wc = w.detach().contiguous()
+        if tf:
+            _lib.call("dp_pack_conv_weight_tiled", _p(wc), _p(dst), cin, cout, k, 1, _DT[dtype], _stream())
+        else:
+            _lib.call("dp_pack_conv_weight_tiled", _p(wc), _p(dst), cout, cin, k, 0, _DT[dtype], _stream())
+        return dst
+    return _packs.get(w, ("conv_tiled", tf, dtype, elems), build)
+
+
 def _pack_tconv(w, transposed, dtype):
     """ConvTranspose3d weight [Cin,Cout,2,2,2] -> [(abc,co)][CinP] (fwd) or [Cin][(abc,co)P] (data grad)."""
     def build():
@@ -271,11 +294,16 @@ class Conv3d(torch.autograd.Function):
             raise ValueError(f"conv3d: input has {cx} channels, weight expects {cin}")
         Do, Ho, Wo = [(s + 2 * pad - dil * (k - 1) - 1) // stride + 1 for s in (Di, Hi, Wi)]
         y = torch.empty((N, Do, Ho, Wo, cout), dtype=x.dtype, device=x.device)
-        wp = _pack_conv(weight, 0, x.dtype)
         b32 = None if bias is None else bias.detach()
-        if k == 1 and stride == 1 and pad == 0:
+        te = _tiled_elems(cin, cout, k, stride, pad, dil, Wi) if k > 1 else 0
+        if te:
+            wq = _pack_conv_tiled(weight, 0, x.dtype, te)
+            _lib.call("dp_conv3d_tiled", _p(x), ldx, _p(wq), _p(b32), _p(y), cout, N, Di, Hi, Wi, cin, cout, k, _dt(x), _stream())
+        elif k == 1 and stride == 1 and pad == 0:
+            wp = _pack_conv(weight, 0, x.dtype)
             gemm_nt(x, wp, y, bias=b32, M=rows, N=cout, K=cin, lda=ldx, ldb=wp.shape[-1], ldc=cout)
         else:
+            wp = _pack_conv(weight, 0, x.dtype)
             _lib.call("dp_conv3d", _p(x), ldx, _p(wp), _p(b32), _p(y), cout, N, Di, Hi, Wi, Do, Ho, Wo, cin, cout,
                       k, stride, pad, dil, 0, _dt(x), _stream())
         ctx.save_for_backward(x, weight)
@@ -301,6 +329,10 @@ class Conv3d(torch.autograd.Function):
             if k == 1 and stride == 1 and pad == 0:
                 wt = _pack_conv(weight, 1, x.dtype)          # [Cin][1][CoutP]
                 gemm_nt(gy, wt, gx, M=grows, N=cin, K=cout, lda=ldg, ldb=wt.shape[-1], ldc=cx)
+            elif stride == 1 and _tiled_elems(cout, cin, k, 1, dil * (k - 1) - pad, dil, Wo):
+                te = _tiled_elems(cout, cin, k, 1, dil * (k - 1) - pad, dil, Wo)
+                wq = _pack_conv_tiled(weight, 1, x.dtype, te)
+                _lib.call("dp_conv3d_tiled", _p(gy), ldg, _p(wq), 0, _p(gx), cx, N, Do, Ho, Wo, cout, cin, k, dtc, _stream())
             elif stride == 1:
                 wt = _pack_conv(weight, 2, x.dtype)          # transposed + flipped: data gradient as a forward conv
                 _lib.call("dp_conv3d", _p(gy), ldg, _p(wt), 0, _p(gx), cx, N, Do, Ho, Wo, Di, Hi, Wi, cout, cin,

@@ -129,6 +129,13 @@ int dp_pack_conv_weight(const float* w, void* dst, int Cout, int Cin, int taps, 
 int dp_conv3d(const void* x, int ldx, const void* wp, const float* bias, void* y, int ldy,
               int N, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int Cin, int Cout,
               int k, int stride, int pad, int dil, int mode, int dtype, void* stream);
+/* LDS-tiled fast path for the hot layers (stride 1, dilation 1, "same" padding, k in {3,7}; forward, and data gradient with
+ * transposed_flipped weights).  dp_conv3d_tiled_weight_elems returns the packed-weight element count for a supported
+ * shape and 0 when the shape must take dp_conv3d (NOT an error code).  Packed layout: see conv_tiled.hip. */
+int dp_conv3d_tiled_weight_elems(int Cin, int Cout, int k, int stride, int pad, int dil, int W);
+int dp_pack_conv_weight_tiled(const float* w, void* dst, int Cout, int Cin, int k, int transposed_flipped, int dtype, void* stream);
+int dp_conv3d_tiled(const void* x, int ldx, const void* wq, const float* bias, void* y, int ldy, int N, int D, int H, int W,
+                    int Cin, int Cout, int k, int dtype, void* stream);
 /* weight gradient (fp32, ACCUMULATES): for every tap t, co, ci:
  *   dw[co*s_co + ci*s_ci + t*s_tap] += sum_v gy[v][co + t*gy_tap_choff] * x[shift ? v*stride - pad + t*dil : v][ci]
  * replaces: autograd's conv/linear/conv-transpose weight gradients.  (v ranges over the gy voxels.) */

@@ -68,6 +68,15 @@ DTYPES = [torch.float32, torch.bfloat16]
     (1, 64, 64, 6, 6, 6, 3, 1, 1, 1, False),
     (1, 128, 80, 4, 4, 4, 7, 1, 3, 1, True),
     (1, 4, 4, 5, 5, 5, 7, 1, 3, 1, True),
+    # LDS-tiled kernel: tap-paired (Cout<=16), Cout<=32, Cout>32 (two N tiles / grid.y), ragged W / H / channel counts
+    (1, 32, 32, 3, 20, 70, 7, 1, 3, 1, True),
+    (1, 16, 64, 2, 18, 33, 3, 1, 1, 1, True),
+    (1, 64, 128, 2, 9, 16, 7, 1, 3, 1, False),
+    (2, 32, 16, 3, 9, 130, 7, 1, 3, 1, True),
+    (1, 24, 40, 2, 7, 40, 3, 1, 1, 1, True),
+    (1, 16, 16, 9, 17, 64, 7, 1, 3, 1, True),
+    (1, 9, 16, 4, 11, 36, 3, 1, 1, 1, True),
+    (1, 128, 64, 2, 6, 32, 3, 1, 1, 1, True),
 ])
 def test_conv3d(cfg, dtype):
     from dose_prediction_amd import ops
