@@ -64,6 +64,12 @@ def conv_flops(args_):
     return 2.0 * N * Do * Ho * Wo * Cin * Cout * k ** 3, k
 
 
+def tiled_flops(args_):
+    # dp_conv3d_tiled(x, ldx, wq, bias, y, ldy, N, D, H, W, Cin, Cout, k, dtype, stream)
+    N, D, H, W, Cin, Cout, k = args_[6:13]
+    return 2.0 * N * D * H * W * Cin * Cout * k ** 3, k
+
+
 def wgrad_flops(args_):
     # dp_conv3d_wgrad(x, ldx, gy, ldgy, dw, N, Di,Hi,Wi, Do,Ho,Wo, Cin, Cout, k, ...)
     N, Do, Ho, Wo, Cin, Cout, k = args_[5], args_[9], args_[10], args_[11], args_[12], args_[13], args_[14]
@@ -76,10 +82,17 @@ def summarize_profile(records, steps):
         ms = e0.elapsed_time(e1)
         if name == "dp_conv3d":
             fl, k = conv_flops(a)
-            key = f"conv{k}x{k}x{k}_igemm"
+            key = f"conv{k}x{k}x{k}_generic"
+        elif name == "dp_conv3d_tiled":
+            fl, k = tiled_flops(a)
+            key = f"conv{k}x{k}x{k}_tiled"
         elif name == "dp_conv3d_wgrad":
             fl, k = wgrad_flops(a)
-            key = f"wgrad{k}x{k}x{k}"
+            key = f"wgrad{k}x{k}x{k}_generic"
+        elif name == "dp_conv3d_wgrad_tiled":
+            # (x, ldx, gy, ldgy, dw, ws, N, D, H, W, Cin, Cout, k, ...)
+            N, D, H, W, Cin, Cout, k = a[6:13]
+            fl, key = 2.0 * N * D * H * W * Cin * Cout * k ** 3, f"wgrad{k}x{k}x{k}_tiled"
         else:
             M, N, K, nb0, nb1 = a[13], a[14], a[15], a[16], a[17]
             fl, key = 2.0 * M * N * K * nb0 * nb1, "gemm_nt"
@@ -191,11 +204,11 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
     if rank == 0:
         prof = summarize_profile(records, args.steps)
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
-        dom = prof.get("conv7x7x7_igemm", {"tflops": 0.0, "avg_launch_ms": 0.0, "launches_per_step": 0})
+        dom = prof.get("conv7x7x7_tiled", prof.get("conv7x7x7_generic", {"tflops": 0.0, "avg_launch_ms": 0.0, "launches_per_step": 0}))
         res = {
             "metric": "128^3 CT volumes/sec (fwd+bwd)", "value": world * B * args.steps / dt, "unit": "volumes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,

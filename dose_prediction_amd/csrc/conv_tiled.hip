@@ -235,3 +235,208 @@ int dp_conv3d_tiled_try(const void*, int, const void*, const float*, void*, int,
                         int, int, void*) { return -1; }
 int dp_wgrad_tiled_try(const void*, int, const void*, int, float*, int, int, int, int, int, int, int, int, int, int, int, int, int, int, int,
                        int64_t, int64_t, int64_t, int, void*) { return -1; }
+
+// ================================================================================================ tiled weight gradient
+// dW[co][ci][kd][kh][kw] = sum_{n,d,h,w} gy[n,d,h,w,co] * x[n, d+kd-P, h+kh-P, w+kw-P, ci]      (stride 1, "same" padding)
+// MFMA 32x32x16 with K = 16 consecutive voxels along W:
+//   A = x^T : M = 32 input channels (Cin <= 16: two horizontal taps kw = 2j, 2j+1 x 16 channels, "M pairing")
+//   B = gy  : N = 32 output channels (Cout <= 16: two vertical taps kh = 2j, 2j+1 x 16 channels, "N pairing")
+// Both operands are voxel-major in memory, so their k-major fragments come from LDS through ds_read_b64_tr_b16 (bf16) or
+// scalar reads (f32).  A block fixes kd and one (M tile, N tile, group of up to 4 kh); its 4 waves own one kh (pair) each
+// -- or split the 16-voxel chunks when there are fewer than 3 kh (pairs) -- and keep the KWT per-kw accumulators in
+// registers while the block sweeps its share of (n, d, h-tile, w-tile) voxel tiles; one atomic pass at the end into a
+// tap-major fp32 scratch [tap][ci][co] (co contiguous => full-rate atomics), unpacked into the caller's layout afterwards.
+struct WgtGeom {
+  int N, D, H, W, Cin, Cout, ldx, ldgy;
+  int tiles_h, tiles_w, MT, NTn, KHG;
+};
+
+template <typename T, int KS, int NPAIR, int MPAIR>
+struct WgtCfg {
+  static constexpr int PAD = KS / 2;
+  static constexpr int JHN = NPAIR == 2 ? (KS + 1) / 2 : KS;      // kh (pairs)
+  static constexpr int KWT = MPAIR == 2 ? (KS + 1) / 2 : KS;      // kw (pairs) = accumulators per wave
+  static constexpr int WKH = JHN >= 3 ? 4 : 2, WCH = 4 / WKH;
+  static constexpr int XC = MPAIR == 2 ? 16 : 32, GC = NPAIR == 2 ? 16 : 32;
+  static constexpr int TH = 8, TW = sizeof(T) == 2 ? 64 : 32, NCHK = TW / 16;
+  static constexpr int GR = NPAIR == 2 ? TH + 2 : TH;
+  static constexpr int LR = NPAIR == 2 ? TH + 2 * JHN - 1 : TH + KS - 1, LP = TW + KS - 1;
+  static constexpr int STEPS = NPAIR == 2 ? TH + 1 : TH;
+  static constexpr size_t SMEM = ((size_t)LR * LP * XC + (size_t)GR * TW * GC) * sizeof(T);
+};
+
+// k-major fragment of a [rows = voxels][pitch] LDS image: lane (col = lane&31, hh = lane>>5) gets, for column `colbase + (col&15)`,
+// the 8 voxels vox0(+shift for the upper 16 columns when SHIFT) + 8*hh .. +7.
+template <int PITCH>
+__device__ __forceinline__ Frag8<bf16_t> ld_kmajor32(const bf16_t* img, int vox_lo, int vox_hi, int col_lo, int col_hi, int lane) {
+  // lanes 16..31 / 48..63 (upper 16 columns) use (vox_hi, col_hi); the others (vox_lo, col_lo)
+  const int upper = (lane >> 4) & 1, hh = lane >> 5, i16 = lane & 15, qq = i16 >> 2, p = i16 & 3;
+  const bf16_t* a = img + ((upper ? vox_hi : vox_lo) + 8 * hh + qq) * PITCH + (upper ? col_hi : col_lo) + 4 * p;
+  v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)a);
+  v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(a + 4 * PITCH));
+  Frag8<bf16_t> f;
+  f.u[0] = (unsigned)(unsigned short)lo[0] | ((unsigned)(unsigned short)lo[1] << 16);
+  f.u[1] = (unsigned)(unsigned short)lo[2] | ((unsigned)(unsigned short)lo[3] << 16);
+  f.u[2] = (unsigned)(unsigned short)hi[0] | ((unsigned)(unsigned short)hi[1] << 16);
+  f.u[3] = (unsigned)(unsigned short)hi[2] | ((unsigned)(unsigned short)hi[3] << 16);
+  return f;
+}
+template <int PITCH>
+__device__ __forceinline__ Frag8<float> ld_kmajor32(const float* img, int vox_lo, int vox_hi, int col_lo, int col_hi, int lane) {
+  const int upper = (lane >> 4) & 1, hh = lane >> 5, i16 = lane & 15;
+  const float* a = img + ((upper ? vox_hi : vox_lo) + 8 * hh) * PITCH + (upper ? col_hi : col_lo) + i16;
+  Frag8<float> f;
+#pragma unroll
+  for (int j = 0; j < 8; j++) f.v[j] = a[j * PITCH];
+  return f;
+}
+
+template <typename T, int KS, int NPAIR, int MPAIR>
+__global__ void __launch_bounds__(256) k_wgrad_tiled(const T* __restrict__ x, const T* __restrict__ gy, float* __restrict__ dwt, WgtGeom g) {
+  using C = WgtCfg<T, KS, NPAIR, MPAIR>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* xs = (T*)smem_raw;
+  T* gs = xs + (size_t)C::LR * C::LP * C::XC;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, hh = lane >> 5;
+  const int kd = blockIdx.x;
+  int z = blockIdx.z;
+  const int khg = z % g.KHG; z /= g.KHG; const int nt = z % g.NTn; const int mt = z / g.NTn;
+  const int khw = wv % C::WKH, chw = wv / C::WKH;
+  const int jh = khg * C::WKH + khw;
+  const bool active = jh < C::JHN;
+  const int units = g.N * g.D * g.tiles_h, per = (units + gridDim.y - 1) / gridDim.y;
+  const int u0 = blockIdx.y * per, u1 = min(units, u0 + per);
+  const int cbase_x = mt * C::XC, cbase_g = nt * C::GC;
+
+  v16f acc[C::KWT];
+#pragma unroll
+  for (int k = 0; k < C::KWT; k++)
+#pragma unroll
+    for (int e = 0; e < 16; e++) acc[k][e] = 0.f;
+
+  constexpr int XPV = C::XC / 8, GPV = C::GC / 8;
+  for (int u = u0; u < u1; u++) {
+    const int th = u % g.tiles_h; const int nd = u / g.tiles_h; const int d = nd % g.D, n = nd / g.D;
+    const int id = d + kd - C::PAD;
+    if (id < 0 || id >= g.D) continue;
+    const int h0 = th * C::TH;
+    for (int tw = 0; tw < g.tiles_w; tw++) {
+      const int w0 = tw * C::TW;
+      __syncthreads();
+      for (int p = tid; p < C::LR * C::LP * XPV; p += 256) {
+        int part = p % XPV, v = p / XPV, lp = v % C::LP, lr = v / C::LP;
+        int ih = h0 - C::PAD + lr, iw = w0 - C::PAD + lp, c = cbase_x + part * 8;
+        int nv = g.Cin - c; nv = nv > 8 ? 8 : nv;
+        bool ok = ih >= 0 && ih < g.H && iw >= 0 && iw < g.W && nv > 0;
+        Frag8<T> f = ok ? frag_load(x + ((((int64_t)n * g.D + id) * g.H + ih) * g.W + iw) * g.ldx + c, nv) : frag_zero<T>();
+        frag_st_lds(xs + (size_t)v * C::XC + part * 8, f);
+      }
+      for (int p = tid; p < C::GR * C::TW * GPV; p += 256) {
+        int part = p % GPV, v = p / GPV, gw = v % C::TW, gr = v / C::TW;
+        int oh = h0 + gr - (NPAIR == 2 ? 1 : 0), ow = w0 + gw, c = cbase_g + part * 8;
+        int nv = g.Cout - c; nv = nv > 8 ? 8 : nv;
+        bool ok = oh >= h0 && oh < h0 + C::TH && oh < g.H && ow < g.W && nv > 0;
+        Frag8<T> f = ok ? frag_load(gy + ((((int64_t)n * g.D + d) * g.H + oh) * g.W + ow) * g.ldgy + c, nv) : frag_zero<T>();
+        frag_st_lds(gs + (size_t)v * C::GC + part * 8, f);
+      }
+      __syncthreads();
+      if (active) {
+#pragma unroll 1
+        for (int i = 0; i < C::STEPS; i++) {
+          const int lr = i + (NPAIR == 2 ? 2 * jh : jh);
+#pragma unroll 1
+          for (int c = chw; c < C::NCHK; c += C::WCH) {
+            Frag8<T> fb;
+            if (NPAIR == 2) fb = ld_kmajor32<C::GC>(gs, (i + 1) * C::TW + 16 * c, i * C::TW + 16 * c, 0, 0, lane);
+            else fb = ld_kmajor32<C::GC>(gs, i * C::TW + 16 * c, i * C::TW + 16 * c, 0, 16, lane);
+#pragma unroll
+            for (int k = 0; k < C::KWT; k++) {
+              Frag8<T> fa;
+              const int vbase = lr * C::LP + 16 * c;
+              if (MPAIR == 2) fa = ld_kmajor32<C::XC>(xs, vbase + 2 * k, vbase + 2 * k + 1, 0, 0, lane);
+              else fa = ld_kmajor32<C::XC>(xs, vbase + k, vbase + k, 0, 16, lane);
+              acc[k] = mma32(fa, fb, acc[k]);
+            }
+          }
+        }
+      }
+    }
+  }
+  if (!active) return;
+  // C/D: col (N index) = lane&31, row (M index) = (e&3) + 8*(e>>2) + 4*hh
+  const int ncol = lane & 31;
+  int co, kh;
+  if (NPAIR == 2) { co = nt * 16 + (ncol & 15); kh = 2 * jh + (ncol >> 4); } else { co = nt * 32 + ncol; kh = jh; }
+  if (kh >= KS || co >= g.Cout) return;
+#pragma unroll
+  for (int k = 0; k < C::KWT; k++)
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+      const int m = (e & 3) + 8 * (e >> 2) + 4 * hh;
+      int ci, kw;
+      if (MPAIR == 2) { ci = mt * 16 + (m & 15); kw = 2 * k + (m >> 4); } else { ci = mt * 32 + m; kw = k; }
+      if (kw < KS && ci < g.Cin) atomicAdd(dwt + ((int64_t)((kd * KS + kh) * KS + kw) * g.Cin + ci) * g.Cout + co, acc[k][e]);
+    }
+}
+
+__global__ void k_wgrad_unpack(const float* __restrict__ dwt, float* __restrict__ dw, int taps, int Cin, int Cout, int64_t s_co, int64_t s_ci, int64_t s_tap) {
+  int64_t total = (int64_t)taps * Cin * Cout;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int tap = (int)(i % taps); int64_t t = i / taps; int ci = (int)(t % Cin); int co = (int)(t / Cin);   // iterate in the OUTPUT's order
+    dw[co * s_co + ci * s_ci + tap * s_tap] += dwt[((int64_t)tap * Cin + ci) * Cout + co];
+  }
+}
+
+static inline bool wgt_applicable(int Cin, int Cout, int k, int stride, int pad, int dil, int shift, int W) {
+  return shift && (k == 3 || k == 7) && stride == 1 && dil == 1 && pad == k / 2 && W >= 16 && Cin >= 8 && Cout >= 8;
+}
+// fp32 scratch elements needed by dp_conv3d_wgrad_tiled (0: shape not supported, use dp_conv3d_wgrad)
+extern "C" int dp_conv3d_wgrad_tiled_ws_elems(int Cin, int Cout, int k, int stride, int pad, int dil, int shift, int W) {
+  if (!wgt_applicable(Cin, Cout, k, stride, pad, dil, shift, W)) return 0;
+  return k * k * k * Cin * Cout;
+}
+
+template <typename T, int KS, int NPAIR, int MPAIR>
+static int launch_wgt(const void* x, const void* gy, float* ws, WgtGeom g, hipStream_t s) {
+  using C = WgtCfg<T, KS, NPAIR, MPAIR>;
+  auto kern = k_wgrad_tiled<T, KS, NPAIR, MPAIR>;
+  if (C::SMEM > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::SMEM);
+    if (e != hipSuccess) { dp_set_error("wgrad_tiled: cannot raise dynamic LDS to %zu: %s", C::SMEM, hipGetErrorString(e)); return 1; }
+  }
+  g.tiles_h = cdiv(g.H, C::TH); g.tiles_w = cdiv(g.W, C::TW);
+  g.MT = cdiv(g.Cin, C::XC); g.NTn = cdiv(g.Cout, C::GC); g.KHG = cdiv(C::JHN, C::WKH);
+  int zdim = g.MT * g.NTn * g.KHG;
+  int units = g.N * g.D * g.tiles_h;
+  int want = (256 * 3) / (KS * zdim); if (want < 1) want = 1;     // ~3 blocks per CU in total
+  int ydim = units < want ? units : want;
+  dim3 grid(KS, ydim, zdim);
+  if (zdim > 65535) { dp_set_error("wgrad_tiled: too many channel tiles"); return 1; }
+  hipLaunchKernelGGL(kern, grid, dim3(256), C::SMEM, s, (const T*)x, (const T*)gy, ws, g);
+  return 0;
+}
+
+// ws: fp32 scratch of dp_conv3d_wgrad_tiled_ws_elems() elements (need not be initialised).  ACCUMULATES into dw.
+extern "C" int dp_conv3d_wgrad_tiled(const void* x, int ldx, const void* gy, int ldgy, float* dw, float* ws, int N, int D, int H, int W,
+                                     int Cin, int Cout, int k, int64_t s_co, int64_t s_ci, int64_t s_tap, int dtype, void* stream) {
+  if (!wgt_applicable(Cin, Cout, k, 1, k / 2, 1, 1, W)) DP_FAIL("wgrad_tiled: shape not supported");
+  hipStream_t s = STREAM;
+  int taps = k * k * k;
+  hipError_t me = hipMemsetAsync(ws, 0, (size_t)taps * Cin * Cout * sizeof(float), s);
+  if (me != hipSuccess) DP_FAIL("wgrad_tiled: memset failed: %s", hipGetErrorString(me));
+  WgtGeom g; g.N = N; g.D = D; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.ldx = ldx; g.ldgy = ldgy;
+  const int np = Cout <= 16 ? 2 : 1, mp = Cin <= 16 ? 2 : 1;
+  int rc = 0;
+#define GO(TT, KS_) do { if (np == 2 && mp == 2) rc = launch_wgt<TT, KS_, 2, 2>(x, gy, ws, g, s); else if (np == 2) rc = launch_wgt<TT, KS_, 2, 1>(x, gy, ws, g, s); \
+                         else if (mp == 2) rc = launch_wgt<TT, KS_, 1, 2>(x, gy, ws, g, s); else rc = launch_wgt<TT, KS_, 1, 1>(x, gy, ws, g, s); } while (0)
+  if (dtype == DP_BF16) { if (k == 7) GO(bf16_t, 7); else GO(bf16_t, 3); }
+  else if (dtype == DP_F32) { if (k == 7) GO(float, 7); else GO(float, 3); }
+  else DP_FAIL("wgrad_tiled: bad dtype");
+#undef GO
+  if (rc) return rc;
+  DP_CHECK_LAUNCH("wgrad_tiled");
+  int64_t total = (int64_t)taps * Cin * Cout;
+  int gb = (int)((total + 255) / 256); if (gb > 4096) gb = 4096;
+  hipLaunchKernelGGL(k_wgrad_unpack, dim3(gb), dim3(256), 0, s, ws, dw, taps, Cin, Cout, s_co, s_ci, s_tap);
+  DP_CHECK_LAUNCH("wgrad_unpack"); return 0;
+}

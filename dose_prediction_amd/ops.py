@@ -344,8 +344,14 @@ class Conv3d(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             gw = torch.zeros(weight.shape, dtype=torch.float32, device=x.device)
             taps = k * k * k
-            wgrad(x, ldx, gy, ldg, gw, (N, Di, Hi, Wi, Do, Ho, Wo), cin, cout, k, stride, pad, dil, 1, 0,
-                  cin * taps, taps, 1, dtc)
+            wse = _lib.lib().dp_conv3d_wgrad_tiled_ws_elems(cin, cout, k, stride, pad, dil, 1, Wo) if (USE_TILED and k > 1) else 0
+            if wse:
+                ws = torch.empty((wse,), dtype=torch.float32, device=x.device)
+                _lib.call("dp_conv3d_wgrad_tiled", _p(x), ldx, _p(gy), ldg, _p(gw), _p(ws), N, Di, Hi, Wi, cin, cout, k,
+                          cin * taps, taps, 1, dtc, _stream())
+            else:
+                wgrad(x, ldx, gy, ldg, gw, (N, Di, Hi, Wi, Do, Ho, Wo), cin, cout, k, stride, pad, dil, 1, 0,
+                      cin * taps, taps, 1, dtc)
         if has_bias and ctx.needs_input_grad[2]:
             gb = torch.zeros((cout,), dtype=torch.float32, device=x.device)
             colsum_into(_p(gy), ldg, grows, cout, gb, dtc)

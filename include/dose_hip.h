@@ -144,6 +144,13 @@ int dp_conv3d_wgrad(const void* x, int ldx, const void* gy, int ldgy, float* dw,
                     int k, int stride, int pad, int dil, int shift, int gy_tap_choff,
                     int64_t s_co, int64_t s_ci, int64_t s_tap, int dtype, void* stream);
 
+/* LDS-tiled weight gradient for the hot layers (stride 1, dilation 1, "same" padding, k in {3,7}).
+ * dp_conv3d_wgrad_tiled_ws_elems: fp32 scratch elements needed, or 0 when the shape must take dp_conv3d_wgrad (NOT an error
+ * code).  dp_conv3d_wgrad_tiled ACCUMULATES into dw[co*s_co + ci*s_ci + tap*s_tap]; ws need not be initialised. */
+int dp_conv3d_wgrad_tiled_ws_elems(int Cin, int Cout, int k, int stride, int pad, int dil, int shift, int W);
+int dp_conv3d_wgrad_tiled(const void* x, int ldx, const void* gy, int ldgy, float* dw, float* ws, int N, int D, int H, int W,
+                          int Cin, int Cout, int k, int64_t s_co, int64_t s_ci, int64_t s_tap, int dtype, void* stream);
+
 /* ---- cascade glue ----------------------------------------------------------------------------- */
 /* replaces: AsDiscrete(argmax=True, to_onehot=True) + channel concat (train_light_linked_model.py:157-167):
  * logits NDHWC [rows][ld] (C classes) -> one-hot of the arg-max (first max wins, as torch.argmax) for classes
