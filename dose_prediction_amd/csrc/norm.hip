@@ -72,32 +72,54 @@ extern "C" int dp_stats_partial(const void* x, int ld, int N, int64_t V, int C, 
   DP_CHECK_LAUNCH("stats_partial"); return 0;
 }
 
-__global__ void k_stats_finalize(const float* __restrict__ part, int N, int nblk, int C, int64_t V, int batch_mode, float eps,
-                                 float* mean, float* rstd, float* rmean, float* rvar, float momentum) {
-  int groups = batch_mode ? 1 : N;
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= groups * C) return;
-  int gidx = i / C, c = i - gidx * C;
-  double s1 = 0, s2 = 0;
-  int n0 = batch_mode ? 0 : gidx, n1 = batch_mode ? N : gidx + 1;
-  for (int n = n0; n < n1; n++) for (int b = 0; b < nblk; b++) {
-    const float* p = part + ((int64_t)n * nblk + b) * 2 * C;
-    s1 += p[c]; s2 += p[C + c];
+// Parallel fp64 combine of the per-block partials: one 256-thread block per (statistics group, 16/32-channel slice);
+// threads are arranged [rows][channels] so every partial row is read coalesced, then the rows are tree-reduced in LDS.
+template <int DUMMY>
+__device__ __forceinline__ void combine_partials(const float* __restrict__ part, int n0, int n1, int nblk, int C, int c0, int cpb,
+                                                 double& s1, double& s2, double* red) {
+  const int t = threadIdx.x, cc = t % cpb, r = t / cpb, rows = 256 / cpb, c = c0 + cc;
+  double a1 = 0, a2 = 0;
+  if (c < C) {
+    const int64_t total = (int64_t)(n1 - n0) * nblk;
+    for (int64_t b = r; b < total; b += rows) {
+      const float* p = part + ((int64_t)n0 * nblk + b) * 2 * C;
+      a1 += p[c]; a2 += p[C + c];
+    }
   }
+  red[t * 2] = a1; red[t * 2 + 1] = a2;
+  __syncthreads();
+  for (int st = rows / 2; st > 0; st >>= 1) {
+    if (r < st) { red[t * 2] += red[(t + st * cpb) * 2]; red[t * 2 + 1] += red[(t + st * cpb) * 2 + 1]; }
+    __syncthreads();
+  }
+  s1 = red[cc * 2]; s2 = red[cc * 2 + 1];
+}
+
+__global__ void __launch_bounds__(256) k_stats_finalize(const float* __restrict__ part, int N, int nblk, int C, int64_t V, int batch_mode, float eps,
+                                                        float* mean, float* rstd, float* rmean, float* rvar, float momentum, int cpb) {
+  __shared__ double red[512];
+  const int gidx = blockIdx.y, c0 = blockIdx.x * cpb;
+  const int n0 = batch_mode ? 0 : gidx, n1 = batch_mode ? N : gidx + 1;
+  double s1, s2;
+  combine_partials<0>(part, n0, n1, nblk, C, c0, cpb, s1, s2, red);
+  const int c = c0 + threadIdx.x;
+  if (threadIdx.x >= cpb || c >= C) return;
   double cnt = (double)V * (n1 - n0);
   double m = s1 / cnt, var = s2 / cnt - m * m;
   if (var < 0) var = 0;
-  mean[i] = (float)m; rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+  mean[gidx * C + c] = (float)m; rstd[gidx * C + c] = (float)(1.0 / sqrt(var + (double)eps));
   if (rmean && batch_mode) {
     double unb = cnt > 1 ? var * cnt / (cnt - 1) : var;
     rmean[c] = (float)((1.0 - momentum) * rmean[c] + momentum * m);
     rvar[c] = (float)((1.0 - momentum) * rvar[c] + momentum * unb);
   }
 }
+static inline int pick_cpb(int C) { return C >= 32 ? 32 : (C >= 16 ? 16 : 8); }
 extern "C" int dp_stats_finalize(const float* part, int N, int nblk, int C, int64_t V, int batch_mode, float eps, float* mean, float* rstd,
                                  float* running_mean, float* running_var, float momentum, void* stream) {
-  int total = (batch_mode ? 1 : N) * C;
-  hipLaunchKernelGGL(k_stats_finalize, dim3(cdiv(total, 128)), dim3(128), 0, STREAM, part, N, nblk, C, V, batch_mode, eps, mean, rstd, running_mean, running_var, momentum);
+  int cpb = pick_cpb(C);
+  hipLaunchKernelGGL(k_stats_finalize, dim3(cdiv(C, cpb), batch_mode ? 1 : N), dim3(256), 0, STREAM, part, N, nblk, C, V, batch_mode, eps, mean, rstd,
+                     running_mean, running_var, momentum, cpb);
   DP_CHECK_LAUNCH("stats_finalize"); return 0;
 }
 
@@ -179,22 +201,23 @@ extern "C" int dp_norm_act_bwd_partial(const void* x, int ldx, const void* gy, i
   DP_CHECK_LAUNCH("norm_act_bwd_partial"); return 0;
 }
 
-__global__ void k_norm_bwd_finalize(const float* __restrict__ part, int N, int nblk, int C, int batch_mode, float* s1, float* s2, float* dgamma, float* dbeta) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double t1 = 0, t2 = 0;
-  for (int n = 0; n < N; n++) {
-    double a1 = 0, a2 = 0;
-    for (int b = 0; b < nblk; b++) { const float* p = part + ((int64_t)n * nblk + b) * 2 * C; a1 += p[c]; a2 += p[C + c]; }
-    if (!batch_mode) { s1[n * C + c] = (float)a1; s2[n * C + c] = (float)a2; }
-    t1 += a1; t2 += a2;
-  }
-  if (batch_mode) { s1[c] = (float)t1; s2[c] = (float)t2; }
-  if (dgamma) dgamma[c] += (float)t2;
-  if (dbeta) dbeta[c] += (float)t1;
+__global__ void __launch_bounds__(256) k_norm_bwd_finalize(const float* __restrict__ part, int N, int nblk, int C, int batch_mode, float* s1o, float* s2o,
+                                                           float* dgamma, float* dbeta, int cpb) {
+  __shared__ double red[512];
+  const int gidx = blockIdx.y, c0 = blockIdx.x * cpb;
+  const int n0 = batch_mode ? 0 : gidx, n1 = batch_mode ? N : gidx + 1;
+  double s1, s2;
+  combine_partials<0>(part, n0, n1, nblk, C, c0, cpb, s1, s2, red);
+  const int c = c0 + threadIdx.x;
+  if (threadIdx.x >= cpb || c >= C) return;
+  s1o[gidx * C + c] = (float)s1; s2o[gidx * C + c] = (float)s2;
+  // dgamma / dbeta are sums over ALL samples: one add per statistics group (N is small)
+  if (dgamma) atomicAdd(dgamma + c, (float)s2);
+  if (dbeta) atomicAdd(dbeta + c, (float)s1);
 }
 extern "C" int dp_norm_bwd_finalize(const float* part, int N, int nblk, int C, int batch_mode, float* s1, float* s2, float* dgamma, float* dbeta, void* stream) {
-  hipLaunchKernelGGL(k_norm_bwd_finalize, dim3(cdiv(C, 128)), dim3(128), 0, STREAM, part, N, nblk, C, batch_mode, s1, s2, dgamma, dbeta);
+  int cpb = pick_cpb(C);
+  hipLaunchKernelGGL(k_norm_bwd_finalize, dim3(cdiv(C, cpb), batch_mode ? 1 : N), dim3(256), 0, STREAM, part, N, nblk, C, batch_mode, s1, s2, dgamma, dbeta, cpb);
   DP_CHECK_LAUNCH("norm_bwd_finalize"); return 0;
 }
 
