@@ -1,0 +1,2 @@
+"""Drop-in for the reference's OARSegmentation/Models/Nets/base_blocks.py (the classes the networks instantiate)."""
+from dose_prediction_amd.models.base_blocks import ModifiedUnetrUpBlock, ModifiedUnetOutBlock, MultiUnetBasicBlock  # noqa: F401
