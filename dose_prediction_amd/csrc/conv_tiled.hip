@@ -15,6 +15,7 @@
 // straight from global/L2 (one 16-byte load per lane per tap, reused over RW rows), A fragments are single
 // ds_read_b128 of 8 consecutive channels of one voxel.
 #include "common.h"
+#include <stdlib.h>
 
 #define STREAM ((hipStream_t)stream)
 typedef float v16f __attribute__((ext_vector_type(16)));
@@ -89,11 +90,16 @@ extern "C" int dp_pack_conv_weight_tiled(const float* w, void* dst, int Cout, in
 
 // ---------------------------------------------------------------------------------------------- the kernel
 template <typename T, int KS, int NPAIR, int RW, int NT>
-__global__ void __launch_bounds__(256) k_conv_tiled(const T* __restrict__ x, const T* __restrict__ wq, const float* __restrict__ bias,
+__global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, const T* __restrict__ wq, const float* __restrict__ bias,
                                                     T* __restrict__ y, TiledGeom g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* slab = (T*)smem_raw;
   constexpr int PAD = KS / 2, JH = NPAIR == 2 ? (KS + 1) / 2 : KS, RWO = RW - (NPAIR - 1), NTAP = JH * KS, CK = 16;
+  // bf16: a voxel is 32 B (two 16-B halves); a ds_read_b128 lane group only ever asks for ONE half of 16 voxels, i.e. 8 of
+  // the 16 slots of the 256-B bank row twice (2-way conflict).  Storing the halves of every other run of 8 voxels swapped
+  // (half ^= bit 3 of the voxel index; LP is a multiple of 8, so rows differ by a known parity) spreads a
+  // group over all 16 slots.
+  constexpr bool SWZ = sizeof(T) == 2;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 31, hh = lane >> 5;
   const int wc = wv % g.TWC, rg = wv / g.TWC;
   int b = blockIdx.x;
@@ -112,42 +118,73 @@ __global__ void __launch_bounds__(256) k_conv_tiled(const T* __restrict__ x, con
   const int pieces = g.LR * g.LP * 2;              // 8-channel pieces of the slab
   const int64_t wtap_stride = (int64_t)g.NCH * g.NTT * 512;      // elements between consecutive (kd,jh,kw) taps
   // lane-constant part of the A address: position (wc*32 + r), channel half hh, first row of this wave's row group
-  const int a_lane = ((rg * RWO) * g.LP + wc * 32 + r) * CK + hh * 8;
+  const int v_lane = (rg * RWO) * g.LP + wc * 32 + r;
+  // fast staging path: bf16, whole 16-channel chunks, 16-byte aligned voxel rows (block-uniform)
+  constexpr int SU = 6;
+  const bool fast = SWZ && (g.Cin % 16 == 0) && (g.ldx % 8 == 0) && (((uintptr_t)x & 15) == 0);
+  const int lp_par = SWZ ? ((g.LP >> 3) & 1) : 0;
+  const int st_half = tid & 1, st_lp0 = (tid >> 1) % g.LP, st_lr0 = (tid >> 1) / g.LP;
 
   for (int kd = 0; kd < KS; kd++) {
     const int id = d + kd - PAD;
     if (id < 0 || id >= g.D) continue;             // block-uniform: the whole depth slice is zero padding
     for (int ch = 0; ch < g.NCH; ch++) {
       __syncthreads();
-      for (int p = tid; p < pieces; p += 256) {
-        int half = p & 1, v = p >> 1, lp = v % g.LP, lr = v / g.LP;
-        int ih = h0 - PAD + lr, iw = w0 - PAD + lp, c = ch * CK + half * 8;
-        int nv = g.Cin - c; nv = nv > 8 ? 8 : nv;
-        bool ok = ih >= 0 && ih < g.H && iw >= 0 && iw < g.W && nv > 0;
-        Frag8<T> f = ok ? frag_load(x + ((((int64_t)n * g.D + id) * g.H + ih) * g.W + iw) * g.ldx + c, nv) : frag_zero<T>();
-        frag_st_lds(slab + (int64_t)v * CK + half * 8, f);
+      if (fast) {
+        // straight-line staging: SU independent 16-byte loads are in flight before the first LDS store (a per-piece
+        // load->store loop serialises on HBM/L2 latency and dominated the kernel); voxel coordinates advance incrementally
+        // (256 threads = 128 voxels per step), no divisions in the loop.
+        const T* xplane = x + (((int64_t)n * g.D + id) * g.H) * (int64_t)g.W * g.ldx + ch * CK + st_half * 8;
+        int lp = st_lp0, lr = st_lr0, v = tid >> 1;
+        for (int p0 = 0; p0 < pieces; p0 += 256 * SU) {
+          v4u buf[SU]; int vv[SU];
+#pragma unroll
+          for (int j = 0; j < SU; j++) {
+            const int ih = h0 - PAD + lr, iw = w0 - PAD + lp;
+            const bool ok = (p0 + j * 256 + tid < pieces) && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W;
+            const T* src = xplane + ((int64_t)(ok ? ih : 0) * g.W + (ok ? iw : 0)) * g.ldx;
+            v4u t = *(const v4u*)src;
+            buf[j] = ok ? t : (v4u){0, 0, 0, 0};
+            vv[j] = (p0 + j * 256 + tid < pieces) ? v : -1;
+            v += 128; lp += 128; while (lp >= g.LP) { lp -= g.LP; lr++; }
+          }
+#pragma unroll
+          for (int j = 0; j < SU; j++)
+            if (vv[j] >= 0) *(v4u*)(slab + (int64_t)vv[j] * CK + (st_half ^ ((vv[j] >> 3) & 1)) * 8) = buf[j];
+        }
+      } else {
+        for (int p = tid; p < pieces; p += 256) {
+          int half = p & 1, v = p >> 1, lp = v % g.LP, lr = v / g.LP;
+          int ih = h0 - PAD + lr, iw = w0 - PAD + lp, c = ch * CK + half * 8;
+          int nv = g.Cin - c; nv = nv > 8 ? 8 : nv;
+          bool ok = ih >= 0 && ih < g.H && iw >= 0 && iw < g.W && nv > 0;
+          Frag8<T> f = ok ? frag_load(x + ((((int64_t)n * g.D + id) * g.H + ih) * g.W + iw) * g.ldx + c, nv) : frag_zero<T>();
+          frag_st_lds(slab + (int64_t)v * CK + (half ^ (SWZ ? ((v >> 3) & 1) : 0)) * 8, f);
+        }
       }
       __syncthreads();
       const T* wbase = wq + ((int64_t)kd * NTAP * g.NCH + ch) * g.NTT * 512 + (int64_t)nt0 * 512 + r * 16 + hh * 8;
-      Frag8<T> bcur[NT], bnext[NT];
+      Frag8<T> bcur[NT], bnext[NT], bnext2[NT];
 #pragma unroll
-      for (int j = 0; j < NT; j++) bcur[j] = frag_load(wbase + j * 512, 8);
+      for (int j = 0; j < NT; j++) { bcur[j] = frag_load(wbase + j * 512, 8); bnext[j] = frag_load(wbase + wtap_stride + j * 512, 8); }
 #pragma unroll 1
       for (int tt = 0; tt < NTAP; tt++) {
         const int jh = tt / KS, kw = tt - jh * KS;
-        if (tt + 1 < NTAP) {
+        if (tt + 2 < NTAP) {                      // weights are fetched two taps ahead (L2 latency ~ one tap of MFMAs)
 #pragma unroll
-          for (int j = 0; j < NT; j++) bnext[j] = frag_load(wbase + (int64_t)(tt + 1) * wtap_stride + j * 512, 8);
+          for (int j = 0; j < NT; j++) bnext2[j] = frag_load(wbase + (int64_t)(tt + 2) * wtap_stride + j * 512, 8);
         }
-        const int a_tap = a_lane + ((NPAIR == 2 ? 2 * jh : jh) * g.LP + kw) * CK;
+        const int v_tap = v_lane + (NPAIR == 2 ? 2 * jh : jh) * g.LP + kw;
+        const int sw0 = SWZ ? (hh ^ ((v_tap >> 3) & 1)) : hh;
+        const int a_even = v_tap * CK + sw0 * 8, a_odd = v_tap * CK + (sw0 ^ lp_par) * 8;   // odd rows flip the half iff LP/8 is odd
 #pragma unroll
         for (int i = 0; i < RW; i++) {
-          Frag8<T> fa = frag_ld_lds(slab + a_tap + i * g.LP * CK);
+          Frag8<T> fa = frag_ld_lds(slab + ((i & 1) ? a_odd : a_even) + i * g.LP * CK);
 #pragma unroll
           for (int j = 0; j < NT; j++) acc[i][j] = mma32(fa, bcur[j], acc[i][j]);
         }
 #pragma unroll
-        for (int j = 0; j < NT; j++) bcur[j] = bnext[j];
+        for (int j = 0; j < NT; j++) { bcur[j] = bnext[j]; bnext[j] = bnext2[j]; }
       }
     }
   }
@@ -197,6 +234,11 @@ static int launch_tiled(const void* x, const void* wq, const float* bias, void* 
     if (e != hipSuccess) { dp_set_error("conv3d_tiled: cannot raise dynamic LDS to %zu: %s", smem, hipGetErrorString(e)); return 1; }
   }
   dim3 grid(g.N * g.D * g.tiles_h * g.tiles_w, ygrid);
+  if (getenv("DP_DEBUG_OCC")) {
+    int nb = -1; hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, 256, smem);
+    fprintf(stderr, "[dp] conv_tiled KS=%d NPAIR=%d RW=%d NT=%d smem=%zu grid=%u x %u occupancy(blocks/CU)=%d (%s)\n", KS, NPAIR, RW, NT, smem, grid.x, grid.y, nb,
+            hipGetErrorString(e));
+  }
   hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, (const T*)x, (const T*)wq, bias, (T*)y, g);
   return 0;
 }
@@ -211,7 +253,7 @@ extern "C" int dp_conv3d_tiled(const void* x, int ldx, const void* wq, const flo
   g.N = N; g.D = D; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.ldx = ldx; g.ldy = ldy;
   if (W > 64) { g.TWC = 4; g.TRG = 1; } else if (W > 32) { g.TWC = 2; g.TRG = 2; } else { g.TWC = 1; g.TRG = 4; }
   g.LR = g.TRG * rwo + (np - 1) + (np == 2 ? 2 * (JH - 1) : k - 1);
-  g.LP = g.TWC * 32 + k - 1;
+  g.LP = (g.TWC * 32 + k - 1 + 7) & ~7;       // multiple of 8: the LDS swizzle bit of a row then differs from row 0 by (row * LP/8) & 1
   g.NCH = (Cin + 15) / 16; g.NTT = (Cout * np + 31) / 32;
   g.tiles_h = cdiv(H, g.TRG * rwo); g.tiles_w = cdiv(W, g.TWC * 32);
   int ygrid = cdiv(g.NTT, nt);
@@ -292,7 +334,7 @@ __device__ __forceinline__ Frag8<float> ld_kmajor32(const float* img, int vox_lo
 }
 
 template <typename T, int KS, int NPAIR, int MPAIR>
-__global__ void __launch_bounds__(256) k_wgrad_tiled(const T* __restrict__ x, const T* __restrict__ gy, float* __restrict__ dwt, WgtGeom g) {
+__global__ void __launch_bounds__(256, 2) k_wgrad_tiled(const T* __restrict__ x, const T* __restrict__ gy, float* __restrict__ dwt, WgtGeom g) {
   using C = WgtCfg<T, KS, NPAIR, MPAIR>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* xs = (T*)smem_raw;

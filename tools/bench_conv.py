@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the conv kernels on the DOSE-PYFER layer shapes (HIP events on the launch stream).
+usage: python tools/bench_conv.py [fwd|wgrad|all] [--dtype bf16|fp32]"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dose_prediction_amd import ops, _lib  # noqa: E402
+
+# (name, N, Cin, Cout, S, k)   S^3 volume
+SHAPES = [
+    ("dec1.c7a 32->16 @128", 2, 32, 16, 128, 7), ("dec1.c7b 16->16 @128", 2, 16, 16, 128, 7),
+    ("dec1.c7a.dgrad 16->32 @128", 2, 16, 32, 128, 7),
+    ("dec2.c7a 64->32 @64", 2, 64, 32, 64, 7), ("dec2.c7b 32->32 @64", 2, 32, 32, 64, 7), ("dec2.dgrad 32->64 @64", 2, 32, 64, 64, 7),
+    ("dec3.c7a 128->64 @32", 2, 128, 64, 32, 7), ("dec3.c7b 64->64 @32", 2, 64, 64, 32, 7),
+    ("dec4.c7a 256->128 @16", 2, 256, 128, 16, 7), ("dec4.c7b 128->128 @16", 2, 128, 128, 16, 7),
+    ("c3 32->16 @128", 2, 32, 16, 128, 3), ("c3 16->16 @128", 2, 16, 16, 128, 3), ("c3 25->16 @128", 2, 32, 16, 128, 3),
+    ("c3 64->32 @64", 2, 64, 32, 64, 3), ("c3 32->32 @64", 2, 32, 32, 64, 3), ("c3 64->64 @32", 2, 64, 64, 32, 3),
+]
+
+
+def timeit(fn, iters=5):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("what", nargs="?", default="all")
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--filter", default="")
+    a = ap.parse_args()
+    dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    dev = torch.device("cuda:0")
+    for name, N, ci, co, S, k in SHAPES:
+        if a.filter and a.filter not in name:
+            continue
+        x = torch.randn((N, S, S, S, ci), device=dev).to(dt)
+        gy = torch.randn((N, S, S, S, co), device=dev).to(dt)
+        w = (torch.randn((co, ci, k, k, k), device=dev) * (ci * k ** 3) ** -0.5).requires_grad_(True)
+        fl = 2.0 * N * S ** 3 * ci * co * k ** 3
+        line = f"{name:28s}"
+        if a.what in ("fwd", "all"):
+            with torch.no_grad():
+                ms = timeit(lambda: ops.conv3d(x, w, None, 1, k // 2, 1))
+            line += f"  fwd {ms:7.3f} ms {fl / ms / 1e9:7.1f} TF"
+        if a.what in ("wgrad", "all"):
+            def wg():
+                gw = torch.zeros(w.shape, dtype=torch.float32, device=dev)
+                taps = k ** 3
+                wse = _lib.lib().dp_conv3d_wgrad_tiled_ws_elems(ci, co, k, 1, k // 2, 1, 1, S)
+                ws = torch.empty((wse,), dtype=torch.float32, device=dev)
+                _lib.call("dp_conv3d_wgrad_tiled", x.data_ptr(), ci, gy.data_ptr(), co, gw.data_ptr(), ws.data_ptr(), N, S, S, S,
+                          ci, co, k, ci * taps, taps, 1, 1 if dt == torch.bfloat16 else 0, torch.cuda.current_stream().cuda_stream)
+            ms = timeit(wg)
+            line += f"  wgrad {ms:7.3f} ms {fl / ms / 1e9:7.1f} TF"
+        print(line, flush=True)
+
+
+if __name__ == "__main__":
+    main()
