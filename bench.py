@@ -65,8 +65,8 @@ def conv_flops(args_):
 
 
 def tiled_flops(args_):
-    # dp_conv3d_tiled(x, ldx, wq, bias, y, ldy, N, D, H, W, Cin, Cout, k, dtype, stream)
-    N, D, H, W, Cin, Cout, k = args_[6:13]
+    # dp_conv3d_tiled(x, ldx, wq, bias, y, ldy, ws, N, D, H, W, Cin, Cout, k, dtype, stream)
+    N, D, H, W, Cin, Cout, k = args_[7:14]
     return 2.0 * N * D * H * W * Cin * Cout * k ** 3, k
 
 

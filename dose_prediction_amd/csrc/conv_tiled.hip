@@ -36,6 +36,7 @@ struct TiledGeom {
   int NCH;             // 16-channel chunks of Cin
   int NTT;             // total 32-column N tiles in the packed weights
   int tiles_h, tiles_w;
+  int splitkd;         // 1: blockIdx.z selects ONE kd; results are atomically accumulated into the fp32 scratch `ws`
 };
 
 // ---------------------------------------------------------------------------------------------- weight packing
@@ -89,9 +90,10 @@ extern "C" int dp_pack_conv_weight_tiled(const float* w, void* dst, int Cout, in
 }
 
 // ---------------------------------------------------------------------------------------------- the kernel
-template <typename T, int KS, int NPAIR, int RW, int NT>
+// W16: volumes with W <= 16 -- one 32-row MFMA tile covers TWO image rows x 16 positions (NPAIR == 1 only).
+template <typename T, int KS, int NPAIR, int RW, int NT, bool W16>
 __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, const T* __restrict__ wq, const float* __restrict__ bias,
-                                                    T* __restrict__ y, TiledGeom g) {
+                                                    T* __restrict__ y, float* __restrict__ ws, TiledGeom g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* slab = (T*)smem_raw;
   constexpr int PAD = KS / 2, JH = NPAIR == 2 ? (KS + 1) / 2 : KS, RWO = RW - (NPAIR - 1), NTAP = JH * KS, CK = 16;
@@ -104,7 +106,8 @@ __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, 
   const int wc = wv % g.TWC, rg = wv / g.TWC;
   int b = blockIdx.x;
   const int tw = b % g.tiles_w; b /= g.tiles_w; const int th = b % g.tiles_h; b /= g.tiles_h; const int d = b % g.D; const int n = b / g.D;
-  const int h0 = th * (g.TRG * RWO), w0 = tw * (g.TWC * 32);
+  constexpr int RPA = W16 ? 2 : 1;                 // image rows per accumulator row
+  const int h0 = th * (g.TRG * RWO * RPA), w0 = W16 ? 0 : tw * (g.TWC * 32);
   const int nt0 = blockIdx.y * NT;                 // first N tile of this block
 
   v16f acc[RW][NT];
@@ -118,14 +121,15 @@ __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, 
   const int pieces = g.LR * g.LP * 2;              // 8-channel pieces of the slab
   const int64_t wtap_stride = (int64_t)g.NCH * g.NTT * 512;      // elements between consecutive (kd,jh,kw) taps
   // lane-constant part of the A address: position (wc*32 + r), channel half hh, first row of this wave's row group
-  const int v_lane = (rg * RWO) * g.LP + wc * 32 + r;
+  const int v_lane = W16 ? (rg * RWO * 2 + (r >> 4)) * g.LP + (r & 15) : (rg * RWO) * g.LP + wc * 32 + r;
   // fast staging path: bf16, whole 16-channel chunks, 16-byte aligned voxel rows (block-uniform)
   constexpr int SU = 6;
   const bool fast = SWZ && (g.Cin % 16 == 0) && (g.ldx % 8 == 0) && (((uintptr_t)x & 15) == 0);
   const int lp_par = SWZ ? ((g.LP >> 3) & 1) : 0;
   const int st_half = tid & 1, st_lp0 = (tid >> 1) % g.LP, st_lr0 = (tid >> 1) / g.LP;
 
-  for (int kd = 0; kd < KS; kd++) {
+  const int kd_lo = g.splitkd ? (int)blockIdx.z : 0, kd_hi = g.splitkd ? kd_lo + 1 : KS;
+  for (int kd = kd_lo; kd < kd_hi; kd++) {
     const int id = d + kd - PAD;
     if (id < 0 || id >= g.D) continue;             // block-uniform: the whole depth slice is zero padding
     for (int ch = 0; ch < g.NCH; ch++) {
@@ -179,7 +183,8 @@ __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, 
         const int a_even = v_tap * CK + sw0 * 8, a_odd = v_tap * CK + (sw0 ^ lp_par) * 8;   // odd rows flip the half iff LP/8 is odd
 #pragma unroll
         for (int i = 0; i < RW; i++) {
-          Frag8<T> fa = frag_ld_lds(slab + ((i & 1) ? a_odd : a_even) + i * g.LP * CK);
+          Frag8<T> fa = W16 ? frag_ld_lds(slab + a_even + 2 * i * g.LP * CK)      // two image rows per step: parity unchanged
+                            : frag_ld_lds(slab + ((i & 1) ? a_odd : a_even) + i * g.LP * CK);
 #pragma unroll
           for (int j = 0; j < NT; j++) acc[i][j] = mma32(fa, bcur[j], acc[i][j]);
         }
@@ -190,7 +195,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, 
   }
 
   // epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
-  const int hw0 = h0 + rg * RWO, wbase_o = w0 + wc * 32;
+  const int hw0 = h0 + rg * RWO * RPA, wbase_o = w0 + wc * 32;
   if (NPAIR == 2) {
     const int co = lane & 15;
     const bool writer = (lane & 16) == 0 && co < g.Cout;
@@ -210,58 +215,104 @@ __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, 
 #pragma unroll
     for (int j = 0; j < NT; j++) {
       const int co = (nt0 + j) * 32 + r;
-      const float bv = (bias && co < g.Cout) ? bias[co] : 0.f;
+      const float bv = (bias && co < g.Cout && !g.splitkd) ? bias[co] : 0.f;
 #pragma unroll
       for (int i = 0; i < RW; i++) {
-        const int oh = hw0 + i;
 #pragma unroll
         for (int e = 0; e < 16; e++) {
-          int ow = wbase_o + (e & 3) + 8 * (e >> 2) + 4 * hh;
-          if (co < g.Cout && oh < g.H && ow < g.W) st_f(y + ((((int64_t)n * g.D + d) * g.H + oh) * g.W + ow) * g.ldy + co, acc[i][j][e] + bv);
+          const int m = (e & 3) + 8 * (e >> 2) + 4 * hh;
+          const int oh = W16 ? hw0 + 2 * i + (m >> 4) : hw0 + i;
+          const int ow = W16 ? (m & 15) : wbase_o + m;
+          if (co < g.Cout && oh < g.H && ow < g.W) {
+            const int64_t vox = (((int64_t)n * g.D + d) * g.H + oh) * g.W + ow;
+            if (g.splitkd) atomicAdd(ws + vox * g.Cout + co, acc[i][j][e]);
+            else st_f(y + vox * g.ldy + co, acc[i][j][e] + bv);
+          }
         }
       }
     }
   }
 }
 
-template <typename T, int KS, int NPAIR, int RW, int NT>
-static int launch_tiled(const void* x, const void* wq, const float* bias, void* y, TiledGeom g, int ygrid, hipStream_t s) {
+// split-kd epilogue: y = T(ws + bias)
+template <typename T>
+__global__ void k_conv_split_finish(const float* __restrict__ ws, const float* __restrict__ bias, T* __restrict__ y, int64_t rows, int C, int ldy) {
+  int64_t total = rows * C;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t rrow = i / C; int c = (int)(i - rrow * C);
+    st_f(y + rrow * ldy + c, ws[i] + (bias ? bias[c] : 0.f));
+  }
+}
+
+template <typename T, int KS, int NPAIR, int RW, int NT, bool W16>
+static int launch_tiled(const void* x, const void* wq, const float* bias, void* y, float* ws, TiledGeom g, int ygrid, hipStream_t s) {
   size_t smem = (size_t)g.LR * g.LP * 16 * sizeof(T);
-  auto kern = k_conv_tiled<T, KS, NPAIR, RW, NT>;
+  auto kern = k_conv_tiled<T, KS, NPAIR, RW, NT, W16>;
   if (smem > 160 * 1024) { dp_set_error("conv3d_tiled: slab %zu B exceeds LDS", smem); return 1; }
   if (smem > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) { dp_set_error("conv3d_tiled: cannot raise dynamic LDS to %zu: %s", smem, hipGetErrorString(e)); return 1; }
   }
-  dim3 grid(g.N * g.D * g.tiles_h * g.tiles_w, ygrid);
+  dim3 grid(g.N * g.D * g.tiles_h * g.tiles_w, ygrid, g.splitkd ? KS : 1);
   if (getenv("DP_DEBUG_OCC")) {
     int nb = -1; hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, 256, smem);
-    fprintf(stderr, "[dp] conv_tiled KS=%d NPAIR=%d RW=%d NT=%d smem=%zu grid=%u x %u occupancy(blocks/CU)=%d (%s)\n", KS, NPAIR, RW, NT, smem, grid.x, grid.y, nb,
-            hipGetErrorString(e));
+    fprintf(stderr, "[dp] conv_tiled KS=%d NPAIR=%d RW=%d NT=%d W16=%d smem=%zu grid=%u x %u x %u occupancy(blocks/CU)=%d (%s)\n", KS, NPAIR, RW, NT, (int)W16, smem,
+            grid.x, grid.y, grid.z, nb, hipGetErrorString(e));
   }
-  hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, (const T*)x, (const T*)wq, bias, (T*)y, g);
+  if (g.splitkd) {
+    hipError_t me = hipMemsetAsync(ws, 0, (size_t)g.N * g.D * g.H * g.W * g.Cout * sizeof(float), s);
+    if (me != hipSuccess) { dp_set_error("conv3d_tiled: memset failed"); return 1; }
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, (const T*)x, (const T*)wq, bias, (T*)y, ws, g);
+  if (g.splitkd) {
+    int64_t rows = (int64_t)g.N * g.D * g.H * g.W;
+    int gb = (int)((rows * g.Cout + 255) / 256); if (gb > 4096) gb = 4096;
+    hipLaunchKernelGGL(k_conv_split_finish<T>, dim3(gb), dim3(256), 0, s, ws, bias, (T*)y, rows, g.Cout, g.ldy);
+  }
   return 0;
 }
 
+static void tiled_geometry(TiledGeom& g, int k, int np, int rw, int nt, int* ygrid, bool* w16) {
+  int rwo = rw - (np - 1), JH = np == 2 ? (k + 1) / 2 : k;
+  *w16 = (g.W <= 16 && np == 1);
+  if (*w16) { g.TWC = 1; g.TRG = 4; } else if (g.W > 64) { g.TWC = 4; g.TRG = 1; } else if (g.W > 32) { g.TWC = 2; g.TRG = 2; } else { g.TWC = 1; g.TRG = 4; }
+  int rpa = *w16 ? 2 : 1;
+  g.LR = g.TRG * rwo * rpa + (np - 1) + (np == 2 ? 2 * (JH - 1) : k - 1);
+  g.LP = ((*w16 ? 16 : g.TWC * 32) + k - 1 + 7) & ~7;   // multiple of 8: the LDS swizzle bit of a row differs from row 0 by (row * LP/8) & 1
+  g.NCH = (g.Cin + 15) / 16; g.NTT = (g.Cout * np + 31) / 32;
+  g.tiles_h = cdiv(g.H, g.TRG * rwo * rpa); g.tiles_w = *w16 ? 1 : cdiv(g.W, g.TWC * 32);
+  *ygrid = cdiv(g.NTT, nt);
+  int64_t blocks = (int64_t)g.N * g.D * g.tiles_h * g.tiles_w * *ygrid;
+  g.splitkd = (np == 1 && blocks < 400) ? 1 : 0;         // small volumes: one block per kd, fp32 atomic accumulation
+}
+
+// fp32 scratch elements dp_conv3d_tiled needs for this shape (0 = none)
+extern "C" int dp_conv3d_tiled_ws_elems(int N, int D, int H, int W, int Cin, int Cout, int k) {
+  if (!tiled_applicable(Cin, Cout, k, 1, k / 2, 1, W)) return 0;
+  int rw, nt; int np = tiled_config(Cout, &rw, &nt);
+  TiledGeom g; g.N = N; g.D = D; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout;
+  int ygrid; bool w16; tiled_geometry(g, k, np, rw, nt, &ygrid, &w16);
+  if (!g.splitkd) return 0;
+  int64_t e = (int64_t)N * D * H * W * Cout;
+  return e > 2000000000LL ? -1 : (int)e;
+}
+
 // Tiled convolution with weights packed by dp_pack_conv_weight_tiled.  Same-size output ("same" padding).
-extern "C" int dp_conv3d_tiled(const void* x, int ldx, const void* wq, const float* bias, void* y, int ldy, int N, int D, int H, int W,
+// ws: fp32 scratch of dp_conv3d_tiled_ws_elems() elements (may be NULL when that is 0).
+extern "C" int dp_conv3d_tiled(const void* x, int ldx, const void* wq, const float* bias, void* y, int ldy, float* ws, int N, int D, int H, int W,
                                int Cin, int Cout, int k, int dtype, void* stream) {
   if (!tiled_applicable(Cin, Cout, k, 1, k / 2, 1, W)) DP_FAIL("conv3d_tiled: shape not supported");
   int rw, nt; int np = tiled_config(Cout, &rw, &nt);
-  int rwo = rw - (np - 1), JH = np == 2 ? (k + 1) / 2 : k;
   TiledGeom g;
   g.N = N; g.D = D; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.ldx = ldx; g.ldy = ldy;
-  if (W > 64) { g.TWC = 4; g.TRG = 1; } else if (W > 32) { g.TWC = 2; g.TRG = 2; } else { g.TWC = 1; g.TRG = 4; }
-  g.LR = g.TRG * rwo + (np - 1) + (np == 2 ? 2 * (JH - 1) : k - 1);
-  g.LP = (g.TWC * 32 + k - 1 + 7) & ~7;       // multiple of 8: the LDS swizzle bit of a row then differs from row 0 by (row * LP/8) & 1
-  g.NCH = (Cin + 15) / 16; g.NTT = (Cout * np + 31) / 32;
-  g.tiles_h = cdiv(H, g.TRG * rwo); g.tiles_w = cdiv(W, g.TWC * 32);
-  int ygrid = cdiv(g.NTT, nt);
+  int ygrid; bool w16; tiled_geometry(g, k, np, rw, nt, &ygrid, &w16);
+  if (g.splitkd && !ws) DP_FAIL("conv3d_tiled: this shape needs the fp32 scratch (dp_conv3d_tiled_ws_elems)");
   if ((int64_t)N * D * g.tiles_h * g.tiles_w > 2000000000LL) DP_FAIL("conv3d_tiled: grid too large");
   int rc = 0;
   hipStream_t s = STREAM;
-#define GO(TT, KS_, NP, RW_, NT_) rc = launch_tiled<TT, KS_, NP, RW_, NT_>(x, wq, bias, y, g, ygrid, s)
-#define BYCFG(TT, KS_) do { if (np == 2) GO(TT, KS_, 2, 9, 1); else if (nt == 1) GO(TT, KS_, 1, 8, 1); else GO(TT, KS_, 1, 4, 2); } while (0)
+#define GO(TT, KS_, NP, RW_, NT_, W16_) rc = launch_tiled<TT, KS_, NP, RW_, NT_, W16_>(x, wq, bias, y, ws, g, ygrid, s)
+#define BYCFG(TT, KS_) do { if (np == 2) GO(TT, KS_, 2, 9, 1, false); else if (nt == 1) { if (w16) GO(TT, KS_, 1, 8, 1, true); else GO(TT, KS_, 1, 8, 1, false); } \
+                            else { if (w16) GO(TT, KS_, 1, 4, 2, true); else GO(TT, KS_, 1, 4, 2, false); } } while (0)
   if (dtype == DP_BF16) { if (k == 7) BYCFG(bf16_t, 7); else BYCFG(bf16_t, 3); }
   else if (dtype == DP_F32) { if (k == 7) BYCFG(float, 7); else BYCFG(float, 3); }
   else DP_FAIL("conv3d_tiled: bad dtype");

@@ -111,6 +111,13 @@ def _tiled_elems(cin, cout, k, stride, pad, dil, W):
     return _lib.lib().dp_conv3d_tiled_weight_elems(cin, cout, k, stride, pad, dil, W)
 
 
+def _tiled_ws(like, N, D, H, W, cin, cout, k):
+    n = _lib.lib().dp_conv3d_tiled_ws_elems(N, D, H, W, cin, cout, k)
+    if n < 0:
+        raise _lib.DoseHipError("conv3d_tiled: scratch too large")
+    return torch.empty((n,), dtype=torch.float32, device=like.device) if n else None
+
+
 def _pack_conv_tiled(w, tf, dtype, elems):
     """Weights for the LDS-tiled conv kernel (tf=1: transposed+flipped, i.e. the data-gradient convolution)."""
     def build():
@@ -298,7 +305,8 @@ class Conv3d(torch.autograd.Function):
         te = _tiled_elems(cin, cout, k, stride, pad, dil, Wi) if k > 1 else 0
         if te:
             wq = _pack_conv_tiled(weight, 0, x.dtype, te)
-            _lib.call("dp_conv3d_tiled", _p(x), ldx, _p(wq), _p(b32), _p(y), cout, N, Di, Hi, Wi, cin, cout, k, _dt(x), _stream())
+            _lib.call("dp_conv3d_tiled", _p(x), ldx, _p(wq), _p(b32), _p(y), cout, _p(_tiled_ws(x, N, Di, Hi, Wi, cin, cout, k)),
+                      N, Di, Hi, Wi, cin, cout, k, _dt(x), _stream())
         elif k == 1 and stride == 1 and pad == 0:
             wp = _pack_conv(weight, 0, x.dtype)
             gemm_nt(x, wp, y, bias=b32, M=rows, N=cout, K=cin, lda=ldx, ldb=wp.shape[-1], ldc=cout)
@@ -332,7 +340,8 @@ class Conv3d(torch.autograd.Function):
             elif stride == 1 and _tiled_elems(cout, cin, k, 1, dil * (k - 1) - pad, dil, Wo):
                 te = _tiled_elems(cout, cin, k, 1, dil * (k - 1) - pad, dil, Wo)
                 wq = _pack_conv_tiled(weight, 1, x.dtype, te)
-                _lib.call("dp_conv3d_tiled", _p(gy), ldg, _p(wq), 0, _p(gx), cx, N, Do, Ho, Wo, cout, cin, k, dtc, _stream())
+                _lib.call("dp_conv3d_tiled", _p(gy), ldg, _p(wq), 0, _p(gx), cx, _p(_tiled_ws(x, N, Do, Ho, Wo, cout, cin, k)),
+                          N, Do, Ho, Wo, cout, cin, k, dtc, _stream())
             elif stride == 1:
                 wt = _pack_conv(weight, 2, x.dtype)          # transposed + flipped: data gradient as a forward conv
                 _lib.call("dp_conv3d", _p(gy), ldg, _p(wt), 0, _p(gx), cx, N, Do, Ho, Wo, Di, Hi, Wi, cout, cin,

@@ -134,7 +134,9 @@ int dp_conv3d(const void* x, int ldx, const void* wp, const float* bias, void* y
  * shape and 0 when the shape must take dp_conv3d (NOT an error code).  Packed layout: see conv_tiled.hip. */
 int dp_conv3d_tiled_weight_elems(int Cin, int Cout, int k, int stride, int pad, int dil, int W);
 int dp_pack_conv_weight_tiled(const float* w, void* dst, int Cout, int Cin, int k, int transposed_flipped, int dtype, void* stream);
-int dp_conv3d_tiled(const void* x, int ldx, const void* wq, const float* bias, void* y, int ldy, int N, int D, int H, int W,
+/* small volumes split the kd loop over blocks and accumulate in an fp32 scratch: dp_conv3d_tiled_ws_elems gives its size (0 = not needed). */
+int dp_conv3d_tiled_ws_elems(int N, int D, int H, int W, int Cin, int Cout, int k);
+int dp_conv3d_tiled(const void* x, int ldx, const void* wq, const float* bias, void* y, int ldy, float* ws, int N, int D, int H, int W,
                     int Cin, int Cout, int k, int dtype, void* stream);
 /* weight gradient (fp32, ACCUMULATES): for every tap t, co, ci:
  *   dw[co*s_co + ci*s_ci + t*s_tap] += sum_v gy[v][co + t*gy_tap_choff] * x[shift ? v*stride - pad + t*dil : v][ci]
