@@ -355,7 +355,9 @@ struct WgtCfg {
   static constexpr int GR = NPAIR == 2 ? TH + 2 : TH;
   static constexpr int LR = NPAIR == 2 ? TH + 2 * JHN - 1 : TH + KS - 1, LP = TW + KS - 1;
   static constexpr int STEPS = NPAIR == 2 ? TH + 1 : TH;
-  static constexpr size_t SMEM = ((size_t)LR * LP * XC + (size_t)GR * TW * GC) * sizeof(T);
+  // gy row pitch in LDS.  Paired N reads rows i and i+1 in the same instruction: +128 B keeps them on different banks.
+  static constexpr int GRP = TW * GC + (NPAIR == 2 ? 128 / (int)sizeof(T) : 0);
+  static constexpr size_t SMEM = ((size_t)LR * LP * XC + (size_t)GR * GRP) * sizeof(T);
 };
 
 // k-major fragment of a [rows = voxels][pitch] LDS image: lane (col = lane&31, hh = lane>>5) gets, for column `colbase + (col&15)`,
@@ -407,7 +409,10 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_tiled(const T* __restrict__ x,
 #pragma unroll
     for (int e = 0; e < 16; e++) acc[k][e] = 0.f;
 
-  constexpr int XPV = C::XC / 8, GPV = C::GC / 8;
+  constexpr int XPV = C::XC / 8, GPV = C::GC / 8, SU = 6;
+  // fast staging: bf16, whole channel tiles, 16-byte aligned voxel rows (block-uniform)
+  const bool fast = sizeof(T) == 2 && cbase_x + C::XC <= g.Cin && cbase_g + C::GC <= g.Cout && (g.ldx % 8 == 0) && (g.ldgy % 8 == 0) &&
+                    (((uintptr_t)x & 15) == 0) && (((uintptr_t)gy & 15) == 0);
   for (int u = u0; u < u1; u++) {
     const int th = u % g.tiles_h; const int nd = u / g.tiles_h; const int d = nd % g.D, n = nd / g.D;
     const int id = d + kd - C::PAD;
@@ -415,22 +420,68 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_tiled(const T* __restrict__ x,
     const int h0 = th * C::TH;
     for (int tw = 0; tw < g.tiles_w; tw++) {
       const int w0 = tw * C::TW;
+      const int nchk = min(C::NCHK, (g.W - w0 + 15) >> 4);          // 16-voxel chunks that hold real output positions
+      const int lpn = nchk * 16 + KS - 1;                            // slab positions actually read
       __syncthreads();
-      for (int p = tid; p < C::LR * C::LP * XPV; p += 256) {
-        int part = p % XPV, v = p / XPV, lp = v % C::LP, lr = v / C::LP;
-        int ih = h0 - C::PAD + lr, iw = w0 - C::PAD + lp, c = cbase_x + part * 8;
-        int nv = g.Cin - c; nv = nv > 8 ? 8 : nv;
-        bool ok = ih >= 0 && ih < g.H && iw >= 0 && iw < g.W && nv > 0;
-        Frag8<T> f = ok ? frag_load(x + ((((int64_t)n * g.D + id) * g.H + ih) * g.W + iw) * g.ldx + c, nv) : frag_zero<T>();
-        frag_st_lds(xs + (size_t)v * C::XC + part * 8, f);
-      }
-      for (int p = tid; p < C::GR * C::TW * GPV; p += 256) {
-        int part = p % GPV, v = p / GPV, gw = v % C::TW, gr = v / C::TW;
-        int oh = h0 + gr - (NPAIR == 2 ? 1 : 0), ow = w0 + gw, c = cbase_g + part * 8;
-        int nv = g.Cout - c; nv = nv > 8 ? 8 : nv;
-        bool ok = oh >= h0 && oh < h0 + C::TH && oh < g.H && ow < g.W && nv > 0;
-        Frag8<T> f = ok ? frag_load(gy + ((((int64_t)n * g.D + d) * g.H + oh) * g.W + ow) * g.ldgy + c, nv) : frag_zero<T>();
-        frag_st_lds(gs + (size_t)v * C::GC + part * 8, f);
+      if (fast) {
+        // straight-line staging (see k_conv_tiled): SU independent 16-byte loads in flight before the first LDS store
+        {
+          const int total = C::LR * lpn * XPV;
+          const T* xplane = x + (((int64_t)n * g.D + id) * g.H) * (int64_t)g.W * g.ldx + cbase_x + (tid % XPV) * 8;
+          int lp = (tid / XPV) % lpn, lr = (tid / XPV) / lpn;
+          for (int p0 = 0; p0 < total; p0 += 256 * SU) {
+            v4u buf[SU]; int dst[SU];
+#pragma unroll
+            for (int j = 0; j < SU; j++) {
+              const int ih = h0 - C::PAD + lr, iw = w0 - C::PAD + lp;
+              const bool in = p0 + j * 256 + tid < total;
+              const bool ok = in && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W;
+              v4u t = *(const v4u*)(xplane + ((int64_t)(ok ? ih : 0) * g.W + (ok ? iw : 0)) * g.ldx);
+              buf[j] = ok ? t : (v4u){0, 0, 0, 0};
+              dst[j] = in ? (lr * C::LP + lp) * C::XC + (tid % XPV) * 8 : -1;
+              lp += 256 / XPV; while (lp >= lpn) { lp -= lpn; lr++; }
+            }
+#pragma unroll
+            for (int j = 0; j < SU; j++) if (dst[j] >= 0) *(v4u*)(xs + dst[j]) = buf[j];
+          }
+        }
+        {
+          const int gwn = nchk * 16, total = C::GR * gwn * GPV;
+          const T* gplane = gy + (((int64_t)n * g.D + d) * g.H) * (int64_t)g.W * g.ldgy + cbase_g + (tid % GPV) * 8;
+          int gw = (tid / GPV) % gwn, gr = (tid / GPV) / gwn;
+          for (int p0 = 0; p0 < total; p0 += 256 * SU) {
+            v4u buf[SU]; int dst[SU];
+#pragma unroll
+            for (int j = 0; j < SU; j++) {
+              const int oh = h0 + gr - (NPAIR == 2 ? 1 : 0), ow = w0 + gw;
+              const bool in = p0 + j * 256 + tid < total;
+              const bool ok = in && oh >= h0 && oh < h0 + C::TH && oh < g.H && ow < g.W;
+              v4u t = *(const v4u*)(gplane + ((int64_t)(ok ? oh : 0) * g.W + (ok ? ow : 0)) * g.ldgy);
+              buf[j] = ok ? t : (v4u){0, 0, 0, 0};
+              dst[j] = in ? gr * C::GRP + gw * C::GC + (tid % GPV) * 8 : -1;
+              gw += 256 / GPV; while (gw >= gwn) { gw -= gwn; gr++; }
+            }
+#pragma unroll
+            for (int j = 0; j < SU; j++) if (dst[j] >= 0) *(v4u*)(gs + dst[j]) = buf[j];
+          }
+        }
+      } else {
+        for (int p = tid; p < C::LR * C::LP * XPV; p += 256) {
+          int part = p % XPV, v = p / XPV, lp = v % C::LP, lr = v / C::LP;
+          int ih = h0 - C::PAD + lr, iw = w0 - C::PAD + lp, c = cbase_x + part * 8;
+          int nv = g.Cin - c; nv = nv > 8 ? 8 : nv;
+          bool ok = ih >= 0 && ih < g.H && iw >= 0 && iw < g.W && nv > 0;
+          Frag8<T> f = ok ? frag_load(x + ((((int64_t)n * g.D + id) * g.H + ih) * g.W + iw) * g.ldx + c, nv) : frag_zero<T>();
+          frag_st_lds(xs + (size_t)v * C::XC + part * 8, f);
+        }
+        for (int p = tid; p < C::GR * C::TW * GPV; p += 256) {
+          int part = p % GPV, v = p / GPV, gw = v % C::TW, gr = v / C::TW;
+          int oh = h0 + gr - (NPAIR == 2 ? 1 : 0), ow = w0 + gw, c = cbase_g + part * 8;
+          int nv = g.Cout - c; nv = nv > 8 ? 8 : nv;
+          bool ok = oh >= h0 && oh < h0 + C::TH && oh < g.H && ow < g.W && nv > 0;
+          Frag8<T> f = ok ? frag_load(gy + ((((int64_t)n * g.D + d) * g.H + oh) * g.W + ow) * g.ldgy + c, nv) : frag_zero<T>();
+          frag_st_lds(gs + (size_t)gr * C::GRP + gw * C::GC + part * 8, f);
+        }
       }
       __syncthreads();
       if (active) {
@@ -438,10 +489,10 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_tiled(const T* __restrict__ x,
         for (int i = 0; i < C::STEPS; i++) {
           const int lr = i + (NPAIR == 2 ? 2 * jh : jh);
 #pragma unroll 1
-          for (int c = chw; c < C::NCHK; c += C::WCH) {
-            Frag8<T> fb;
-            if (NPAIR == 2) fb = ld_kmajor32<C::GC>(gs, (i + 1) * C::TW + 16 * c, i * C::TW + 16 * c, 0, 0, lane);
-            else fb = ld_kmajor32<C::GC>(gs, i * C::TW + 16 * c, i * C::TW + 16 * c, 0, 16, lane);
+          for (int c = chw; c < nchk; c += C::WCH) {
+            Frag8<T> fb;      // gy rows are GRP apart: express the row offset in "voxels" of pitch GC (GRP is a multiple of GC)
+            if (NPAIR == 2) fb = ld_kmajor32<C::GC>(gs, (i + 1) * (C::GRP / C::GC) + 16 * c, i * (C::GRP / C::GC) + 16 * c, 0, 0, lane);
+            else fb = ld_kmajor32<C::GC>(gs, i * (C::GRP / C::GC) + 16 * c, i * (C::GRP / C::GC) + 16 * c, 0, 16, lane);
 #pragma unroll
             for (int k = 0; k < C::KWT; k++) {
               Frag8<T> fa;
