@@ -5,8 +5,15 @@
 #include "common.h"
 
 #define STREAM ((hipStream_t)stream)
-#define ROWS_PER_BLOCK 2048
 #define NT 256
+// Voxel rows per block of the row-stream kernels: 2048 for big volumes, fewer for small ones so that even an 8^3 / 16^3
+// feature map spreads over a few hundred blocks (a 4-block launch over 768 channels took ~190 us).
+static inline int rows_per_block(int64_t V) {
+  int64_t r = V / 128;
+  if (r < 32) r = 32;
+  if (r > 2048) r = 2048;
+  return (int)r;
+}
 
 template <typename T> __device__ __forceinline__ void unpack8(const T* p, int nv, float* o);
 template <> __device__ __forceinline__ void unpack8<float>(const float* p, int nv, float* o) {
@@ -27,7 +34,7 @@ __device__ __forceinline__ void pack8(bf16_t* p, int nv, const float* o) {
   } else for (int i = 0; i < 8; i++) if (i < nv) p[i] = f2bf(o[i]);
 }
 
-extern "C" int dp_stats_nblk(int64_t V) { return (int)((V + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK); }
+extern "C" int dp_stats_nblk(int64_t V) { int r = rows_per_block(V); return (int)((V + r - 1) / r); }
 
 // Common geometry: block b of sample n covers voxels [b*RPB, min(V,(b+1)*RPB)); thread t owns chunk cg = t % cg8 and
 // rows r0 + k*rpi.  (cg8 = chunks per row, rpi = rows per iteration = NT / cg8.)
@@ -52,7 +59,7 @@ __device__ __forceinline__ void block_reduce_store(float* red, const float* a1, 
 }
 
 template <typename T>
-__global__ void __launch_bounds__(NT) k_stats_partial(const T* __restrict__ x, int ld, int64_t V, int C, float* __restrict__ part, int nblk) {
+__global__ void __launch_bounds__(NT) k_stats_partial(const T* __restrict__ x, int ld, int64_t V, int C, float* __restrict__ part, int nblk, int ROWS_PER_BLOCK) {
   __shared__ float red[NT * 16];
   if (C > 8 * NT) return;
   int b = blockIdx.x, n = blockIdx.y;
@@ -68,7 +75,7 @@ __global__ void __launch_bounds__(NT) k_stats_partial(const T* __restrict__ x, i
 extern "C" int dp_stats_partial(const void* x, int ld, int N, int64_t V, int C, float* part, int dtype, void* stream) {
   if (C > 8 * NT) DP_FAIL("stats: C too large");
   int nblk = dp_stats_nblk(V);
-  DP_DISPATCH(dtype, hipLaunchKernelGGL(k_stats_partial<T>, dim3(nblk, N), dim3(NT), 0, STREAM, (const T*)x, ld, V, C, part, nblk));
+  DP_DISPATCH(dtype, hipLaunchKernelGGL(k_stats_partial<T>, dim3(nblk, N), dim3(NT), 0, STREAM, (const T*)x, ld, V, C, part, nblk, rows_per_block(V)));
   DP_CHECK_LAUNCH("stats_partial"); return 0;
 }
 
@@ -138,7 +145,7 @@ __device__ __forceinline__ NormConst load_consts(const float* mean, const float*
 template <typename T>
 __global__ void __launch_bounds__(NT) k_norm_act_fwd(const T* __restrict__ x, int ldx, const float* mean, const float* rstd, int ssn,
                                                      const float* gamma, const float* beta, const T* __restrict__ res, int ldr, int act,
-                                                     T* __restrict__ y, int ldy, int64_t V, int C) {
+                                                     T* __restrict__ y, int ldy, int64_t V, int C, int ROWS_PER_BLOCK) {
   int b = blockIdx.x, n = blockIdx.y;
   RowGeom g = row_geom(C);
   if (!g.active) return;
@@ -161,7 +168,7 @@ extern "C" int dp_norm_act_fwd(const void* x, int ldx, const float* mean, const 
                                const void* res, int ldr, int act, void* y, int ldy, int N, int64_t V, int C, int dtype, void* stream) {
   if (C > 8 * NT) DP_FAIL("norm_act_fwd: C too large");
   DP_DISPATCH(dtype, hipLaunchKernelGGL(k_norm_act_fwd<T>, dim3(dp_stats_nblk(V), N), dim3(NT), 0, STREAM, (const T*)x, ldx, mean, rstd, ssn,
-                                        gamma, beta, (const T*)res, ldr, act, (T*)y, ldy, V, C));
+                                        gamma, beta, (const T*)res, ldr, act, (T*)y, ldy, V, C, rows_per_block(V)));
   DP_CHECK_LAUNCH("norm_act_fwd"); return 0;
 }
 
@@ -169,7 +176,7 @@ template <typename T>
 __global__ void __launch_bounds__(NT) k_norm_act_bwd_partial(const T* __restrict__ x, int ldx, const T* __restrict__ gy, int ldgy, const float* mean,
                                                              const float* rstd, int ssn, const float* gamma, const float* beta,
                                                              const T* __restrict__ res, int ldr, int act, int64_t V, int C,
-                                                             float* __restrict__ part, int nblk) {
+                                                             float* __restrict__ part, int nblk, int ROWS_PER_BLOCK) {
   __shared__ float red[NT * 16];
   int b = blockIdx.x, n = blockIdx.y;
   RowGeom g = row_geom(C);
@@ -197,7 +204,7 @@ extern "C" int dp_norm_act_bwd_partial(const void* x, int ldx, const void* gy, i
   if (C > 8 * NT) DP_FAIL("norm_act_bwd_partial: C too large");
   int nblk = dp_stats_nblk(V);
   DP_DISPATCH(dtype, hipLaunchKernelGGL(k_norm_act_bwd_partial<T>, dim3(nblk, N), dim3(NT), 0, STREAM, (const T*)x, ldx, (const T*)gy, ldgy, mean, rstd, ssn,
-                                        gamma, beta, (const T*)res, ldr, act, V, C, part, nblk));
+                                        gamma, beta, (const T*)res, ldr, act, V, C, part, nblk, rows_per_block(V)));
   DP_CHECK_LAUNCH("norm_act_bwd_partial"); return 0;
 }
 
@@ -226,7 +233,7 @@ __global__ void __launch_bounds__(NT) k_norm_act_bwd_apply(const T* __restrict__
                                                            const float* rstd, int ssn, const float* gamma, const float* beta,
                                                            const T* __restrict__ res, int ldr, int act, const float* s1, const float* s2,
                                                            float inv_count, int use_stats, T* __restrict__ gx, int ldgx, T* __restrict__ gres, int ldgres,
-                                                           int64_t V, int C) {
+                                                           int64_t V, int C, int ROWS_PER_BLOCK) {
   int b = blockIdx.x, n = blockIdx.y;
   RowGeom g = row_geom(C);
   if (!g.active) return;
@@ -260,7 +267,7 @@ extern "C" int dp_norm_act_bwd_apply(const void* x, int ldx, const void* gy, int
                                      int dtype, void* stream) {
   if (C > 8 * NT) DP_FAIL("norm_act_bwd_apply: C too large");
   DP_DISPATCH(dtype, hipLaunchKernelGGL(k_norm_act_bwd_apply<T>, dim3(dp_stats_nblk(V), N), dim3(NT), 0, STREAM, (const T*)x, ldx, (const T*)gy, ldgy, mean, rstd,
-                                        ssn, gamma, beta, (const T*)res, ldr, act, s1, s2, inv_count, use_stats, (T*)gx, ldgx, (T*)gres, ldgres, V, C));
+                                        ssn, gamma, beta, (const T*)res, ldr, act, s1, s2, inv_count, use_stats, (T*)gx, ldgx, (T*)gres, ldgres, V, C, rows_per_block(V)));
   DP_CHECK_LAUNCH("norm_act_bwd_apply"); return 0;
 }
 

@@ -637,8 +637,14 @@ class AddBroadcast(torch.autograd.Function):
             B = g.numel() // per
             gp = torch.zeros((per,), dtype=torch.float32, device=g.device)
             # sum over the batch with the column-sum reduction: rows = B, "channels" = per  (chunked to <= 2048 cols)
-            colsum_into(g.data_ptr(), per, B, per, gp, _dt(g))
-            gp = gp.view(ctx.pshape)
+            # sum over the batch in fp32: B-1 elementwise adds (a column-sum launch per 2048 columns would be ~200 launches)
+            g32 = _cast_vec(g.view(B, per), torch.float32)
+            gp = g32[0]
+            for b in range(1, B):
+                nxt = torch.empty_like(gp)
+                _lib.call("dp_add", _p(gp), _p(g32[b]), _p(nxt), per, per, 0, _stream())
+                gp = nxt
+            gp = gp.clone().view(ctx.pshape) if B == 1 else gp.view(ctx.pshape)
         return g, gp
 
 
