@@ -349,7 +349,7 @@ struct WgtCfg {
   static constexpr int PAD = KS / 2;
   static constexpr int JHN = NPAIR == 2 ? (KS + 1) / 2 : KS;      // kh (pairs)
   static constexpr int KWT = MPAIR == 2 ? (KS + 1) / 2 : KS;      // kw (pairs) = accumulators per wave
-  static constexpr int WKH = JHN >= 3 ? 4 : 2, WCH = 4 / WKH;
+  static constexpr int WKH = JHN >= 3 ? 4 : (JHN == 2 ? 2 : 1), WCH = 4 / WKH;
   static constexpr int XC = MPAIR == 2 ? 16 : 32, GC = NPAIR == 2 ? 16 : 32;
   static constexpr int TH = 8, TW = sizeof(T) == 2 ? 64 : 32, NCHK = TW / 16;
   static constexpr int GR = NPAIR == 2 ? TH + 2 : TH;
@@ -532,6 +532,7 @@ __global__ void k_wgrad_unpack(const float* __restrict__ dwt, float* __restrict_
 }
 
 static inline bool wgt_applicable(int Cin, int Cout, int k, int stride, int pad, int dil, int shift, int W) {
+  if (k == 1) return stride == 1 && pad == 0 && W >= 16 && Cin >= 8 && Cout >= 8 && Cin <= 128 && Cout <= 128;   // pointwise: HBM-bound row stream
   return shift && (k == 3 || k == 7) && stride == 1 && dil == 1 && pad == k / 2 && W >= 16 && Cin >= 8 && Cout >= 8;
 }
 // fp32 scratch elements needed by dp_conv3d_wgrad_tiled (0: shape not supported, use dp_conv3d_wgrad)
@@ -564,17 +565,18 @@ static int launch_wgt(const void* x, const void* gy, float* ws, WgtGeom g, hipSt
 extern "C" int dp_conv3d_wgrad_tiled(const void* x, int ldx, const void* gy, int ldgy, float* dw, float* ws, int N, int D, int H, int W,
                                      int Cin, int Cout, int k, int64_t s_co, int64_t s_ci, int64_t s_tap, int dtype, void* stream) {
   if (!wgt_applicable(Cin, Cout, k, 1, k / 2, 1, 1, W)) DP_FAIL("wgrad_tiled: shape not supported");
+  if (k == 1 && H * (int64_t)D * N > 2000000000LL) DP_FAIL("wgrad_tiled: too many rows");
   hipStream_t s = STREAM;
   int taps = k * k * k;
   hipError_t me = hipMemsetAsync(ws, 0, (size_t)taps * Cin * Cout * sizeof(float), s);
   if (me != hipSuccess) DP_FAIL("wgrad_tiled: memset failed: %s", hipGetErrorString(me));
   WgtGeom g; g.N = N; g.D = D; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.ldx = ldx; g.ldgy = ldgy;
-  const int np = Cout <= 16 ? 2 : 1, mp = Cin <= 16 ? 2 : 1;
+  const int np = (Cout <= 16 && k > 1) ? 2 : 1, mp = (Cin <= 16 && k > 1) ? 2 : 1;
   int rc = 0;
 #define GO(TT, KS_) do { if (np == 2 && mp == 2) rc = launch_wgt<TT, KS_, 2, 2>(x, gy, ws, g, s); else if (np == 2) rc = launch_wgt<TT, KS_, 2, 1>(x, gy, ws, g, s); \
                          else if (mp == 2) rc = launch_wgt<TT, KS_, 1, 2>(x, gy, ws, g, s); else rc = launch_wgt<TT, KS_, 1, 1>(x, gy, ws, g, s); } while (0)
-  if (dtype == DP_BF16) { if (k == 7) GO(bf16_t, 7); else GO(bf16_t, 3); }
-  else if (dtype == DP_F32) { if (k == 7) GO(float, 7); else GO(float, 3); }
+  if (dtype == DP_BF16) { if (k == 7) GO(bf16_t, 7); else if (k == 3) GO(bf16_t, 3); else rc = launch_wgt<bf16_t, 1, 1, 1>(x, gy, ws, g, s); }
+  else if (dtype == DP_F32) { if (k == 7) GO(float, 7); else if (k == 3) GO(float, 3); else rc = launch_wgt<float, 1, 1, 1>(x, gy, ws, g, s); }
   else DP_FAIL("wgrad_tiled: bad dtype");
 #undef GO
   if (rc) return rc;

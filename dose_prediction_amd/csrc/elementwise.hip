@@ -318,3 +318,47 @@ extern "C" int dp_argmax_onehot(const void* logits, int ld, void* out, int ldo, 
   DP_DISPATCH(dtype, hipLaunchKernelGGL(k_argmax_onehot<T>, dim3(grid_for(rows, 256)), dim3(256), 0, STREAM, (const T*)logits, ld, (T*)out, ldo, choff, labels, rows, C));
   DP_CHECK_LAUNCH("argmax_onehot"); return 0;
 }
+
+// ------------------------------------------------------------------------------------------------ skinny pointwise conv
+// y[v][co] = sum_ci x[v][ci] * w[co][ci] (+ bias) for few channels (Cin <= 64, Cout <= 32) over millions of voxels:
+// an HBM-bound row stream (AI ~ Cout FLOP/B), so one thread owns one voxel row, reads it as 16-byte chunks, keeps the
+// Cout accumulators in registers and takes the weights from LDS (every lane reads the same address: a broadcast).
+template <typename T, int COUT>
+__global__ void __launch_bounds__(256) k_pointwise_rows(const T* __restrict__ x, int ldx, const T* __restrict__ w, int ldw, const float* __restrict__ bias,
+                                                        T* __restrict__ y, int ldy, int64_t rows, int Cin, int Cout) {
+  __shared__ float ws[64 * COUT];
+  for (int i = threadIdx.x; i < Cin * COUT; i += 256) { int ci = i / COUT, co = i - ci * COUT; ws[i] = co < Cout ? ld_f(w + (int64_t)co * ldw + ci) : 0.f; }
+  __syncthreads();
+  const int nch = (Cin + 7) >> 3;
+  for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < rows; v += (int64_t)gridDim.x * blockDim.x) {
+    float acc[COUT];
+#pragma unroll
+    for (int c = 0; c < COUT; c++) acc[c] = (bias && c < Cout) ? bias[c] : 0.f;
+    for (int ch = 0; ch < nch; ch++) {
+      float t[8];
+      frag_unpack(frag_load(x + v * ldx + ch * 8, min(8, Cin - ch * 8)), t);
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const float* wr = ws + (ch * 8 + j) * COUT;
+        if (ch * 8 + j < Cin) {
+#pragma unroll
+          for (int c = 0; c < COUT; c++) acc[c] += t[j] * wr[c];
+        }
+      }
+    }
+    T* o = y + v * ldy;
+#pragma unroll
+    for (int c8 = 0; c8 < COUT; c8 += 8) {
+      if (c8 < Cout) { Frag8<T> f; frag_pack(f, acc + c8); frag_store<T>(o + c8, f, min(8, Cout - c8)); }
+    }
+  }
+}
+extern "C" int dp_pointwise_rows(const void* x, int ldx, const void* w, int ldw, const float* bias, void* y, int ldy, int64_t rows, int Cin, int Cout,
+                                 int dtype, void* stream) {
+  if (Cin > 64 || Cout > 32 || Cin < 1 || Cout < 1) DP_FAIL("pointwise_rows: needs Cin <= 64 and Cout <= 32");
+  int g = grid_for(rows, 256, 256 * 32);
+#define GO(CO) DP_DISPATCH(dtype, hipLaunchKernelGGL((k_pointwise_rows<T, CO>), dim3(g), dim3(256), 0, STREAM, (const T*)x, ldx, (const T*)w, ldw, bias, (T*)y, ldy, rows, Cin, Cout))
+  if (Cout <= 8) GO(8); else if (Cout <= 16) GO(16); else GO(32);
+#undef GO
+  DP_CHECK_LAUNCH("pointwise_rows"); return 0;
+}

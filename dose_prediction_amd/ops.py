@@ -181,6 +181,11 @@ def gemm_nt(A, B, out, bias=None, alpha=1.0, M=None, N=None, K=None, batch=(1, 1
     out_f32 = 1 if (out.dtype == torch.float32 and A.dtype != torch.float32) or splitk > 1 else 0
     if splitk > 1 and out.dtype != torch.float32:
         raise ValueError("split-K needs an fp32 output")
+    if (batch == (1, 1) and splitk == 1 and not out_f32 and alpha == 1.0 and M >= 32768 and K <= 64 and N <= 32
+            and out.dtype == A.dtype):
+        # millions of voxel rows x a handful of channels: HBM-bound row stream, not a GEMM
+        _lib.call("dp_pointwise_rows", _p(A), lda, _p(B), ldb, _p(bias), _p(out), ldc, M, K, N, _dt(A), _stream())
+        return
     _lib.call("dp_gemm_nt", _p(A), lda, sa[0], sa[1], _p(B), ldb, sb[0], sb[1], _p(out), ldc, sc[0], sc[1], _p(bias),
               M, N, K, batch[0], batch[1], float(alpha), out_f32, splitk, _dt(A), _stream())
 
@@ -353,7 +358,9 @@ class Conv3d(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             gw = torch.zeros(weight.shape, dtype=torch.float32, device=x.device)
             taps = k * k * k
-            wse = _lib.lib().dp_conv3d_wgrad_tiled_ws_elems(cin, cout, k, stride, pad, dil, 1, Wo) if (USE_TILED and k > 1) else 0
+            wse = 0
+            if USE_TILED and (k > 1 or grows >= 32768):
+                wse = _lib.lib().dp_conv3d_wgrad_tiled_ws_elems(cin, cout, k, stride, pad, dil, 1, Wo)
             if wse:
                 ws = torch.empty((wse,), dtype=torch.float32, device=x.device)
                 _lib.call("dp_conv3d_wgrad_tiled", _p(x), ldx, _p(gy), ldg, _p(gw), _p(ws), N, Di, Hi, Wi, cin, cout, k,
@@ -410,8 +417,17 @@ class ConvTranspose2x(torch.autograd.Function):
             gemm_nt(gu, wt, gx, M=rows, N=cin, K=8 * cout, lda=8 * cout, ldb=wt.shape[-1], ldc=cx)
         if ctx.needs_input_grad[1]:
             gw = torch.zeros(weight.shape, dtype=torch.float32, device=x.device)   # [Cin][Cout][8]
-            # "tap" = abc selects the gy column block abc*Cout; x is not shifted
-            wgrad(x, ldx, gu, 8 * cout, gw, (1, 1, 1, rows, 1, 1, rows), cin, cout, 2, 1, 0, 1, 0, cout, 8, cout * 8, 1, dtc)
+            wse = _lib.lib().dp_conv3d_wgrad_tiled_ws_elems(cin, cout, 1, 1, 0, 1, 1, W) if (USE_TILED and rows >= 32768) else 0
+            if wse:
+                # 8 pointwise weight gradients: tap abc pairs x with the gy column block abc*Cout
+                ws = torch.empty((wse,), dtype=torch.float32, device=x.device)
+                es = gu.element_size()
+                for t in range(8):
+                    _lib.call("dp_conv3d_wgrad_tiled", _p(x), ldx, gu.data_ptr() + t * cout * es, 8 * cout, gw.data_ptr() + 4 * t, _p(ws),
+                              N, D, H, W, cin, cout, 1, 8, cout * 8, 0, dtc, _stream())
+            else:
+                # "tap" = abc selects the gy column block abc*Cout; x is not shifted
+                wgrad(x, ldx, gu, 8 * cout, gw, (1, 1, 1, rows, 1, 1, rows), cin, cout, 2, 1, 0, 1, 0, cout, 8, cout * 8, 1, dtc)
         return gx, gw
 
 

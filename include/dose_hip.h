@@ -115,6 +115,12 @@ int dp_gemm_nt(const void* A, int64_t lda, int64_t sa0, int64_t sa1, const void*
                void* C, int64_t ldc, int64_t sc0, int64_t sc1, const float* bias, int M, int N, int K, int nb0, int nb1,
                float alpha, int out_f32, int splitk, int dtype, void* stream);
 
+/* skinny pointwise (1x1x1) convolution over voxel rows, Cin <= 64 and Cout <= 32: y[v][co] = sum_ci x[v][ci] w[co*ldw + ci] (+bias).
+ * HBM-bound row stream on the vector ALU.  replaces: nn.Conv3d k1 at the 128^3 / 64^3 levels (blocks_MDUNet.py:146,
+ * dose_pyfer.py:292,353) forward, and their data gradient with a transposed weight matrix. */
+int dp_pointwise_rows(const void* x, int ldx, const void* w, int ldw, const float* bias, void* y, int ldy, int64_t rows, int Cin, int Cout,
+                      int dtype, void* stream);
+
 /* ---- convolution ------------------------------------------------------------------------------ */
 /* weight packing: torch fp32 [Cout][Cin][k^3] -> T [Cout][k^3][CinP] (mode 0, forward),
  * -> T [Cin][k^3][CoutP] (mode 1: transposed, for data-gradient "gather" form),
