@@ -6,22 +6,24 @@
 #include "common.h"
 
 #define STREAM ((hipStream_t)stream)
-#define BM 128
-#define BN 128
 #define BK 32
 #define LDP (BK + 8)   // padded LDS row (elements): 80 B (bf16) / 160 B (f32) keeps 16-B alignment, breaks the 64-B stride
 
-template <typename T>
+// TI x TJ = MFMA tiles per wave in M / N: block tile = (2*TI*16) x (2*TJ*16): 128x128 (4,4) for big problems, 64x64 (2,2)
+// when a 128x128 grid would leave most of the 256 CUs idle (ViT token matrices: M = B*512).
+template <typename T, int TI, int TJ>
 __global__ void __launch_bounds__(256) k_gemm_nt(const T* __restrict__ A, int64_t lda, int64_t sa0, int64_t sa1,
                                                  const T* __restrict__ B, int64_t ldb, int64_t sb0, int64_t sb1,
                                                  void* __restrict__ Cv, int64_t ldc, int64_t sc0, int64_t sc1,
                                                  const float* __restrict__ bias, int M, int N, int K, int nb1,
                                                  float alpha, int out_f32, int splitk) {
+  constexpr int BM = 32 * TI, BN = 32 * TJ, WMR = 16 * TI, WNR = 16 * TJ;
+  constexpr int UA = BM * 4 / 256 > 0 ? BM * 4 / 256 : 1, UB = BN * 4 / 256 > 0 ? BN * 4 / 256 : 1;   // 16-byte chunks per thread
   __shared__ __attribute__((aligned(16))) T As[BM * LDP];
   __shared__ __attribute__((aligned(16))) T Bs[BN * LDP];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
   const int r = lane & 15, q = lane >> 4;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int m0 = blockIdx.x * (32 * TI), n0 = blockIdx.y * (32 * TJ);
   const int bz = blockIdx.z / splitk, ks = blockIdx.z - bz * splitk;
   const int b0 = bz / nb1, b1 = bz - b0 * nb1;
   A += b0 * sa0 + b1 * sa1; B += b0 * sb0 + b1 * sb1;
@@ -29,59 +31,69 @@ __global__ void __launch_bounds__(256) k_gemm_nt(const T* __restrict__ A, int64_
   int ktiles = (K + BK - 1) / BK, per = (ktiles + splitk - 1) / splitk;
   int kt0 = ks * per, kt1 = min(ktiles, kt0 + per);
 
-  v4f acc[4][4];
+  v4f acc[TI][TJ];
 #pragma unroll
-  for (int i = 0; i < 4; i++)
+  for (int i = 0; i < TI; i++)
 #pragma unroll
-    for (int j = 0; j < 4; j++) acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < TJ; j++) acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
 
-  const int imax = min(4, (M - m0 - wm * 64 + 15) / 16), jmax = min(4, (N - n0 - wn * 64 + 15) / 16);
-  Frag8<T> ra[2], rb[2];
+  const int imax = min(TI, (M - m0 - wm * WMR + 15) / 16), jmax = min(TJ, (N - n0 - wn * WNR + 15) / 16);
+  Frag8<T> ra[UA], rb[UB];
   auto gload = [&](int kt) {
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
+    for (int u = 0; u < UA; u++) {
       int c = tid + u * 256, row = c >> 2, kc = c & 3, k = kt * BK + kc * 8;
       int nv = K - k; nv = nv < 0 ? 0 : (nv > 8 ? 8 : nv);
-      int gm = m0 + row, gn = n0 + row;
-      ra[u] = (gm < M && nv > 0) ? frag_load(A + (int64_t)gm * lda + k, nv) : frag_zero<T>();
-      rb[u] = (gn < N && nv > 0) ? frag_load(B + (int64_t)gn * ldb + k, nv) : frag_zero<T>();
+      int gm = m0 + row;
+      ra[u] = (row < BM && gm < M && nv > 0) ? frag_load(A + (int64_t)gm * lda + k, nv) : frag_zero<T>();
+    }
+#pragma unroll
+    for (int u = 0; u < UB; u++) {
+      int c = tid + u * 256, row = c >> 2, kc = c & 3, k = kt * BK + kc * 8;
+      int nv = K - k; nv = nv < 0 ? 0 : (nv > 8 ? 8 : nv);
+      int gn = n0 + row;
+      rb[u] = (row < BN && gn < N && nv > 0) ? frag_load(B + (int64_t)gn * ldb + k, nv) : frag_zero<T>();
     }
   };
   if (kt0 < kt1) gload(kt0);
   for (int kt = kt0; kt < kt1; kt++) {
     __syncthreads();
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
+    for (int u = 0; u < UA; u++) {
       int c = tid + u * 256, row = c >> 2, kc = c & 3;
-      frag_st_lds(As + row * LDP + kc * 8, ra[u]);
-      frag_st_lds(Bs + row * LDP + kc * 8, rb[u]);
+      if (row < BM) frag_st_lds(As + row * LDP + kc * 8, ra[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < UB; u++) {
+      int c = tid + u * 256, row = c >> 2, kc = c & 3;
+      if (row < BN) frag_st_lds(Bs + row * LDP + kc * 8, rb[u]);
     }
     __syncthreads();
     if (kt + 1 < kt1) gload(kt + 1);
-    Frag8<T> fa[4], fb[4];
+    Frag8<T> fa[TI], fb[TJ];
 #pragma unroll
-    for (int i = 0; i < 4; i++) fa[i] = frag_ld_lds(As + (wm * 64 + i * 16 + r) * LDP + q * 8);
+    for (int i = 0; i < TI; i++) fa[i] = frag_ld_lds(As + (wm * WMR + i * 16 + r) * LDP + q * 8);
 #pragma unroll
-    for (int j = 0; j < 4; j++) fb[j] = frag_ld_lds(Bs + (wn * 64 + j * 16 + r) * LDP + q * 8);
+    for (int j = 0; j < TJ; j++) fb[j] = frag_ld_lds(Bs + (wn * WNR + j * 16 + r) * LDP + q * 8);
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < TI; i++) {
       if (i >= imax) continue;      // wave-uniform: skip MFMA tiles that lie wholly outside M x N (skinny problems)
 #pragma unroll
-      for (int j = 0; j < 4; j++) if (j < jmax) acc[i][j] = mma16(fa[i], fb[j], acc[i][j]);
+      for (int j = 0; j < TJ; j++) if (j < jmax) acc[i][j] = mma16(fa[i], fb[j], acc[i][j]);
     }
   }
   // epilogue: C/D layout col = lane&15, row = 4*(lane>>4) + reg
   const int64_t coff = b0 * sc0 + b1 * sc1;
 #pragma unroll
-  for (int j = 0; j < 4; j++) {
-    int col = n0 + wn * 64 + j * 16 + r;
+  for (int j = 0; j < TJ; j++) {
+    int col = n0 + wn * WNR + j * 16 + r;
     if (col >= N) continue;
     float bv = (bias && ks == 0) ? bias[col] : 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < TI; i++) {
 #pragma unroll
       for (int e = 0; e < 4; e++) {
-        int row = m0 + wm * 64 + i * 16 + q * 4 + e;
+        int row = m0 + wm * WMR + i * 16 + q * 4 + e;
         if (row >= M) continue;
         float v = alpha * acc[i][j][e] + bv;
         int64_t idx = coff + (int64_t)row * ldc + col;
@@ -98,9 +110,14 @@ extern "C" int dp_gemm_nt(const void* A, int64_t lda, int64_t sa0, int64_t sa1, 
   if (M <= 0 || N <= 0 || K <= 0) DP_FAIL("gemm_nt: empty problem %d %d %d", M, N, K);
   if (splitk < 1) splitk = 1;
   if (splitk > 1 && !out_f32) DP_FAIL("gemm_nt: split-K needs fp32 (atomic) output");
-  dim3 g(cdiv(M, BM), cdiv(N, BN), nb0 * nb1 * splitk);
+  int64_t big_blocks = (int64_t)cdiv(M, 128) * cdiv(N, 128) * nb0 * nb1 * splitk;
+  bool small = big_blocks < 256 && N > 32;        // 64x64 tiles: 4x the blocks (skinny N keeps the 128-row tile: it is a row stream)
+  int bm = small ? 64 : 128, bn = small ? 64 : 128;
+  dim3 g(cdiv(M, bm), cdiv(N, bn), nb0 * nb1 * splitk);
   if (g.y > 65535 || g.z > 65535) DP_FAIL("gemm_nt: grid too large");
-  DP_DISPATCH(dtype, hipLaunchKernelGGL(k_gemm_nt<T>, g, dim3(256), 0, STREAM, (const T*)A, lda, sa0, sa1, (const T*)B, ldb, sb0, sb1,
-                                        C, ldc, sc0, sc1, bias, M, N, K, nb1, alpha, out_f32, splitk));
+  if (small) DP_DISPATCH(dtype, hipLaunchKernelGGL((k_gemm_nt<T, 2, 2>), g, dim3(256), 0, STREAM, (const T*)A, lda, sa0, sa1, (const T*)B, ldb, sb0, sb1,
+                                                  C, ldc, sc0, sc1, bias, M, N, K, nb1, alpha, out_f32, splitk));
+  else DP_DISPATCH(dtype, hipLaunchKernelGGL((k_gemm_nt<T, 4, 4>), g, dim3(256), 0, STREAM, (const T*)A, lda, sa0, sa1, (const T*)B, ldb, sb0, sb1,
+                                             C, ldc, sc0, sc1, bias, M, N, K, nb1, alpha, out_f32, splitk));
   DP_CHECK_LAUNCH("gemm_nt"); return 0;
 }

@@ -473,8 +473,17 @@ class Linear(torch.autograd.Function):
             gx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
             gemm_nt(gy, wt, gx, M=rows, N=K, K=nout, lda=ldg, ldb=wt.shape[-1], ldc=K)
         if ctx.needs_input_grad[1]:
-            gw = torch.zeros(weight.shape, dtype=torch.float32, device=x.device)
-            wgrad(x, ldx, gy, ldg, gw, (1, 1, 1, rows, 1, 1, rows), K, nout, 1, 1, 0, 1, 0, 0, K, 1, 0, dtc)
+            if rows <= 16384 and rows % 8 == 0:
+                # token matrices: dW[out][in] = gy^T x as an NT GEMM on the transposed operands (K = rows), fp32 output
+                gyt = torch.empty((nout, rows), dtype=x.dtype, device=x.device)
+                xt = torch.empty((K, rows), dtype=x.dtype, device=x.device)
+                _transpose(_p(gy), ldg, (0, 0), _p(gyt), rows, (0, 0), rows, nout, (1, 1), dtc)
+                _transpose(_p(x), ldx, (0, 0), _p(xt), rows, (0, 0), rows, K, (1, 1), dtc)
+                gw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
+                gemm_nt(gyt, xt, gw, M=nout, N=K, K=rows, lda=rows, ldb=rows, ldc=K)
+            else:
+                gw = torch.zeros(weight.shape, dtype=torch.float32, device=x.device)
+                wgrad(x, ldx, gy, ldg, gw, (1, 1, 1, rows, 1, 1, rows), K, nout, 1, 1, 0, 1, 0, 0, K, 1, 0, dtc)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = torch.zeros((nout,), dtype=torch.float32, device=x.device)
             colsum_into(_p(gy), ldg, rows, nout, gb, dtc)
