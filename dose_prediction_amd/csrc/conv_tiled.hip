@@ -17,6 +17,9 @@
 #include "common.h"
 #include <stdlib.h>
 
+#ifndef STAGE_UNROLL
+#define STAGE_UNROLL 9
+#endif
 #define STREAM ((hipStream_t)stream)
 typedef float v16f __attribute__((ext_vector_type(16)));
 
@@ -36,6 +39,7 @@ struct TiledGeom {
   int NCH;             // 16-channel chunks of Cin
   int NTT;             // total 32-column N tiles in the packed weights
   int tiles_h, tiles_w;
+  int dbg;             // experiments only (env DP_DBG): 1 = skip staging, 2 = skip the MFMA sweep
   int splitkd;         // 1: blockIdx.z selects ONE kd; results are atomically accumulated into the fp32 scratch `ws`
 };
 
@@ -123,7 +127,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, 
   // lane-constant part of the A address: position (wc*32 + r), channel half hh, first row of this wave's row group
   const int v_lane = W16 ? (rg * RWO * 2 + (r >> 4)) * g.LP + (r & 15) : (rg * RWO) * g.LP + wc * 32 + r;
   // fast staging path: bf16, whole 16-channel chunks, 16-byte aligned voxel rows (block-uniform)
-  constexpr int SU = 6;
+  constexpr int SU = STAGE_UNROLL;
   const bool fast = SWZ && (g.Cin % 16 == 0) && (g.ldx % 8 == 0) && (((uintptr_t)x & 15) == 0);
   const int lp_par = SWZ ? ((g.LP >> 3) & 1) : 0;
   const int st_half = tid & 1, st_lp0 = (tid >> 1) % g.LP, st_lr0 = (tid >> 1) / g.LP;
@@ -134,7 +138,8 @@ __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, 
     if (id < 0 || id >= g.D) continue;             // block-uniform: the whole depth slice is zero padding
     for (int ch = 0; ch < g.NCH; ch++) {
       __syncthreads();
-      if (fast) {
+      if (g.dbg == 1) {
+      } else if (fast) {
         // straight-line staging: SU independent 16-byte loads are in flight before the first LDS store (a per-piece
         // load->store loop serialises on HBM/L2 latency and dominated the kernel); voxel coordinates advance incrementally
         // (256 threads = 128 voxels per step), no divisions in the loop.
@@ -167,29 +172,47 @@ __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, 
         }
       }
       __syncthreads();
+      if (g.dbg == 2) continue;
       const T* wbase = wq + ((int64_t)kd * NTAP * g.NCH + ch) * g.NTT * 512 + (int64_t)nt0 * 512 + r * 16 + hh * 8;
-      Frag8<T> bcur[NT], bnext[NT], bnext2[NT];
+      // Weights are fetched TWO taps ahead into three rotating NAMED register sets (loop unrolled by three).  Rotating
+      // through copies (bcur = bnext; ...) would be a USE of the just-issued load and force s_waitcnt vmcnt(0) every tap:
+      // that exposed the full L2 latency per tap and held the sweep at ~40 % of the MFMA rate.
+      auto load_b = [&](int tt, Frag8<T>* bb) {
 #pragma unroll
-      for (int j = 0; j < NT; j++) { bcur[j] = frag_load(wbase + j * 512, 8); bnext[j] = frag_load(wbase + wtap_stride + j * 512, 8); }
-#pragma unroll 1
-      for (int tt = 0; tt < NTAP; tt++) {
+        for (int j = 0; j < NT; j++) bb[j] = frag_load(wbase + (int64_t)tt * wtap_stride + j * 512, 8);
+      };
+      auto do_tap = [&](int tt, const Frag8<T>* bb) {
         const int jh = tt / KS, kw = tt - jh * KS;
-        if (tt + 2 < NTAP) {                      // weights are fetched two taps ahead (L2 latency ~ one tap of MFMAs)
-#pragma unroll
-          for (int j = 0; j < NT; j++) bnext2[j] = frag_load(wbase + (int64_t)(tt + 2) * wtap_stride + j * 512, 8);
-        }
         const int v_tap = v_lane + (NPAIR == 2 ? 2 * jh : jh) * g.LP + kw;
         const int sw0 = SWZ ? (hh ^ ((v_tap >> 3) & 1)) : hh;
         const int a_even = v_tap * CK + sw0 * 8, a_odd = v_tap * CK + (sw0 ^ lp_par) * 8;   // odd rows flip the half iff LP/8 is odd
 #pragma unroll
         for (int i = 0; i < RW; i++) {
+#ifdef DP_EXPERIMENT_ONE_LDS_READ
+          Frag8<T> fa = frag_ld_lds(slab + a_even);     // experiment: same LDS address for every row (MFMA-issue ceiling)
+#else
           Frag8<T> fa = W16 ? frag_ld_lds(slab + a_even + 2 * i * g.LP * CK)      // two image rows per step: parity unchanged
                             : frag_ld_lds(slab + ((i & 1) ? a_odd : a_even) + i * g.LP * CK);
+#endif
 #pragma unroll
-          for (int j = 0; j < NT; j++) acc[i][j] = mma32(fa, bcur[j], acc[i][j]);
+          for (int j = 0; j < NT; j++) acc[i][j] = mma32(fa, bb[j], acc[i][j]);
         }
-#pragma unroll
-        for (int j = 0; j < NT; j++) { bcur[j] = bnext[j]; bnext[j] = bnext2[j]; }
+      };
+      Frag8<T> b0[NT], b1[NT], b2[NT];
+      load_b(0, b0);
+      if (NTAP > 1) load_b(1, b1);
+#pragma unroll 1
+      for (int tt = 0; tt < NTAP; tt += 3) {
+        if (tt + 2 < NTAP) load_b(tt + 2, b2);
+        do_tap(tt, b0);
+        if (tt + 1 < NTAP) {
+          if (tt + 3 < NTAP) load_b(tt + 3, b0);
+          do_tap(tt + 1, b1);
+        }
+        if (tt + 2 < NTAP) {
+          if (tt + 4 < NTAP) load_b(tt + 4, b1);
+          do_tap(tt + 2, b2);
+        }
       }
     }
   }
@@ -290,7 +313,7 @@ static void tiled_geometry(TiledGeom& g, int k, int np, int rw, int nt, int* ygr
 extern "C" int dp_conv3d_tiled_ws_elems(int N, int D, int H, int W, int Cin, int Cout, int k) {
   if (!tiled_applicable(Cin, Cout, k, 1, k / 2, 1, W)) return 0;
   int rw, nt; int np = tiled_config(Cout, &rw, &nt);
-  TiledGeom g; g.N = N; g.D = D; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout;
+  TiledGeom g; g.N = N; g.D = D; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.dbg = 0;
   int ygrid; bool w16; tiled_geometry(g, k, np, rw, nt, &ygrid, &w16);
   if (!g.splitkd) return 0;
   int64_t e = (int64_t)N * D * H * W * Cout;
@@ -306,6 +329,7 @@ extern "C" int dp_conv3d_tiled(const void* x, int ldx, const void* wq, const flo
   TiledGeom g;
   g.N = N; g.D = D; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.ldx = ldx; g.ldy = ldy;
   int ygrid; bool w16; tiled_geometry(g, k, np, rw, nt, &ygrid, &w16);
+  { const char* e = getenv("DP_DBG"); g.dbg = e ? atoi(e) : 0; }
   if (g.splitkd && !ws) DP_FAIL("conv3d_tiled: this shape needs the fp32 scratch (dp_conv3d_tiled_ws_elems)");
   if ((int64_t)N * D * g.tiles_h * g.tiles_w > 2000000000LL) DP_FAIL("conv3d_tiled: grid too large");
   int rc = 0;
