@@ -138,7 +138,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, 
     if (id < 0 || id >= g.D) continue;             // block-uniform: the whole depth slice is zero padding
     for (int ch = 0; ch < g.NCH; ch++) {
       __syncthreads();
-      if (g.dbg == 1) {
+      if (g.dbg == 1 || g.dbg == 3) {
       } else if (fast) {
         // straight-line staging: SU independent 16-byte loads are in flight before the first LDS store (a per-piece
         // load->store loop serialises on HBM/L2 latency and dominated the kernel); voxel coordinates advance incrementally
@@ -172,7 +172,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, 
         }
       }
       __syncthreads();
-      if (g.dbg == 2) continue;
+      if (g.dbg >= 2) continue;
       const T* wbase = wq + ((int64_t)kd * NTAP * g.NCH + ch) * g.NTT * 512 + (int64_t)nt0 * 512 + r * 16 + hh * 8;
       // Weights are fetched TWO taps ahead into three rotating NAMED register sets (loop unrolled by three).  Rotating
       // through copies (bcur = bnext; ...) would be a USE of the just-issued load and force s_waitcnt vmcnt(0) every tap:
@@ -217,11 +217,34 @@ __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, 
     }
   }
 
-  // epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+  // epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).
+  // A lane holds ONE channel of 16 positions, so direct stores are 2-byte scatters (measured: 0.8 TB/s, 0.16 ms of a 0.49 ms
+  // 3x3x3 layer).  Each wave therefore transposes its 32-position x NC-channel tile through a private LDS patch (the slab
+  // is dead by now) and writes 16 contiguous bytes per lane: whole voxel rows, 1 KiB per wave-instruction.
   const int hw0 = h0 + rg * RWO * RPA, wbase_o = w0 + wc * 32;
+  constexpr int NC = NPAIR == 2 ? 16 : 32;                       // channels per output tile
+  constexpr int EPC = 16 / (int)sizeof(T);                       // elements per 16-byte chunk
+  constexpr int CPP = NC / EPC;                                  // chunks per position
+  constexpr int PASSES = 32 * CPP / 64;
+  __syncthreads();                                               // every wave is done reading the slab
+  T* patch = slab + (wv & 3) * (32 * 32);
+  const bool wide = !g.splitkd && (g.ldy * (int)sizeof(T)) % 16 == 0 && (((uintptr_t)y & 15) == 0);
+  auto store_tile = [&](int oh_lo, int nt_idx) {   // tile in `patch` as [32 positions][NC channels]; oh_lo: image row of position 0
+    const int cbase = NPAIR == 2 ? 0 : nt_idx * 32;
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ps++) {
+      const int q = ps * 64 + lane, m = q / CPP, cc = (q % CPP) * EPC;
+      const int oh = W16 ? oh_lo + (m >> 4) : oh_lo, ow = W16 ? (m & 15) : wbase_o + m;
+      if (oh < g.H && ow < g.W && cbase + cc < g.Cout) {
+        T* dst = y + ((((int64_t)n * g.D + d) * g.H + oh) * g.W + ow) * g.ldy + cbase + cc;
+        if (cbase + cc + EPC <= g.Cout) *(v4u*)dst = *(const v4u*)(patch + m * NC + cc);
+        else for (int k = 0; k < EPC; k++) if (cbase + cc + k < g.Cout) dst[k] = patch[m * NC + cc + k];
+      }
+    }
+  };
   if (NPAIR == 2) {
     const int co = lane & 15;
-    const bool writer = (lane & 16) == 0 && co < g.Cout;
+    const bool writer = (lane & 16) == 0;
     const float bv = (bias && co < g.Cout) ? bias[co] : 0.f;
 #pragma unroll
     for (int t = 0; t < RWO; t++) {
@@ -230,8 +253,15 @@ __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, 
       for (int e = 0; e < 16; e++) {
         float z1 = __shfl_down(acc[t + 1 < RW ? t + 1 : t][0][e], 16, 64);    // odd tap of the pair: accumulated one row below
         float v = acc[t][0][e] + z1 + bv;
-        int ow = wbase_o + (e & 3) + 8 * (e >> 2) + 4 * hh;
-        if (writer && oh < g.H && ow < g.W) st_f(y + ((((int64_t)n * g.D + d) * g.H + oh) * g.W + ow) * g.ldy + co, v);
+        const int m = (e & 3) + 8 * (e >> 2) + 4 * hh;
+        if (wide) { if (writer) st_f(patch + m * NC + co, v); }
+        else if (writer && co < g.Cout && oh < g.H && wbase_o + m < g.W)
+          st_f(y + ((((int64_t)n * g.D + d) * g.H + oh) * g.W + wbase_o + m) * g.ldy + co, v);
+      }
+      if (wide) {
+        __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier();
+        store_tile(oh, 0);
+        __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier();
       }
     }
   } else {
@@ -244,6 +274,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, 
 #pragma unroll
         for (int e = 0; e < 16; e++) {
           const int m = (e & 3) + 8 * (e >> 2) + 4 * hh;
+          if (wide) { st_f(patch + m * NC + r, acc[i][j][e] + bv); continue; }
           const int oh = W16 ? hw0 + 2 * i + (m >> 4) : hw0 + i;
           const int ow = W16 ? (m & 15) : wbase_o + m;
           if (co < g.Cout && oh < g.H && ow < g.W) {
@@ -251,6 +282,11 @@ __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, 
             if (g.splitkd) atomicAdd(ws + vox * g.Cout + co, acc[i][j][e]);
             else st_f(y + vox * g.ldy + co, acc[i][j][e] + bv);
           }
+        }
+        if (wide) {
+          __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier();
+          store_tile(W16 ? hw0 + 2 * i : hw0 + i, nt0 + j);
+          __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier();
         }
       }
     }
@@ -270,6 +306,7 @@ __global__ void k_conv_split_finish(const float* __restrict__ ws, const float* _
 template <typename T, int KS, int NPAIR, int RW, int NT, bool W16>
 static int launch_tiled(const void* x, const void* wq, const float* bias, void* y, float* ws, TiledGeom g, int ygrid, hipStream_t s) {
   size_t smem = (size_t)g.LR * g.LP * 16 * sizeof(T);
+  if (smem < 4 * 32 * 32 * sizeof(T)) smem = 4 * 32 * 32 * sizeof(T);     // the epilogue transposes through 4 per-wave patches
   auto kern = k_conv_tiled<T, KS, NPAIR, RW, NT, W16>;
   if (smem > 160 * 1024) { dp_set_error("conv3d_tiled: slab %zu B exceeds LDS", smem); return 1; }
   if (smem > 48 * 1024) {
@@ -366,6 +403,7 @@ int dp_wgrad_tiled_try(const void*, int, const void*, int, float*, int, int, int
 struct WgtGeom {
   int N, D, H, W, Cin, Cout, ldx, ldgy;
   int tiles_h, tiles_w, MT, NTn, KHG;
+  int dbg;             // experiments only (env DP_DBG): 1 = skip staging, 2 = skip the MFMA sweep
 };
 
 template <typename T, int KS, int NPAIR, int MPAIR>
@@ -447,7 +485,8 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_tiled(const T* __restrict__ x,
       const int nchk = min(C::NCHK, (g.W - w0 + 15) >> 4);          // 16-voxel chunks that hold real output positions
       const int lpn = nchk * 16 + KS - 1;                            // slab positions actually read
       __syncthreads();
-      if (fast) {
+      if (g.dbg == 1) {
+      } else if (fast) {
         // straight-line staging (see k_conv_tiled): SU independent 16-byte loads in flight before the first LDS store
         {
           const int total = C::LR * lpn * XPV;
@@ -508,7 +547,7 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_tiled(const T* __restrict__ x,
         }
       }
       __syncthreads();
-      if (active) {
+      if (active && g.dbg != 2) {
 #pragma unroll 1
         for (int i = 0; i < C::STEPS; i++) {
           const int lr = i + (NPAIR == 2 ? 2 * jh : jh);
@@ -595,6 +634,7 @@ extern "C" int dp_conv3d_wgrad_tiled(const void* x, int ldx, const void* gy, int
   hipError_t me = hipMemsetAsync(ws, 0, (size_t)taps * Cin * Cout * sizeof(float), s);
   if (me != hipSuccess) DP_FAIL("wgrad_tiled: memset failed: %s", hipGetErrorString(me));
   WgtGeom g; g.N = N; g.D = D; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.ldx = ldx; g.ldgy = ldgy;
+  { const char* e = getenv("DP_DBG"); g.dbg = e ? atoi(e) : 0; }
   const int np = (Cout <= 16 && k > 1) ? 2 : 1, mp = (Cin <= 16 && k > 1) ? 2 : 1;
   int rc = 0;
 #define GO(TT, KS_) do { if (np == 2 && mp == 2) rc = launch_wgt<TT, KS_, 2, 2>(x, gy, ws, g, s); else if (np == 2) rc = launch_wgt<TT, KS_, 2, 1>(x, gy, ws, g, s); \
