@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optimizer", action="store_true")
     ap.add_argument("--cpu-size", type=int, default=64)
+    ap.add_argument("--no-graph", action="store_true", help="do not replay the step from a captured HIP graph")
     return ap.parse_args()
 
 
@@ -159,8 +160,9 @@ def main():
     if world > 1:
         attach_gradient_allreduce(net, bucket_mb=32.0)
     params = [p for p in net.parameters() if p.requires_grad]
+    use_graph = (world == 1) and not args.no_graph
     opt = None if args.no_optimizer else torch.optim.Adam(params, lr=1e-4, weight_decay=3e-5, betas=(0.9, 0.999), eps=1e-8,
-                                                          amsgrad=True)   # network_trainer.py:120-125
+                                                          amsgrad=True, capturable=use_graph)   # network_trainer.py:120-125
     B = args.batch
     if args.model == "pyfer":
         x = synth.dose_input(B, shape, seed=1234 + rank).to(dev)
@@ -190,23 +192,51 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    # The step is launch-bound on the host (~1900 kernel launches): after the eager warm-up the whole step (forward, loss,
+    # backward, optimizer) is captured ONCE into a HIP graph and the timed region replays it.  Every kernel still runs every
+    # step (weights are re-packed inside the graph because the optimizer changes them); nothing is cached across steps.
+    graph = None
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(max(1, args.warmup)):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
     sync()
+    # per-kernel HIP-event timing: one eager step on the launch stream (events cannot be recorded inside a capture)
     _lib.PROFILE = []
+    step()
+    sync()
+    records, _lib.PROFILE = _lib.PROFILE, None
+    prof_steps = 1
+    if use_graph:
+        try:
+            if opt is not None:
+                opt.zero_grad(set_to_none=True)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_loss = step()
+            graph.replay()          # one untimed replay
+            sync()
+        except Exception as e:      # capture is an optimisation: fall back to eager launches
+            print(f"[bench] HIP-graph capture failed ({e!r}); timing eager launches", file=sys.stderr)
+            graph = None
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = step()
+        if graph is not None:
+            graph.replay()
+            loss = static_loss
+        else:
+            loss = step()
     sync()
     dt = time.perf_counter() - t0
-    records, _lib.PROFILE = _lib.PROFILE, None
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     final_loss = float(loss.detach())
     if rank == 0:
-        prof = summarize_profile(records, args.steps)
+        prof = summarize_profile(records, prof_steps)
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
         dom = prof.get("conv7x7x7_tiled", prof.get("conv7x7x7_generic", {"tflops": 0.0, "avg_launch_ms": 0.0, "launches_per_step": 0}))
         res = {
@@ -217,6 +247,7 @@ def main():
                                     else "OAR-TRANSEG segmentation path (BASELINE.json configs[2])"),
                        "volume": list(shape), "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
                        "net_A_frozen": args.model == "pyfer", "optimizer_step_in_timed_region": opt is not None,
+                       "launch": "hipGraph replay" if graph is not None else "eager",
                        "final_loss": final_loss},
             "roofline": {"bound": "mfma", "kernel": "conv3d 7x7x7 implicit GEMM (forward + data-gradient launches)",
                          "achieved": dom["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": dom["tflops"] / peak,
