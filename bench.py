@@ -37,7 +37,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optimizer", action="store_true")
     ap.add_argument("--cpu-size", type=int, default=64)
-    ap.add_argument("--no-graph", action="store_true", help="do not replay the step from a captured HIP graph")
+    ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph (GPU-bound either way)")
+    ap.add_argument("--torch-adam", action="store_true", help="use torch.optim.Adam instead of the fused HIP Adam")
     return ap.parse_args()
 
 
@@ -160,9 +161,13 @@ def main():
     if world > 1:
         attach_gradient_allreduce(net, bucket_mb=32.0)
     params = [p for p in net.parameters() if p.requires_grad]
-    use_graph = (world == 1) and not args.no_graph
-    opt = None if args.no_optimizer else torch.optim.Adam(params, lr=1e-4, weight_decay=3e-5, betas=(0.9, 0.999), eps=1e-8,
-                                                          amsgrad=True, capturable=use_graph)   # network_trainer.py:120-125
+    use_graph = (world == 1) and args.graph
+    from dose_prediction_amd.optim import FusedAdam
+    # optimizer exactly as NetworkTrainer.set_optimizer builds it (network_trainer.py:120-125), as the fused HIP kernel
+    opt = None
+    if not args.no_optimizer:
+        cls = torch.optim.Adam if args.torch_adam else FusedAdam
+        opt = cls(params, lr=1e-4, weight_decay=3e-5, betas=(0.9, 0.999), eps=1e-8, amsgrad=True)
     B = args.batch
     if args.model == "pyfer":
         x = synth.dose_input(B, shape, seed=1234 + rank).to(dev)
@@ -247,6 +252,7 @@ def main():
                                     else "OAR-TRANSEG segmentation path (BASELINE.json configs[2])"),
                        "volume": list(shape), "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
                        "net_A_frozen": args.model == "pyfer", "optimizer_step_in_timed_region": opt is not None,
+                       "optimizer": (type(opt).__name__ + "(amsgrad)") if opt is not None else None,
                        "launch": "hipGraph replay" if graph is not None else "eager",
                        "final_loss": final_loss},
             "roofline": {"bound": "mfma", "kernel": "conv3d 7x7x7 implicit GEMM (forward + data-gradient launches)",

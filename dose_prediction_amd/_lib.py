@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libdose_hip.so")
 
 _CTYPES = {
     "int": ctypes.c_int, "int64_t": ctypes.c_int64, "float": ctypes.c_float, "int32_t": ctypes.c_int32,
+    "double": ctypes.c_double,
 }
 
 

@@ -1,0 +1,54 @@
+// Fused multi-tensor Adam (AMSGrad, L2 weight decay) -- SURVEY.md section 8f "next-4": the optimizer NetworkTrainer builds
+// (network_trainer.py:120-125: optim.Adam(lr, weight_decay=3e-5, betas=(0.9,0.999), eps=1e-8, amsgrad=True)) as ONE launch
+// over all parameter tensors.  Pure HBM stream: 5 reads + 4 writes of fp32 per parameter (36 B), float4 accesses.
+#include "common.h"
+
+#define STREAM ((hipStream_t)stream)
+#define ADAM_CHUNK 8192          // elements per block
+
+struct AdamTensor { float* p; const float* g; float* m; float* v; float* vmax; int64_t n; };
+
+__global__ void __launch_bounds__(256) k_adam_multi(const AdamTensor* __restrict__ tab, const int* __restrict__ chunk_t, const int* __restrict__ chunk_i,
+                                                    float lr_c1, float beta1, float beta2, float omb1, float omb2, float eps, float wd, float rsqrt_c2, int amsgrad) {
+  const AdamTensor T = tab[chunk_t[blockIdx.x]];
+  const int64_t base = (int64_t)chunk_i[blockIdx.x] * ADAM_CHUNK;
+  const int64_t end = min(T.n, base + ADAM_CHUNK);
+  const bool vec = (((uintptr_t)T.p | (uintptr_t)T.g | (uintptr_t)T.m | (uintptr_t)T.v | (uintptr_t)T.vmax) & 15) == 0;
+  auto upd = [&](float& p, float g, float& m, float& v, float& vm) {
+    g += wd * p;
+    m = beta1 * m + omb1 * g;            // (1 - beta) is formed in double on the host, as torch does
+    v = beta2 * v + omb2 * g * g;
+    float vv = v;
+    if (amsgrad) { vm = fmaxf(vm, v); vv = vm; }
+    p -= lr_c1 * m / (sqrtf(vv) * rsqrt_c2 + eps);
+  };
+  if (vec) {
+    for (int64_t i = base + threadIdx.x * 4; i < end; i += 256 * 4) {
+      if (i + 4 <= end) {
+        v4f p = *(v4f*)(T.p + i), g = *(const v4f*)(T.g + i), m = *(v4f*)(T.m + i), v = *(v4f*)(T.v + i);
+        v4f vm = amsgrad ? *(v4f*)(T.vmax + i) : (v4f){0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 4; k++) { float pp = p[k], mm = m[k], vv = v[k], vx = vm[k]; upd(pp, g[k], mm, vv, vx); p[k] = pp; m[k] = mm; v[k] = vv; vm[k] = vx; }
+        *(v4f*)(T.p + i) = p; *(v4f*)(T.m + i) = m; *(v4f*)(T.v + i) = v;
+        if (amsgrad) *(v4f*)(T.vmax + i) = vm;
+      } else {
+        for (int64_t j = i; j < end; j++) { float vx = amsgrad ? T.vmax[j] : 0.f; upd(T.p[j], T.g[j], T.m[j], T.v[j], vx); if (amsgrad) T.vmax[j] = vx; }
+      }
+    }
+  } else {
+    for (int64_t j = base + threadIdx.x; j < end; j += 256) { float vx = amsgrad ? T.vmax[j] : 0.f; upd(T.p[j], T.g[j], T.m[j], T.v[j], vx); if (amsgrad) T.vmax[j] = vx; }
+  }
+}
+
+// table: device array of {p, g, m, v, vmax, n} (6 x 8 bytes per tensor); chunk_t / chunk_i: device int arrays mapping each
+// block to (tensor, chunk index of ADAM_CHUNK elements).  step >= 1 is the step count AFTER this update.
+extern "C" int dp_adam_chunk(void) { return ADAM_CHUNK; }
+extern "C" int dp_adam_multi(const void* table, const int32_t* chunk_t, const int32_t* chunk_i, int nchunks, double lr, double beta1, double beta2,
+                             double eps, double weight_decay, int step, int amsgrad, void* stream) {
+  if (nchunks <= 0) return 0;
+  if (step < 1) DP_FAIL("adam: step must be >= 1");
+  double c1 = 1.0 - pow(beta1, (double)step), c2 = 1.0 - pow(beta2, (double)step);
+  hipLaunchKernelGGL(k_adam_multi, dim3(nchunks), dim3(256), 0, STREAM, (const AdamTensor*)table, (const int*)chunk_t, (const int*)chunk_i,
+                     (float)(lr / c1), (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)weight_decay, (float)(1.0 / sqrt(c2)), amsgrad);
+  DP_CHECK_LAUNCH("adam_multi"); return 0;
+}

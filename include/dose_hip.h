@@ -159,6 +159,14 @@ int dp_conv3d_wgrad_tiled_ws_elems(int Cin, int Cout, int k, int stride, int pad
 int dp_conv3d_wgrad_tiled(const void* x, int ldx, const void* gy, int ldgy, float* dw, float* ws, int N, int D, int H, int W,
                           int Cin, int Cout, int k, int64_t s_co, int64_t s_ci, int64_t s_tap, int dtype, void* stream);
 
+/* ---- optimizer ------------------------------------------------------------ */
+/* replaces: optim.Adam(..., amsgrad=True).step() as built by NetworkTrainer.set_optimizer (network_trainer.py:120-125): one
+ * launch over all parameter tensors.  table: device array of {float* p; const float* g; float* m; float* v; float* vmax;
+ * int64_t n}; chunk_t/chunk_i map each block to (tensor, chunk of dp_adam_chunk() elements); step = count after this update. */
+int dp_adam_chunk(void);
+int dp_adam_multi(const void* table, const int32_t* chunk_t, const int32_t* chunk_i, int nchunks, double lr, double beta1, double beta2,
+                  double eps, double weight_decay, int step, int amsgrad, void* stream);
+
 /* ---- cascade glue ----------------------------------------------------------------------------- */
 /* replaces: AsDiscrete(argmax=True, to_onehot=True) + channel concat (train_light_linked_model.py:157-167):
  * logits NDHWC [rows][ld] (C classes) -> one-hot of the arg-max (first max wins, as torch.argmax) for classes

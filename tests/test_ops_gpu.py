@@ -304,3 +304,27 @@ def test_argmax_onehot():
     assert torch.equal(out[..., 1:8].cpu(), ref)
     assert torch.equal(lab.cpu().long(), lg.argmax(-1))
     assert out[..., 0].abs().max().item() == 0 and out[..., 8:].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("amsgrad", [True, False])
+def test_fused_adam_matches_torch(amsgrad):
+    """FusedAdam (dp_adam_multi) == torch.optim.Adam as NetworkTrainer.set_optimizer builds it (network_trainer.py:120-125)."""
+    from dose_prediction_amd.optim import FusedAdam
+    dev = _dev()
+    shapes = [(16, 9, 3, 3, 3), (16,), (768, 3000), (5,), (1, 512, 768), (33333,)]
+    ps = [rnd(s, 10 + i).to(dev) for i, s in enumerate(shapes)]
+    a = [p.clone().requires_grad_(True) for p in ps]
+    b = [p.clone().requires_grad_(True) for p in ps]
+    kw = dict(lr=1e-3, weight_decay=3e-5, betas=(0.9, 0.999), eps=1e-8, amsgrad=amsgrad)
+    oa, ob = torch.optim.Adam(a, **kw), FusedAdam(b, **kw)
+    for it in range(4):
+        for i, (x, y) in enumerate(zip(a, b)):
+            g = rnd(x.shape, 100 * it + i).to(dev) * (0.1 if it == 2 else 1.0)
+            x.grad, y.grad = g.clone(), g.clone()
+        oa.step()
+        ob.step()
+    for x, y in zip(a, b):
+        assert rel_err(y.detach().cpu(), x.detach().cpu()) < 2e-6
+    for x, y in zip(a, b):
+        for k in ("exp_avg", "exp_avg_sq") + (("max_exp_avg_sq",) if amsgrad else ()):
+            assert rel_err(ob.state[y][k].cpu(), oa.state[x][k].cpu()) < 2e-6, k
