@@ -149,11 +149,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback for the HIP path)"
+    ndev = torch.cuda.device_count()
+    if world > 1 and ndev < world and os.environ.get("DOSE_DDP_BACKEND") != "gloo":
+        raise SystemExit(f"bench.py --gpus {world}: only {ndev} GPU(s) visible")
+    local = local % max(1, ndev)          # (gloo self-test: several ranks may share one GPU)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("DOSE_DDP_BACKEND", "nccl")      # nccl == RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     shape = tuple(args.size * 3) if len(args.size) == 1 else tuple(args.size)
     from dose_prediction_amd import synth, losses, _lib
     from dose_prediction_amd.ddp import attach_gradient_allreduce
