@@ -75,7 +75,7 @@ static inline int tiled_config(int Cout, int* rw, int* nt) {
   *rw = 4; *nt = 2; return 1;
 }
 static inline bool tiled_applicable(int Cin, int Cout, int k, int stride, int pad, int dil, int W) {
-  return (k == 3 || k == 7) && stride == 1 && dil == 1 && pad == k / 2 && W >= 16 && Cin >= 8 && Cout >= 8;
+  return (k == 3 || k == 7) && stride == 1 && dil == 1 && pad == k / 2 && W >= 16 && Cin >= 1 && Cout >= 8;
 }
 
 extern "C" int dp_conv3d_tiled_weight_elems(int Cin, int Cout, int k, int stride, int pad, int dil, int W) {
@@ -596,7 +596,7 @@ __global__ void k_wgrad_unpack(const float* __restrict__ dwt, float* __restrict_
 
 static inline bool wgt_applicable(int Cin, int Cout, int k, int stride, int pad, int dil, int shift, int W) {
   if (k == 1) return stride == 1 && pad == 0 && W >= 16 && Cin >= 8 && Cout >= 8 && Cin <= 128 && Cout <= 128;   // pointwise: HBM-bound row stream
-  return shift && (k == 3 || k == 7) && stride == 1 && dil == 1 && pad == k / 2 && W >= 16 && Cin >= 8 && Cout >= 8;
+  return shift && (k == 3 || k == 7) && stride == 1 && dil == 1 && pad == k / 2 && W >= 16 && Cin >= 1 && Cout >= 8;
 }
 // fp32 scratch elements needed by dp_conv3d_wgrad_tiled (0: shape not supported, use dp_conv3d_wgrad)
 extern "C" int dp_conv3d_wgrad_tiled_ws_elems(int Cin, int Cout, int k, int stride, int pad, int dil, int shift, int W) {

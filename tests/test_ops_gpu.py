@@ -77,6 +77,8 @@ DTYPES = [torch.float32, torch.bfloat16]
     (1, 16, 16, 9, 17, 64, 7, 1, 3, 1, True),
     (1, 9, 16, 4, 11, 36, 3, 1, 1, 1, True),
     (1, 128, 64, 2, 6, 32, 3, 1, 1, 1, True),
+    (2, 1, 16, 3, 9, 40, 3, 1, 1, 1, False),      # single input channel (OAR-TRANSEG encoder1: CT -> 16)
+    (1, 3, 16, 2, 9, 32, 7, 1, 3, 1, True),
 ])
 def test_conv3d(cfg, dtype):
     from dose_prediction_amd import ops
