@@ -104,7 +104,11 @@ __device__ __forceinline__ float act_fwd(float z, int act) {
   switch (act) {
     case DP_ACT_RELU: return z > 0.f ? z : 0.f;
     case DP_ACT_LRELU: return z >= 0.f ? z : 0.01f * z;
-    case DP_ACT_MISH: { float sp = z > 20.f ? z : log1pf(expf(z)); return z * tanhf(sp); }
+    case DP_ACT_MISH: {   // z*tanh(softplus(z)) with n = e^z: tanh(log(1+n)) = t/(t+2), t = n(n+2)  (one exp, one divide)
+      if (z > 20.f) return z;
+      float n = expf(z), t = n * (n + 2.f);
+      return z * (t / (t + 2.f));
+    }
     case DP_ACT_GELU: return 0.5f * z * (1.f + erff(z * 0.70710678118654752f));
     default: return z;
   }
@@ -113,11 +117,10 @@ __device__ __forceinline__ float act_bwd(float z, int act) {
   switch (act) {
     case DP_ACT_RELU: return z > 0.f ? 1.f : 0.f;
     case DP_ACT_LRELU: return z >= 0.f ? 1.f : 0.01f;
-    case DP_ACT_MISH: {
-      float sp = z > 20.f ? z : log1pf(expf(z));
-      float t = tanhf(sp);
-      float sg = 1.f / (1.f + expf(-z));
-      return t + z * (1.f - t * t) * sg;
+    case DP_ACT_MISH: {   // d/dz [z tanh(sp)] = th + z (1 - th^2) sigmoid(z), th = t/(t+2), sigmoid = n/(1+n)
+      if (z > 20.f) return 1.f;
+      float n = expf(z), t = n * (n + 2.f), th = t / (t + 2.f);
+      return th + z * (1.f - th * th) * (n / (1.f + n));
     }
     case DP_ACT_GELU: return 0.5f * (1.f + erff(z * 0.70710678118654752f)) + z * 0.3989422804014327f * expf(-0.5f * z * z);
     default: return 1.f;

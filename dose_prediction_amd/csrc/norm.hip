@@ -34,6 +34,23 @@ __device__ __forceinline__ void pack8(bf16_t* p, int nv, const float* o) {
   } else for (int i = 0; i < 8; i++) if (i < nv) p[i] = f2bf(o[i]);
 }
 
+// unguarded 8-element row-chunk access for the fast paths (C % 8 == 0, pitches % 8 == 0, 16-byte aligned bases)
+__device__ __forceinline__ void ld8(const float* p, float* o) { v4f a = *(const v4f*)p, b = *(const v4f*)(p + 4); o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3]; }
+__device__ __forceinline__ void ld8(const bf16_t* p, float* o) {
+  v4u u = *(const v4u*)p;
+#pragma unroll
+  for (int i = 0; i < 4; i++) { o[2 * i] = __uint_as_float(u[i] << 16); o[2 * i + 1] = __uint_as_float(u[i] & 0xffff0000u); }
+}
+__device__ __forceinline__ void st8(float* p, const float* o) { *(v4f*)p = (v4f){o[0], o[1], o[2], o[3]}; *(v4f*)(p + 4) = (v4f){o[4], o[5], o[6], o[7]}; }
+__device__ __forceinline__ void st8(bf16_t* p, const float* o) {
+  v4u u;
+#pragma unroll
+  for (int i = 0; i < 4; i++) u[i] = (unsigned)f2bf(o[2 * i]) | ((unsigned)f2bf(o[2 * i + 1]) << 16);
+  *(v4u*)p = u;
+}
+static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+#define RU 4     // rows in flight per thread in the fast paths
+
 extern "C" int dp_stats_nblk(int64_t V) { int r = rows_per_block(V); return (int)((V + r - 1) / r); }
 
 // Common geometry: block b of sample n covers voxels [b*RPB, min(V,(b+1)*RPB)); thread t owns chunk cg = t % cg8 and
@@ -59,14 +76,27 @@ __device__ __forceinline__ void block_reduce_store(float* red, const float* a1, 
 }
 
 template <typename T>
-__global__ void __launch_bounds__(NT) k_stats_partial(const T* __restrict__ x, int ld, int64_t V, int C, float* __restrict__ part, int nblk, int ROWS_PER_BLOCK) {
+__global__ void __launch_bounds__(NT) k_stats_partial(const T* __restrict__ x, int ld, int64_t V, int C, float* __restrict__ part, int nblk, int ROWS_PER_BLOCK, int fast) {
   __shared__ float red[NT * 16];
   if (C > 8 * NT) return;
   int b = blockIdx.x, n = blockIdx.y;
   RowGeom g = row_geom(C);
   int64_t v0 = (int64_t)b * ROWS_PER_BLOCK, v1 = min(V, v0 + ROWS_PER_BLOCK);
   float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (g.active) for (int64_t v = v0 + g.r0; v < v1; v += g.rpi) {
+  int64_t vs = v0 + g.r0;
+  if (g.active && fast) {
+    const T* xb = x + (int64_t)n * V * ld + g.cg * 8;
+    for (; vs + (RU - 1) * (int64_t)g.rpi < v1; vs += RU * g.rpi) {
+      float t[RU][8];
+#pragma unroll
+      for (int u = 0; u < RU; u++) ld8(xb + (vs + u * g.rpi) * ld, t[u]);
+#pragma unroll
+      for (int u = 0; u < RU; u++)
+#pragma unroll
+        for (int i = 0; i < 8; i++) { s1[i] += t[u][i]; s2[i] += t[u][i] * t[u][i]; }
+    }
+  }
+  if (g.active) for (int64_t v = vs; v < v1; v += g.rpi) {
     float t[8]; unpack8<T>(x + ((int64_t)n * V + v) * ld + g.cg * 8, g.nv, t);
     for (int i = 0; i < 8; i++) { s1[i] += t[i]; s2[i] += t[i] * t[i]; }
   }
@@ -75,7 +105,8 @@ __global__ void __launch_bounds__(NT) k_stats_partial(const T* __restrict__ x, i
 extern "C" int dp_stats_partial(const void* x, int ld, int N, int64_t V, int C, float* part, int dtype, void* stream) {
   if (C > 8 * NT) DP_FAIL("stats: C too large");
   int nblk = dp_stats_nblk(V);
-  DP_DISPATCH(dtype, hipLaunchKernelGGL(k_stats_partial<T>, dim3(nblk, N), dim3(NT), 0, STREAM, (const T*)x, ld, V, C, part, nblk, rows_per_block(V)));
+  int fast = (C % 8 == 0) && (ld % 8 == 0) && aligned16(x);
+  DP_DISPATCH(dtype, hipLaunchKernelGGL(k_stats_partial<T>, dim3(nblk, N), dim3(NT), 0, STREAM, (const T*)x, ld, V, C, part, nblk, rows_per_block(V), fast));
   DP_CHECK_LAUNCH("stats_partial"); return 0;
 }
 
@@ -142,69 +173,183 @@ __device__ __forceinline__ NormConst load_consts(const float* mean, const float*
   return k;
 }
 
-template <typename T>
-__global__ void __launch_bounds__(NT) k_norm_act_fwd(const T* __restrict__ x, int ldx, const float* mean, const float* rstd, int ssn,
-                                                     const float* gamma, const float* beta, const T* __restrict__ res, int ldr, int act,
-                                                     T* __restrict__ y, int ldy, int64_t V, int C, int ROWS_PER_BLOCK) {
-  int b = blockIdx.x, n = blockIdx.y;
-  RowGeom g = row_geom(C);
+// The three row-stream kernels are templated on the activation (no per-element switch) and have a fast path (C % 8 == 0,
+// pitches % 8 == 0, aligned bases: unguarded 16-byte accesses, RU rows in flight per thread) next to the generic guarded loop.
+struct NormArgs {
+  const void* x; int ldx; const void* gy; int ldgy; const float* mean; const float* rstd; int ssn; const float* gamma; const float* beta;
+  const void* res; int ldr; void* y; int ldy; void* gres; int ldgres; const float* s1; const float* s2; float inv_count; int use_stats;
+  int64_t V; int C; int rpb; int nblk; float* part; int fast;
+};
+
+template <typename T, int ACT>
+__global__ void __launch_bounds__(NT) k_norm_act_fwd(NormArgs a) {
+  const T* x = (const T*)a.x; const T* res = (const T*)a.res; T* y = (T*)a.y;
+  const int b = blockIdx.x, n = blockIdx.y;
+  RowGeom g = row_geom(a.C);
   if (!g.active) return;
-  NormConst k = load_consts(mean, rstd, n * ssn, gamma, beta, g.cg * 8, g.nv);
-  int64_t v0 = (int64_t)b * ROWS_PER_BLOCK, v1 = min(V, v0 + ROWS_PER_BLOCK);
-  for (int64_t v = v0 + g.r0; v < v1; v += g.rpi) {
-    int64_t row = (int64_t)n * V + v;
-    float t[8], rr[8];
-    unpack8<T>(x + row * ldx + g.cg * 8, g.nv, t);
-    if (res) unpack8<T>(res + row * ldr + g.cg * 8, g.nv, rr);
-    for (int i = 0; i < 8; i++) {
-      float z = (t[i] - k.m[i]) * k.r[i] * k.ga[i] + k.be[i];
-      if (res) z += rr[i];
-      t[i] = act_fwd(z, act);
+  NormConst k = load_consts(a.mean, a.rstd, n * a.ssn, a.gamma, a.beta, g.cg * 8, g.nv);
+  float sc[8], sh[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) { sc[i] = k.r[i] * k.ga[i]; sh[i] = k.be[i] - k.m[i] * sc[i]; }     // z = x*sc + sh
+  const int64_t v0 = (int64_t)b * a.rpb, v1 = min(a.V, v0 + a.rpb), nb = (int64_t)n * a.V;
+  int64_t vs = v0 + g.r0;
+  if (a.fast) {
+    for (; vs + (RU - 1) * (int64_t)g.rpi < v1; vs += RU * g.rpi) {
+      float t[RU][8], rr[RU][8];
+#pragma unroll
+      for (int u = 0; u < RU; u++) {
+        const int64_t row = nb + vs + u * g.rpi;
+        ld8(x + row * a.ldx + g.cg * 8, t[u]);
+        if (res) ld8(res + row * a.ldr + g.cg * 8, rr[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < RU; u++) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) { float z = t[u][i] * sc[i] + sh[i]; if (res) z += rr[u][i]; t[u][i] = act_fwd(z, ACT); }
+        st8(y + (nb + vs + u * g.rpi) * a.ldy + g.cg * 8, t[u]);
+      }
     }
-    pack8(y + row * ldy + g.cg * 8, g.nv, t);
+  }
+  for (int64_t v = vs; v < v1; v += g.rpi) {
+    const int64_t row = nb + v;
+    float t[8], rr[8];
+    unpack8<T>(x + row * a.ldx + g.cg * 8, g.nv, t);
+    if (res) unpack8<T>(res + row * a.ldr + g.cg * 8, g.nv, rr);
+#pragma unroll
+    for (int i = 0; i < 8; i++) { float z = t[i] * sc[i] + sh[i]; if (res) z += rr[i]; t[i] = act_fwd(z, ACT); }
+    pack8(y + row * a.ldy + g.cg * 8, g.nv, t);
   }
 }
-extern "C" int dp_norm_act_fwd(const void* x, int ldx, const float* mean, const float* rstd, int ssn, const float* gamma, const float* beta,
-                               const void* res, int ldr, int act, void* y, int ldy, int N, int64_t V, int C, int dtype, void* stream) {
-  if (C > 8 * NT) DP_FAIL("norm_act_fwd: C too large");
-  DP_DISPATCH(dtype, hipLaunchKernelGGL(k_norm_act_fwd<T>, dim3(dp_stats_nblk(V), N), dim3(NT), 0, STREAM, (const T*)x, ldx, mean, rstd, ssn,
-                                        gamma, beta, (const T*)res, ldr, act, (T*)y, ldy, V, C, rows_per_block(V)));
-  DP_CHECK_LAUNCH("norm_act_fwd"); return 0;
-}
 
-template <typename T>
-__global__ void __launch_bounds__(NT) k_norm_act_bwd_partial(const T* __restrict__ x, int ldx, const T* __restrict__ gy, int ldgy, const float* mean,
-                                                             const float* rstd, int ssn, const float* gamma, const float* beta,
-                                                             const T* __restrict__ res, int ldr, int act, int64_t V, int C,
-                                                             float* __restrict__ part, int nblk, int ROWS_PER_BLOCK) {
+template <typename T, int ACT>
+__global__ void __launch_bounds__(NT) k_norm_act_bwd_partial(NormArgs a) {
   __shared__ float red[NT * 16];
-  int b = blockIdx.x, n = blockIdx.y;
-  RowGeom g = row_geom(C);
-  NormConst k = load_consts(mean, rstd, n * ssn, gamma, beta, g.cg * 8, g.active ? g.nv : 0);
-  int64_t v0 = (int64_t)b * ROWS_PER_BLOCK, v1 = min(V, v0 + ROWS_PER_BLOCK);
+  const T* x = (const T*)a.x; const T* gy = (const T*)a.gy; const T* res = (const T*)a.res;
+  const int b = blockIdx.x, n = blockIdx.y;
+  RowGeom g = row_geom(a.C);
+  NormConst k = load_consts(a.mean, a.rstd, n * a.ssn, a.gamma, a.beta, g.cg * 8, g.active ? g.nv : 0);
+  const int64_t v0 = (int64_t)b * a.rpb, v1 = min(a.V, v0 + a.rpb), nb = (int64_t)n * a.V;
   float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (g.active) for (int64_t v = v0 + g.r0; v < v1; v += g.rpi) {
-    int64_t row = (int64_t)n * V + v;
-    float t[8], d[8], rr[8];
-    unpack8<T>(x + row * ldx + g.cg * 8, g.nv, t);
-    unpack8<T>(gy + row * ldgy + g.cg * 8, g.nv, d);
-    if (res) unpack8<T>(res + row * ldr + g.cg * 8, g.nv, rr);
+  int64_t vs = v0 + g.r0;
+  auto body = [&](const float* t, const float* d, const float* rr) {
+#pragma unroll
     for (int i = 0; i < 8; i++) {
       float xh = (t[i] - k.m[i]) * k.r[i];
       float z = xh * k.ga[i] + k.be[i]; if (res) z += rr[i];
-      float gg = d[i] * act_bwd(z, act);
+      float gg = d[i] * act_bwd(z, ACT);
       s1[i] += gg; s2[i] += gg * xh;
     }
+  };
+  if (g.active && a.fast) {
+    for (; vs + (RU - 1) * (int64_t)g.rpi < v1; vs += RU * g.rpi) {
+      float t[RU][8], d[RU][8], rr[RU][8];
+#pragma unroll
+      for (int u = 0; u < RU; u++) {
+        const int64_t row = nb + vs + u * g.rpi;
+        ld8(x + row * a.ldx + g.cg * 8, t[u]); ld8(gy + row * a.ldgy + g.cg * 8, d[u]);
+        if (res) ld8(res + row * a.ldr + g.cg * 8, rr[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < RU; u++) body(t[u], d[u], rr[u]);
+    }
   }
-  block_reduce_store(red, s1, s2, g, C, part + ((int64_t)n * nblk + b) * 2 * C);
+  if (g.active) for (int64_t v = vs; v < v1; v += g.rpi) {
+    const int64_t row = nb + v;
+    float t[8], d[8], rr[8];
+    unpack8<T>(x + row * a.ldx + g.cg * 8, g.nv, t);
+    unpack8<T>(gy + row * a.ldgy + g.cg * 8, g.nv, d);
+    if (res) unpack8<T>(res + row * a.ldr + g.cg * 8, g.nv, rr);
+    body(t, d, rr);
+  }
+  block_reduce_store(red, s1, s2, g, a.C, a.part + ((int64_t)n * a.nblk + b) * 2 * a.C);
+}
+
+template <typename T, int ACT>
+__global__ void __launch_bounds__(NT) k_norm_act_bwd_apply(NormArgs a) {
+  const T* x = (const T*)a.x; const T* gy = (const T*)a.gy; const T* res = (const T*)a.res; T* gx = (T*)a.y; T* gres = (T*)a.gres;
+  const int b = blockIdx.x, n = blockIdx.y;
+  RowGeom g = row_geom(a.C);
+  if (!g.active) return;
+  NormConst k = load_consts(a.mean, a.rstd, n * a.ssn, a.gamma, a.beta, g.cg * 8, g.nv);
+  float a1[8], a2[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    bool ok = a.use_stats && i < g.nv;
+    a1[i] = ok ? a.s1[n * a.ssn + g.cg * 8 + i] * a.inv_count : 0.f;
+    a2[i] = ok ? a.s2[n * a.ssn + g.cg * 8 + i] * a.inv_count : 0.f;
+  }
+  const int64_t v0 = (int64_t)b * a.rpb, v1 = min(a.V, v0 + a.rpb), nb = (int64_t)n * a.V;
+  int64_t vs = v0 + g.r0;
+  auto body = [&](float* t, const float* d, const float* rr, float* gg) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      float xh = (t[i] - k.m[i]) * k.r[i];
+      float z = xh * k.ga[i] + k.be[i]; if (res) z += rr[i];
+      gg[i] = d[i] * act_bwd(z, ACT);
+      t[i] = k.ga[i] * k.r[i] * (gg[i] - a1[i] - xh * a2[i]);
+    }
+  };
+  if (a.fast) {
+    for (; vs + (RU - 1) * (int64_t)g.rpi < v1; vs += RU * g.rpi) {
+      float t[RU][8], d[RU][8], rr[RU][8], gg[RU][8];
+#pragma unroll
+      for (int u = 0; u < RU; u++) {
+        const int64_t row = nb + vs + u * g.rpi;
+        ld8(x + row * a.ldx + g.cg * 8, t[u]); ld8(gy + row * a.ldgy + g.cg * 8, d[u]);
+        if (res) ld8(res + row * a.ldr + g.cg * 8, rr[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < RU; u++) {
+        const int64_t row = nb + vs + u * g.rpi;
+        body(t[u], d[u], rr[u], gg[u]);
+        if (gx) st8(gx + row * a.ldy + g.cg * 8, t[u]);
+        if (gres) st8(gres + row * a.ldgres + g.cg * 8, gg[u]);
+      }
+    }
+  }
+  for (int64_t v = vs; v < v1; v += g.rpi) {
+    const int64_t row = nb + v;
+    float t[8], d[8], rr[8], gg[8];
+    unpack8<T>(x + row * a.ldx + g.cg * 8, g.nv, t);
+    unpack8<T>(gy + row * a.ldgy + g.cg * 8, g.nv, d);
+    if (res) unpack8<T>(res + row * a.ldr + g.cg * 8, g.nv, rr);
+    body(t, d, rr, gg);
+    if (gx) pack8(gx + row * a.ldy + g.cg * 8, g.nv, t);
+    if (gres) pack8(gres + row * a.ldgres + g.cg * 8, g.nv, gg);
+  }
+}
+
+#define NORM_LAUNCH(KERN, args, grid) do { \
+    switch (act) { \
+      case DP_ACT_NONE: DP_DISPATCH(dtype, hipLaunchKernelGGL((KERN<T, DP_ACT_NONE>), grid, dim3(NT), 0, STREAM, args)); break; \
+      case DP_ACT_RELU: DP_DISPATCH(dtype, hipLaunchKernelGGL((KERN<T, DP_ACT_RELU>), grid, dim3(NT), 0, STREAM, args)); break; \
+      case DP_ACT_LRELU: DP_DISPATCH(dtype, hipLaunchKernelGGL((KERN<T, DP_ACT_LRELU>), grid, dim3(NT), 0, STREAM, args)); break; \
+      case DP_ACT_MISH: DP_DISPATCH(dtype, hipLaunchKernelGGL((KERN<T, DP_ACT_MISH>), grid, dim3(NT), 0, STREAM, args)); break; \
+      case DP_ACT_GELU: DP_DISPATCH(dtype, hipLaunchKernelGGL((KERN<T, DP_ACT_GELU>), grid, dim3(NT), 0, STREAM, args)); break; \
+      default: DP_FAIL("bad activation %d", act); } } while (0)
+
+static inline int norm_fast(int C, int ldx, const void* x, int ldg, const void* gy, int ldr, const void* res, int ldy, const void* y, int ldgr, const void* gr) {
+  auto ok = [](int ld, const void* p) { return p == nullptr || (ld % 8 == 0 && aligned16(p)); };
+  return (C % 8 == 0) && ok(ldx, x) && ok(ldg, gy) && ok(ldr, res) && ok(ldy, y) && ok(ldgr, gr);
+}
+
+extern "C" int dp_norm_act_fwd(const void* x, int ldx, const float* mean, const float* rstd, int ssn, const float* gamma, const float* beta,
+                               const void* res, int ldr, int act, void* y, int ldy, int N, int64_t V, int C, int dtype, void* stream) {
+  if (C > 8 * NT) DP_FAIL("norm_act_fwd: C too large");
+  NormArgs a = {}; a.x = x; a.ldx = ldx; a.mean = mean; a.rstd = rstd; a.ssn = ssn; a.gamma = gamma; a.beta = beta; a.res = res; a.ldr = ldr;
+  a.y = y; a.ldy = ldy; a.V = V; a.C = C; a.rpb = rows_per_block(V); a.nblk = dp_stats_nblk(V);
+  a.fast = norm_fast(C, ldx, x, 0, nullptr, ldr, res, ldy, y, 0, nullptr);
+  NORM_LAUNCH(k_norm_act_fwd, a, dim3(a.nblk, N));
+  DP_CHECK_LAUNCH("norm_act_fwd"); return 0;
 }
 extern "C" int dp_norm_act_bwd_partial(const void* x, int ldx, const void* gy, int ldgy, const float* mean, const float* rstd, int ssn,
                                        const float* gamma, const float* beta, const void* res, int ldr, int act, int N, int64_t V, int C,
                                        float* part, int dtype, void* stream) {
   if (C > 8 * NT) DP_FAIL("norm_act_bwd_partial: C too large");
-  int nblk = dp_stats_nblk(V);
-  DP_DISPATCH(dtype, hipLaunchKernelGGL(k_norm_act_bwd_partial<T>, dim3(nblk, N), dim3(NT), 0, STREAM, (const T*)x, ldx, (const T*)gy, ldgy, mean, rstd, ssn,
-                                        gamma, beta, (const T*)res, ldr, act, V, C, part, nblk, rows_per_block(V)));
+  NormArgs a = {}; a.x = x; a.ldx = ldx; a.gy = gy; a.ldgy = ldgy; a.mean = mean; a.rstd = rstd; a.ssn = ssn; a.gamma = gamma; a.beta = beta;
+  a.res = res; a.ldr = ldr; a.V = V; a.C = C; a.rpb = rows_per_block(V); a.nblk = dp_stats_nblk(V); a.part = part;
+  a.fast = norm_fast(C, ldx, x, ldgy, gy, ldr, res, 0, nullptr, 0, nullptr);
+  NORM_LAUNCH(k_norm_act_bwd_partial, a, dim3(a.nblk, N));
   DP_CHECK_LAUNCH("norm_act_bwd_partial"); return 0;
 }
 
@@ -228,46 +373,16 @@ extern "C" int dp_norm_bwd_finalize(const float* part, int N, int nblk, int C, i
   DP_CHECK_LAUNCH("norm_bwd_finalize"); return 0;
 }
 
-template <typename T>
-__global__ void __launch_bounds__(NT) k_norm_act_bwd_apply(const T* __restrict__ x, int ldx, const T* __restrict__ gy, int ldgy, const float* mean,
-                                                           const float* rstd, int ssn, const float* gamma, const float* beta,
-                                                           const T* __restrict__ res, int ldr, int act, const float* s1, const float* s2,
-                                                           float inv_count, int use_stats, T* __restrict__ gx, int ldgx, T* __restrict__ gres, int ldgres,
-                                                           int64_t V, int C, int ROWS_PER_BLOCK) {
-  int b = blockIdx.x, n = blockIdx.y;
-  RowGeom g = row_geom(C);
-  if (!g.active) return;
-  NormConst k = load_consts(mean, rstd, n * ssn, gamma, beta, g.cg * 8, g.nv);
-  float a1[8], a2[8];
-  for (int i = 0; i < 8; i++) {
-    bool ok = use_stats && i < g.nv;
-    a1[i] = ok ? s1[n * ssn + g.cg * 8 + i] * inv_count : 0.f;
-    a2[i] = ok ? s2[n * ssn + g.cg * 8 + i] * inv_count : 0.f;
-  }
-  int64_t v0 = (int64_t)b * ROWS_PER_BLOCK, v1 = min(V, v0 + ROWS_PER_BLOCK);
-  for (int64_t v = v0 + g.r0; v < v1; v += g.rpi) {
-    int64_t row = (int64_t)n * V + v;
-    float t[8], d[8], rr[8], gg[8];
-    unpack8<T>(x + row * ldx + g.cg * 8, g.nv, t);
-    unpack8<T>(gy + row * ldgy + g.cg * 8, g.nv, d);
-    if (res) unpack8<T>(res + row * ldr + g.cg * 8, g.nv, rr);
-    for (int i = 0; i < 8; i++) {
-      float xh = (t[i] - k.m[i]) * k.r[i];
-      float z = xh * k.ga[i] + k.be[i]; if (res) z += rr[i];
-      gg[i] = d[i] * act_bwd(z, act);
-      t[i] = k.ga[i] * k.r[i] * (gg[i] - a1[i] - xh * a2[i]);
-    }
-    if (gx) pack8(gx + row * ldgx + g.cg * 8, g.nv, t);
-    if (gres) pack8(gres + row * ldgres + g.cg * 8, g.nv, gg);
-  }
-}
 extern "C" int dp_norm_act_bwd_apply(const void* x, int ldx, const void* gy, int ldgy, const float* mean, const float* rstd, int ssn,
                                      const float* gamma, const float* beta, const void* res, int ldr, int act, const float* s1, const float* s2,
                                      float inv_count, int use_stats, void* gx, int ldgx, void* gres, int ldgres, int N, int64_t V, int C,
                                      int dtype, void* stream) {
   if (C > 8 * NT) DP_FAIL("norm_act_bwd_apply: C too large");
-  DP_DISPATCH(dtype, hipLaunchKernelGGL(k_norm_act_bwd_apply<T>, dim3(dp_stats_nblk(V), N), dim3(NT), 0, STREAM, (const T*)x, ldx, (const T*)gy, ldgy, mean, rstd,
-                                        ssn, gamma, beta, (const T*)res, ldr, act, s1, s2, inv_count, use_stats, (T*)gx, ldgx, (T*)gres, ldgres, V, C, rows_per_block(V)));
+  NormArgs a = {}; a.x = x; a.ldx = ldx; a.gy = gy; a.ldgy = ldgy; a.mean = mean; a.rstd = rstd; a.ssn = ssn; a.gamma = gamma; a.beta = beta;
+  a.res = res; a.ldr = ldr; a.y = gx; a.ldy = ldgx; a.gres = gres; a.ldgres = ldgres; a.s1 = s1; a.s2 = s2; a.inv_count = inv_count;
+  a.use_stats = use_stats; a.V = V; a.C = C; a.rpb = rows_per_block(V); a.nblk = dp_stats_nblk(V);
+  a.fast = norm_fast(C, ldx, x, ldgy, gy, ldr, res, ldgx, gx, ldgres, gres);
+  NORM_LAUNCH(k_norm_act_bwd_apply, a, dim3(a.nblk, N));
   DP_CHECK_LAUNCH("norm_act_bwd_apply"); return 0;
 }
 
