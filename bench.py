@@ -88,6 +88,14 @@ def summarize_profile(records, steps):
         elif name == "dp_conv3d_tiled":
             fl, k = tiled_flops(a)
             key = f"conv{k}x{k}x{k}_tiled"
+        elif name == "dp_conv3d_tiled2":
+            # (x, ldx, x2, ldx2, csplit, wq, bias, y, ldy, y2, ldy2, osplit, ws, N, D, H, W, Cin, Cout, k, dtype, stream)
+            N, D, H, W, Cin, Cout, k = a[13:20]
+            fl, key = 2.0 * N * D * H * W * Cin * Cout * k ** 3, f"conv{k}x{k}x{k}_tiled"
+        elif name == "dp_conv3d_wgrad_tiled2":
+            # (x, ldx, x2, ldx2, csplit, gy, ldgy, dw, ws, N, D, H, W, Cin, Cout, k, ...)
+            N, D, H, W, Cin, Cout, k = a[9:16]
+            fl, key = 2.0 * N * D * H * W * Cin * Cout * k ** 3, f"wgrad{k}x{k}x{k}_tiled"
         elif name == "dp_conv3d_wgrad":
             fl, k = wgrad_flops(a)
             key = f"wgrad{k}x{k}x{k}_generic"

@@ -28,6 +28,7 @@ class SingleConv(nn.Module):
             nn.ReLU(inplace=True))
 
     def forward(self, x):
+        """x: an NDHWC tensor, or a pair (a, b) standing for torch.cat((a, b), channels) (virtual concat)."""
         conv, norm = self.single_conv[0], self.single_conv[1]
         y = ops.conv3d(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0], conv.dilation[0])
         return ops.norm_act(y, "instance", norm.weight, norm.bias, act="relu", eps=norm.eps)
@@ -121,6 +122,7 @@ class conv_3_1(nn.Module):
         self._act = _act_name(act)
 
     def forward(self, x):
+        """x: tensor or (a, b) pair = virtual torch.cat (the two first convolutions then read the operands directly)."""
         x3 = ops.norm_act(self.conv_3[0](x), "instance", act=self._act)
         x7 = ops.norm_act(self.conv_7[0](x), "instance", act=self._act)
         y = ops.conv3d(ops.cat((x3, x7)), self.conv[0].weight, self.conv[0].bias)
@@ -159,6 +161,8 @@ class DualDilatedBlock(nn.Module):
         self._act = _act_name(act)
 
     def forward(self, x):
+        if isinstance(x, (tuple, list)):          # dilated convolutions take the generic kernel: materialise the concat once
+            x = ops.cat(x)
         y = ops.cat((self.conv_3(x), self.conv_5(x), self.conv_7(x)))
         y = ops.conv3d(y, self.conv[0].weight, self.conv[0].bias)
         return ops.norm_act(y, "instance", act=self._act)
@@ -206,8 +210,9 @@ class UnetResBlock(nn.Module):
         self.norm1, self.norm2, self.norm3 = (nn.InstanceNorm3d(out_channels) for _ in range(3))
         self.downsample = in_channels != out_channels or stride != 1
 
-    def forward(self, inp):
-        out = ops.norm_act(_run_conv(self.conv1, inp), "instance", act="lrelu")
+    def forward(self, inp, inp_cat=None):
+        """inp_cat: optional (a, b) pair with cat((a, b)) == inp, used by the 3x3x3 convolution (virtual concat)."""
+        out = ops.norm_act(_run_conv(self.conv1, inp_cat if inp_cat is not None else inp), "instance", act="lrelu")
         out = _run_conv(self.conv2, out)
         res = inp
         if self.downsample:
@@ -226,6 +231,7 @@ class UnetBasicBlock(nn.Module):
         self.norm1, self.norm2 = nn.InstanceNorm3d(out_channels), nn.InstanceNorm3d(out_channels)
 
     def forward(self, inp):
+        """inp: tensor or (a, b) pair = virtual torch.cat."""
         out = ops.norm_act(_run_conv(self.conv1, inp), "instance", act="lrelu")
         return ops.norm_act(_run_conv(self.conv2, out), "instance", act="lrelu")
 
@@ -236,7 +242,9 @@ class UnetrBasicBlock(nn.Module):
         cls = UnetResBlock if res_block else UnetBasicBlock
         self.layer = cls(spatial_dims, in_channels, out_channels, kernel_size, stride, norm_name)
 
-    def forward(self, inp):
+    def forward(self, inp, inp_cat=None):
+        if inp_cat is not None and isinstance(self.layer, UnetResBlock):
+            return self.layer(inp, inp_cat)
         return self.layer(inp)
 
 
@@ -273,7 +281,7 @@ class UnetrUpBlock(nn.Module):
         self.conv_block = cls(spatial_dims, out_channels + out_channels, out_channels, kernel_size, 1, norm_name)
 
     def forward(self, inp, skip):
-        return self.conv_block(ops.cat((_run_conv(self.transp_conv, inp), skip)))
+        return self.conv_block((_run_conv(self.transp_conv, inp), skip))
 
 
 # ------------------------------------------------------------------------------------------------ ViT (MONAI 0.7.0 semantics)

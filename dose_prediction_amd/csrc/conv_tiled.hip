@@ -41,6 +41,11 @@ struct TiledGeom {
   int tiles_h, tiles_w;
   int dbg;             // experiments only (env DP_DBG): 1 = skip staging, 2 = skip the MFMA sweep
   int splitkd;         // 1: blockIdx.z selects ONE kd; results are atomically accumulated into the fp32 scratch `ws`
+  // "virtual concat": input channels >= csplit come from x2 (pitch ldx2), output channels >= osplit go to y2 (pitch ldy2).
+  // torch.cat((a, b), dim=1) feeding a convolution is never materialised -- and each 16-channel chunk pass then reads whole,
+  // contiguous voxel rows of ONE tensor (a 32-channel row read 16 channels at a time touches every cache line twice and
+  // held the L2 hit rate of the 32->16 7x7x7 layer at ~25 % against ~90 % for 16-channel inputs).
+  const void* x2; void* y2; int ldx2, csplit, ldy2, osplit;
 };
 
 // ---------------------------------------------------------------------------------------------- weight packing
@@ -128,7 +133,8 @@ __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, 
   const int v_lane = W16 ? (rg * RWO * 2 + (r >> 4)) * g.LP + (r & 15) : (rg * RWO) * g.LP + wc * 32 + r;
   // fast staging path: bf16, whole 16-channel chunks, 16-byte aligned voxel rows (block-uniform)
   constexpr int SU = STAGE_UNROLL;
-  const bool fast = SWZ && (g.Cin % 16 == 0) && (g.ldx % 8 == 0) && (((uintptr_t)x & 15) == 0);
+  const bool fast = SWZ && (g.Cin % 16 == 0) && (g.ldx % 8 == 0) && (((uintptr_t)x & 15) == 0) &&
+                    (!g.x2 || ((g.csplit % 16 == 0) && (g.ldx2 % 8 == 0) && (((uintptr_t)g.x2 & 15) == 0)));
   const int lp_par = SWZ ? ((g.LP >> 3) & 1) : 0;
   const int st_half = tid & 1, st_lp0 = (tid >> 1) % g.LP, st_lr0 = (tid >> 1) / g.LP;
 
@@ -143,7 +149,10 @@ __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, 
         // straight-line staging: SU independent 16-byte loads are in flight before the first LDS store (a per-piece
         // load->store loop serialises on HBM/L2 latency and dominated the kernel); voxel coordinates advance incrementally
         // (256 threads = 128 voxels per step), no divisions in the loop.
-        const T* xplane = x + (((int64_t)n * g.D + id) * g.H) * (int64_t)g.W * g.ldx + ch * CK + st_half * 8;
+        const bool second = g.x2 && ch * CK >= g.csplit;                    // block-uniform: which concat operand this chunk reads
+        const T* xsrc = second ? (const T*)g.x2 : x;
+        const int ldsrc = second ? g.ldx2 : g.ldx, c0 = ch * CK - (second ? g.csplit : 0);
+        const T* xplane = xsrc + (((int64_t)n * g.D + id) * g.H) * (int64_t)g.W * ldsrc + c0 + st_half * 8;
         int lp = st_lp0, lr = st_lr0, v = tid >> 1;
         for (int p0 = 0; p0 < pieces; p0 += 256 * SU) {
           v4u buf[SU]; int vv[SU];
@@ -167,7 +176,11 @@ __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, 
           int ih = h0 - PAD + lr, iw = w0 - PAD + lp, c = ch * CK + half * 8;
           int nv = g.Cin - c; nv = nv > 8 ? 8 : nv;
           bool ok = ih >= 0 && ih < g.H && iw >= 0 && iw < g.W && nv > 0;
-          Frag8<T> f = ok ? frag_load(x + ((((int64_t)n * g.D + id) * g.H + ih) * g.W + iw) * g.ldx + c, nv) : frag_zero<T>();
+          const bool second = g.x2 && c >= g.csplit;
+          if (!second && g.x2 && c + nv > g.csplit) nv = g.csplit - c;        // a piece never straddles the two operands (csplit % 8 == 0 is required)
+          const T* xsrc = second ? (const T*)g.x2 : x;
+          const int ldsrc = second ? g.ldx2 : g.ldx, cc = c - (second ? g.csplit : 0);
+          Frag8<T> f = ok ? frag_load(xsrc + ((((int64_t)n * g.D + id) * g.H + ih) * g.W + iw) * ldsrc + cc, nv) : frag_zero<T>();
           frag_st_lds(slab + (int64_t)v * CK + (half ^ (SWZ ? ((v >> 3) & 1) : 0)) * 8, f);
         }
       }
@@ -228,7 +241,11 @@ __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, 
   constexpr int PASSES = 32 * CPP / 64;
   __syncthreads();                                               // every wave is done reading the slab
   T* patch = slab + (wv & 3) * (32 * 32);
-  const bool wide = !g.splitkd && (g.ldy * (int)sizeof(T)) % 16 == 0 && (((uintptr_t)y & 15) == 0);
+  T* y2 = (T*)g.y2;
+  const bool wide = !g.splitkd && (g.ldy * (int)sizeof(T)) % 16 == 0 && (((uintptr_t)y & 15) == 0) &&
+                    (!y2 || ((g.ldy2 * (int)sizeof(T)) % 16 == 0 && (((uintptr_t)y2 & 15) == 0) && g.osplit % EPC == 0));
+  // destination of output channel c of voxel `vox` (virtual concat: channels >= osplit live in y2)
+  auto out_ptr = [&](int64_t vox, int c) -> T* { return (y2 && c >= g.osplit) ? y2 + vox * g.ldy2 + (c - g.osplit) : y + vox * g.ldy + c; };
   auto store_tile = [&](int oh_lo, int nt_idx) {   // tile in `patch` as [32 positions][NC channels]; oh_lo: image row of position 0
     const int cbase = NPAIR == 2 ? 0 : nt_idx * 32;
 #pragma unroll
@@ -236,7 +253,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, 
       const int q = ps * 64 + lane, m = q / CPP, cc = (q % CPP) * EPC;
       const int oh = W16 ? oh_lo + (m >> 4) : oh_lo, ow = W16 ? (m & 15) : wbase_o + m;
       if (oh < g.H && ow < g.W && cbase + cc < g.Cout) {
-        T* dst = y + ((((int64_t)n * g.D + d) * g.H + oh) * g.W + ow) * g.ldy + cbase + cc;
+        T* dst = out_ptr((((int64_t)n * g.D + d) * g.H + oh) * g.W + ow, cbase + cc);
         if (cbase + cc + EPC <= g.Cout) *(v4u*)dst = *(const v4u*)(patch + m * NC + cc);
         else for (int k = 0; k < EPC; k++) if (cbase + cc + k < g.Cout) dst[k] = patch[m * NC + cc + k];
       }
@@ -256,7 +273,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, 
         const int m = (e & 3) + 8 * (e >> 2) + 4 * hh;
         if (wide) { if (writer) st_f(patch + m * NC + co, v); }
         else if (writer && co < g.Cout && oh < g.H && wbase_o + m < g.W)
-          st_f(y + ((((int64_t)n * g.D + d) * g.H + oh) * g.W + wbase_o + m) * g.ldy + co, v);
+          st_f(out_ptr((((int64_t)n * g.D + d) * g.H + oh) * g.W + wbase_o + m, co), v);
       }
       if (wide) {
         __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier();
@@ -280,7 +297,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, 
           if (co < g.Cout && oh < g.H && ow < g.W) {
             const int64_t vox = (((int64_t)n * g.D + d) * g.H + oh) * g.W + ow;
             if (g.splitkd) atomicAdd(ws + vox * g.Cout + co, acc[i][j][e]);
-            else st_f(y + vox * g.ldy + co, acc[i][j][e] + bv);
+            else st_f(out_ptr(vox, co), acc[i][j][e] + bv);
           }
         }
         if (wide) {
@@ -295,11 +312,13 @@ __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, 
 
 // split-kd epilogue: y = T(ws + bias)
 template <typename T>
-__global__ void k_conv_split_finish(const float* __restrict__ ws, const float* __restrict__ bias, T* __restrict__ y, int64_t rows, int C, int ldy) {
+__global__ void k_conv_split_finish(const float* __restrict__ ws, const float* __restrict__ bias, T* __restrict__ y, int64_t rows, int C, int ldy,
+                                    T* __restrict__ y2, int ldy2, int osplit) {
   int64_t total = rows * C;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     int64_t rrow = i / C; int c = (int)(i - rrow * C);
-    st_f(y + rrow * ldy + c, ws[i] + (bias ? bias[c] : 0.f));
+    T* dst = (y2 && c >= osplit) ? y2 + rrow * ldy2 + (c - osplit) : y + rrow * ldy + c;
+    st_f(dst, ws[i] + (bias ? bias[c] : 0.f));
   }
 }
 
@@ -327,7 +346,7 @@ static int launch_tiled(const void* x, const void* wq, const float* bias, void* 
   if (g.splitkd) {
     int64_t rows = (int64_t)g.N * g.D * g.H * g.W;
     int gb = (int)((rows * g.Cout + 255) / 256); if (gb > 4096) gb = 4096;
-    hipLaunchKernelGGL(k_conv_split_finish<T>, dim3(gb), dim3(256), 0, s, ws, bias, (T*)y, rows, g.Cout, g.ldy);
+    hipLaunchKernelGGL(k_conv_split_finish<T>, dim3(gb), dim3(256), 0, s, ws, bias, (T*)y, rows, g.Cout, g.ldy, (T*)g.y2, g.ldy2, g.osplit);
   }
   return 0;
 }
@@ -350,7 +369,7 @@ static void tiled_geometry(TiledGeom& g, int k, int np, int rw, int nt, int* ygr
 extern "C" int dp_conv3d_tiled_ws_elems(int N, int D, int H, int W, int Cin, int Cout, int k) {
   if (!tiled_applicable(Cin, Cout, k, 1, k / 2, 1, W)) return 0;
   int rw, nt; int np = tiled_config(Cout, &rw, &nt);
-  TiledGeom g; g.N = N; g.D = D; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.dbg = 0;
+  TiledGeom g; g.N = N; g.D = D; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.dbg = 0; g.x2 = nullptr; g.y2 = nullptr;
   int ygrid; bool w16; tiled_geometry(g, k, np, rw, nt, &ygrid, &w16);
   if (!g.splitkd) return 0;
   int64_t e = (int64_t)N * D * H * W * Cout;
@@ -359,12 +378,23 @@ extern "C" int dp_conv3d_tiled_ws_elems(int N, int D, int H, int W, int Cin, int
 
 // Tiled convolution with weights packed by dp_pack_conv_weight_tiled.  Same-size output ("same" padding).
 // ws: fp32 scratch of dp_conv3d_tiled_ws_elems() elements (may be NULL when that is 0).
+extern "C" int dp_conv3d_tiled2(const void* x, int ldx, const void* x2, int ldx2, int csplit, const void* wq, const float* bias,
+                                void* y, int ldy, void* y2, int ldy2, int osplit, float* ws, int N, int D, int H, int W,
+                                int Cin, int Cout, int k, int dtype, void* stream);
 extern "C" int dp_conv3d_tiled(const void* x, int ldx, const void* wq, const float* bias, void* y, int ldy, float* ws, int N, int D, int H, int W,
                                int Cin, int Cout, int k, int dtype, void* stream) {
+  return dp_conv3d_tiled2(x, ldx, nullptr, 0, 0, wq, bias, y, ldy, nullptr, 0, 0, ws, N, D, H, W, Cin, Cout, k, dtype, stream);
+}
+extern "C" int dp_conv3d_tiled2(const void* x, int ldx, const void* x2, int ldx2, int csplit, const void* wq, const float* bias,
+                                void* y, int ldy, void* y2, int ldy2, int osplit, float* ws, int N, int D, int H, int W,
+                                int Cin, int Cout, int k, int dtype, void* stream) {
   if (!tiled_applicable(Cin, Cout, k, 1, k / 2, 1, W)) DP_FAIL("conv3d_tiled: shape not supported");
+  if (x2 && (csplit <= 0 || csplit >= Cin || csplit % 8)) DP_FAIL("conv3d_tiled: input split must be a multiple of 8 inside (0, Cin)");
+  if (y2 && (osplit <= 0 || osplit >= Cout || osplit % 8)) DP_FAIL("conv3d_tiled: output split must be a multiple of 8 inside (0, Cout)");
   int rw, nt; int np = tiled_config(Cout, &rw, &nt);
   TiledGeom g;
   g.N = N; g.D = D; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.ldx = ldx; g.ldy = ldy;
+  g.x2 = x2; g.ldx2 = ldx2; g.csplit = csplit; g.y2 = y2; g.ldy2 = ldy2; g.osplit = osplit;
   int ygrid; bool w16; tiled_geometry(g, k, np, rw, nt, &ygrid, &w16);
   { const char* e = getenv("DP_DBG"); g.dbg = e ? atoi(e) : 0; }
   if (g.splitkd && !ws) DP_FAIL("conv3d_tiled: this shape needs the fp32 scratch (dp_conv3d_tiled_ws_elems)");
@@ -403,6 +433,7 @@ int dp_wgrad_tiled_try(const void*, int, const void*, int, float*, int, int, int
 struct WgtGeom {
   int N, D, H, W, Cin, Cout, ldx, ldgy;
   int tiles_h, tiles_w, MT, NTn, KHG;
+  const void* x2; int ldx2, csplit;   // virtual concat of the input (see TiledGeom)
   int dbg;             // experiments only (env DP_DBG): 1 = skip staging, 2 = skip the MFMA sweep
 };
 
@@ -474,7 +505,8 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_tiled(const T* __restrict__ x,
   constexpr int XPV = C::XC / 8, GPV = C::GC / 8, SU = 6;
   // fast staging: bf16, whole channel tiles, 16-byte aligned voxel rows (block-uniform)
   const bool fast = sizeof(T) == 2 && cbase_x + C::XC <= g.Cin && cbase_g + C::GC <= g.Cout && (g.ldx % 8 == 0) && (g.ldgy % 8 == 0) &&
-                    (((uintptr_t)x & 15) == 0) && (((uintptr_t)gy & 15) == 0);
+                    (((uintptr_t)x & 15) == 0) && (((uintptr_t)gy & 15) == 0) &&
+                    (!g.x2 || ((g.csplit % 8 == 0) && (g.ldx2 % 8 == 0) && (((uintptr_t)g.x2 & 15) == 0)));
   for (int u = u0; u < u1; u++) {
     const int th = u % g.tiles_h; const int nd = u / g.tiles_h; const int d = nd % g.D, n = nd / g.D;
     const int id = d + kd - C::PAD;
@@ -490,7 +522,11 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_tiled(const T* __restrict__ x,
         // straight-line staging (see k_conv_tiled): SU independent 16-byte loads in flight before the first LDS store
         {
           const int total = C::LR * lpn * XPV;
-          const T* xplane = x + (((int64_t)n * g.D + id) * g.H) * (int64_t)g.W * g.ldx + cbase_x + (tid % XPV) * 8;
+          const int cpiece = cbase_x + (tid % XPV) * 8;                         // this thread's 8-channel piece: fixed for the launch
+          const bool second = g.x2 && cpiece >= g.csplit;
+          const T* xsrc = second ? (const T*)g.x2 : x;
+          const int ldsrc = second ? g.ldx2 : g.ldx;
+          const T* xplane = xsrc + (((int64_t)n * g.D + id) * g.H) * (int64_t)g.W * ldsrc + cpiece - (second ? g.csplit : 0);
           int lp = (tid / XPV) % lpn, lr = (tid / XPV) / lpn;
           for (int p0 = 0; p0 < total; p0 += 256 * SU) {
             v4u buf[SU]; int dst[SU];
@@ -499,7 +535,7 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_tiled(const T* __restrict__ x,
               const int ih = h0 - C::PAD + lr, iw = w0 - C::PAD + lp;
               const bool in = p0 + j * 256 + tid < total;
               const bool ok = in && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W;
-              v4u t = *(const v4u*)(xplane + ((int64_t)(ok ? ih : 0) * g.W + (ok ? iw : 0)) * g.ldx);
+              v4u t = *(const v4u*)(xplane + ((int64_t)(ok ? ih : 0) * g.W + (ok ? iw : 0)) * ldsrc);
               buf[j] = ok ? t : (v4u){0, 0, 0, 0};
               dst[j] = in ? (lr * C::LP + lp) * C::XC + (tid % XPV) * 8 : -1;
               lp += 256 / XPV; while (lp >= lpn) { lp -= lpn; lr++; }
@@ -534,7 +570,11 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_tiled(const T* __restrict__ x,
           int ih = h0 - C::PAD + lr, iw = w0 - C::PAD + lp, c = cbase_x + part * 8;
           int nv = g.Cin - c; nv = nv > 8 ? 8 : nv;
           bool ok = ih >= 0 && ih < g.H && iw >= 0 && iw < g.W && nv > 0;
-          Frag8<T> f = ok ? frag_load(x + ((((int64_t)n * g.D + id) * g.H + ih) * g.W + iw) * g.ldx + c, nv) : frag_zero<T>();
+          const bool second = g.x2 && c >= g.csplit;
+          if (!second && g.x2 && c + nv > g.csplit) nv = g.csplit - c;
+          const T* xsrc = second ? (const T*)g.x2 : x;
+          const int ldsrc = second ? g.ldx2 : g.ldx, cc = c - (second ? g.csplit : 0);
+          Frag8<T> f = ok ? frag_load(xsrc + ((((int64_t)n * g.D + id) * g.H + ih) * g.W + iw) * ldsrc + cc, nv) : frag_zero<T>();
           frag_st_lds(xs + (size_t)v * C::XC + part * 8, f);
         }
         for (int p = tid; p < C::GR * C::TW * GPV; p += 256) {
@@ -625,15 +665,23 @@ static int launch_wgt(const void* x, const void* gy, float* ws, WgtGeom g, hipSt
 }
 
 // ws: fp32 scratch of dp_conv3d_wgrad_tiled_ws_elems() elements (need not be initialised).  ACCUMULATES into dw.
+extern "C" int dp_conv3d_wgrad_tiled2(const void* x, int ldx, const void* x2, int ldx2, int csplit, const void* gy, int ldgy, float* dw, float* ws,
+                                      int N, int D, int H, int W, int Cin, int Cout, int k, int64_t s_co, int64_t s_ci, int64_t s_tap, int dtype, void* stream);
 extern "C" int dp_conv3d_wgrad_tiled(const void* x, int ldx, const void* gy, int ldgy, float* dw, float* ws, int N, int D, int H, int W,
                                      int Cin, int Cout, int k, int64_t s_co, int64_t s_ci, int64_t s_tap, int dtype, void* stream) {
+  return dp_conv3d_wgrad_tiled2(x, ldx, nullptr, 0, 0, gy, ldgy, dw, ws, N, D, H, W, Cin, Cout, k, s_co, s_ci, s_tap, dtype, stream);
+}
+extern "C" int dp_conv3d_wgrad_tiled2(const void* x, int ldx, const void* x2, int ldx2, int csplit, const void* gy, int ldgy, float* dw, float* ws,
+                                      int N, int D, int H, int W, int Cin, int Cout, int k, int64_t s_co, int64_t s_ci, int64_t s_tap, int dtype, void* stream) {
   if (!wgt_applicable(Cin, Cout, k, 1, k / 2, 1, 1, W)) DP_FAIL("wgrad_tiled: shape not supported");
+  if (x2 && (csplit <= 0 || csplit >= Cin || csplit % 8)) DP_FAIL("wgrad_tiled: input split must be a multiple of 8 inside (0, Cin)");
   if (k == 1 && H * (int64_t)D * N > 2000000000LL) DP_FAIL("wgrad_tiled: too many rows");
   hipStream_t s = STREAM;
   int taps = k * k * k;
   hipError_t me = hipMemsetAsync(ws, 0, (size_t)taps * Cin * Cout * sizeof(float), s);
   if (me != hipSuccess) DP_FAIL("wgrad_tiled: memset failed: %s", hipGetErrorString(me));
   WgtGeom g; g.N = N; g.D = D; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.ldx = ldx; g.ldgy = ldgy;
+  g.x2 = x2; g.ldx2 = ldx2; g.csplit = csplit;
   { const char* e = getenv("DP_DBG"); g.dbg = e ? atoi(e) : 0; }
   const int np = (Cout <= 16 && k > 1) ? 2 : 1, mp = (Cin <= 16 && k > 1) ? 2 : 1;
   int rc = 0;

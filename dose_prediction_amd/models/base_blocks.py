@@ -32,7 +32,7 @@ class ModifiedUnetrUpBlock(nn.Module):
 
     def forward(self, inp, skip):
         out = _run_conv(self.transp_conv, inp)
-        return self.conv_block(ops.cat((out, skip)))
+        return self.conv_block((out, skip))          # virtual torch.cat((out, skip), dim=1): base_blocks.py:139
 
 
 class ModifiedUnetOutBlock(nn.Module):

@@ -53,7 +53,7 @@ class Decoder(nn.Module):
         d = out_encoder[4]
         for lvl in (4, 3, 2, 1):
             up = getattr(self, f"upconv_{lvl}")(d)
-            d = getattr(self, f"decoder_conv_{lvl}")(ops.cat((up, out_encoder[lvl - 1])))
+            d = getattr(self, f"decoder_conv_{lvl}")((up, out_encoder[lvl - 1]))      # virtual torch.cat (c3d.py:103-113)
         return d
 
 

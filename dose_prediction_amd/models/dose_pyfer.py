@@ -52,10 +52,11 @@ class ViTEncoder(nn.Module):
         """[B, N, hidden] -> feature map.  In NDHWC the reference's view+permute+contiguous (118-122) is a free view."""
         return x.view([x.size(0)] + self.proj_view_shape)
 
-    def forward(self, x_in):
+    def forward(self, x_in, x_cat=None):
+        """x_cat: optional (a, b) pair with cat((a, b)) == x_in (virtual concat for skip1's 3x3x3 convolution)."""
         i = self.num_layers // 4
         z12, hidden_states_out = self.vit(x_in)
-        out_encoder_1 = self.skip1(x_in)
+        out_encoder_1 = self.skip1(x_in, x_cat)
         out_encoder_2 = self.skip2(self.proj_feat(hidden_states_out[i]))
         out_encoder_3 = self.skip3(self.proj_feat(hidden_states_out[i * 2]))
         out_encoder_4 = self.skip4(self.proj_feat(hidden_states_out[i * 3]))
@@ -115,8 +116,8 @@ class MainSubsetModel(nn.Module):
         self.encoder.hidden_size = config_hparam["hidden_size"]
         self.encoder.num_layers = config_hparam["hidden_size"]
 
-    def forward_ndhwc(self, x):
-        out_decoders = self.decoder(self.encoder(x))
+    def forward_ndhwc(self, x, x_cat=None):
+        out_decoders = self.decoder(self.encoder(x, x_cat))
         return [ops.conv3d(d, conv[0].weight, conv[0].bias) for d, conv in zip(out_decoders, self.dose_convertors)]
 
     def forward(self, x):
@@ -138,7 +139,7 @@ class Model(nn.Module):
     def forward(self, x):
         xh = to_ndhwc(x)
         out_net_A = self.net_A.forward_ndhwc(xh)
-        out_net_B = self.net_B.forward_ndhwc(ops.cat((out_net_A, xh)))
+        out_net_B = self.net_B.forward_ndhwc(ops.cat((out_net_A, xh)), (out_net_A, xh))
         output_A = ops.conv3d(out_net_A, self.conv_out_A.weight, self.conv_out_A.bias)
         return [from_ndhwc(output_A), [from_ndhwc(o) for o in out_net_B]]
 

@@ -375,7 +375,78 @@ class Conv3d(torch.autograd.Function):
 
 
 def conv3d(x, weight, bias=None, stride=1, pad=0, dil=1):
+    if isinstance(x, (tuple, list)):
+        return conv3d_cat(x[0], x[1], weight, bias, stride, pad, dil)
     return Conv3d.apply(x, weight, bias, stride, pad, dil)
+
+
+class Conv3dCat(torch.autograd.Function):
+    """nn.Conv3d applied to torch.cat((xa, xb), dim=channels) WITHOUT materialising the concatenation ("virtual concat",
+    dp_conv3d_tiled2 / dp_conv3d_wgrad_tiled2): reference call sites base_blocks.py:139-140, c3d.py:103-113.
+    Only built by conv3d_cat() for shapes the tiled kernels support (k in {3,7}, stride 1, "same" padding)."""
+
+    @staticmethod
+    def forward(ctx, xa, xb, weight, bias, pad):
+        _chk_dev(xa, xb, weight)
+        xa, xb = as_rows(xa), as_rows(xb)
+        _, ca, lda = rows_ld(xa)
+        _, cbp, ldb = rows_ld(xb)
+        N, D, H, W = xa.shape[:4]
+        cout, cin, k = weight.shape[0], weight.shape[1], weight.shape[2]
+        y = torch.empty((N, D, H, W, cout), dtype=xa.dtype, device=xa.device)
+        wq = _pack_conv_tiled(weight, 0, xa.dtype, _tiled_elems(cin, cout, k, 1, pad, 1, W))
+        b32 = None if bias is None else bias.detach()
+        _lib.call("dp_conv3d_tiled2", _p(xa), lda, _p(xb), ldb, ca, _p(wq), _p(b32), _p(y), cout, 0, 0, 0,
+                  _p(_tiled_ws(xa, N, D, H, W, cin, cout, k)), N, D, H, W, cin, cout, k, _dt(xa), _stream())
+        ctx.save_for_backward(xa, xb, weight)
+        ctx.cfg = (pad, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        xa, xb, weight = ctx.saved_tensors
+        pad, has_bias = ctx.cfg
+        gy = as_rows(gy)
+        grows, cout, ldg = rows_ld(gy)
+        _, ca, lda = rows_ld(xa)
+        _, cbp, ldb = rows_ld(xb)
+        N, D, H, W = xa.shape[:4]
+        cin, k = weight.shape[1], weight.shape[2]
+        dtc = _dt(xa)
+        gxa = gxb = gw = gb = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            gxa = torch.empty((N, D, H, W, ca), dtype=xa.dtype, device=xa.device)
+            gxb = torch.empty((N, D, H, W, cbp), dtype=xa.dtype, device=xa.device)
+            if cbp > cin - ca:
+                gxb.zero_()
+            wq = _pack_conv_tiled(weight, 1, xa.dtype, _tiled_elems(cout, cin, k, 1, k - 1 - pad, 1, W))
+            _lib.call("dp_conv3d_tiled2", _p(gy), ldg, 0, 0, 0, _p(wq), 0, _p(gxa), ca, _p(gxb), cbp, ca,
+                      _p(_tiled_ws(xa, N, D, H, W, cout, cin, k)), N, D, H, W, cout, cin, k, dtc, _stream())
+        if ctx.needs_input_grad[2]:
+            gw = torch.zeros(weight.shape, dtype=torch.float32, device=xa.device)
+            taps = k * k * k
+            ws = torch.empty((taps * cin * cout,), dtype=torch.float32, device=xa.device)
+            _lib.call("dp_conv3d_wgrad_tiled2", _p(xa), lda, _p(xb), ldb, ca, _p(gy), ldg, _p(gw), _p(ws), N, D, H, W, cin, cout, k,
+                      cin * taps, taps, 1, dtc, _stream())
+        if has_bias and ctx.needs_input_grad[3]:
+            gb = torch.zeros((cout,), dtype=torch.float32, device=xa.device)
+            colsum_into(_p(gy), ldg, grows, cout, gb, dtc)
+        return gxa, gxb, gw, gb, None
+
+
+def conv3d_cat(xa, xb, weight, bias=None, stride=1, pad=0, dil=1):
+    """conv3d(cat((xa, xb), channels)): virtual concat when the tiled kernels support the shape, else a real cat."""
+    cout, cin, k = weight.shape[0], weight.shape[1], weight.shape[2]
+    ca, W = xa.shape[-1], xa.shape[3]
+    ok = (USE_TILED and k > 1 and stride == 1 and dil == 1 and pad == k // 2 and ca % 8 == 0 and 0 < ca < cin
+          and xb.shape[-1] >= cin - ca and xa.dtype == xb.dtype and tuple(xa.shape[:4]) == tuple(xb.shape[:4]))
+    if ok:
+        L = _lib.lib()
+        ok = bool(_tiled_elems(cin, cout, k, 1, pad, 1, W)) and bool(_tiled_elems(cout, cin, k, 1, k - 1 - pad, 1, W)) and \
+            bool(L.dp_conv3d_wgrad_tiled_ws_elems(cin, cout, k, 1, pad, 1, 1, W))
+    if not ok:
+        return Conv3d.apply(cat((xa, xb)), weight, bias, stride, pad, dil)
+    return Conv3dCat.apply(xa, xb, weight, bias, pad)
 
 
 class ConvTranspose2x(torch.autograd.Function):

@@ -144,6 +144,14 @@ int dp_pack_conv_weight_tiled(const float* w, void* dst, int Cout, int Cin, int 
 int dp_conv3d_tiled_ws_elems(int N, int D, int H, int W, int Cin, int Cout, int k);
 int dp_conv3d_tiled(const void* x, int ldx, const void* wq, const float* bias, void* y, int ldy, float* ws, int N, int D, int H, int W,
                     int Cin, int Cout, int k, int dtype, void* stream);
+/* "virtual concat" forms: torch.cat((a, b), dim=1) feeding (or, for a data gradient, fed by) a convolution is never
+ * materialised.  Input channels >= csplit come from x2 (pitch ldx2); output channels >= osplit go to y2 (pitch ldy2); splits are
+ * multiples of 8; NULL x2 / y2 = single operand.  replaces: torch.cat + nn.Conv3d (base_blocks.py:139, c3d.py:103-113). */
+int dp_conv3d_tiled2(const void* x, int ldx, const void* x2, int ldx2, int csplit, const void* wq, const float* bias,
+                     void* y, int ldy, void* y2, int ldy2, int osplit, float* ws, int N, int D, int H, int W,
+                     int Cin, int Cout, int k, int dtype, void* stream);
+int dp_conv3d_wgrad_tiled2(const void* x, int ldx, const void* x2, int ldx2, int csplit, const void* gy, int ldgy, float* dw, float* ws,
+                           int N, int D, int H, int W, int Cin, int Cout, int k, int64_t s_co, int64_t s_ci, int64_t s_tap, int dtype, void* stream);
 /* weight gradient (fp32, ACCUMULATES): for every tap t, co, ci:
  *   dw[co*s_co + ci*s_ci + t*s_tap] += sum_v gy[v][co + t*gy_tap_choff] * x[shift ? v*stride - pad + t*dil : v][ci]
  * replaces: autograd's conv/linear/conv-transpose weight gradients.  (v ranges over the gy voxels.) */

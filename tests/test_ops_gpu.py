@@ -330,3 +330,38 @@ def test_fused_adam_matches_torch(amsgrad):
     for x, y in zip(a, b):
         for k in ("exp_avg", "exp_avg_sq") + (("max_exp_avg_sq",) if amsgrad else ()):
             assert rel_err(ob.state[y][k].cpu(), oa.state[x][k].cpu()) < 2e-6, k
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [
+    # (N, Ca, Cb_logical, Cb_physical, Cout, D, H, W, k)
+    (2, 16, 16, 16, 16, 3, 9, 40, 7), (1, 16, 9, 16, 16, 4, 10, 32, 3), (1, 32, 32, 32, 32, 2, 9, 33, 7),
+    (1, 64, 64, 64, 64, 2, 6, 16, 3), (1, 16, 16, 16, 8, 2, 5, 20, 3), (1, 8, 8, 8, 16, 3, 5, 6, 3)])
+def test_conv3d_virtual_concat(cfg, dtype):
+    """conv3d((a, b)) == conv3d(cat(a, b)) of the oracle, forward and every gradient (dp_conv3d_tiled2 / dp_conv3d_wgrad_tiled2;
+    the last config is too narrow for the tiled kernels and must take the materialised-cat fallback)."""
+    from dose_prediction_amd import ops
+    dev = _dev()
+    N, Ca, Cb, Cbp, Cout, D, H, W, k = cfg
+    a = q(rnd((N, Ca, D, H, W), 1), dtype)
+    b = q(rnd((N, Cb, D, H, W), 2), dtype)
+    w = q(rnd((Cout, Ca + Cb, k, k, k), 3, ((Ca + Cb) * k ** 3) ** -0.5), dtype)
+    bias = 0.1 * rnd((Cout,), 4)
+    ar, br, wr, biasr = (t.double().requires_grad_(True) for t in (a, b, w, bias))
+    yr = oracle.conv3d(torch.cat((ar, br), dim=1), wr, biasr, 1, k // 2, 1)
+    r = q(rnd(yr.shape, 5), dtype)
+    (yr * r.double()).sum().backward()
+    ah = ndhwc(a).to(dev, dtype).requires_grad_(True)
+    bp = torch.zeros((N, D, H, W, Cbp), dtype=dtype)
+    bp[..., :Cb] = ndhwc(b).to(dtype)
+    bh = bp.to(dev).requires_grad_(True)
+    wh, biash = w.to(dev).requires_grad_(True), bias.to(dev).requires_grad_(True)
+    yh = ops.conv3d((ah, bh), wh, biash, 1, k // 2, 1)
+    yh.backward(ndhwc(r).to(dev, dtype))
+    check("y", ncdhw(yh), yr, dtype)
+    check("ga", ncdhw(ah.grad), ar.grad, dtype)
+    check("gb", ncdhw(bh.grad[..., :Cb]), br.grad, dtype)
+    if Cbp > Cb:
+        assert bh.grad[..., Cb:].abs().max().item() == 0
+    check("gw", wh.grad, wr.grad, dtype)
+    check("gbias", biash.grad, biasr.grad, dtype)
