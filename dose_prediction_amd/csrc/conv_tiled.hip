@@ -635,7 +635,7 @@ __global__ void k_wgrad_unpack(const float* __restrict__ dwt, float* __restrict_
 }
 
 static inline bool wgt_applicable(int Cin, int Cout, int k, int stride, int pad, int dil, int shift, int W) {
-  if (k == 1) return stride == 1 && pad == 0 && W >= 16 && Cin >= 8 && Cout >= 8 && Cin <= 128 && Cout <= 128;   // pointwise: HBM-bound row stream
+  if (k == 1) return stride == 1 && pad == 0 && W >= 16 && Cin >= 8 && Cout >= 8 && Cin <= 256 && Cout <= 256;   // pointwise: HBM-bound row stream
   return shift && (k == 3 || k == 7) && stride == 1 && dil == 1 && pad == k / 2 && W >= 16 && Cin >= 1 && Cout >= 8;
 }
 // fp32 scratch elements needed by dp_conv3d_wgrad_tiled (0: shape not supported, use dp_conv3d_wgrad)

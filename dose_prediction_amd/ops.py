@@ -487,17 +487,18 @@ class ConvTranspose2x(torch.autograd.Function):
                 gx.zero_()
             gemm_nt(gu, wt, gx, M=rows, N=cin, K=8 * cout, lda=8 * cout, ldb=wt.shape[-1], ldc=cx)
         if ctx.needs_input_grad[1]:
-            gw = torch.zeros(weight.shape, dtype=torch.float32, device=x.device)   # [Cin][Cout][8]
-            wse = _lib.lib().dp_conv3d_wgrad_tiled_ws_elems(cin, cout, 1, 1, 0, 1, 1, W) if (USE_TILED and rows >= 32768) else 0
+            wse = _lib.lib().dp_conv3d_wgrad_tiled_ws_elems(cin, 8 * cout, 1, 1, 0, 1, 1, W) if (USE_TILED and rows >= 32768) else 0
             if wse:
-                # 8 pointwise weight gradients: tap abc pairs x with the gy column block abc*Cout
+                # ONE pointwise weight gradient with 8*Cout "output channels" (column (abc, co) of the unshuffled gradient):
+                # x is read once instead of 8 times; the small fp32 result [(abc,co)][ci] is permuted into torch's [ci][co][abc]
                 ws = torch.empty((wse,), dtype=torch.float32, device=x.device)
-                es = gu.element_size()
-                for t in range(8):
-                    _lib.call("dp_conv3d_wgrad_tiled", _p(x), ldx, gu.data_ptr() + t * cout * es, 8 * cout, gw.data_ptr() + 4 * t, _p(ws),
-                              N, D, H, W, cin, cout, 1, 8, cout * 8, 0, dtc, _stream())
+                tmp = torch.zeros((8 * cout, cin), dtype=torch.float32, device=x.device)
+                _lib.call("dp_conv3d_wgrad_tiled", _p(x), ldx, _p(gu), 8 * cout, _p(tmp), _p(ws), N, D, H, W, cin, 8 * cout, 1,
+                          cin, 1, 0, dtc, _stream())
+                gw = tmp.view(8, cout, cin).permute(2, 1, 0).contiguous().view(weight.shape)
             else:
                 # "tap" = abc selects the gy column block abc*Cout; x is not shifted
+                gw = torch.zeros(weight.shape, dtype=torch.float32, device=x.device)   # [Cin][Cout][8]
                 wgrad(x, ldx, gu, 8 * cout, gw, (1, 1, 1, rows, 1, 1, rows), cin, cout, 2, 1, 0, 1, 0, cout, 8, cout * 8, 1, dtc)
         return gx, gw
 
