@@ -211,3 +211,72 @@ def test_bf16_mode_tracks_fp32():
             assert rel_l2(o.cpu(), g[f"y{i}"]) < 0.15, (i, rel_l2(o.cpu(), g[f"y{i}"]))
     finally:
         _set(torch.float32)
+
+
+def test_cascade_glue():
+    """TRANSEG -> arg-max -> one-hot -> axis reversal -> cat(ptv, oars, ct) -> PYFER -> mask/clip x70
+    (train_light_linked_model.py:143-173) against the oracle.  The dose comparison feeds the ORACLE dose network with the
+    HIP path's own masks, so a (legitimate) arg-max flip on a near-tie cannot hide or fake an error."""
+    import dose_prediction_amd
+    from dose_prediction_amd import cascade
+    from dose_prediction_amd.models import dose_pyfer, oar_transeg
+    dev = _dev()
+    _set(torch.float32)
+    torch.manual_seed(3)
+    S = (32, 32, 32)
+    seg = oar_transeg.Model(1, 8, S, feature_size=4, hidden_size=48, mlp_dim=96, num_heads=12, pos_embed="perceptron").to(dev).eval()
+    dose = dose_pyfer.Model(9, 1, [-1, 4, 8, 8, 16, 16], feature_size=4, img_size=S, num_layers=4, num_heads=6).to(dev).eval()
+    g = torch.Generator().manual_seed(5)
+    ct = torch.randn((1, 1) + S, generator=g)
+    ptv = (torch.rand((1, 1) + S, generator=g) > 0.7).float()
+    mask = (torch.rand((1, 1) + S, generator=g) > 0.4).float()
+    dose_gy, labels = cascade.cascade_forward(seg, dose, ct.to(dev), ptv.to(dev), mask.to(dev))
+    # stage 1: segmentation logits and masks
+    sd_seg = {k: v.detach().cpu() for k, v in seg.state_dict().items()}
+    with torch.no_grad():
+        ref_logits = oracle.oar_transeg(sd_seg, ct, num_heads=12, training=False)
+    top2 = ref_logits.topk(2, dim=1).values
+    safe = (top2[:, 0] - top2[:, 1]) > 1e-3 * ref_logits.abs().max()
+    lab = labels.cpu().long()
+    assert torch.equal(lab[safe], ref_logits.argmax(1)[safe]) and safe.float().mean() > 0.98
+    # stage 2: dose network on the HIP path's own masks
+    onehot = torch.nn.functional.one_hot(lab, 8).permute(0, 4, 1, 2, 3).float()          # [1,8,D,H,W]
+    oars = onehot[0].permute(0, 3, 2, 1).unsqueeze(0)[:, 1:]                               # lines 158, 165
+    structures = torch.cat((ptv, oars, ct.permute(0, 1, 4, 3, 2)), dim=1)                 # lines 163, 167
+    sd_dose = {k: v.detach().cpu() for k, v in dose.state_dict().items()}
+    with torch.no_grad():
+        ref = oracle.dose_pyfer(sd_dose, structures, num_layers=4, num_heads=6, act="mish", training=False)[1][0]
+    ref_gy = oracle.dose_postprocess(ref, mask)
+    assert rel_err(dose_gy.cpu(), ref_gy) < OUT_TOL
+
+
+def test_activation_checkpointing():
+    """BASELINE.json configs[4] trains with activation checkpointing: torch.utils.checkpoint around a decoder block must give the
+    same outputs and gradients as the plain HIP path (custom autograd Functions are re-run in the backward)."""
+    from torch.utils.checkpoint import checkpoint
+    from dose_prediction_amd.models.base_blocks import ModifiedUnetrUpBlock
+    from dose_prediction_amd.models.c3d import to_ndhwc, from_ndhwc
+    dev = _dev()
+    _set(torch.float32)
+    torch.manual_seed(1)
+    blk = ModifiedUnetrUpBlock(3, 16, 8, 2, act="mish").to(dev).train()
+    x = torch.randn(1, 16, 4, 6, 8, device=dev, requires_grad=True)
+    skip = torch.randn(1, 8, 8, 12, 16, device=dev, requires_grad=True)
+    sd0 = {k: v.clone() for k, v in blk.state_dict().items()}
+
+    def run(use_ckpt):
+        blk.load_state_dict(sd0)                       # same BatchNorm buffers at the start of both runs
+        blk.zero_grad()
+        for t in (x, skip):
+            t.grad = None
+        a, b = to_ndhwc(x), to_ndhwc(skip)
+        y = checkpoint(blk, a, b, use_reentrant=False) if use_ckpt else blk(a, b)
+        out = from_ndhwc(y)
+        out.square().mean().backward()
+        return out.detach().clone(), x.grad.clone(), skip.grad.clone(), {k: p.grad.clone() for k, p in blk.named_parameters()}
+
+    o1, gx1, gs1, gp1 = run(False)
+    o2, gx2, gs2, gp2 = run(True)
+    assert rel_err(o2.cpu(), o1.cpu()) < 1e-6 and rel_l2(gx2.cpu(), gx1.cpu()) < 1e-4 and rel_l2(gs2.cpu(), gs1.cpu()) < 1e-4
+    for k in gp1:
+        assert rel_l2(gp2[k].cpu(), gp1[k].cpu()) < 1e-3, k
