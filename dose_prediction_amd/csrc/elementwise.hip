@@ -362,3 +362,80 @@ extern "C" int dp_pointwise_rows(const void* x, int ldx, const void* w, int ldw,
 #undef GO
   DP_CHECK_LAUNCH("pointwise_rows"); return 0;
 }
+
+// Weight (and bias) gradient of the same skinny pointwise conv: dw[co][ci] = sum_v gy[v][co] x[v][ci], db[co] = sum_v gy[v][co].
+// One 16-byte chunk of one voxel row per thread (CPR = Cin/8 chunks per row, a power of two), COUT x 8 accumulators in
+// registers over a grid-stride sweep, a wave shuffle tree, an LDS sum over the 4 waves and one partial row per block in
+// the workspace; a second tiny kernel adds the partials in a fixed order (deterministic, no same-address atomics).
+template <typename T, int COUT>
+__global__ void __launch_bounds__(256) k_pointwise_wgrad_rows(const T* __restrict__ x, int ldx, const T* __restrict__ gy, int ldgy, float* __restrict__ ws,
+                                                              int64_t rows, int Cin, int Cout, int cpr_log2) {
+  __shared__ float sm[4][COUT][72];     // [wave][co][ci | 64: bias]
+  const int CPR = 1 << cpr_log2, RPI = 256 >> cpr_log2, chunk = threadIdx.x & (CPR - 1), roff = threadIdx.x >> cpr_log2;
+  float acc[COUT][8], accb[COUT];
+#pragma unroll
+  for (int c = 0; c < COUT; c++) { accb[c] = 0.f; for (int j = 0; j < 8; j++) acc[c][j] = 0.f; }
+  const int nv = min(8, Cin - chunk * 8);
+  for (int64_t r = (int64_t)blockIdx.x * RPI + roff; r < rows; r += (int64_t)gridDim.x * RPI) {
+    float t[8];
+    frag_unpack(frag_load(x + r * ldx + chunk * 8, nv), t);
+    const T* g = gy + r * ldgy;
+#pragma unroll
+    for (int c = 0; c < COUT; c++) {
+      float gv = c < Cout ? ld_f(g + c) : 0.f;
+      accb[c] += gv;
+#pragma unroll
+      for (int j = 0; j < 8; j++) acc[c][j] += gv * t[j];
+    }
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int c = 0; c < COUT; c++) {
+    for (int o = 32; o >= CPR; o >>= 1) {
+      accb[c] += __shfl_xor(accb[c], o, 64);
+#pragma unroll
+      for (int j = 0; j < 8; j++) acc[c][j] += __shfl_xor(acc[c][j], o, 64);
+    }
+    if (lane < CPR) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) sm[wv][c][chunk * 8 + j] = acc[c][j];
+      if (lane == 0) sm[wv][c][64] = accb[c];
+    }
+  }
+  __syncthreads();
+  const int E = Cout * (Cin + 1);          // [co][ci] then [co] bias sums
+  for (int e = threadIdx.x; e < E; e += 256) {
+    int c = e < Cout * Cin ? e / Cin : e - Cout * Cin, i = e < Cout * Cin ? e - c * Cin : 64;
+    ws[(int64_t)blockIdx.x * E + e] = sm[0][c][i] + sm[1][c][i] + sm[2][c][i] + sm[3][c][i];
+  }
+}
+__global__ void k_pointwise_wgrad_finish(const float* __restrict__ ws, int nblk, int E, int Cin, int Cout, float* __restrict__ dw, int s_co, float* __restrict__ db) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int b = 0;
+  for (; b + 3 < nblk; b += 4) { a0 += ws[(int64_t)b * E + e]; a1 += ws[(int64_t)(b + 1) * E + e]; a2 += ws[(int64_t)(b + 2) * E + e]; a3 += ws[(int64_t)(b + 3) * E + e]; }
+  for (; b < nblk; b++) a0 += ws[(int64_t)b * E + e];
+  float v = (a0 + a1) + (a2 + a3);
+  if (e < Cout * Cin) { int c = e / Cin; dw[(int64_t)c * s_co + (e - c * Cin)] = v; }
+  else if (db) db[e - Cout * Cin] = v;
+}
+static int pw_wgrad_grid(int64_t rows, int Cin) { int cpr = (Cin + 7) / 8, rpi = 256 / cpr; int64_t g = (rows + rpi - 1) / rpi; return (int)(g > 1024 ? 1024 : g); }
+extern "C" int64_t dp_pointwise_wgrad_ws_elems(int64_t rows, int Cin, int Cout) {
+  int cpr = (Cin + 7) / 8;
+  if (Cin < 1 || Cin > 64 || (cpr & (cpr - 1)) || Cout < 1 || Cout > 16) return 0;
+  return (int64_t)pw_wgrad_grid(rows, Cin) * Cout * (Cin + 1);
+}
+extern "C" int dp_pointwise_wgrad_rows(const void* x, int ldx, const void* gy, int ldgy, float* dw, int s_co, float* db, float* ws, int64_t rows,
+                                       int Cin, int Cout, int dtype, void* stream) {
+  int cpr = (Cin + 7) / 8, lg = 0;
+  while ((1 << lg) < cpr) lg++;
+  if (Cin < 1 || Cin > 64 || (1 << lg) != cpr || Cout < 1 || Cout > 16) DP_FAIL("pointwise_wgrad_rows: needs Cin in {<=8,16,32,64} and Cout <= 16");
+  if (!ws) DP_FAIL("pointwise_wgrad_rows: workspace missing");
+  int g = pw_wgrad_grid(rows, Cin), E = Cout * (Cin + 1);
+#define GO(CO) DP_DISPATCH(dtype, hipLaunchKernelGGL((k_pointwise_wgrad_rows<T, CO>), dim3(g), dim3(256), 0, STREAM, (const T*)x, ldx, (const T*)gy, ldgy, ws, rows, Cin, Cout, lg))
+  if (Cout <= 1) GO(1); else if (Cout <= 4) GO(4); else GO(16);
+#undef GO
+  hipLaunchKernelGGL(k_pointwise_wgrad_finish, dim3(cdiv(E, 128)), dim3(128), 0, STREAM, (const float*)ws, g, E, Cin, Cout, dw, s_co, db);
+  DP_CHECK_LAUNCH("pointwise_wgrad_rows"); return 0;
+}

@@ -6,19 +6,18 @@
 #include "common.h"
 
 #define STREAM ((hipStream_t)stream)
-#define BK 32
-#define LDP (BK + 8)   // padded LDS row (elements): 80 B (bf16) / 160 B (f32) keeps 16-B alignment, breaks the 64-B stride
+// BK: k-depth of one LDS stage (32 or 64).  LDP = padded LDS row (elements): keeps 16-B alignment, breaks the power-of-two stride.
 
 // TI x TJ = MFMA tiles per wave in M / N: block tile = (2*TI*16) x (2*TJ*16): 128x128 (4,4) for big problems, 64x64 (2,2)
 // when a 128x128 grid would leave most of the 256 CUs idle (ViT token matrices: M = B*512).
-template <typename T, int TI, int TJ>
+template <typename T, int TI, int TJ, int BK>
 __global__ void __launch_bounds__(256) k_gemm_nt(const T* __restrict__ A, int64_t lda, int64_t sa0, int64_t sa1,
                                                  const T* __restrict__ B, int64_t ldb, int64_t sb0, int64_t sb1,
                                                  void* __restrict__ Cv, int64_t ldc, int64_t sc0, int64_t sc1,
                                                  const float* __restrict__ bias, int M, int N, int K, int nb1,
                                                  float alpha, int out_f32, int splitk) {
-  constexpr int BM = 32 * TI, BN = 32 * TJ, WMR = 16 * TI, WNR = 16 * TJ;
-  constexpr int UA = BM * 4 / 256 > 0 ? BM * 4 / 256 : 1, UB = BN * 4 / 256 > 0 ? BN * 4 / 256 : 1;   // 16-byte chunks per thread
+  constexpr int BM = 32 * TI, BN = 32 * TJ, WMR = 16 * TI, WNR = 16 * TJ, LDP = BK + 8, CPR = BK / 8;   // CPR: 16-byte chunks per row
+  constexpr int UA = BM * CPR / 256 > 0 ? BM * CPR / 256 : 1, UB = BN * CPR / 256 > 0 ? BN * CPR / 256 : 1;   // chunks per thread
   __shared__ __attribute__((aligned(16))) T As[BM * LDP];
   __shared__ __attribute__((aligned(16))) T Bs[BN * LDP];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
@@ -39,17 +38,27 @@ __global__ void __launch_bounds__(256) k_gemm_nt(const T* __restrict__ A, int64_
 
   const int imax = min(TI, (M - m0 - wm * WMR + 15) / 16), jmax = min(TJ, (N - n0 - wn * WNR + 15) / 16);
   Frag8<T> ra[UA], rb[UB];
+  // interior tiles of aligned operands: straight-line 16-byte loads (no per-chunk guards -> all of a stage's loads are in flight together)
+  const bool fast = (BM * CPR) % 256 == 0 && (BN * CPR) % 256 == 0 && m0 + BM <= M && n0 + BN <= N && K % BK == 0 &&
+                    ((lda | ldb) & 7) == 0 && (((uintptr_t)A | (uintptr_t)B) & 15) == 0 && ((sa0 | sa1 | sb0 | sb1) & 7) == 0;
   auto gload = [&](int kt) {
+    if (fast) {
+#pragma unroll
+      for (int u = 0; u < UA; u++) { int c = tid + u * 256, row = c / CPR, kc = c % CPR; ra[u] = frag_ld_lds(A + (int64_t)(m0 + row) * lda + kt * BK + kc * 8); }
+#pragma unroll
+      for (int u = 0; u < UB; u++) { int c = tid + u * 256, row = c / CPR, kc = c % CPR; rb[u] = frag_ld_lds(B + (int64_t)(n0 + row) * ldb + kt * BK + kc * 8); }
+      return;
+    }
 #pragma unroll
     for (int u = 0; u < UA; u++) {
-      int c = tid + u * 256, row = c >> 2, kc = c & 3, k = kt * BK + kc * 8;
+      int c = tid + u * 256, row = c / CPR, kc = c % CPR, k = kt * BK + kc * 8;
       int nv = K - k; nv = nv < 0 ? 0 : (nv > 8 ? 8 : nv);
       int gm = m0 + row;
       ra[u] = (row < BM && gm < M && nv > 0) ? frag_load(A + (int64_t)gm * lda + k, nv) : frag_zero<T>();
     }
 #pragma unroll
     for (int u = 0; u < UB; u++) {
-      int c = tid + u * 256, row = c >> 2, kc = c & 3, k = kt * BK + kc * 8;
+      int c = tid + u * 256, row = c / CPR, kc = c % CPR, k = kt * BK + kc * 8;
       int nv = K - k; nv = nv < 0 ? 0 : (nv > 8 ? 8 : nv);
       int gn = n0 + row;
       rb[u] = (row < BN && gn < N && nv > 0) ? frag_load(B + (int64_t)gn * ldb + k, nv) : frag_zero<T>();
@@ -60,26 +69,29 @@ __global__ void __launch_bounds__(256) k_gemm_nt(const T* __restrict__ A, int64_
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < UA; u++) {
-      int c = tid + u * 256, row = c >> 2, kc = c & 3;
+      int c = tid + u * 256, row = c / CPR, kc = c % CPR;
       if (row < BM) frag_st_lds(As + row * LDP + kc * 8, ra[u]);
     }
 #pragma unroll
     for (int u = 0; u < UB; u++) {
-      int c = tid + u * 256, row = c >> 2, kc = c & 3;
+      int c = tid + u * 256, row = c / CPR, kc = c % CPR;
       if (row < BN) frag_st_lds(Bs + row * LDP + kc * 8, rb[u]);
     }
     __syncthreads();
     if (kt + 1 < kt1) gload(kt + 1);
-    Frag8<T> fa[TI], fb[TJ];
 #pragma unroll
-    for (int i = 0; i < TI; i++) fa[i] = frag_ld_lds(As + (wm * WMR + i * 16 + r) * LDP + q * 8);
+    for (int kk = 0; kk < BK; kk += 32) {
+      Frag8<T> fa[TI], fb[TJ];
 #pragma unroll
-    for (int j = 0; j < TJ; j++) fb[j] = frag_ld_lds(Bs + (wn * WNR + j * 16 + r) * LDP + q * 8);
+      for (int i = 0; i < TI; i++) fa[i] = frag_ld_lds(As + (wm * WMR + i * 16 + r) * LDP + kk + q * 8);
 #pragma unroll
-    for (int i = 0; i < TI; i++) {
-      if (i >= imax) continue;      // wave-uniform: skip MFMA tiles that lie wholly outside M x N (skinny problems)
+      for (int j = 0; j < TJ; j++) fb[j] = frag_ld_lds(Bs + (wn * WNR + j * 16 + r) * LDP + kk + q * 8);
 #pragma unroll
-      for (int j = 0; j < TJ; j++) if (j < jmax) acc[i][j] = mma16(fa[i], fb[j], acc[i][j]);
+      for (int i = 0; i < TI; i++) {
+        if (i >= imax) continue;      // wave-uniform: skip MFMA tiles that lie wholly outside M x N (skinny problems)
+#pragma unroll
+        for (int j = 0; j < TJ; j++) if (j < jmax) acc[i][j] = mma16(fa[i], fb[j], acc[i][j]);
+      }
     }
   }
   // epilogue: C/D layout col = lane&15, row = 4*(lane>>4) + reg
@@ -115,9 +127,16 @@ extern "C" int dp_gemm_nt(const void* A, int64_t lda, int64_t sa0, int64_t sa1, 
   int bm = small ? 64 : 128, bn = small ? 64 : 128;
   dim3 g(cdiv(M, bm), cdiv(N, bn), nb0 * nb1 * splitk);
   if (g.y > 65535 || g.z > 65535) DP_FAIL("gemm_nt: grid too large");
-  if (small) DP_DISPATCH(dtype, hipLaunchKernelGGL((k_gemm_nt<T, 2, 2>), g, dim3(256), 0, STREAM, (const T*)A, lda, sa0, sa1, (const T*)B, ldb, sb0, sb1,
-                                                  C, ldc, sc0, sc1, bias, M, N, K, nb1, alpha, out_f32, splitk));
-  else DP_DISPATCH(dtype, hipLaunchKernelGGL((k_gemm_nt<T, 4, 4>), g, dim3(256), 0, STREAM, (const T*)A, lda, sa0, sa1, (const T*)B, ldb, sb0, sb1,
-                                             C, ldc, sc0, sc1, bias, M, N, K, nb1, alpha, out_f32, splitk));
+  // bf16 and deep K: 64-deep LDS stages halve the number of barrier pairs (the token GEMMs are latency-, not MFMA-bound)
+  bool deep = dtype == DP_BF16 && K >= 256;
+#define GEMM_ARGS g, dim3(256), 0, STREAM, (const T*)A, lda, sa0, sa1, (const T*)B, ldb, sb0, sb1, C, ldc, sc0, sc1, bias, M, N, K, nb1, alpha, out_f32, splitk
+#define GEMM_GO(TI_, TJ_, BK_) DP_DISPATCH(dtype, hipLaunchKernelGGL((k_gemm_nt<T, TI_, TJ_, BK_>), GEMM_ARGS))
+  if (deep) {   // bf16 only: the deeper stage keeps (BM + BN) * BK * 2 bytes of loads in flight per block
+    typedef bf16_t T;
+    if (small) hipLaunchKernelGGL((k_gemm_nt<T, 2, 2, 128>), GEMM_ARGS); else hipLaunchKernelGGL((k_gemm_nt<T, 4, 4, 64>), GEMM_ARGS);
+  } else if (small) GEMM_GO(2, 2, 32);
+  else GEMM_GO(4, 4, 32);
+#undef GEMM_ARGS
+#undef GEMM_GO
   DP_CHECK_LAUNCH("gemm_nt"); return 0;
 }

@@ -428,6 +428,44 @@ __global__ void k_layernorm_bwd(const T* __restrict__ x, const T* __restrict__ g
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += blockDim.x) { atomicAdd(dgamma + c, sm[c]); atomicAdd(dbeta + c, sm[C + c]); }
 }
+// C <= 1024: every lane keeps its (up to 16) columns of the row in registers -> one read of x / gy per row, and the
+// dgamma / dbeta partials stay in registers over the wave's rows (no LDS atomics in the row loop).
+template <typename T>
+__global__ void __launch_bounds__(256) k_layernorm_bwd_reg(const T* __restrict__ x, const T* __restrict__ gy, const float* __restrict__ gamma,
+                                const float* __restrict__ mean, const float* __restrict__ rstd, T* __restrict__ gx, float* __restrict__ dgamma,
+                                float* __restrict__ dbeta, int64_t rows, int C, int rows_per_block) {
+  __shared__ float sm[4][2][1024];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float gam[16], ag[16], ab[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) { int c = lane + 64 * i; gam[i] = c < C ? gamma[c] : 0.f; ag[i] = 0.f; ab[i] = 0.f; }
+  int64_t rbeg = (int64_t)blockIdx.x * rows_per_block, rend = min(rows, rbeg + rows_per_block);
+  for (int64_t row = rbeg + wv; row < rend; row += 4) {
+    const T* a = x + row * C; const T* g = gy + row * C; T* o = gx + row * C;
+    float m = mean[row], r = rstd[row];
+    float xh[16], d[16], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      int c = lane + 64 * i;
+      if (c < C) { xh[i] = (ld_f(a + c) - m) * r; d[i] = ld_f(g + c); } else { xh[i] = 0.f; d[i] = 0.f; }
+      float dg = d[i] * gam[i]; s1 += dg; s2 += dg * xh[i];
+    }
+    s1 = wave_sum(s1) / C; s2 = wave_sum(s2) / C;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      int c = lane + 64 * i;
+      if (c < C) st_f(o + c, r * (d[i] * gam[i] - s1 - xh[i] * s2));
+      ag[i] += d[i] * xh[i]; ab[i] += d[i];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 16; i++) { int c = lane + 64 * i; sm[wv][0][c] = ag[i]; sm[wv][1][c] = ab[i]; }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    atomicAdd(dgamma + c, sm[0][0][c] + sm[1][0][c] + sm[2][0][c] + sm[3][0][c]);
+    atomicAdd(dbeta + c, sm[0][1][c] + sm[1][1][c] + sm[2][1][c] + sm[3][1][c]);
+  }
+}
 extern "C" int dp_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int64_t rows, int C,
                                 float eps, int dtype, void* stream) {
   DP_DISPATCH(dtype, hipLaunchKernelGGL(k_layernorm_fwd<T>, dim3(cdiv(rows, 4)), dim3(256), 0, STREAM, (const T*)x, gamma, beta, (T*)y, mean, rstd, rows, C, eps));
@@ -435,6 +473,12 @@ extern "C" int dp_layernorm_fwd(const void* x, const float* gamma, const float* 
 }
 extern "C" int dp_layernorm_bwd(const void* x, const void* gy, const float* gamma, const float* mean, const float* rstd, void* gx, float* dgamma,
                                 float* dbeta, int64_t rows, int C, int dtype, void* stream) {
+  if (C <= 1024) {
+    int rpb = rows >= 4096 ? 16 : 8;
+    DP_DISPATCH(dtype, hipLaunchKernelGGL(k_layernorm_bwd_reg<T>, dim3(cdiv(rows, rpb)), dim3(256), 0, STREAM, (const T*)x, (const T*)gy, gamma,
+                                          mean, rstd, (T*)gx, dgamma, dbeta, rows, C, rpb));
+    DP_CHECK_LAUNCH("layernorm_bwd"); return 0;
+  }
   int rpb = 16;
   if ((size_t)2 * C * sizeof(float) > 64 * 1024) DP_FAIL("layernorm_bwd: C too large");
   DP_DISPATCH(dtype, hipLaunchKernelGGL(k_layernorm_bwd<T>, dim3(cdiv(rows, rpb)), dim3(256), 2 * C * sizeof(float), STREAM, (const T*)x, (const T*)gy, gamma,

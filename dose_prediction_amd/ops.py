@@ -355,6 +355,16 @@ class Conv3d(torch.autograd.Function):
                 wt = _pack_conv(weight, 1, x.dtype)
                 _lib.call("dp_conv3d", _p(gy), ldg, _p(wt), 0, _p(gx), cx, N, Do, Ho, Wo, Di, Hi, Wi, cout, cin,
                           k, stride, pad, dil, 1, dtc, _stream())
+        wse = _lib.lib().dp_pointwise_wgrad_ws_elems(grows, cin, cout) if (
+            k == 1 and stride == 1 and pad == 0 and ctx.needs_input_grad[1] and grows >= 32768 and cout * cin <= 256) else 0
+        if wse:
+            # heads: a handful of channels over millions of voxels -> one HBM row stream gives dW and db together
+            gw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
+            want_b = has_bias and ctx.needs_input_grad[2]
+            gb = torch.empty((cout,), dtype=torch.float32, device=x.device) if want_b else None
+            ws = torch.empty((wse,), dtype=torch.float32, device=x.device)
+            _lib.call("dp_pointwise_wgrad_rows", _p(x), ldx, _p(gy), ldg, _p(gw), cin, _p(gb), _p(ws), grows, cin, cout, dtc, _stream())
+            return gx, gw, gb, None, None, None
         if ctx.needs_input_grad[1]:
             gw = torch.zeros(weight.shape, dtype=torch.float32, device=x.device)
             taps = k * k * k
@@ -495,6 +505,18 @@ class ConvTranspose2x(torch.autograd.Function):
                 tmp = torch.zeros((8 * cout, cin), dtype=torch.float32, device=x.device)
                 _lib.call("dp_conv3d_wgrad_tiled", _p(x), ldx, _p(gu), 8 * cout, _p(tmp), _p(ws), N, D, H, W, cin, 8 * cout, 1,
                           cin, 1, 0, dtc, _stream())
+                gw = tmp.view(8, cout, cin).permute(2, 1, 0).contiguous().view(weight.shape)
+            elif rows <= 16384 and rows % 8 == 0:
+                # few voxels, many channels (the decoder's deep stages): dW^T[(abc,co)][ci] = gu^T x as an NT GEMM on the
+                # transposed operands (K = rows, split so that the small output grid still fills the chip)
+                gut = torch.empty((8 * cout, rows), dtype=x.dtype, device=x.device)
+                xt = torch.empty((cin, rows), dtype=x.dtype, device=x.device)
+                _transpose(_p(gu), 8 * cout, (0, 0), _p(gut), rows, (0, 0), rows, 8 * cout, (1, 1), dtc)
+                _transpose(_p(x), ldx, (0, 0), _p(xt), rows, (0, 0), rows, cin, (1, 1), dtc)
+                tiles = -(-8 * cout // 64) * -(-cin // 64)
+                sk = max(1, min(rows // 512, 512 // tiles))
+                tmp = (torch.zeros if sk > 1 else torch.empty)((8 * cout, cin), dtype=torch.float32, device=x.device)
+                gemm_nt(gut, xt, tmp, M=8 * cout, N=cin, K=rows, lda=rows, ldb=rows, ldc=cin, splitk=sk)
                 gw = tmp.view(8, cout, cin).permute(2, 1, 0).contiguous().view(weight.shape)
             else:
                 # "tap" = abc selects the gy column block abc*Cout; x is not shifted

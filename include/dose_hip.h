@@ -120,6 +120,13 @@ int dp_gemm_nt(const void* A, int64_t lda, int64_t sa0, int64_t sa1, const void*
  * dose_pyfer.py:292,353) forward, and their data gradient with a transposed weight matrix. */
 int dp_pointwise_rows(const void* x, int ldx, const void* w, int ldw, const float* bias, void* y, int ldy, int64_t rows, int Cin, int Cout,
                       int dtype, void* stream);
+/* Weight + bias gradient of that skinny pointwise conv (the deep-supervision heads, dose_pyfer.py:330-350; autograd of
+ * nn.Conv3d k=1): dw[co*s_co + ci] = sum_v gy[v][co] x[v][ci] (fp32), db[co] = sum_v gy[v][co] (db may be NULL).
+ * Cin in {<=8, 16, 32, 64}, Cout <= 16.  ws: fp32 workspace of dp_pointwise_wgrad_ws_elems() elements (0 = unsupported
+ * shape); per-block partials are added in a fixed order, so the result is run-to-run deterministic. */
+int64_t dp_pointwise_wgrad_ws_elems(int64_t rows, int Cin, int Cout);
+int dp_pointwise_wgrad_rows(const void* x, int ldx, const void* gy, int ldgy, float* dw, int s_co, float* db, float* ws,
+                            int64_t rows, int Cin, int Cout, int dtype, void* stream);
 
 /* ---- convolution ------------------------------------------------------------------------------ */
 /* weight packing: torch fp32 [Cout][Cin][k^3] -> T [Cout][k^3][CinP] (mode 0, forward),

@@ -79,6 +79,9 @@ DTYPES = [torch.float32, torch.bfloat16]
     (1, 128, 64, 2, 6, 32, 3, 1, 1, 1, True),
     (2, 1, 16, 3, 9, 40, 3, 1, 1, 1, False),      # single input channel (OAR-TRANSEG encoder1: CT -> 16)
     (1, 3, 16, 2, 9, 32, 7, 1, 3, 1, True),
+    (1, 16, 1, 32, 32, 40, 1, 1, 0, 1, True),     # deep-supervision head at >= 32768 voxels: row-stream forward + wgrad
+    (2, 32, 3, 16, 32, 40, 1, 1, 0, 1, True),
+    (1, 64, 2, 16, 32, 64, 1, 1, 0, 1, False),
 ])
 def test_conv3d(cfg, dtype):
     from dose_prediction_amd import ops
@@ -211,11 +214,11 @@ def test_linear(cfg, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_layernorm_gelu_add(dtype):
+def test_layernorm_gelu_add(dtype, C=768):
     from dose_prediction_amd import ops
     dev = _dev()
-    x = q(rnd((2, 37, 768), 1) * 2 + 0.5, dtype)
-    g, b = 1 + 0.2 * rnd((768,), 2), 0.1 * rnd((768,), 3)
+    x = q(rnd((2, 37, C), 1) * 2 + 0.5, dtype)
+    g, b = 1 + 0.2 * rnd((C,), 2), 0.1 * rnd((C,), 3)
     xr, gr, br = x.double().requires_grad_(True), g.double().requires_grad_(True), b.double().requires_grad_(True)
     yr = oracle.gelu(oracle.layer_norm(xr, gr, br)) + xr
     r = q(rnd(yr.shape, 4), dtype)
@@ -227,6 +230,11 @@ def test_layernorm_gelu_add(dtype):
     check("gx", xh.grad, xr.grad, dtype, scale=2.0)
     check("ggamma", gh.grad, gr.grad, dtype, scale=2.0)
     check("gbeta", bh.grad, br.grad, dtype, scale=2.0)
+
+
+@pytest.mark.parametrize("C", [48, 1000, 1536])
+def test_layernorm_widths(C):
+    test_layernorm_gelu_add(torch.float32, C)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
