@@ -22,6 +22,7 @@
 #endif
 #define STREAM ((hipStream_t)stream)
 typedef float v16f __attribute__((ext_vector_type(16)));
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ v16f mma32(const Frag8<bf16_t>& a, const Frag8<bf16_t>& b, v16f c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, a.u), __builtin_bit_cast(v8bf, b.u), c, 0, 0, 0);
@@ -39,7 +40,7 @@ struct TiledGeom {
   int NCH;             // 16-channel chunks of Cin
   int NTT;             // total 32-column N tiles in the packed weights
   int tiles_h, tiles_w;
-  int dbg;             // experiments only (env DP_DBG): 1 = skip staging, 2 = skip the MFMA sweep
+  int dbg;             // experiments only (env DP_DBG): 1 = skip staging, 2 = skip the MFMA sweep, 3 = both, 4 = also skip the epilogue
   int splitkd;         // 1: blockIdx.z selects ONE kd; results are atomically accumulated into the fp32 scratch `ws`
   // "virtual concat": input channels >= csplit come from x2 (pitch ldx2), output channels >= osplit go to y2 (pitch ldy2).
   // torch.cat((a, b), dim=1) feeding a convolution is never materialised -- and each 16-channel chunk pass then reads whole,
@@ -144,7 +145,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, 
     if (id < 0 || id >= g.D) continue;             // block-uniform: the whole depth slice is zero padding
     for (int ch = 0; ch < g.NCH; ch++) {
       __syncthreads();
-      if (g.dbg == 1 || g.dbg == 3) {
+      if (g.dbg == 1 || g.dbg == 3 || g.dbg == 4) {
       } else if (fast) {
         // straight-line staging: SU independent 16-byte loads are in flight before the first LDS store (a per-piece
         // load->store loop serialises on HBM/L2 latency and dominated the kernel); voxel coordinates advance incrementally
@@ -185,7 +186,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, 
         }
       }
       __syncthreads();
-      if (g.dbg >= 2) continue;
+      if (g.dbg >= 2 && g.dbg != 5) continue;
       const T* wbase = wq + ((int64_t)kd * NTAP * g.NCH + ch) * g.NTT * 512 + (int64_t)nt0 * 512 + r * 16 + hh * 8;
       // Weights are fetched TWO taps ahead into three rotating NAMED register sets (loop unrolled by three).  Rotating
       // through copies (bcur = bnext; ...) would be a USE of the just-issued load and force s_waitcnt vmcnt(0) every tap:
@@ -234,19 +235,20 @@ __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, 
   // A lane holds ONE channel of 16 positions, so direct stores are 2-byte scatters (measured: 0.8 TB/s, 0.16 ms of a 0.49 ms
   // 3x3x3 layer).  Each wave therefore transposes its 32-position x NC-channel tile through a private LDS patch (the slab
   // is dead by now) and writes 16 contiguous bytes per lane: whole voxel rows, 1 KiB per wave-instruction.
+  if (g.dbg == 4) return;                                         // experiment: loop skeleton only
   const int hw0 = h0 + rg * RWO * RPA, wbase_o = w0 + wc * 32;
   constexpr int NC = NPAIR == 2 ? 16 : 32;                       // channels per output tile
   constexpr int EPC = 16 / (int)sizeof(T);                       // elements per 16-byte chunk
   constexpr int CPP = NC / EPC;                                  // chunks per position
   constexpr int PASSES = 32 * CPP / 64;
   __syncthreads();                                               // every wave is done reading the slab
-  T* patch = slab + (wv & 3) * (32 * 32);
+  T* patch = slab + (wv & 3) * (2 * 32 * 32);                      // two alternating [32 positions][NC] patches per wave
   T* y2 = (T*)g.y2;
   const bool wide = !g.splitkd && (g.ldy * (int)sizeof(T)) % 16 == 0 && (((uintptr_t)y & 15) == 0) &&
                     (!y2 || ((g.ldy2 * (int)sizeof(T)) % 16 == 0 && (((uintptr_t)y2 & 15) == 0) && g.osplit % EPC == 0));
   // destination of output channel c of voxel `vox` (virtual concat: channels >= osplit live in y2)
   auto out_ptr = [&](int64_t vox, int c) -> T* { return (y2 && c >= g.osplit) ? y2 + vox * g.ldy2 + (c - g.osplit) : y + vox * g.ldy + c; };
-  auto store_tile = [&](int oh_lo, int nt_idx) {   // tile in `patch` as [32 positions][NC channels]; oh_lo: image row of position 0
+  auto store_tile = [&](const T* pt, int oh_lo, int nt_idx) {   // tile in `pt` as [32 positions][NC channels]; oh_lo: image row of position 0
     const int cbase = NPAIR == 2 ? 0 : nt_idx * 32;
 #pragma unroll
     for (int ps = 0; ps < PASSES; ps++) {
@@ -254,31 +256,64 @@ __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, 
       const int oh = W16 ? oh_lo + (m >> 4) : oh_lo, ow = W16 ? (m & 15) : wbase_o + m;
       if (oh < g.H && ow < g.W && cbase + cc < g.Cout) {
         T* dst = out_ptr((((int64_t)n * g.D + d) * g.H + oh) * g.W + ow, cbase + cc);
-        if (cbase + cc + EPC <= g.Cout) *(v4u*)dst = *(const v4u*)(patch + m * NC + cc);
-        else for (int k = 0; k < EPC; k++) if (cbase + cc + k < g.Cout) dst[k] = patch[m * NC + cc + k];
+        if (cbase + cc + EPC <= g.Cout) *(v4u*)dst = *(const v4u*)(pt + m * NC + cc);
+        else for (int k = 0; k < EPC; k++) if (cbase + cc + k < g.Cout) dst[k] = pt[m * NC + cc + k];
       }
     }
   };
+  // The wide path is straight-line code: one runtime `wide` test per element used to put a branch and a full
+  // ds_bpermute -> s_waitcnt round trip between consecutive LDS writes (16 serialised LDS latencies per row: the epilogue
+  // wrote at 1.7 TB/s and cost 40 % of a 3x3x3 layer).  Two patches per wave alternate so that a row's LDS writes never
+  // wait for the previous row's read.
   if (NPAIR == 2) {
     const int co = lane & 15;
-    const bool writer = (lane & 16) == 0;
+    const bool low = (lane & 16) == 0;
     const float bv = (bias && co < g.Cout) ? bias[co] : 0.f;
+    if (wide) {
 #pragma unroll
-    for (int t = 0; t < RWO; t++) {
-      const int oh = hw0 + t;
+      for (int t = 0; t < RWO; t++) {
+        T* pp = patch + (t & 1) * (32 * NC);
 #pragma unroll
-      for (int e = 0; e < 16; e++) {
-        float z1 = __shfl_down(acc[t + 1 < RW ? t + 1 : t][0][e], 16, 64);    // odd tap of the pair: accumulated one row below
-        float v = acc[t][0][e] + z1 + bv;
-        const int m = (e & 3) + 8 * (e >> 2) + 4 * hh;
-        if (wide) { if (writer) st_f(patch + m * NC + co, v); }
-        else if (writer && co < g.Cout && oh < g.H && wbase_o + m < g.W)
-          st_f(out_ptr((((int64_t)n * g.D + d) * g.H + oh) * g.W + wbase_o + m, co), v);
+        for (int k = 0; k < 8; k++) {
+          // v_permlane16_swap: lanes 16-31 / 48-63 of the first operand <-> lanes 0-15 / 32-47 of the second.  The low lanes
+          // receive the odd tap (row t+1, element k) they must add to their own even-tap sum; the high lanes receive the even
+          // tap (row t, element k+8) that completes THEIR odd-tap sum: one VALU swap finishes two output elements.
+          v2u sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[t + 1][0][k]), __float_as_uint(acc[t][0][k + 8]), false, false);
+          const float v = (low ? acc[t][0][k] + __uint_as_float(sw[1]) : acc[t + 1][0][k + 8] + __uint_as_float(sw[0])) + bv;
+          const int m = (k & 3) + 8 * (k >> 2) + 4 * hh + (low ? 0 : 16);
+          st_f(pp + m * NC + co, v);
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier();
+        store_tile(pp, hw0 + t, 0);
+        __builtin_amdgcn_wave_barrier();
       }
-      if (wide) {
+    } else {
+#pragma unroll
+      for (int t = 0; t < RWO; t++) {
+        const int oh = hw0 + t;
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+          float z1 = __shfl_down(acc[t + 1][0][e], 16, 64);            // odd tap of the pair: accumulated one row below
+          float v = acc[t][0][e] + z1 + bv;
+          const int m = (e & 3) + 8 * (e >> 2) + 4 * hh;
+          if (low && co < g.Cout && oh < g.H && wbase_o + m < g.W)
+            st_f(out_ptr((((int64_t)n * g.D + d) * g.H + oh) * g.W + wbase_o + m, co), v);
+        }
+      }
+    }
+  } else if (wide) {
+#pragma unroll
+    for (int j = 0; j < NT; j++) {
+      const int co = (nt0 + j) * 32 + r;
+      const float bv = (bias && co < g.Cout) ? bias[co] : 0.f;
+#pragma unroll
+      for (int i = 0; i < RW; i++) {
+        T* pp = patch + (i & 1) * (32 * NC);
+#pragma unroll
+        for (int e = 0; e < 16; e++) st_f(pp + ((e & 3) + 8 * (e >> 2) + 4 * hh) * NC + r, acc[i][j][e] + bv);
         __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier();
-        store_tile(oh, 0);
-        __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier();
+        store_tile(pp, W16 ? hw0 + 2 * i : hw0 + i, nt0 + j);
+        __builtin_amdgcn_wave_barrier();
       }
     }
   } else {
@@ -291,7 +326,6 @@ __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, 
 #pragma unroll
         for (int e = 0; e < 16; e++) {
           const int m = (e & 3) + 8 * (e >> 2) + 4 * hh;
-          if (wide) { st_f(patch + m * NC + r, acc[i][j][e] + bv); continue; }
           const int oh = W16 ? hw0 + 2 * i + (m >> 4) : hw0 + i;
           const int ow = W16 ? (m & 15) : wbase_o + m;
           if (co < g.Cout && oh < g.H && ow < g.W) {
@@ -299,11 +333,6 @@ __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, 
             if (g.splitkd) atomicAdd(ws + vox * g.Cout + co, acc[i][j][e]);
             else st_f(out_ptr(vox, co), acc[i][j][e] + bv);
           }
-        }
-        if (wide) {
-          __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier();
-          store_tile(W16 ? hw0 + 2 * i : hw0 + i, nt0 + j);
-          __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier();
         }
       }
     }
@@ -325,7 +354,7 @@ __global__ void k_conv_split_finish(const float* __restrict__ ws, const float* _
 template <typename T, int KS, int NPAIR, int RW, int NT, bool W16>
 static int launch_tiled(const void* x, const void* wq, const float* bias, void* y, float* ws, TiledGeom g, int ygrid, hipStream_t s) {
   size_t smem = (size_t)g.LR * g.LP * 16 * sizeof(T);
-  if (smem < 4 * 32 * 32 * sizeof(T)) smem = 4 * 32 * 32 * sizeof(T);     // the epilogue transposes through 4 per-wave patches
+  if (smem < 8 * 32 * 32 * sizeof(T)) smem = 8 * 32 * 32 * sizeof(T);     // the epilogue transposes through 2 patches per wave
   auto kern = k_conv_tiled<T, KS, NPAIR, RW, NT, W16>;
   if (smem > 160 * 1024) { dp_set_error("conv3d_tiled: slab %zu B exceeds LDS", smem); return 1; }
   if (smem > 48 * 1024) {
@@ -434,7 +463,7 @@ struct WgtGeom {
   int N, D, H, W, Cin, Cout, ldx, ldgy;
   int tiles_h, tiles_w, MT, NTn, KHG;
   const void* x2; int ldx2, csplit;   // virtual concat of the input (see TiledGeom)
-  int dbg;             // experiments only (env DP_DBG): 1 = skip staging, 2 = skip the MFMA sweep
+  int dbg;             // experiments only (env DP_DBG): 1 = skip staging, 2 = skip the MFMA sweep, 3 = both, 4 = also skip the epilogue
 };
 
 template <typename T, int KS, int NPAIR, int MPAIR>
