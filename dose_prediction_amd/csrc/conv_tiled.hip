@@ -16,6 +16,7 @@
 // ds_read_b128 of 8 consecutive channels of one voxel.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 #ifndef STAGE_UNROLL
 #define STAGE_UNROLL 9
@@ -100,24 +101,30 @@ extern "C" int dp_pack_conv_weight_tiled(const float* w, void* dst, int Cout, in
 }
 
 // ---------------------------------------------------------------------------------------------- the kernel
-// W16: volumes with W <= 16 -- one 32-row MFMA tile covers TWO image rows x 16 positions (NPAIR == 1 only).
-template <typename T, int KS, int NPAIR, int RW, int NT, bool W16>
+// TWP: wave columns (1, 2 or 4 x 32 positions; the other waves stack as row groups), or 0 = "W16": volumes with W <= 16,
+// where one 32-row MFMA tile covers TWO image rows x 16 positions (NPAIR == 1 only).  A template parameter so that the slab
+// pitch is a compile-time constant: every LDS row address is then one base register + an immediate offset.
+template <typename T, int KS, int NPAIR, int RW, int NT, int TWP>
 __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, const T* __restrict__ wq, const float* __restrict__ bias,
                                                     T* __restrict__ y, float* __restrict__ ws, TiledGeom g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* slab = (T*)smem_raw;
   constexpr int PAD = KS / 2, JH = NPAIR == 2 ? (KS + 1) / 2 : KS, RWO = RW - (NPAIR - 1), NTAP = JH * KS, CK = 16;
+  constexpr bool W16 = TWP == 0;
+  constexpr int TWC = W16 ? 1 : TWP, TRG = 4 / TWC;
+  constexpr int LP = ((W16 ? 16 : TWC * 32) + KS - 1 + 7) & ~7;   // multiple of 8: the swizzle bit of a row differs from row 0 by (row * LP/8) & 1
+  constexpr int LR = TRG * RWO * (W16 ? 2 : 1) + (NPAIR - 1) + (NPAIR == 2 ? 2 * (JH - 1) : KS - 1);
   // bf16: a voxel is 32 B (two 16-B halves); a ds_read_b128 lane group only ever asks for ONE half of 16 voxels, i.e. 8 of
   // the 16 slots of the 256-B bank row twice (2-way conflict).  Storing the halves of every other run of 8 voxels swapped
   // (half ^= bit 3 of the voxel index; LP is a multiple of 8, so rows differ by a known parity) spreads a
   // group over all 16 slots.
   constexpr bool SWZ = sizeof(T) == 2;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 31, hh = lane >> 5;
-  const int wc = wv % g.TWC, rg = wv / g.TWC;
+  const int wc = wv % TWC, rg = wv / TWC;
   int b = blockIdx.x;
   const int tw = b % g.tiles_w; b /= g.tiles_w; const int th = b % g.tiles_h; b /= g.tiles_h; const int d = b % g.D; const int n = b / g.D;
   constexpr int RPA = W16 ? 2 : 1;                 // image rows per accumulator row
-  const int h0 = th * (g.TRG * RWO * RPA), w0 = W16 ? 0 : tw * (g.TWC * 32);
+  const int h0 = th * (TRG * RWO * RPA), w0 = W16 ? 0 : tw * (TWC * 32);
   const int nt0 = blockIdx.y * NT;                 // first N tile of this block
 
   v16f acc[RW][NT];
@@ -128,22 +135,36 @@ __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, 
 #pragma unroll
       for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
 
-  const int pieces = g.LR * g.LP * 2;              // 8-channel pieces of the slab
-  const int64_t wtap_stride = (int64_t)g.NCH * g.NTT * 512;      // elements between consecutive (kd,jh,kw) taps
+  const int pieces = LR * LP * 2;              // 8-channel pieces of the slab
+  const int wts = g.NCH * g.NTT * 512;             // elements between consecutive (kd,jh,kw) taps (a pass spans < 2^31)
   // lane-constant part of the A address: position (wc*32 + r), channel half hh, first row of this wave's row group
-  const int v_lane = W16 ? (rg * RWO * 2 + (r >> 4)) * g.LP + (r & 15) : (rg * RWO) * g.LP + wc * 32 + r;
+  const int v_lane = W16 ? (rg * RWO * 2 + (r >> 4)) * LP + (r & 15) : (rg * RWO) * LP + wc * 32 + r;
   // fast staging path: bf16, whole 16-channel chunks, 16-byte aligned voxel rows (block-uniform)
   constexpr int SU = STAGE_UNROLL;
   const bool fast = SWZ && (g.Cin % 16 == 0) && (g.ldx % 8 == 0) && (((uintptr_t)x & 15) == 0) &&
                     (!g.x2 || ((g.csplit % 16 == 0) && (g.ldx2 % 8 == 0) && (((uintptr_t)g.x2 & 15) == 0)));
-  const int lp_par = SWZ ? ((g.LP >> 3) & 1) : 0;
-  const int st_half = tid & 1, st_lp0 = (tid >> 1) % g.LP, st_lr0 = (tid >> 1) / g.LP;
+  const int lp_par = SWZ ? ((LP >> 3) & 1) : 0;
+  const int st_half = tid & 1, st_lp0 = (tid >> 1) % LP, st_lr0 = (tid >> 1) / LP;
 
+  constexpr int RS = W16 ? 2 : 1, TS = NPAIR == 2 ? 2 : 1;        // slab rows per accumulator row / per kh tap (pair)
+  constexpr int ROWS = RS * (RW - 1) + TS * (JH - 1) + 1;          // slab rows one wave sweeps per kw column
+  // the JH weight fragments (all kh taps / pairs) of one kw column and one N tile.  `wb` is wave-uniform (SGPR base); the
+  // lane part is ONE 32-bit offset shared by every load, so the 2*JH pointers do not live in VGPRs.
+  const int lane_off = r * 16 + hh * 8;
+  auto load_bk = [&](const T* wb, int kw, int j, Frag8<T>* bb) {
+#pragma unroll
+    for (int jh = 0; jh < JH; jh++) bb[jh] = frag_ld_lds(wb + ((jh * KS + kw) * wts + j * 512) + lane_off);   // 32-bit uniform + lane offsets: saddr loads
+  };
   const int kd_lo = g.splitkd ? (int)blockIdx.z : 0, kd_hi = g.splitkd ? kd_lo + 1 : KS;
   for (int kd = kd_lo; kd < kd_hi; kd++) {
     const int id = d + kd - PAD;
     if (id < 0 || id >= g.D) continue;             // block-uniform: the whole depth slice is zero padding
     for (int ch = 0; ch < g.NCH; ch++) {
+      // packed weights of this (kd, chunk) pass; the first kw column is requested BEFORE the slab is staged so that its
+      // L2 latency hides behind the staging loads.
+      const T* wbase = wq + ((int64_t)kd * NTAP * g.NCH + ch) * g.NTT * 512 + (int64_t)nt0 * 512;
+      Frag8<T> b0[JH], b1[JH];
+      load_bk(wbase, 0, 0, b0);
       __syncthreads();
       if (g.dbg == 1 || g.dbg == 3 || g.dbg == 4) {
       } else if (fast) {
@@ -165,7 +186,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, 
             v4u t = *(const v4u*)src;
             buf[j] = ok ? t : (v4u){0, 0, 0, 0};
             vv[j] = (p0 + j * 256 + tid < pieces) ? v : -1;
-            v += 128; lp += 128; while (lp >= g.LP) { lp -= g.LP; lr++; }
+            v += 128; lp += 128; while (lp >= LP) { lp -= LP; lr++; }
           }
 #pragma unroll
           for (int j = 0; j < SU; j++)
@@ -173,7 +194,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, 
         }
       } else {
         for (int p = tid; p < pieces; p += 256) {
-          int half = p & 1, v = p >> 1, lp = v % g.LP, lr = v / g.LP;
+          int half = p & 1, v = p >> 1, lp = v % LP, lr = v / LP;
           int ih = h0 - PAD + lr, iw = w0 - PAD + lp, c = ch * CK + half * 8;
           int nv = g.Cin - c; nv = nv > 8 ? 8 : nv;
           bool ok = ih >= 0 && ih < g.H && iw >= 0 && iw < g.W && nv > 0;
@@ -186,46 +207,50 @@ __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, 
         }
       }
       __syncthreads();
-      if (g.dbg >= 2 && g.dbg != 5) continue;
-      const T* wbase = wq + ((int64_t)kd * NTAP * g.NCH + ch) * g.NTT * 512 + (int64_t)nt0 * 512 + r * 16 + hh * 8;
-      // Weights are fetched TWO taps ahead into three rotating NAMED register sets (loop unrolled by three).  Rotating
-      // through copies (bcur = bnext; ...) would be a USE of the just-issued load and force s_waitcnt vmcnt(0) every tap:
-      // that exposed the full L2 latency per tap and held the sweep at ~40 % of the MFMA rate.
-      auto load_b = [&](int tt, Frag8<T>* bb) {
-#pragma unroll
-        for (int j = 0; j < NT; j++) bb[j] = frag_load(wbase + (int64_t)tt * wtap_stride + j * 512, 8);
-      };
-      auto do_tap = [&](int tt, const Frag8<T>* bb) {
-        const int jh = tt / KS, kw = tt - jh * KS;
-        const int v_tap = v_lane + (NPAIR == 2 ? 2 * jh : jh) * g.LP + kw;
+      if (g.dbg >= 2) continue;
+      // Sweep: for one kw column, EVERY slab row is read from LDS once and feeds all the kh taps (pairs) that use it
+      // (output row i and tap jh share the input row RS*i + TS*jh).  A tap-outer loop read the A fragment again for every
+      // (row, tap) pair -- 1 KiB of LDS per 32-cycle MFMA per SIMD, i.e. exactly the CU's whole LDS bandwidth -- and held
+      // the sweep near half the MFMA rate; row-outer needs ROWS reads for RW*JH MFMAs (15 for 36 with 7x7x7 pairs, 14 for 56
+      // unpaired).  The JH weight fragments of the NEXT column are in flight (two named register sets) while this one runs.
+      auto do_kw = [&](int kw, auto jc, const Frag8<T>* bb) {
+        constexpr int j = decltype(jc)::value;
+        const int v_tap = v_lane + kw;
         const int sw0 = SWZ ? (hh ^ ((v_tap >> 3) & 1)) : hh;
         const int a_even = v_tap * CK + sw0 * 8, a_odd = v_tap * CK + (sw0 ^ lp_par) * 8;   // odd rows flip the half iff LP/8 is odd
 #pragma unroll
-        for (int i = 0; i < RW; i++) {
-#ifdef DP_EXPERIMENT_ONE_LDS_READ
-          Frag8<T> fa = frag_ld_lds(slab + a_even);     // experiment: same LDS address for every row (MFMA-issue ceiling)
-#else
-          Frag8<T> fa = W16 ? frag_ld_lds(slab + a_even + 2 * i * g.LP * CK)      // two image rows per step: parity unchanged
-                            : frag_ld_lds(slab + ((i & 1) ? a_odd : a_even) + i * g.LP * CK);
-#endif
+        for (int rho = 0; rho < ROWS; rho++) {
+          Frag8<T> fa = frag_ld_lds(slab + ((rho & 1) ? a_odd : a_even) + rho * LP * CK);
 #pragma unroll
-          for (int j = 0; j < NT; j++) acc[i][j] = mma32(fa, bb[j], acc[i][j]);
+          for (int jh = 0; jh < JH; jh++) {
+            const int num = rho - TS * jh;
+            if (num < 0 || num % RS != 0 || num / RS >= RW) continue;      // compile-time after unrolling
+            acc[num / RS][j] = mma32(fa, bb[jh], acc[num / RS][j]);
+          }
+          if (rho & 1) __builtin_amdgcn_sched_barrier(0);   // at most two A rows in flight: hoisting all ROWS reads costs 4 VGPRs each and spills
         }
       };
-      Frag8<T> b0[NT], b1[NT], b2[NT];
-      load_b(0, b0);
-      if (NTAP > 1) load_b(1, b1);
+      std::integral_constant<int, 0> J0;
+      // sched_barrier: without it the scheduler sinks the prefetch loads down to their first use (to shorten live ranges)
+      // and every column pays the full L2 latency.
+      if (NT == 1) {
 #pragma unroll 1
-      for (int tt = 0; tt < NTAP; tt += 3) {
-        if (tt + 2 < NTAP) load_b(tt + 2, b2);
-        do_tap(tt, b0);
-        if (tt + 1 < NTAP) {
-          if (tt + 3 < NTAP) load_b(tt + 3, b0);
-          do_tap(tt + 1, b1);
+        for (int kw = 0; kw < KS; kw += 2) {        // KS is odd: the pass ends on b0, which is free again at the next pass's top
+          if (kw + 1 < KS) { load_bk(wbase, kw + 1, 0, b1); __builtin_amdgcn_sched_barrier(0); }
+          do_kw(kw, J0, b0);
+          if (kw + 1 < KS) {
+            if (kw + 2 < KS) { load_bk(wbase, kw + 2, 0, b0); __builtin_amdgcn_sched_barrier(0); }
+            do_kw(kw + 1, J0, b1);
+          }
         }
-        if (tt + 2 < NTAP) {
-          if (tt + 4 < NTAP) load_b(tt + 4, b1);
-          do_tap(tt + 2, b2);
+      } else {                                      // two N tiles: they alternate between the register sets (A rows are read once per tile)
+        std::integral_constant<int, NT - 1> J1;
+#pragma unroll 1
+        for (int kw = 0; kw < KS; kw++) {
+          load_bk(wbase, kw, 1, b1); __builtin_amdgcn_sched_barrier(0);
+          do_kw(kw, J0, b0);
+          if (kw + 1 < KS) { load_bk(wbase, kw + 1, 0, b0); __builtin_amdgcn_sched_barrier(0); }
+          do_kw(kw, J1, b1);
         }
       }
     }
@@ -351,11 +376,11 @@ __global__ void k_conv_split_finish(const float* __restrict__ ws, const float* _
   }
 }
 
-template <typename T, int KS, int NPAIR, int RW, int NT, bool W16>
+template <typename T, int KS, int NPAIR, int RW, int NT, int TWP>
 static int launch_tiled(const void* x, const void* wq, const float* bias, void* y, float* ws, TiledGeom g, int ygrid, hipStream_t s) {
   size_t smem = (size_t)g.LR * g.LP * 16 * sizeof(T);
   if (smem < 8 * 32 * 32 * sizeof(T)) smem = 8 * 32 * 32 * sizeof(T);     // the epilogue transposes through 2 patches per wave
-  auto kern = k_conv_tiled<T, KS, NPAIR, RW, NT, W16>;
+  auto kern = k_conv_tiled<T, KS, NPAIR, RW, NT, TWP>;
   if (smem > 160 * 1024) { dp_set_error("conv3d_tiled: slab %zu B exceeds LDS", smem); return 1; }
   if (smem > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -364,7 +389,7 @@ static int launch_tiled(const void* x, const void* wq, const float* bias, void* 
   dim3 grid(g.N * g.D * g.tiles_h * g.tiles_w, ygrid, g.splitkd ? KS : 1);
   if (getenv("DP_DEBUG_OCC")) {
     int nb = -1; hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, 256, smem);
-    fprintf(stderr, "[dp] conv_tiled KS=%d NPAIR=%d RW=%d NT=%d W16=%d smem=%zu grid=%u x %u x %u occupancy(blocks/CU)=%d (%s)\n", KS, NPAIR, RW, NT, (int)W16, smem,
+    fprintf(stderr, "[dp] conv_tiled KS=%d NPAIR=%d RW=%d NT=%d TWP=%d smem=%zu grid=%u x %u x %u occupancy(blocks/CU)=%d (%s)\n", KS, NPAIR, RW, NT, TWP, smem,
             grid.x, grid.y, grid.z, nb, hipGetErrorString(e));
   }
   if (g.splitkd) {
@@ -430,13 +455,16 @@ extern "C" int dp_conv3d_tiled2(const void* x, int ldx, const void* x2, int ldx2
   if ((int64_t)N * D * g.tiles_h * g.tiles_w > 2000000000LL) DP_FAIL("conv3d_tiled: grid too large");
   int rc = 0;
   hipStream_t s = STREAM;
-#define GO(TT, KS_, NP, RW_, NT_, W16_) rc = launch_tiled<TT, KS_, NP, RW_, NT_, W16_>(x, wq, bias, y, ws, g, ygrid, s)
-#define BYCFG(TT, KS_) do { if (np == 2) GO(TT, KS_, 2, 9, 1, false); else if (nt == 1) { if (w16) GO(TT, KS_, 1, 8, 1, true); else GO(TT, KS_, 1, 8, 1, false); } \
-                            else { if (w16) GO(TT, KS_, 1, 4, 2, true); else GO(TT, KS_, 1, 4, 2, false); } } while (0)
+#define GO(TT, KS_, NP, RW_, NT_, TWP_) rc = launch_tiled<TT, KS_, NP, RW_, NT_, TWP_>(x, wq, bias, y, ws, g, ygrid, s)
+#define BYTW(TT, KS_, NP, RW_, NT_) do { if (g.TWC == 4) GO(TT, KS_, NP, RW_, NT_, 4); else if (g.TWC == 2) GO(TT, KS_, NP, RW_, NT_, 2); \
+                                         else GO(TT, KS_, NP, RW_, NT_, 1); } while (0)
+#define BYCFG(TT, KS_) do { if (np == 2) BYTW(TT, KS_, 2, 9, 1); else if (nt == 1) { if (w16) GO(TT, KS_, 1, 8, 1, 0); else BYTW(TT, KS_, 1, 8, 1); } \
+                            else { if (w16) GO(TT, KS_, 1, 4, 2, 0); else BYTW(TT, KS_, 1, 4, 2); } } while (0)
   if (dtype == DP_BF16) { if (k == 7) BYCFG(bf16_t, 7); else BYCFG(bf16_t, 3); }
   else if (dtype == DP_F32) { if (k == 7) BYCFG(float, 7); else BYCFG(float, 3); }
   else DP_FAIL("conv3d_tiled: bad dtype");
 #undef BYCFG
+#undef BYTW
 #undef GO
   if (rc) return rc;
   DP_CHECK_LAUNCH("conv3d_tiled"); return 0;
