@@ -17,6 +17,7 @@
 #include "common.h"
 #include <stdlib.h>
 #include <type_traits>
+#include <utility>
 
 #ifndef STAGE_UNROLL
 #define STAGE_UNROLL 9
@@ -501,7 +502,9 @@ struct WgtCfg {
   static constexpr int KWT = MPAIR == 2 ? (KS + 1) / 2 : KS;      // kw (pairs) = accumulators per wave
   static constexpr int WKH = JHN >= 3 ? 4 : (JHN == 2 ? 2 : 1), WCH = 4 / WKH;
   static constexpr int XC = MPAIR == 2 ? 16 : 32, GC = NPAIR == 2 ? 16 : 32;
-  static constexpr int TH = 8, TW = sizeof(T) == 2 ? 64 : 32, NCHK = TW / 16;
+  // 64-voxel tiles only while x slab + gy tile stay near 64 KB: with 32 input channels per voxel the wide tile needs ~90 KB,
+  // i.e. ONE block (one wave per SIMD) per CU, and the sweep ran at a third of the MFMA rate with nothing to overlap
+  static constexpr int TH = 8, TW = (sizeof(T) == 2 && MPAIR == 2) ? 64 : 32, NCHK = TW / 16;
   static constexpr int GR = NPAIR == 2 ? TH + 2 : TH;
   static constexpr int LR = NPAIR == 2 ? TH + 2 * JHN - 1 : TH + KS - 1, LP = TW + KS - 1;
   static constexpr int STEPS = NPAIR == 2 ? TH + 1 : TH;
@@ -536,19 +539,80 @@ __device__ __forceinline__ Frag8<float> ld_kmajor32(const float* img, int vox_lo
   return f;
 }
 
+// two ds_read_b64_tr_b16 at a lane address and OFF elements further: 8 consecutive voxels (k) of one column
+template <int OFF>
+__device__ __forceinline__ Frag8<bf16_t> tr_pair(const bf16_t* a) {
+  v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)a);
+  v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(a + OFF));
+  Frag8<bf16_t> f;
+  f.u[0] = (unsigned)(unsigned short)lo[0] | ((unsigned)(unsigned short)lo[1] << 16);
+  f.u[1] = (unsigned)(unsigned short)lo[2] | ((unsigned)(unsigned short)lo[3] << 16);
+  f.u[2] = (unsigned)(unsigned short)hi[0] | ((unsigned)(unsigned short)hi[1] << 16);
+  f.u[3] = (unsigned)(unsigned short)hi[2] | ((unsigned)(unsigned short)hi[3] << 16);
+  return f;
+}
+// 16 consecutive voxels (k-major) of one column per lane: the window every kw tap of a 16-voxel chunk reads from.  Two
+// aligned fragment loads (voxels +0 and +8) fill it; the per-tap fragments are then register sub-ranges (even voxel
+// offsets) or sub-ranges of a copy shifted by one voxel (odd offsets; 7 v_perm/v_alignbit per window) instead of one more
+// pair of LDS transpose reads per tap -- the x operand was 7 of the 8 fragment loads per 7 MFMAs of a 7x7x7 layer.
+// With M pairing the odd tap of a pair lives on the upper 16 columns, whose lanes simply READ their window one voxel later.
+template <typename T> struct Win16;
+template <> struct Win16<bf16_t> { unsigned w[8], wo[7]; };
+template <> struct Win16<float> { float w[16]; };
+__device__ __forceinline__ Win16<bf16_t> make_win(const Frag8<bf16_t>& a, const Frag8<bf16_t>& b) {
+  Win16<bf16_t> W;
+#pragma unroll
+  for (int r = 0; r < 4; r++) { W.w[r] = a.u[r]; W.w[4 + r] = b.u[r]; }
+  return W;
+}
+__device__ __forceinline__ Win16<float> make_win(const Frag8<float>& a, const Frag8<float>& b) {
+  Win16<float> W;
+#pragma unroll
+  for (int j = 0; j < 8; j++) { W.w[j] = a.v[j]; W.w[8 + j] = b.v[j]; }
+  return W;
+}
+// the copy shifted by one voxel; called AFTER the MFMAs of the previous window have been issued, so that the LDS
+// latency of the window's loads is not exposed in front of them
+template <bool ODD> __device__ __forceinline__ void win_finish(Win16<bf16_t>& W) {
+#pragma unroll
+  for (int r = 0; r < 7; r++) W.wo[r] = ODD ? __builtin_amdgcn_alignbit(W.w[r + 1], W.w[r], 16) : 0u;
+}
+template <bool ODD> __device__ __forceinline__ void win_finish(Win16<float>&) {}
+// fragment = voxels [S, S + 8) of the window (S compile-time)
+template <int S>
+__device__ __forceinline__ Frag8<bf16_t> win_frag(const Win16<bf16_t>& W) {
+  Frag8<bf16_t> f;
+#pragma unroll
+  for (int r = 0; r < 4; r++) f.u[r] = (S & 1) ? W.wo[S / 2 + r] : W.w[S / 2 + r];
+  return f;
+}
+template <int S>
+__device__ __forceinline__ Frag8<float> win_frag(const Win16<float>& W) {
+  Frag8<float> f;
+#pragma unroll
+  for (int j = 0; j < 8; j++) f.v[j] = W.w[S + j];
+  return f;
+}
+
 template <typename T, int KS, int NPAIR, int MPAIR>
 __global__ void __launch_bounds__(256, 2) k_wgrad_tiled(const T* __restrict__ x, const T* __restrict__ gy, float* __restrict__ dwt, WgtGeom g) {
   using C = WgtCfg<T, KS, NPAIR, MPAIR>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* xs = (T*)smem_raw;
   T* gs = xs + (size_t)C::LR * C::LP * C::XC;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, hh = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), hh = lane >> 5;   // wv in an SGPR: the (i, c) counters stay scalar
   const int kd = blockIdx.x;
   int z = blockIdx.z;
   const int khg = z % g.KHG; z /= g.KHG; const int nt = z % g.NTn; const int mt = z / g.NTn;
   const int khw = wv % C::WKH, chw = wv / C::WKH;
   const int jh = khg * C::WKH + khw;
   const bool active = jh < C::JHN;
+  // lane-constant element offsets of the k-major (transposing) LDS reads: lane = 16*g + 4*qq + p supplies row qq, columns
+  // 4p..4p+3 of an 4x16 block; the upper 16 columns of a 32-wide operand are the second channel half, or (pairing) a
+  // shifted copy: x by one voxel (done in registers, see Win16), gy by one image row.
+  const int tr_i16 = lane & 15, tr_up = (lane >> 4) & 1;
+  const int x_lane = (8 * hh + (tr_i16 >> 2) + (MPAIR == 2 ? tr_up : 0)) * C::XC + (MPAIR == 2 ? 0 : 16 * tr_up) + 4 * (tr_i16 & 3);
+  const int g_lane = (8 * hh + (tr_i16 >> 2)) * C::GC + 4 * (tr_i16 & 3) + (NPAIR == 2 ? (tr_up ? 0 : C::GRP) : 16 * tr_up);
   const int units = g.N * g.D * g.tiles_h, per = (units + gridDim.y - 1) / gridDim.y;
   const int u0 = blockIdx.y * per, u1 = min(units, u0 + per);
   const int cbase_x = mt * C::XC, cbase_g = nt * C::GC;
@@ -645,22 +709,53 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_tiled(const T* __restrict__ x,
       }
       __syncthreads();
       if (active && g.dbg != 2) {
-#pragma unroll 1
-        for (int i = 0; i < C::STEPS; i++) {
-          const int lr = i + (NPAIR == 2 ? 2 * jh : jh);
-#pragma unroll 1
-          for (int c = chw; c < nchk; c += C::WCH) {
-            Frag8<T> fb;      // gy rows are GRP apart: express the row offset in "voxels" of pitch GC (GRP is a multiple of GC)
+        // flat loop over (gy row i, 16-voxel chunk c) with the NEXT pair's operands in flight: two named register sets
+        const int ncw = (nchk - chw + C::WCH - 1) / C::WCH, nit = C::STEPS * ncw;     // chunks of this wave x rows
+        constexpr bool WODD = MPAIR == 1 && KS > 1;        // odd voxel shifts are needed only without M pairing
+        // (i, c) advance with wave-uniform (scalar) counters; the lane part of every LDS address is constant for the launch,
+        // so one VALU add per image and immediate offsets cover the six transpose reads of an iteration (the address
+        // arithmetic used to cost several times the issue slots of the MFMAs it fed).
+        int it_i = 0, it_c = chw;
+        auto load_ic = [&](Frag8<T>& fb, Win16<T>& W, Frag8<T>& r0, Frag8<T>& r1) {
+          const int i = it_i, c = it_c;
+          it_c += C::WCH; if (it_c >= nchk) { it_c = chw; it_i++; }
+          const int lr = i + (NPAIR == 2 ? 2 * jh : jh), vbase = lr * C::LP + 16 * c;
+          if constexpr (sizeof(T) == 2) {
+            const bf16_t* ga = (const bf16_t*)gs + g_lane + (i * C::GRP + 16 * c * C::GC);
+            const bf16_t* xa = (const bf16_t*)xs + x_lane + vbase * C::XC;
+            fb = tr_pair<4 * C::GC>(ga);
+            r0 = tr_pair<4 * C::XC>(xa);
+            if (KS > 1) r1 = tr_pair<4 * C::XC>(xa + 8 * C::XC);                    // reads past a row end only feed unused window slots
+          } else {
+            // gy rows are GRP apart: express the row offset in "voxels" of pitch GC (GRP is a multiple of GC)
             if (NPAIR == 2) fb = ld_kmajor32<C::GC>(gs, (i + 1) * (C::GRP / C::GC) + 16 * c, i * (C::GRP / C::GC) + 16 * c, 0, 0, lane);
             else fb = ld_kmajor32<C::GC>(gs, i * (C::GRP / C::GC) + 16 * c, i * (C::GRP / C::GC) + 16 * c, 0, 16, lane);
-#pragma unroll
-            for (int k = 0; k < C::KWT; k++) {
-              Frag8<T> fa;
-              const int vbase = lr * C::LP + 16 * c;
-              if (MPAIR == 2) fa = ld_kmajor32<C::XC>(xs, vbase + 2 * k, vbase + 2 * k + 1, 0, 0, lane);
-              else fa = ld_kmajor32<C::XC>(xs, vbase + k, vbase + k, 0, 16, lane);
-              acc[k] = mma32(fa, fb, acc[k]);
-            }
+            const int chi = MPAIR == 2 ? 0 : 16;
+            const int vup = vbase + (MPAIR == 2 ? 1 : 0);
+            r0 = ld_kmajor32<C::XC>(xs, vbase, vup, 0, chi, lane);
+            if (KS > 1) r1 = ld_kmajor32<C::XC>(xs, vbase + 8, vup + 8, 0, chi, lane);
+          }
+          if (!WODD) W = make_win(r0, KS == 1 ? r0 : r1);          // nothing to derive: the loads ARE the window
+        };
+        auto sweep = [&](const Frag8<T>& fb, const Win16<T>& W) {
+          [&]<int... K>(std::integer_sequence<int, K...>) {
+            ((acc[K] = mma32(win_frag<(MPAIR == 2 ? 2 * K : K)>(W), fb, acc[K])), ...);
+          }(std::make_integer_sequence<int, C::KWT>{});
+        };
+        // Per set: the raw loads (fb, r0, r1) are issued one iteration ahead; the window (copies + one-voxel-shifted copy)
+        // is built from them AFTER the previous window's MFMAs have been issued, so no LDS latency sits in front of an MFMA.
+        Frag8<T> fbA, fbB, r0, r1; Win16<T> WA, WB;
+        auto finish = [&](Win16<T>& W) { if (WODD) { W = make_win(r0, r1); win_finish<true>(W); } };
+        if (nit > 0) { load_ic(fbA, WA, r0, r1); finish(WA); }
+#pragma unroll 1
+        for (int t = 0; t < nit; t += 2) {
+          if (t + 1 < nit) load_ic(fbB, WB, r0, r1);
+          sweep(fbA, WA);
+          if (t + 1 < nit) {
+            finish(WB);
+            if (t + 2 < nit) load_ic(fbA, WA, r0, r1);
+            sweep(fbB, WB);
+            if (t + 2 < nit) finish(WA);
           }
         }
       }
@@ -713,7 +808,15 @@ static int launch_wgt(const void* x, const void* gy, float* ws, WgtGeom g, hipSt
   g.MT = cdiv(g.Cin, C::XC); g.NTn = cdiv(g.Cout, C::GC); g.KHG = cdiv(C::JHN, C::WKH);
   int zdim = g.MT * g.NTn * g.KHG;
   int units = g.N * g.D * g.tiles_h;
-  int want = (256 * 3) / (KS * zdim); if (want < 1) want = 1;     // ~3 blocks per CU in total
+  // one resident wave of blocks: occupancy x CUs blocks in total (a 1.5-round grid left a quarter of the chip idle in round two)
+  static int occ = 0, ncu = 0;
+  if (!occ) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)kern, 256, C::SMEM) != hipSuccess || occ < 1) occ = 2;
+    int dev = 0; hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount;
+    if (ncu < 1) ncu = 256;
+  }
+  int want = (ncu * occ) / (KS * zdim); if (want < 1) want = 1;
   int ydim = units < want ? units : want;
   dim3 grid(KS, ydim, zdim);
   if (zdim > 65535) { dp_set_error("wgrad_tiled: too many channel tiles"); return 1; }
