@@ -87,6 +87,15 @@ __device__ __forceinline__ v4f mma16(const Frag8<float>& a, const Frag8<float>& 
   return c;
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a release fence over ALL address spaces, which on
+// gfx9 is s_waitcnt vmcnt(0): every global load still in flight (the software-prefetched next tile) is drained at each
+// barrier.  Use this one when the barrier only publishes LDS data and the kernel has no global producer/consumer pair.
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // wave (64-lane) reductions
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

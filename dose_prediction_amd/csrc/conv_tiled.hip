@@ -623,69 +623,88 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_tiled(const T* __restrict__ x,
 #pragma unroll
     for (int e = 0; e < 16; e++) acc[k][e] = 0.f;
 
-  constexpr int XPV = C::XC / 8, GPV = C::GC / 8, SU = 6;
+  constexpr int XPV = C::XC / 8, GPV = C::GC / 8;
   // fast staging: bf16, whole channel tiles, 16-byte aligned voxel rows (block-uniform)
   const bool fast = sizeof(T) == 2 && cbase_x + C::XC <= g.Cin && cbase_g + C::GC <= g.Cout && (g.ldx % 8 == 0) && (g.ldgy % 8 == 0) &&
                     (((uintptr_t)x & 15) == 0) && (((uintptr_t)gy & 15) == 0) &&
-                    (!g.x2 || ((g.csplit % 8 == 0) && (g.ldx2 % 8 == 0) && (((uintptr_t)g.x2 & 15) == 0)));
-  for (int u = u0; u < u1; u++) {
-    const int th = u % g.tiles_h; const int nd = u / g.tiles_h; const int d = nd % g.D, n = nd / g.D;
-    const int id = d + kd - C::PAD;
-    if (id < 0 || id >= g.D) continue;
-    const int h0 = th * C::TH;
-    for (int tw = 0; tw < g.tiles_w; tw++) {
-      const int w0 = tw * C::TW;
-      const int nchk = min(C::NCHK, (g.W - w0 + 15) >> 4);          // 16-voxel chunks that hold real output positions
-      const int lpn = nchk * 16 + KS - 1;                            // slab positions actually read
-      __syncthreads();
-      if (g.dbg == 1) {
-      } else if (fast) {
-        // straight-line staging (see k_conv_tiled): SU independent 16-byte loads in flight before the first LDS store
-        {
-          const int total = C::LR * lpn * XPV;
-          const int cpiece = cbase_x + (tid % XPV) * 8;                         // this thread's 8-channel piece: fixed for the launch
-          const bool second = g.x2 && cpiece >= g.csplit;
-          const T* xsrc = second ? (const T*)g.x2 : x;
-          const int ldsrc = second ? g.ldx2 : g.ldx;
-          const T* xplane = xsrc + (((int64_t)n * g.D + id) * g.H) * (int64_t)g.W * ldsrc + cpiece - (second ? g.csplit : 0);
-          int lp = (tid / XPV) % lpn, lr = (tid / XPV) / lpn;
-          for (int p0 = 0; p0 < total; p0 += 256 * SU) {
-            v4u buf[SU]; int dst[SU];
+                    (!g.x2 || ((g.csplit % 8 == 0) && (g.ldx2 % 8 == 0) && (((uintptr_t)g.x2 & 15) == 0))) &&
+                    (g.tiles_w == 1 || g.W % C::TW == 0) &&                   // one tile width per launch (piece coordinates are precomputed)
+                    (int64_t)g.H * g.W * max(max(g.ldx, g.ldx2), g.ldgy) < (1ll << 30);   // 32-bit offsets inside a plane
+  // ---- tile iteration: (u, tw) pairs whose input depth slice exists
+  struct Tile { int n, d, id, h0, w0, nchk, lpn; };
+  auto tile_ok = [&](int u) { const int d = (u / g.tiles_h) % g.D, id = d + kd - C::PAD; return id >= 0 && id < g.D; };
+  auto tile_of = [&](int u, int tw) {
+    Tile t; const int th = u % g.tiles_h, nd = u / g.tiles_h;
+    t.d = nd % g.D; t.n = nd / g.D; t.id = t.d + kd - C::PAD; t.h0 = th * C::TH; t.w0 = tw * C::TW;
+    t.nchk = min(C::NCHK, (g.W - t.w0 + 15) >> 4);             // 16-voxel chunks that hold real output positions
+    t.lpn = t.nchk * 16 + KS - 1;                                // slab positions actually read
+    return t;
+  };
+  auto advance = [&](int& u, int& tw) { if (++tw >= g.tiles_w) { tw = 0; u++; while (u < u1 && !tile_ok(u)) u++; } };
+  int cu = u0, ctw = 0;
+  while (cu < u1 && !tile_ok(cu)) cu++;
+
+  // ---- register-staged tile loads (fast path): ALL 16-byte pieces of one tile live in registers, requested while the
+  // previous tile is being swept and written to LDS after the barrier that ends that sweep (the synchronous
+  // load -> store -> sweep sequence left the MFMAs idle for the whole staging time: 0.5 of 1.25 ms on 16->16 at 128^3)
+  constexpr int PX = (C::LR * C::LP * XPV + 255) / 256, PG = (C::GR * C::TW * GPV + 255) / 256;
+  v4u rx[PX], rg[PG];
+  const int cpiece = cbase_x + (tid % XPV) * 8;                  // this thread's 8-channel piece of x: fixed for the launch
+  const bool xsecond = g.x2 && cpiece >= g.csplit;
+  const T* xsrc = (xsecond ? (const T*)g.x2 : x) + cpiece - (xsecond ? g.csplit : 0);
+  const int ldsrc = xsecond ? g.ldx2 : g.ldx;
+  const T* gsrc = gy + cbase_g + (tid % GPV) * 8;
+  // Piece coordinates are launch constants on the fast path (it requires one tile width for the whole launch): walk them
+  // ONCE here, packed (row << 16 | position); -1 = no piece.  Per tile a piece then costs two range checks and one 32-bit
+  // multiply-add -- the per-tile coordinate walk (divergent carry loops, 64-bit address products) used to issue as many
+  // instructions as the MFMA sweep it was supposed to hide behind.
+  const int nchk_c = min(C::NCHK, (g.W + 15) >> 4), lpn_c = nchk_c * 16 + KS - 1, gwn_c = nchk_c * 16;
+  int pkx[PX], pkg[PG];
+  {
+    const int totx = C::LR * lpn_c * XPV, totg = C::GR * gwn_c * GPV;
+    int lp = (tid / XPV) % lpn_c, lr = (tid / XPV) / lpn_c;
 #pragma unroll
-            for (int j = 0; j < SU; j++) {
-              const int ih = h0 - C::PAD + lr, iw = w0 - C::PAD + lp;
-              const bool in = p0 + j * 256 + tid < total;
-              const bool ok = in && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W;
-              v4u t = *(const v4u*)(xplane + ((int64_t)(ok ? ih : 0) * g.W + (ok ? iw : 0)) * ldsrc);
-              buf[j] = ok ? t : (v4u){0, 0, 0, 0};
-              dst[j] = in ? (lr * C::LP + lp) * C::XC + (tid % XPV) * 8 : -1;
-              lp += 256 / XPV; while (lp >= lpn) { lp -= lpn; lr++; }
-            }
+    for (int j = 0; j < PX; j++) {
+      pkx[j] = (j * 256 + tid < totx) ? (lr << 16 | lp) : -1;
+      lp += 256 / XPV; while (lp >= lpn_c) { lp -= lpn_c; lr++; }
+    }
+    int gw = (tid / GPV) % gwn_c, gr = (tid / GPV) / gwn_c;
 #pragma unroll
-            for (int j = 0; j < SU; j++) if (dst[j] >= 0) *(v4u*)(xs + dst[j]) = buf[j];
-          }
-        }
-        {
-          const int gwn = nchk * 16, total = C::GR * gwn * GPV;
-          const T* gplane = gy + (((int64_t)n * g.D + d) * g.H) * (int64_t)g.W * g.ldgy + cbase_g + (tid % GPV) * 8;
-          int gw = (tid / GPV) % gwn, gr = (tid / GPV) / gwn;
-          for (int p0 = 0; p0 < total; p0 += 256 * SU) {
-            v4u buf[SU]; int dst[SU];
+    for (int j = 0; j < PG; j++) {
+      pkg[j] = (j * 256 + tid < totg) ? (gr << 16 | gw) : -1;
+      gw += 256 / GPV; while (gw >= gwn_c) { gw -= gwn_c; gr++; }
+    }
+  }
+  auto issue = [&](const Tile& t) {
+    const T* xplane = xsrc + (((int64_t)t.n * g.D + t.id) * g.H) * (int64_t)g.W * ldsrc;      // one (n, depth) plane: 32-bit offsets inside
+    const int ihb = t.h0 - C::PAD, iwb = t.w0 - C::PAD;
 #pragma unroll
-            for (int j = 0; j < SU; j++) {
-              const int oh = h0 + gr - (NPAIR == 2 ? 1 : 0), ow = w0 + gw;
-              const bool in = p0 + j * 256 + tid < total;
-              const bool ok = in && oh >= h0 && oh < h0 + C::TH && oh < g.H && ow < g.W;
-              v4u t = *(const v4u*)(gplane + ((int64_t)(ok ? oh : 0) * g.W + (ok ? ow : 0)) * g.ldgy);
-              buf[j] = ok ? t : (v4u){0, 0, 0, 0};
-              dst[j] = in ? gr * C::GRP + gw * C::GC + (tid % GPV) * 8 : -1;
-              gw += 256 / GPV; while (gw >= gwn) { gw -= gwn; gr++; }
-            }
+    for (int j = 0; j < PX; j++) {
+      const int ih = ihb + (pkx[j] >> 16), iw = iwb + (pkx[j] & 0xffff);
+      const bool ok = pkx[j] >= 0 && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
+      v4u v = *(const v4u*)(xplane + (ok ? (ih * g.W + iw) * ldsrc : 0));
+      rx[j] = ok ? v : (v4u){0, 0, 0, 0};
+    }
+    const T* gplane = gsrc + (((int64_t)t.n * g.D + t.d) * g.H) * (int64_t)g.W * g.ldgy;
+    const int ohb = t.h0 - (NPAIR == 2 ? 1 : 0);
 #pragma unroll
-            for (int j = 0; j < SU; j++) if (dst[j] >= 0) *(v4u*)(gs + dst[j]) = buf[j];
-          }
-        }
-      } else {
+    for (int j = 0; j < PG; j++) {
+      const int gr = pkg[j] >> 16, oh = ohb + gr, ow = t.w0 + (pkg[j] & 0xffff);
+      const bool ok = pkg[j] >= 0 && oh >= t.h0 && oh < t.h0 + C::TH && oh < g.H && ow < g.W;
+      v4u v = *(const v4u*)(gplane + (ok ? (oh * g.W + ow) * g.ldgy : 0));
+      rg[j] = ok ? v : (v4u){0, 0, 0, 0};
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int j = 0; j < PX; j++)
+      if (pkx[j] >= 0) *(v4u*)(xs + ((pkx[j] >> 16) * C::LP + (pkx[j] & 0xffff)) * C::XC + (tid % XPV) * 8) = rx[j];
+#pragma unroll
+    for (int j = 0; j < PG; j++)
+      if (pkg[j] >= 0) *(v4u*)(gs + (pkg[j] >> 16) * C::GRP + (pkg[j] & 0xffff) * C::GC + (tid % GPV) * 8) = rg[j];
+  };
+  auto stage_slow = [&](const Tile& t) {                           // guarded loads (fp32, ragged channel tiles, unaligned rows)
+    const int n = t.n, d = t.d, id = t.id, h0 = t.h0, w0 = t.w0;
         for (int p = tid; p < C::LR * C::LP * XPV; p += 256) {
           int part = p % XPV, v = p / XPV, lp = v % C::LP, lr = v / C::LP;
           int ih = h0 - C::PAD + lr, iw = w0 - C::PAD + lp, c = cbase_x + part * 8;
@@ -706,8 +725,9 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_tiled(const T* __restrict__ x,
           Frag8<T> f = ok ? frag_load(gy + ((((int64_t)n * g.D + d) * g.H + oh) * g.W + ow) * g.ldgy + c, nv) : frag_zero<T>();
           frag_st_lds(gs + (size_t)gr * C::GRP + gw * C::GC + part * 8, f);
         }
-      }
-      __syncthreads();
+  };
+  auto sweep_tile = [&](const Tile& tl) {
+    const int nchk = tl.nchk;
       if (active && g.dbg != 2) {
         // flat loop over (gy row i, 16-voxel chunk c) with the NEXT pair's operands in flight: two named register sets
         const int ncw = (nchk - chw + C::WCH - 1) / C::WCH, nit = C::STEPS * ncw;     // chunks of this wave x rows
@@ -759,6 +779,28 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_tiled(const T* __restrict__ x,
           }
         }
       }
+  };
+
+  if (fast && g.dbg != 1) {
+    if (cu < u1) issue(tile_of(cu, ctw));
+    while (cu < u1) {
+      const Tile t = tile_of(cu, ctw);
+      lds_barrier();                                               // every wave is done sweeping the previous tile
+      commit();
+      int nu = cu, ntw = ctw; advance(nu, ntw);
+      if (nu < u1) issue(tile_of(nu, ntw));                        // in flight during the sweep below (lds_barrier does not drain it)
+      lds_barrier();
+      sweep_tile(t);
+      cu = nu; ctw = ntw;
+    }
+  } else {
+    while (cu < u1) {
+      const Tile t = tile_of(cu, ctw);
+      __syncthreads();
+      if (g.dbg != 1) stage_slow(t);
+      __syncthreads();
+      sweep_tile(t);
+      advance(cu, ctw);
     }
   }
   if (!active) return;
@@ -782,7 +824,7 @@ __global__ void k_wgrad_unpack(const float* __restrict__ dwt, float* __restrict_
   int64_t total = (int64_t)taps * Cin * Cout;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     int tap = (int)(i % taps); int64_t t = i / taps; int ci = (int)(t % Cin); int co = (int)(t / Cin);   // iterate in the OUTPUT's order
-    dw[co * s_co + ci * s_ci + tap * s_tap] += dwt[((int64_t)tap * Cin + ci) * Cout + co];
+    dw[co * s_co + ci * s_ci + tap * s_tap] = dwt[((int64_t)tap * Cin + ci) * Cout + co];
   }
 }
 
@@ -824,7 +866,7 @@ static int launch_wgt(const void* x, const void* gy, float* ws, WgtGeom g, hipSt
   return 0;
 }
 
-// ws: fp32 scratch of dp_conv3d_wgrad_tiled_ws_elems() elements (need not be initialised).  ACCUMULATES into dw.
+// ws: fp32 scratch of dp_conv3d_wgrad_tiled_ws_elems() elements (need not be initialised).  OVERWRITES dw (need not be initialised).
 extern "C" int dp_conv3d_wgrad_tiled2(const void* x, int ldx, const void* x2, int ldx2, int csplit, const void* gy, int ldgy, float* dw, float* ws,
                                       int N, int D, int H, int W, int Cin, int Cout, int k, int64_t s_co, int64_t s_ci, int64_t s_tap, int dtype, void* stream);
 extern "C" int dp_conv3d_wgrad_tiled(const void* x, int ldx, const void* gy, int ldgy, float* dw, float* ws, int N, int D, int H, int W,

@@ -409,16 +409,15 @@ __global__ void __launch_bounds__(256) k_pointwise_wgrad_rows(const T* __restric
     ws[(int64_t)blockIdx.x * E + e] = sm[0][c][i] + sm[1][c][i] + sm[2][c][i] + sm[3][c][i];
   }
 }
-__global__ void k_pointwise_wgrad_finish(const float* __restrict__ ws, int nblk, int E, int Cin, int Cout, float* __restrict__ dw, int s_co, float* __restrict__ db) {
-  int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= E) return;
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  int b = 0;
-  for (; b + 3 < nblk; b += 4) { a0 += ws[(int64_t)b * E + e]; a1 += ws[(int64_t)(b + 1) * E + e]; a2 += ws[(int64_t)(b + 2) * E + e]; a3 += ws[(int64_t)(b + 3) * E + e]; }
-  for (; b < nblk; b++) a0 += ws[(int64_t)b * E + e];
-  float v = (a0 + a1) + (a2 + a3);
-  if (e < Cout * Cin) { int c = e / Cin; dw[(int64_t)c * s_co + (e - c * Cin)] = v; }
-  else if (db) db[e - Cout * Cin] = v;
+__global__ void __launch_bounds__(64) k_pointwise_wgrad_finish(const float* __restrict__ ws, int nblk, int E, int Cin, int Cout, float* __restrict__ dw, int s_co, float* __restrict__ db) {
+  // one wave per output element: lanes stride over the per-block partials (fixed order => deterministic), then a shuffle tree
+  const int e = blockIdx.x;
+  float a = 0.f;
+  for (int b = threadIdx.x; b < nblk; b += 64) a += ws[(int64_t)b * E + e];
+  a = wave_sum(a);
+  if (threadIdx.x != 0) return;
+  if (e < Cout * Cin) { int c = e / Cin; dw[(int64_t)c * s_co + (e - c * Cin)] = a; }
+  else if (db) db[e - Cout * Cin] = a;
 }
 static int pw_wgrad_grid(int64_t rows, int Cin) { int cpr = (Cin + 7) / 8, rpi = 256 / cpr; int64_t g = (rows + rpi - 1) / rpi; return (int)(g > 1024 ? 1024 : g); }
 extern "C" int64_t dp_pointwise_wgrad_ws_elems(int64_t rows, int Cin, int Cout) {
@@ -436,6 +435,6 @@ extern "C" int dp_pointwise_wgrad_rows(const void* x, int ldx, const void* gy, i
 #define GO(CO) DP_DISPATCH(dtype, hipLaunchKernelGGL((k_pointwise_wgrad_rows<T, CO>), dim3(g), dim3(256), 0, STREAM, (const T*)x, ldx, (const T*)gy, ldgy, ws, rows, Cin, Cout, lg))
   if (Cout <= 1) GO(1); else if (Cout <= 4) GO(4); else GO(16);
 #undef GO
-  hipLaunchKernelGGL(k_pointwise_wgrad_finish, dim3(cdiv(E, 128)), dim3(128), 0, STREAM, (const float*)ws, g, E, Cin, Cout, dw, s_co, db);
+  hipLaunchKernelGGL(k_pointwise_wgrad_finish, dim3(E), dim3(64), 0, STREAM, (const float*)ws, g, E, Cin, Cout, dw, s_co, db);
   DP_CHECK_LAUNCH("pointwise_wgrad_rows"); return 0;
 }

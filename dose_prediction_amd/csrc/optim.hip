@@ -23,16 +23,29 @@ __global__ void __launch_bounds__(256) k_adam_multi(const AdamTensor* __restrict
     p -= lr_c1 * m / (sqrtf(vv) * rsqrt_c2 + eps);
   };
   if (vec) {
-    for (int64_t i = base + threadIdx.x * 4; i < end; i += 256 * 4) {
-      if (i + 4 <= end) {
-        v4f p = *(v4f*)(T.p + i), g = *(const v4f*)(T.g + i), m = *(v4f*)(T.m + i), v = *(v4f*)(T.v + i);
-        v4f vm = amsgrad ? *(v4f*)(T.vmax + i) : (v4f){0, 0, 0, 0};
+    // two float4 groups per thread per trip: 10 independent 16-byte loads in flight (one group left HBM at ~3 TB/s)
+    for (int64_t i0 = base + threadIdx.x * 4; i0 < end; i0 += 2 * 256 * 4) {
+      const int64_t i1 = i0 + 256 * 4;
+      const bool f0 = i0 + 4 <= end, f1 = i1 + 4 <= end;
+      v4f p0, g0, m0, v0, x0, p1, g1, m1, v1, x1;
+      const v4f z4 = (v4f){0, 0, 0, 0};
+      if (f0) { p0 = *(v4f*)(T.p + i0); g0 = *(const v4f*)(T.g + i0); m0 = *(v4f*)(T.m + i0); v0 = *(v4f*)(T.v + i0); x0 = amsgrad ? *(v4f*)(T.vmax + i0) : z4; }
+      if (f1) { p1 = *(v4f*)(T.p + i1); g1 = *(const v4f*)(T.g + i1); m1 = *(v4f*)(T.m + i1); v1 = *(v4f*)(T.v + i1); x1 = amsgrad ? *(v4f*)(T.vmax + i1) : z4; }
+      if (f0) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) { float pp = p[k], mm = m[k], vv = v[k], vx = vm[k]; upd(pp, g[k], mm, vv, vx); p[k] = pp; m[k] = mm; v[k] = vv; vm[k] = vx; }
-        *(v4f*)(T.p + i) = p; *(v4f*)(T.m + i) = m; *(v4f*)(T.v + i) = v;
-        if (amsgrad) *(v4f*)(T.vmax + i) = vm;
+        for (int k = 0; k < 4; k++) { float pp = p0[k], mm = m0[k], vv = v0[k], vx = x0[k]; upd(pp, g0[k], mm, vv, vx); p0[k] = pp; m0[k] = mm; v0[k] = vv; x0[k] = vx; }
+        *(v4f*)(T.p + i0) = p0; *(v4f*)(T.m + i0) = m0; *(v4f*)(T.v + i0) = v0;
+        if (amsgrad) *(v4f*)(T.vmax + i0) = x0;
       } else {
-        for (int64_t j = i; j < end; j++) { float vx = amsgrad ? T.vmax[j] : 0.f; upd(T.p[j], T.g[j], T.m[j], T.v[j], vx); if (amsgrad) T.vmax[j] = vx; }
+        for (int64_t j = i0; j < end; j++) { float vx = amsgrad ? T.vmax[j] : 0.f; upd(T.p[j], T.g[j], T.m[j], T.v[j], vx); if (amsgrad) T.vmax[j] = vx; }
+      }
+      if (f1) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) { float pp = p1[k], mm = m1[k], vv = v1[k], vx = x1[k]; upd(pp, g1[k], mm, vv, vx); p1[k] = pp; m1[k] = mm; v1[k] = vv; x1[k] = vx; }
+        *(v4f*)(T.p + i1) = p1; *(v4f*)(T.m + i1) = m1; *(v4f*)(T.v + i1) = v1;
+        if (amsgrad) *(v4f*)(T.vmax + i1) = x1;
+      } else {
+        for (int64_t j = i1; j < end; j++) { float vx = amsgrad ? T.vmax[j] : 0.f; upd(T.p[j], T.g[j], T.m[j], T.v[j], vx); if (amsgrad) T.vmax[j] = vx; }
       }
     }
   } else {

@@ -366,11 +366,12 @@ class Conv3d(torch.autograd.Function):
             _lib.call("dp_pointwise_wgrad_rows", _p(x), ldx, _p(gy), ldg, _p(gw), cin, _p(gb), _p(ws), grows, cin, cout, dtc, _stream())
             return gx, gw, gb, None, None, None
         if ctx.needs_input_grad[1]:
-            gw = torch.zeros(weight.shape, dtype=torch.float32, device=x.device)
             taps = k * k * k
             wse = 0
             if USE_TILED and (k > 1 or grows >= 32768):
                 wse = _lib.lib().dp_conv3d_wgrad_tiled_ws_elems(cin, cout, k, stride, pad, dil, 1, Wo)
+            # the tiled kernel overwrites dW; the generic one accumulates into it
+            gw = (torch.empty if wse else torch.zeros)(weight.shape, dtype=torch.float32, device=x.device)
             if wse:
                 ws = torch.empty((wse,), dtype=torch.float32, device=x.device)
                 _lib.call("dp_conv3d_wgrad_tiled", _p(x), ldx, _p(gy), ldg, _p(gw), _p(ws), N, Di, Hi, Wi, cin, cout, k,
@@ -433,7 +434,7 @@ class Conv3dCat(torch.autograd.Function):
             _lib.call("dp_conv3d_tiled2", _p(gy), ldg, 0, 0, 0, _p(wq), 0, _p(gxa), ca, _p(gxb), cbp, ca,
                       _p(_tiled_ws(xa, N, D, H, W, cout, cin, k)), N, D, H, W, cout, cin, k, dtc, _stream())
         if ctx.needs_input_grad[2]:
-            gw = torch.zeros(weight.shape, dtype=torch.float32, device=xa.device)
+            gw = torch.empty(weight.shape, dtype=torch.float32, device=xa.device)      # overwritten by the tiled kernel
             taps = k * k * k
             ws = torch.empty((taps * cin * cout,), dtype=torch.float32, device=xa.device)
             _lib.call("dp_conv3d_wgrad_tiled2", _p(xa), lda, _p(xb), ldb, ca, _p(gy), ldg, _p(gw), _p(ws), N, D, H, W, cin, cout, k,
@@ -502,7 +503,7 @@ class ConvTranspose2x(torch.autograd.Function):
                 # ONE pointwise weight gradient with 8*Cout "output channels" (column (abc, co) of the unshuffled gradient):
                 # x is read once instead of 8 times; the small fp32 result [(abc,co)][ci] is permuted into torch's [ci][co][abc]
                 ws = torch.empty((wse,), dtype=torch.float32, device=x.device)
-                tmp = torch.zeros((8 * cout, cin), dtype=torch.float32, device=x.device)
+                tmp = torch.empty((8 * cout, cin), dtype=torch.float32, device=x.device)
                 _lib.call("dp_conv3d_wgrad_tiled", _p(x), ldx, _p(gu), 8 * cout, _p(tmp), _p(ws), N, D, H, W, cin, 8 * cout, 1,
                           cin, 1, 0, dtc, _stream())
                 gw = tmp.view(8, cout, cin).permute(2, 1, 0).contiguous().view(weight.shape)

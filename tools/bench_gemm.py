@@ -40,12 +40,13 @@ def main():
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     dev = torch.device("cuda:0")
     for name, M, N, K, nb, f32 in SHAPES:
-        A = torch.randn((nb, M, K), device=dev).to(dt)
-        B = torch.randn((nb, N, K), device=dev).to(dt)
+        pad = int(os.environ.get("PAD", "0"))          # extra elements per row: tests address-interleave (channel) effects of the row pitch
+        A = torch.randn((nb, M, K + pad), device=dev).to(dt)
+        B = torch.randn((nb, N, K + pad), device=dev).to(dt)
         C = torch.empty((nb, M, N), device=dev, dtype=torch.float32 if f32 else dt)
-        ms = timeit(lambda: ops.gemm_nt(A, B, C, M=M, N=N, K=K, batch=(nb, 1), sa=(M * K, 0), sb=(N * K, 0), sc=(M * N, 0),
-                                        lda=K, ldb=K, ldc=N))
-        ref = timeit(lambda: torch.matmul(A, B.transpose(1, 2))) if not os.environ.get("NO_REF") else float("nan")
+        ms = timeit(lambda: ops.gemm_nt(A, B, C, M=M, N=N, K=K, batch=(nb, 1), sa=(M * (K + pad), 0), sb=(N * (K + pad), 0), sc=(M * N, 0),
+                                        lda=K + pad, ldb=K + pad, ldc=N))
+        ref = timeit(lambda: torch.matmul(A[:, :, :K], B[:, :, :K].transpose(1, 2))) if not os.environ.get("NO_REF") else float("nan")
         fl = 2.0 * nb * M * N * K
         print(f"{name:28s} {ms * 1e3:8.1f} us {fl / ms / 1e9:7.1f} TF   (torch.matmul {ref * 1e3:8.1f} us {fl / ref / 1e9:7.1f} TF)", flush=True)
 
