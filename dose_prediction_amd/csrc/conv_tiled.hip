@@ -143,7 +143,8 @@ __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, 
   // fast staging path: bf16, whole 16-channel chunks, 16-byte aligned voxel rows (block-uniform)
   constexpr int SU = STAGE_UNROLL;
   const bool fast = SWZ && (g.Cin % 16 == 0) && (g.ldx % 8 == 0) && (((uintptr_t)x & 15) == 0) &&
-                    (!g.x2 || ((g.csplit % 16 == 0) && (g.ldx2 % 8 == 0) && (((uintptr_t)g.x2 & 15) == 0)));
+                    (!g.x2 || ((g.csplit % 16 == 0) && (g.ldx2 % 8 == 0) && (((uintptr_t)g.x2 & 15) == 0))) &&
+                    (int64_t)g.H * g.W * max(g.ldx, g.x2 ? g.ldx2 : 0) < (1ll << 30);
   const int lp_par = SWZ ? ((LP >> 3) & 1) : 0;
   const int st_half = tid & 1, st_lp0 = (tid >> 1) % LP, st_lr0 = (tid >> 1) / LP;
 
@@ -166,7 +167,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, 
       const T* wbase = wq + ((int64_t)kd * NTAP * g.NCH + ch) * g.NTT * 512 + (int64_t)nt0 * 512;
       Frag8<T> b0[JH], b1[JH];
       load_bk(wbase, 0, 0, b0);
-      __syncthreads();
+      lds_barrier();                    // LDS-only: __syncthreads() would drain the weight loads just issued (vmcnt(0))
       if (g.dbg == 1 || g.dbg == 3 || g.dbg == 4) {
       } else if (fast) {
         // straight-line staging: SU independent 16-byte loads are in flight before the first LDS store (a per-piece
@@ -183,11 +184,12 @@ __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, 
           for (int j = 0; j < SU; j++) {
             const int ih = h0 - PAD + lr, iw = w0 - PAD + lp;
             const bool ok = (p0 + j * 256 + tid < pieces) && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W;
-            const T* src = xplane + ((int64_t)(ok ? ih : 0) * g.W + (ok ? iw : 0)) * g.ldx;
-            v4u t = *(const v4u*)src;
+            v4u t = *(const v4u*)(xplane + (ok ? (ih * g.W + iw) * ldsrc : 0));     // 32-bit offset inside one (n, depth) plane
             buf[j] = ok ? t : (v4u){0, 0, 0, 0};
             vv[j] = (p0 + j * 256 + tid < pieces) ? v : -1;
-            v += 128; lp += 128; while (lp >= LP) { lp -= LP; lr++; }
+            v += 128; lp += 128;
+#pragma unroll
+            for (int wq_ = 0; wq_ < (128 + LP - 1) / LP; wq_++) if (lp >= LP) { lp -= LP; lr++; }   // branch-free carry (LP is a constant)
           }
 #pragma unroll
           for (int j = 0; j < SU; j++)
@@ -207,7 +209,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, 
           frag_st_lds(slab + (int64_t)v * CK + (half ^ (SWZ ? ((v >> 3) & 1) : 0)) * 8, f);
         }
       }
-      __syncthreads();
+      lds_barrier();
       if (g.dbg >= 2) continue;
       // Sweep: for one kw column, EVERY slab row is read from LDS once and feeds all the kh taps (pairs) that use it
       // (output row i and tap jh share the input row RS*i + TS*jh).  A tap-outer loop read the A fragment again for every
