@@ -122,7 +122,12 @@ __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, 
   constexpr bool SWZ = sizeof(T) == 2;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 31, hh = lane >> 5;
   const int wc = wv % TWC, rg = wv / TWC;
+  // XCD-aware block order: workgroups are dealt round-robin over the 8 XCDs (private 4 MiB L2 each), while the decode below
+  // puts consecutive ids on neighbouring tiles / depth slices.  Give every XCD one CONTIGUOUS id range (= a range of depth
+  // slices): the kd-neighbour slabs a block re-reads then come from its own L2 (the 3x3x3 layers fetched 2.7x and the
+  // 7x7x7 layers 4-8x their input through the fabric with the round-robin order).
   int b = blockIdx.x;
+  if ((gridDim.x & 7) == 0) b = (b & 7) * (gridDim.x >> 3) + (b >> 3);
   const int tw = b % g.tiles_w; b /= g.tiles_w; const int th = b % g.tiles_h; b /= g.tiles_h; const int d = b % g.D; const int n = b / g.D;
   constexpr int RPA = W16 ? 2 : 1;                 // image rows per accumulator row
   const int h0 = th * (TRG * RWO * RPA), w0 = W16 ? 0 : tw * (TWC * 32);
@@ -492,7 +497,7 @@ int dp_wgrad_tiled_try(const void*, int, const void*, int, float*, int, int, int
 // tap-major fp32 scratch [tap][ci][co] (co contiguous => full-rate atomics), unpacked into the caller's layout afterwards.
 struct WgtGeom {
   int N, D, H, W, Cin, Cout, ldx, ldgy;
-  int tiles_h, tiles_w, MT, NTn, KHG;
+  int tiles_h, tiles_w, MT, NTn, KHG, ydim, zdim;
   const void* x2; int ldx2, csplit;   // virtual concat of the input (see TiledGeom)
   int dbg;             // experiments only (env DP_DBG): 1 = skip staging, 2 = skip the MFMA sweep, 3 = both, 4 = also skip the epilogue
 };
@@ -603,8 +608,15 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_tiled(const T* __restrict__ x,
   T* xs = (T*)smem_raw;
   T* gs = xs + (size_t)C::LR * C::LP * C::XC;
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), hh = lane >> 5;   // wv in an SGPR: the (i, c) counters stay scalar
-  const int kd = blockIdx.x;
-  int z = blockIdx.z;
+  // 1-D grid, decoded XCD-aware: the KS * zdim blocks that sweep the SAME unit range (all kd, channel tiles and kh groups)
+  // sit on one XCD (ids with equal id % 8), so the gy tile and the overlapping x slices they all read are fetched into
+  // that XCD's L2 once (round-robin order: 4.3 GB of fabric reads for 0.4 GB of operands on the 32->16 7x7x7 layer).
+  int kd, z, yb;
+  {
+    const int L = blockIdx.x, inner = KS * g.zdim;
+    if (g.ydim % 8 == 0) { const int xcd = L & 7, slot = L >> 3, c = slot % inner; yb = (slot / inner) * 8 + xcd; kd = c % KS; z = c / KS; }
+    else { kd = L % KS; const int q = L / KS; yb = q % g.ydim; z = q / g.ydim; }
+  }
   const int khg = z % g.KHG; z /= g.KHG; const int nt = z % g.NTn; const int mt = z / g.NTn;
   const int khw = wv % C::WKH, chw = wv / C::WKH;
   const int jh = khg * C::WKH + khw;
@@ -615,8 +627,8 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_tiled(const T* __restrict__ x,
   const int tr_i16 = lane & 15, tr_up = (lane >> 4) & 1;
   const int x_lane = (8 * hh + (tr_i16 >> 2) + (MPAIR == 2 ? tr_up : 0)) * C::XC + (MPAIR == 2 ? 0 : 16 * tr_up) + 4 * (tr_i16 & 3);
   const int g_lane = (8 * hh + (tr_i16 >> 2)) * C::GC + 4 * (tr_i16 & 3) + (NPAIR == 2 ? (tr_up ? 0 : C::GRP) : 16 * tr_up);
-  const int units = g.N * g.D * g.tiles_h, per = (units + gridDim.y - 1) / gridDim.y;
-  const int u0 = blockIdx.y * per, u1 = min(units, u0 + per);
+  const int units = g.N * g.D * g.tiles_h, per = (units + g.ydim - 1) / g.ydim;
+  const int u0 = yb * per, u1 = min(units, u0 + per);
   const int cbase_x = mt * C::XC, cbase_g = nt * C::GC;
 
   v16f acc[C::KWT];
@@ -862,8 +874,9 @@ static int launch_wgt(const void* x, const void* gy, float* ws, WgtGeom g, hipSt
   }
   int want = (ncu * occ) / (KS * zdim); if (want < 1) want = 1;
   int ydim = units < want ? units : want;
-  dim3 grid(KS, ydim, zdim);
-  if (zdim > 65535) { dp_set_error("wgrad_tiled: too many channel tiles"); return 1; }
+  if (ydim >= 8) ydim &= ~7;                                       // multiple of 8: XCD-aware decode in the kernel
+  g.ydim = ydim; g.zdim = zdim;
+  dim3 grid(KS * ydim * zdim, 1, 1);
   hipLaunchKernelGGL(kern, grid, dim3(256), C::SMEM, s, (const T*)x, (const T*)gy, ws, g);
   return 0;
 }
