@@ -151,6 +151,25 @@ def cpu_baseline(args):
             "seconds": dt}
 
 
+def pmc_traffic(kernel_prefix):
+    """HBM/fabric bytes per launch of the roofline kernel from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic.json,
+    written by tools/pmc_summary.py: --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs, FETCH doubled for gfx950).  PMC
+    counters cannot be read from inside the timed run, so this is the last profiled value for this exact workload, or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        ks = json.load(open(files[-1]))["kernels"]
+        sel = [v for k, v in ks.items() if kernel_prefix in k]
+        n = sum(v["launches"] for v in sel)
+        if not n:
+            return None, None
+        return sum(v["launches"] * v["hbm_bytes_per_launch"] for v in sel) / n, os.path.basename(files[-1])
+    except Exception:
+        return None, None
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", 0))
@@ -260,6 +279,8 @@ def main():
         prof = summarize_profile(records, prof_steps)
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
         dom = prof.get("conv7x7x7_tiled", prof.get("conv7x7x7_generic", {"tflops": 0.0, "avg_launch_ms": 0.0, "launches_per_step": 0}))
+        default_cfg = args.model == "pyfer" and args.dtype == "bf16" and tuple(shape) == (128, 128, 128) and B == 2
+        traffic, traffic_src = pmc_traffic("k_conv_tiled<unsigned short, 7,") if default_cfg else (None, None)
         res = {
             "metric": "128^3 CT volumes/sec (fwd+bwd)", "value": world * B * args.steps / dt, "unit": "volumes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
@@ -273,7 +294,9 @@ def main():
                        "final_loss": final_loss},
             "roofline": {"bound": "mfma", "kernel": "conv3d 7x7x7 implicit GEMM (forward + data-gradient launches)",
                          "achieved": dom["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": dom["tflops"] / peak,
-                         "traffic": None, "avg_launch_ms": dom["avg_launch_ms"], "launches_per_step": dom["launches_per_step"]},
+                         "traffic": traffic, "traffic_unit": "bytes/launch (fabric reads x2-corrected + writes, PMC)",
+                         "traffic_source": traffic_src, "avg_launch_ms": dom["avg_launch_ms"],
+                         "launches_per_step": dom["launches_per_step"]},
             "kernels": prof,
         }
         if not args.no_cpu_baseline:
