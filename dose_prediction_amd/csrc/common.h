@@ -87,6 +87,19 @@ __device__ __forceinline__ v4f mma16(const Frag8<float>& a, const Frag8<float>& 
   return c;
 }
 
+// two ds_read_b64_tr_b16 at a lane address and OFF elements further: 8 consecutive voxels (k) of one column
+template <int OFF>
+__device__ __forceinline__ Frag8<bf16_t> tr_pair(const bf16_t* a) {
+  v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)a);
+  v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(a + OFF));
+  Frag8<bf16_t> f;
+  f.u[0] = (unsigned)(unsigned short)lo[0] | ((unsigned)(unsigned short)lo[1] << 16);
+  f.u[1] = (unsigned)(unsigned short)lo[2] | ((unsigned)(unsigned short)lo[3] << 16);
+  f.u[2] = (unsigned)(unsigned short)hi[0] | ((unsigned)(unsigned short)hi[1] << 16);
+  f.u[3] = (unsigned)(unsigned short)hi[2] | ((unsigned)(unsigned short)hi[3] << 16);
+  return f;
+}
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a release fence over ALL address spaces, which on
 // gfx9 is s_waitcnt vmcnt(0): every global load still in flight (the software-prefetched next tile) is drained at each
 // barrier.  Use this one when the barrier only publishes LDS data and the kernel has no global producer/consumer pair.

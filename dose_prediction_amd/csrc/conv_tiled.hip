@@ -546,18 +546,6 @@ __device__ __forceinline__ Frag8<float> ld_kmajor32(const float* img, int vox_lo
   return f;
 }
 
-// two ds_read_b64_tr_b16 at a lane address and OFF elements further: 8 consecutive voxels (k) of one column
-template <int OFF>
-__device__ __forceinline__ Frag8<bf16_t> tr_pair(const bf16_t* a) {
-  v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)a);
-  v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(a + OFF));
-  Frag8<bf16_t> f;
-  f.u[0] = (unsigned)(unsigned short)lo[0] | ((unsigned)(unsigned short)lo[1] << 16);
-  f.u[1] = (unsigned)(unsigned short)lo[2] | ((unsigned)(unsigned short)lo[3] << 16);
-  f.u[2] = (unsigned)(unsigned short)hi[0] | ((unsigned)(unsigned short)hi[1] << 16);
-  f.u[3] = (unsigned)(unsigned short)hi[2] | ((unsigned)(unsigned short)hi[3] << 16);
-  return f;
-}
 // 16 consecutive voxels (k-major) of one column per lane: the window every kw tap of a 16-voxel chunk reads from.  Two
 // aligned fragment loads (voxels +0 and +8) fill it; the per-tap fragments are then register sub-ranges (even voxel
 // offsets) or sub-ranges of a copy shifted by one voxel (odd offsets; 7 v_perm/v_alignbit per window) instead of one more
@@ -835,10 +823,14 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_tiled(const T* __restrict__ x,
 }
 
 __global__ void k_wgrad_unpack(const float* __restrict__ dwt, float* __restrict__ dw, int taps, int Cin, int Cout, int64_t s_co, int64_t s_ci, int64_t s_tap) {
-  int64_t total = (int64_t)taps * Cin * Cout;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    int tap = (int)(i % taps); int64_t t = i / taps; int ci = (int)(t % Cin); int co = (int)(t / Cin);   // iterate in the OUTPUT's order
-    dw[co * s_co + ci * s_ci + tap * s_tap] = dwt[((int64_t)tap * Cin + ci) * Cout + co];
+  // one (ci, co) pair per thread, co fastest: every read of the tap-major scratch is coalesced, and a thread writes its own
+  // run of taps (contiguous when s_tap == 1: the lines are completed in L2).  Iterating in output order instead made
+  // every read a different 128-B line (207 us for the 343 x 256 x 128 layer).
+  const int64_t pairs = (int64_t)Cin * Cout;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < pairs; i += (int64_t)gridDim.x * blockDim.x) {
+    const int co = (int)(i % Cout), ci = (int)(i / Cout);
+    float* o = dw + co * s_co + ci * s_ci;
+    for (int tap = blockIdx.y; tap < taps; tap += gridDim.y) o[tap * s_tap] = dwt[(int64_t)tap * pairs + i];   // small layers: taps spread over blockIdx.y
   }
 }
 
@@ -910,8 +902,8 @@ extern "C" int dp_conv3d_wgrad_tiled2(const void* x, int ldx, const void* x2, in
 #undef GO
   if (rc) return rc;
   DP_CHECK_LAUNCH("wgrad_tiled");
-  int64_t total = (int64_t)taps * Cin * Cout;
-  int gb = (int)((total + 255) / 256); if (gb > 4096) gb = 4096;
-  hipLaunchKernelGGL(k_wgrad_unpack, dim3(gb), dim3(256), 0, s, ws, dw, taps, Cin, Cout, s_co, s_ci, s_tap);
+  int64_t pairs = (int64_t)Cin * Cout;
+  int gb = (int)((pairs + 63) / 64); if (gb > 8192) gb = 8192;
+  hipLaunchKernelGGL(k_wgrad_unpack, dim3(gb, (pairs < 16384 && taps >= 7) ? 7 : 1), dim3(64), 0, s, ws, dw, taps, Cin, Cout, s_co, s_ci, s_tap);
   DP_CHECK_LAUNCH("wgrad_unpack"); return 0;
 }

@@ -140,3 +140,91 @@ extern "C" int dp_gemm_nt(const void* A, int64_t lda, int64_t sa0, int64_t sa1, 
 #undef GEMM_GO
   DP_CHECK_LAUNCH("gemm_nt"); return 0;
 }
+
+// ------------------------------------------------------------------------------------------------ TN GEMM
+// C[m][n] (fp32) = sum_k A[k][m] * B[k][n]: both operands are k-major in MEMORY (rows = k), which is what every weight
+// gradient of a row-major layer looks like (dW[out][in] = gy^T x with k = token / voxel rows).  The 64-row k slabs are
+// staged as they lie; the MFMA fragments (8 consecutive k of one column per lane) come out of LDS through
+// ds_read_b64_tr_b16 (fp32: scalar column reads).  Replaces two k_transpose launches + k_gemm_nt per weight gradient.
+template <typename T>
+__global__ void __launch_bounds__(256) k_gemm_tn(const T* __restrict__ A, int64_t lda, const T* __restrict__ B, int64_t ldb, float* __restrict__ C,
+                                                 int64_t ldc, int M, int N, int K, int splitk) {
+  constexpr int BT = 64, BKT = 64, LDPT = BT + 8, CPRT = BT / 8, UT = BKT * CPRT / 256;     // 72-element LDS rows; 2 chunks per thread per operand
+  __shared__ __attribute__((aligned(16))) T As[BKT * LDPT];
+  __shared__ __attribute__((aligned(16))) T Bs[BKT * LDPT];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1, r = lane & 15, q = lane >> 4;
+  const int m0 = blockIdx.x * BT, n0 = blockIdx.y * BT, ks = blockIdx.z;
+  const int ktiles = (K + BKT - 1) / BKT, per = (ktiles + splitk - 1) / splitk, kt0 = ks * per, kt1 = min(ktiles, kt0 + per);
+  v4f acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++) acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
+  Frag8<T> ra[UT], rb[UT];
+  const bool fast = m0 + BT <= M && n0 + BT <= N && ((lda | ldb) & 7) == 0 && (((uintptr_t)A | (uintptr_t)B) & 15) == 0;
+  auto gload = [&](int kt) {
+#pragma unroll
+    for (int u = 0; u < UT; u++) {
+      const int c = tid + u * 256, row = c / CPRT, cc = (c % CPRT) * 8, k = kt * BKT + row;
+      if (fast && k < K) { ra[u] = frag_ld_lds(A + (int64_t)k * lda + m0 + cc); rb[u] = frag_ld_lds(B + (int64_t)k * ldb + n0 + cc); }
+      else {
+        int nva = M - m0 - cc, nvb = N - n0 - cc; nva = nva < 0 ? 0 : (nva > 8 ? 8 : nva); nvb = nvb < 0 ? 0 : (nvb > 8 ? 8 : nvb);
+        ra[u] = (k < K && nva > 0) ? frag_load(A + (int64_t)k * lda + m0 + cc, nva) : frag_zero<T>();
+        rb[u] = (k < K && nvb > 0) ? frag_load(B + (int64_t)k * ldb + n0 + cc, nvb) : frag_zero<T>();
+      }
+    }
+  };
+  // lane part of the k-major fragment address: MFMA k group q = lane>>4 (8 consecutive k), column r = lane&15
+  const int i16 = lane & 15, tr_lane = (8 * q + (i16 >> 2)) * LDPT + 4 * (i16 & 3);
+  auto frag = [&](const T* img, int kk, int col0) {
+    if constexpr (sizeof(T) == 2) return tr_pair<4 * LDPT>((const bf16_t*)img + kk * LDPT + col0 + tr_lane);
+    else { Frag8<float> f;
+#pragma unroll
+      for (int j = 0; j < 8; j++) f.v[j] = img[(kk + 8 * q + j) * LDPT + col0 + r];
+      return f; }
+  };
+  if (kt0 < kt1) gload(kt0);
+  for (int kt = kt0; kt < kt1; kt++) {
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < UT; u++) {
+      const int c = tid + u * 256, row = c / CPRT, cc = (c % CPRT) * 8;
+      frag_st_lds(As + row * LDPT + cc, ra[u]); frag_st_lds(Bs + row * LDPT + cc, rb[u]);
+    }
+    __syncthreads();
+    if (kt + 1 < kt1) gload(kt + 1);
+#pragma unroll
+    for (int kk = 0; kk < BKT; kk += 32) {
+      Frag8<T> fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; i++) { fa[i] = frag(As, kk, wm * 32 + i * 16); fb[i] = frag(Bs, kk, wn * 32 + i * 16); }
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) acc[i][j] = mma16(fa[i], fb[j], acc[i][j]);
+    }
+  }
+  // C/D layout: col (n) = lane&15, row (m) = 4*(lane>>4) + reg
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    const int col = n0 + wn * 32 + j * 16 + r;
+    if (col >= N) continue;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const int row = m0 + wm * 32 + i * 16 + q * 4 + e;
+        if (row >= M) continue;
+        if (splitk > 1) atomicAdd(C + (int64_t)row * ldc + col, acc[i][j][e]); else C[(int64_t)row * ldc + col] = acc[i][j][e];
+      }
+  }
+}
+extern "C" int dp_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int M, int N, int K, int splitk,
+                          int dtype, void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0) DP_FAIL("gemm_tn: empty problem %d %d %d", M, N, K);
+  if (splitk < 1) splitk = 1;
+  dim3 g(cdiv(M, 64), cdiv(N, 64), splitk);
+  if (g.y > 65535 || g.z > 65535) DP_FAIL("gemm_tn: grid too large");
+  DP_DISPATCH(dtype, hipLaunchKernelGGL(k_gemm_tn<T>, g, dim3(256), 0, STREAM, (const T*)A, lda, (const T*)B, ldb, C, ldc, M, N, K, splitk));
+  DP_CHECK_LAUNCH("gemm_tn"); return 0;
+}

@@ -507,17 +507,13 @@ class ConvTranspose2x(torch.autograd.Function):
                 _lib.call("dp_conv3d_wgrad_tiled", _p(x), ldx, _p(gu), 8 * cout, _p(tmp), _p(ws), N, D, H, W, cin, 8 * cout, 1,
                           cin, 1, 0, dtc, _stream())
                 gw = tmp.view(8, cout, cin).permute(2, 1, 0).contiguous().view(weight.shape)
-            elif rows <= 16384 and rows % 8 == 0:
-                # few voxels, many channels (the decoder's deep stages): dW^T[(abc,co)][ci] = gu^T x as an NT GEMM on the
-                # transposed operands (K = rows, split so that the small output grid still fills the chip)
-                gut = torch.empty((8 * cout, rows), dtype=x.dtype, device=x.device)
-                xt = torch.empty((cin, rows), dtype=x.dtype, device=x.device)
-                _transpose(_p(gu), 8 * cout, (0, 0), _p(gut), rows, (0, 0), rows, 8 * cout, (1, 1), dtc)
-                _transpose(_p(x), ldx, (0, 0), _p(xt), rows, (0, 0), rows, cin, (1, 1), dtc)
+            elif rows <= 16384:
+                # few voxels, many channels (the decoder's deep stages): dW^T[(abc,co)][ci] = gu^T x as a TN GEMM (k = voxel rows,
+                # split so that the small output grid still fills the chip)
                 tiles = -(-8 * cout // 64) * -(-cin // 64)
                 sk = max(1, min(rows // 512, 512 // tiles))
                 tmp = (torch.zeros if sk > 1 else torch.empty)((8 * cout, cin), dtype=torch.float32, device=x.device)
-                gemm_nt(gut, xt, tmp, M=8 * cout, N=cin, K=rows, lda=rows, ldb=rows, ldc=cin, splitk=sk)
+                _lib.call("dp_gemm_tn", _p(gu), 8 * cout, _p(x), ldx, _p(tmp), cin, 8 * cout, cin, rows, sk, dtc, _stream())
                 gw = tmp.view(8, cout, cin).permute(2, 1, 0).contiguous().view(weight.shape)
             else:
                 # "tap" = abc selects the gy column block abc*Cout; x is not shifted
@@ -568,14 +564,10 @@ class Linear(torch.autograd.Function):
             gx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
             gemm_nt(gy, wt, gx, M=rows, N=K, K=nout, lda=ldg, ldb=wt.shape[-1], ldc=K)
         if ctx.needs_input_grad[1]:
-            if rows <= 16384 and rows % 8 == 0:
-                # token matrices: dW[out][in] = gy^T x as an NT GEMM on the transposed operands (K = rows), fp32 output
-                gyt = torch.empty((nout, rows), dtype=x.dtype, device=x.device)
-                xt = torch.empty((K, rows), dtype=x.dtype, device=x.device)
-                _transpose(_p(gy), ldg, (0, 0), _p(gyt), rows, (0, 0), rows, nout, (1, 1), dtc)
-                _transpose(_p(x), ldx, (0, 0), _p(xt), rows, (0, 0), rows, K, (1, 1), dtc)
+            if rows <= 16384:
+                # token matrices: dW[out][in] = gy^T x, both operands k-major (k = token rows) as they lie in memory
                 gw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
-                gemm_nt(gyt, xt, gw, M=nout, N=K, K=rows, lda=rows, ldb=rows, ldc=K)
+                _lib.call("dp_gemm_tn", _p(gy), ldg, _p(x), ldx, _p(gw), K, nout, K, rows, 1, dtc, _stream())
             else:
                 gw = torch.zeros(weight.shape, dtype=torch.float32, device=x.device)
                 wgrad(x, ldx, gy, ldg, gw, (1, 1, 1, rows, 1, 1, rows), K, nout, 1, 1, 0, 1, 0, 0, K, 1, 0, dtc)

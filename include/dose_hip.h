@@ -114,6 +114,12 @@ int dp_layernorm_bwd(const void* x, const void* gy, const float* gamma, const fl
 int dp_gemm_nt(const void* A, int64_t lda, int64_t sa0, int64_t sa1, const void* B, int64_t ldb, int64_t sb0, int64_t sb1,
                void* C, int64_t ldc, int64_t sc0, int64_t sc1, const float* bias, int M, int N, int K, int nb0, int nb1,
                float alpha, int out_f32, int splitk, int dtype, void* stream);
+/* C[m*ldc + n] (fp32) = sum_k A[k*lda + m] * B[k*ldb + n]  -- both operands k-major in memory: the weight gradient of
+ * nn.Linear / ConvTranspose3d (autograd of MONAI's ViT blocks, base_blocks.py:118-127) dW = gy^T x with k = token or voxel
+ * rows, without transposing either operand.  splitk > 1: K is split over blockIdx.z and C (pre-zeroed) is accumulated
+ * atomically; splitk == 1 overwrites C. */
+int dp_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int M, int N, int K, int splitk,
+               int dtype, void* stream);
 
 /* skinny pointwise (1x1x1) convolution over voxel rows, Cin <= 64 and Cout <= 32: y[v][co] = sum_ci x[v][ci] w[co*ldw + ci] (+bias).
  * HBM-bound row stream on the vector ALU.  replaces: nn.Conv3d k1 at the 128^3 / 64^3 levels (blocks_MDUNet.py:146,

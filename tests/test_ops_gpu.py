@@ -373,3 +373,21 @@ def test_conv3d_virtual_concat(cfg, dtype):
         assert bh.grad[..., Cb:].abs().max().item() == 0
     check("gw", wh.grad, wr.grad, dtype)
     check("gbias", biash.grad, biasr.grad, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [(768, 96, 1024, 1), (100, 37, 200, 1), (64, 64, 2048, 4), (130, 70, 333, 2)])
+def test_gemm_tn(cfg, dtype):
+    """dp_gemm_tn: C = A^T B with k-major operands (weight gradients of row-major layers), ragged tiles and split-K."""
+    from dose_prediction_amd import _lib
+    dev = _dev()
+    M, N, K, sk = cfg
+    lda, ldb = M + (8 - M % 8) % 8, N + (8 - N % 8) % 8
+    A = q(rnd((K, lda), 1), dtype)
+    B = q(rnd((K, ldb), 2), dtype)
+    ref = A[:, :M].double().t() @ B[:, :N].double()
+    Ad, Bd = A.to(dev, dtype), B.to(dev, dtype)
+    C = (torch.zeros if sk > 1 else torch.empty)((M, N), dtype=torch.float32, device=dev)
+    _lib.call("dp_gemm_tn", Ad.data_ptr(), lda, Bd.data_ptr(), ldb, C.data_ptr(), N, M, N, K, sk, 0 if dtype == torch.float32 else 1,
+              torch.cuda.current_stream().cuda_stream)
+    assert rel_l2(C.cpu().double(), ref) < (2e-5 if dtype == torch.float32 else 2e-5)   # inputs are pre-rounded: fp32 accumulation in both modes
