@@ -103,6 +103,9 @@ def summarize_profile(records, steps):
             # (x, ldx, gy, ldgy, dw, ws, N, D, H, W, Cin, Cout, k, ...)
             N, D, H, W, Cin, Cout, k = a[6:13]
             fl, key = 2.0 * N * D * H * W * Cin * Cout * k ** 3, f"wgrad{k}x{k}x{k}_tiled"
+        elif name == "dp_gemm_tn":
+            # (A, lda, B, ldb, C, ldc, M, N, K, splitk, dtype, stream)
+            fl, key = 2.0 * a[6] * a[7] * a[8], "gemm_tn"
         else:
             M, N, K, nb0, nb1 = a[13], a[14], a[15], a[16], a[17]
             fl, key = 2.0 * M * N * K * nb0 * nb1, "gemm_nt"

@@ -68,7 +68,7 @@ def lib():
 # (name, args, start_event, end_event).
 PROFILE = None
 PROFILE_NAMES = ("dp_conv3d", "dp_conv3d_tiled", "dp_conv3d_tiled2", "dp_conv3d_wgrad", "dp_conv3d_wgrad_tiled", "dp_conv3d_wgrad_tiled2",
-                 "dp_gemm_nt")
+                 "dp_gemm_nt", "dp_gemm_tn")
 
 
 def call(name, *args):

@@ -1,14 +1,14 @@
-"""Device-side restatement of the reference's training losses (DosePrediction/Train/loss.py) for the benchmark /
-trainer harness.  Masked means are written as sum(|p-g|*m)/sum(m) instead of boolean-mask indexing (identical value,
-no dynamic shapes, no host synchronisation).  Plain torch ops: the loss is SURVEY.md section 8f "next-1", not yet a
-HIP kernel."""
+"""The reference's training losses (DosePrediction/Train/loss.py) on device for the benchmark / trainer harness
+(SURVEY.md section 8f row 1).  The masked means sum(|p-g|*m)/sum(m) are one fused HIP reduction each (ops.masked_l1:
+dp_masked_l1_fwd / _bwd) instead of boolean-mask indexing: same value, no dynamic shapes, no host synchronisation.  Only the
+ground-truth down-sampling (no gradient, a few MB) stays in torch."""
 import torch
 import torch.nn.functional as F
 
 
 def _masked_l1(pred, gt, mask):
-    m = (mask > 0).to(pred.dtype)
-    return ((pred - gt).abs() * m).sum() / m.sum().clamp_min(1.0)
+    from . import ops
+    return ops.masked_l1(pred, gt, mask)
 
 
 def gen_loss(predictions, gt, delta1=10.0, delta2=1.0, casecade=True, freez=True):

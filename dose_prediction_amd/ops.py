@@ -943,3 +943,57 @@ def argmax_onehot(logits, out=None, choff=0, labels=False):
         ldo = rows_ld(out)[2]
     _lib.call("dp_argmax_onehot", _p(logits), ld, _p(out), ldo, choff, _p(lab), rows, C, _dt(logits), _stream())
     return lab
+
+
+# ------------------------------------------------------------------------------------------------ loss / metrics
+class MaskedL1(torch.autograd.Function):
+    """mean |pred - gt| over mask > 0 (Train/loss.py:13-28, 69-107) without boolean indexing: dp_masked_l1_fwd / _bwd.
+    pred, gt, mask: fp32 device tensors of equal numel (any shape); returns a 0-dim fp32 tensor."""
+
+    @staticmethod
+    def forward(ctx, pred, gt, mask):
+        _chk_dev(pred, gt, mask)
+        if pred.dtype != torch.float32:
+            raise _lib.DoseHipError("masked_l1 takes the fp32 tensors of the module boundary")
+        pred, gt, mask = pred.contiguous(), gt.contiguous().float(), mask.contiguous().float()
+        n = pred.numel()
+        if gt.numel() != n or mask.numel() != n:
+            raise ValueError("masked_l1: pred, gt and mask must have the same number of elements")
+        ws = torch.empty((_lib.lib().dp_masked_l1_ws_elems(n),), dtype=torch.float32, device=pred.device)
+        out = torch.empty((3,), dtype=torch.float32, device=pred.device)
+        _lib.call("dp_masked_l1_fwd", _p(pred), _p(gt), _p(mask), n, _p(ws), _p(out), 0, _stream())
+        ctx.save_for_backward(pred, gt, mask, out)
+        return out[2]
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, gt, mask, out = ctx.saved_tensors
+        gp = torch.empty_like(pred)
+        gup = g.contiguous().float().reshape(1)
+        _lib.call("dp_masked_l1_bwd", _p(pred), _p(gt), _p(mask), _p(out), _p(gup), _p(gp), pred.numel(), _stream())
+        return gp, None, None
+
+
+def masked_l1(pred, gt, mask):
+    return MaskedL1.apply(pred, gt, mask)
+
+
+def dose_score(pred, gt, mask, scale=70.0):
+    """Validation metric of train_light_pyfer.py:166-172: post-process (zero where mask < 1 or pred < 0), then
+    scale * mean |pred - gt| over mask > 0 (evaluate_openKBP.get_3D_Dose_dif).  No gradient; 0-dim device tensor."""
+    _chk_dev(pred, gt, mask)
+    pred, gt, mask = pred.detach().contiguous().float(), gt.contiguous().float(), mask.contiguous().float()
+    n = pred.numel()
+    ws = torch.empty((_lib.lib().dp_masked_l1_ws_elems(n),), dtype=torch.float32, device=pred.device)
+    out = torch.empty((3,), dtype=torch.float32, device=pred.device)
+    _lib.call("dp_masked_l1_fwd", _p(pred), _p(gt), _p(mask), n, _p(ws), _p(out), 1, _stream())
+    return out[2] * scale
+
+
+def dose_postprocess(pred, mask, scale=70.0):
+    """pred[(mask < 1) | (pred < 0)] = 0; x scale (train_light_pyfer.py:166-172)."""
+    _chk_dev(pred, mask)
+    pred, mask = pred.detach().contiguous().float(), mask.contiguous().float()
+    out = torch.empty_like(pred)
+    _lib.call("dp_dose_postprocess", _p(pred), _p(mask), _p(out), pred.numel(), float(scale), _stream())
+    return out

@@ -196,6 +196,20 @@ int dp_adam_multi(const void* table, const int32_t* chunk_t, const int32_t* chun
 int dp_argmax_onehot(const void* logits, int ld, void* out, int ldo, int choff, int32_t* labels, int64_t rows, int C,
                      int dtype, void* stream);
 
+/* ---- loss and dose metrics on device ------------------------------------------------------
+ * Masked L1 of DosePrediction/Train/loss.py:13-28,69-107 (Loss / GenLoss: mean |pred - gt| over possible_dose_mask > 0) and
+ * the validation metric of train_light_pyfer.py:166-172 + Evaluate/evaluate_openKBP.py:42-48.  fp32 tensors of n elements.
+ * out3 = { sum |p - g| over the mask, number of masked elements, their ratio (0 for an empty mask) }; ws holds
+ * dp_masked_l1_ws_elems(n) floats.  postprocess != 0 first applies p = (mask < 1 || p < 0) ? 0 : p (dose score; multiply
+ * the ratio by 70 for Gy).  Backward: gpred = gup[0] * sign(p - g) * (mask > 0) / max(out3[1], 1), gup on the device. */
+int64_t dp_masked_l1_ws_elems(int64_t n);
+int dp_masked_l1_fwd(const float* pred, const float* gt, const float* mask, int64_t n, float* ws, float* out3, int postprocess,
+                     void* stream);
+int dp_masked_l1_bwd(const float* pred, const float* gt, const float* mask, const float* out3, const float* gup, float* gpred,
+                     int64_t n, void* stream);
+/* out = (mask < 1 || pred < 0) ? 0 : scale * pred   (train_light_pyfer.py:166-172, scale = 70 Gy) */
+int dp_dose_postprocess(const float* pred, const float* mask, float* out, int64_t n, float scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

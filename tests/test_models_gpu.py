@@ -280,3 +280,42 @@ def test_activation_checkpointing():
     assert rel_err(o2.cpu(), o1.cpu()) < 1e-6 and rel_l2(gx2.cpu(), gx1.cpu()) < 1e-4 and rel_l2(gs2.cpu(), gs1.cpu()) < 1e-4
     for k in gp1:
         assert rel_l2(gp2[k].cpu(), gp1[k].cpu()) < 1e-3, k
+
+
+def test_losses_and_dose_metrics_against_reference_goldens():
+    """GenLoss / Loss (Train/loss.py) and the validation dose score (train_light_pyfer.py:166-172,
+    evaluate_openKBP.py:42-48) through dp_masked_l1_fwd/_bwd and dp_dose_postprocess, against the values and gradients the
+    reference's own loss module produced (fixture g5_loss) and against the oracle's post-processing."""
+    from dose_prediction_amd import losses, ops
+    dev = torch.device("cuda:0")
+    g = load_golden("g5_loss")
+    gt = g["gt"].to(dev)
+    for freez in (True, False):
+        pa = g["pa"].to(dev).requires_grad_(True)
+        pbs = [g[f"pb{i}"].to(dev).requires_grad_(True) for i in range(4)]
+        l = losses.gen_loss([pa, pbs], gt, 10.0, 1.0, casecade=True, freez=freez)
+        tag = f"gen_freez{int(freez)}"
+        assert abs(l.item() - g[tag].item()) < 2e-5 * abs(g[tag].item()), (l.item(), g[tag].item())
+        l.backward()
+        for i in range(4):
+            assert cmp_prefix(pbs[i].grad.cpu(), g[f"{tag}/gpb{i}"]) < 2e-5
+        if not freez:
+            assert cmp_prefix(pa.grad.cpu(), g[f"{tag}/gpa"]) < 2e-5
+        pb0 = g["pb0"].to(dev).requires_grad_(True)
+        l = losses.l1_loss([g["pa"].to(dev), pb0], gt, freez=freez)
+        tag = f"l1_freez{int(freez)}"
+        assert abs(l.item() - g[tag].item()) < 2e-5 * abs(g[tag].item())
+        l.backward()
+        assert cmp_prefix(pb0.grad.cpu(), g[f"{tag}/gpb0"]) < 2e-5
+    # dose score: post-processing + masked MAE in Gy, ragged length (not a multiple of 4) and an empty mask
+    torch.manual_seed(7)
+    for n in (5003, 8192 * 3 + 1):
+        pred, dose = torch.randn(n) * 0.5 + 0.3, torch.rand(n)
+        mask = (torch.rand(n) > 0.6).float()
+        ref = 70.0 * oracle.dose_mae(oracle.dose_postprocess(pred, mask) / 70.0, dose, mask)
+        got = ops.dose_score(pred.to(dev), dose.to(dev), mask.to(dev))
+        assert abs(got.item() - ref.item()) < 2e-5 * abs(ref.item())
+        pp = ops.dose_postprocess(pred.to(dev), mask.to(dev))
+        assert torch.equal(pp.cpu(), oracle.dose_postprocess(pred, mask))
+    z = ops.masked_l1(torch.randn(100, device=dev), torch.randn(100, device=dev), torch.zeros(100, device=dev))
+    assert z.item() == 0.0
