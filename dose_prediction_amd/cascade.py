@@ -8,12 +8,58 @@
     dose = PYFER(structures)[1][0]; dose[mask < 1 or dose < 0] = 0; dose *= 70   (168-173)
 
 The arg-max / one-hot / channel packing is one HIP kernel (dp_argmax_onehot) writing straight into the NDHWC 9-channel
-PYFER input; the axis reversal is a strided copy.  Sliding-window stitching for volumes larger than the segmentation crop
-is not implemented yet: the segmentation model must be built for the full volume size."""
+PYFER input; the axis reversal is a strided copy.  Volumes larger than the segmentation crop go through
+sliding_window_logits() (MONAI sliding_window_inference with constant blending, the call at 152-153: roi = IMAGE_SIZE^3,
+overlap 0.25, sw_batch_size 4), stitched on device by dp_window_accumulate / dp_window_normalize."""
+import math
+
 import torch
 
-from . import config, ops
+from . import _lib, config, ops
 from .models.c3d import to_ndhwc, from_ndhwc
+
+
+def window_starts(image_size, roi_size, overlap=0.25):
+    """Window origins per axis exactly as MONAI 0.7 lays them out (_get_scan_interval + dense_patch_slices): interval =
+    int(roi * (1 - overlap)) (the whole roi when the axis fits in one window), windows i * interval until one reaches the
+    end of the axis, the last one pulled back inside the volume."""
+    starts = []
+    for size, roi in zip(image_size, roi_size):
+        if roi > size:
+            raise ValueError(f"volume axis {size} is smaller than the segmentation crop {roi}: padding is not supported")
+        interval = roi if roi == size else max(1, int(roi * (1 - overlap)))
+        num = int(math.ceil(float(size) / interval))
+        first = next((d for d in range(num) if d * interval + roi >= size), None)
+        count = first + 1 if first is not None else 1
+        starts.append([i * interval - max(i * interval + roi - size, 0) for i in range(count)])
+    return starts
+
+
+@torch.no_grad()
+def sliding_window_logits(seg_model, ct, roi_size, sw_batch_size=4, overlap=0.25):
+    """ct [B,1,D,H,W] fp32 -> NDHWC logits over the whole volume, averaged over overlapping roi windows (constant blend).
+    seg_model is built for img_size == roi_size; windows run sw_batch_size at a time in image-major order like MONAI."""
+    B, _, D, H, W = ct.shape
+    rz, ry, rx = roi_size
+    sz, sy, sx = window_starts((D, H, W), roi_size, overlap)
+    wins = [(n, z, y, x) for n in range(B) for z in sz for y in sy for x in sx]
+    x_all = to_ndhwc(ct)
+    dt, acc, cnt, C = x_all.dtype, None, None, None
+    for g0 in range(0, len(wins), sw_batch_size):
+        grp = wins[g0:g0 + sw_batch_size]
+        batch = torch.stack([x_all[n, z:z + rz, y:y + ry, x:x + rx] for n, z, y, x in grp]).contiguous()
+        logits = ops.as_rows(seg_model.forward_ndhwc(batch))
+        if acc is None:
+            C = logits.shape[-1]
+            acc = torch.zeros((B, D, H, W, C), dtype=torch.float32, device=ct.device)
+            cnt = torch.zeros((B, D, H, W), dtype=torch.float32, device=ct.device)
+        for i, (n, z, y, x) in enumerate(grp):
+            _lib.call("dp_window_accumulate", logits[i].data_ptr(), logits.stride(-2), acc.data_ptr(), cnt.data_ptr(), n, D, H, W,
+                      rz, ry, rx, z, y, x, C, 0 if dt == torch.float32 else 1, torch.cuda.current_stream().cuda_stream)
+    out = torch.empty((B, D, H, W, C), dtype=dt, device=ct.device)
+    _lib.call("dp_window_normalize", acc.data_ptr(), cnt.data_ptr(), out.data_ptr(), C, B * D * H * W, C,
+              0 if dt == torch.float32 else 1, torch.cuda.current_stream().cuda_stream)
+    return out
 
 
 @torch.no_grad()
@@ -25,11 +71,16 @@ def oar_masks(seg_model, ct):
 
 
 @torch.no_grad()
-def cascade_forward(seg_model, dose_model, ct, ptv, possible_dose_mask=None, reverse_axes=True):
+def cascade_forward(seg_model, dose_model, ct, ptv, possible_dose_mask=None, reverse_axes=True, roi_size=None,
+                    sw_batch_size=4, overlap=0.25):
     """Returns (dose_gy [B,1,...] fp32 in Gy, labels).  ct, ptv: [B,1,D,H,W] fp32 on the GPU.  With reverse_axes the OAR masks
-    and the CT are flipped to the dose loader's axis order (W,H,D) exactly as lines 158/163 do; ptv is taken as given."""
+    and the CT are flipped to the dose loader's axis order (W,H,D) exactly as lines 158/163 do; ptv is taken as given.
+    roi_size: crop the segmentation network was built for (sliding-window inference when it is smaller than the volume)."""
     B = ct.shape[0]
-    logits = seg_model.forward_ndhwc(to_ndhwc(ct))                       # [B,D,H,W,8]
+    if roi_size is not None and tuple(roi_size) != tuple(ct.shape[2:]):
+        logits = sliding_window_logits(seg_model, ct, tuple(roi_size), sw_batch_size, overlap)
+    else:
+        logits = seg_model.forward_ndhwc(to_ndhwc(ct))                   # [B,D,H,W,8]
     dt = config.compute_dtype()
     D, H, W = logits.shape[1:4]
     staged = torch.zeros((B, D, H, W, 16), dtype=dt, device=ct.device)   # channels: 0 PTV | 1..7 OARs | 8 CT | pad

@@ -438,3 +438,42 @@ extern "C" int dp_pointwise_wgrad_rows(const void* x, int ldx, const void* gy, i
   hipLaunchKernelGGL(k_pointwise_wgrad_finish, dim3(E), dim3(64), 0, STREAM, (const float*)ws, g, E, Cin, Cout, dw, s_co, db);
   DP_CHECK_LAUNCH("pointwise_wgrad_rows"); return 0;
 }
+
+// ------------------------------------------------------------------------------------------------ sliding-window stitching
+// MONAI sliding_window_inference (constant blend mode), call site train_light_linked_model.py:152-153: window predictions are
+// summed into an fp32 volume with a per-voxel visit count, then divided.  One thread per (window voxel, 8-channel chunk).
+template <typename T>
+__global__ void k_window_accumulate(const T* __restrict__ win, int ldw, float* __restrict__ acc, float* __restrict__ cnt, int n, int D, int H, int W,
+                                    int rz, int ry, int rx, int z0, int y0, int x0, int C) {
+  const int cg8 = (C + 7) >> 3;
+  const int64_t total = (int64_t)rz * ry * rx * cg8;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int cg = (int)(i % cg8); int64_t v = i / cg8;
+    const int x = (int)(v % rx); v /= rx; const int y = (int)(v % ry); const int z = (int)(v / ry);
+    const int64_t src = ((int64_t)(z * ry + y) * rx + x), dst = (((int64_t)n * D + z0 + z) * H + y0 + y) * W + x0 + x;
+    const int nv = min(8, C - cg * 8);
+    for (int k = 0; k < nv; k++) acc[dst * C + cg * 8 + k] += ld_f(win + src * ldw + cg * 8 + k);
+    if (cg == 0) cnt[dst] += 1.f;
+  }
+}
+template <typename T>
+__global__ void k_window_normalize(const float* __restrict__ acc, const float* __restrict__ cnt, T* __restrict__ out, int ldo, int64_t rows, int C) {
+  const int64_t total = rows * C;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / C; const int c = (int)(i - r * C);
+    st_f(out + r * ldo + c, acc[i] / cnt[r]);
+  }
+}
+extern "C" int dp_window_accumulate(const void* win, int ldw, float* acc, float* cnt, int n, int D, int H, int W, int rz, int ry, int rx,
+                                    int z0, int y0, int x0, int C, int dtype, void* stream) {
+  if (z0 < 0 || y0 < 0 || x0 < 0 || z0 + rz > D || y0 + ry > H || x0 + rx > W) DP_FAIL("window_accumulate: window outside the volume");
+  int64_t total = (int64_t)rz * ry * rx * ((C + 7) / 8);
+  int g = grid_for(total, 256, 256 * 64);
+  DP_DISPATCH(dtype, hipLaunchKernelGGL(k_window_accumulate<T>, dim3(g), dim3(256), 0, STREAM, (const T*)win, ldw, acc, cnt, n, D, H, W, rz, ry, rx, z0, y0, x0, C));
+  DP_CHECK_LAUNCH("window_accumulate"); return 0;
+}
+extern "C" int dp_window_normalize(const float* acc, const float* cnt, void* out, int ldo, int64_t rows, int C, int dtype, void* stream) {
+  int g = grid_for(rows * C, 256, 256 * 64);
+  DP_DISPATCH(dtype, hipLaunchKernelGGL(k_window_normalize<T>, dim3(g), dim3(256), 0, STREAM, acc, cnt, (T*)out, ldo, rows, C));
+  DP_CHECK_LAUNCH("window_normalize"); return 0;
+}

@@ -196,6 +196,13 @@ int dp_adam_multi(const void* table, const int32_t* chunk_t, const int32_t* chun
 int dp_argmax_onehot(const void* logits, int ld, void* out, int ldo, int choff, int32_t* labels, int64_t rows, int C,
                      int dtype, void* stream);
 
+/* ---- sliding-window stitching (MONAI sliding_window_inference, constant blending; train_light_linked_model.py:152-153) --
+ * acc[n][z0+z][y0+y][x0+x][c] += win[z][y][x][c] (fp32, C channels dense), cnt[voxel] += 1 for one rz x ry x rx window of
+ * image n; then out[row][c] = acc / cnt.  acc and cnt are zero-initialised by the caller. */
+int dp_window_accumulate(const void* win, int ldw, float* acc, float* cnt, int n, int D, int H, int W, int rz, int ry, int rx,
+                         int z0, int y0, int x0, int C, int dtype, void* stream);
+int dp_window_normalize(const float* acc, const float* cnt, void* out, int ldo, int64_t rows, int C, int dtype, void* stream);
+
 /* ---- loss and dose metrics on device ------------------------------------------------------
  * Masked L1 of DosePrediction/Train/loss.py:13-28,69-107 (Loss / GenLoss: mean |pred - gt| over possible_dose_mask > 0) and
  * the validation metric of train_light_pyfer.py:166-172 + Evaluate/evaluate_openKBP.py:42-48.  fp32 tensors of n elements.

@@ -15,7 +15,7 @@ __all__ = [
     "single_conv", "base_unet", "c3d_model", "conv_block_3", "conv_block_7", "conv_3_1", "conv_3_1_old",
     "dilated_conv_block", "dual_dilated_block", "unet_res_block", "unet_basic_block", "unetr_pr_up_block",
     "modified_unetr_up_block", "unetr_up_block", "vit", "vit_encoder", "main_subset_model", "dose_pyfer",
-    "oar_transeg", "loss_l1_masked", "gen_loss", "dose_postprocess", "dose_mae",
+    "oar_transeg", "loss_l1_masked", "gen_loss", "dose_postprocess", "dose_mae", "sliding_window_inference",
 ]
 
 
@@ -289,3 +289,47 @@ def dose_mae(pred, gt, mask):
     """evaluate_openKBP.get_3D_Dose_dif, 42-48: mean |pred-gt| over possible_dose_mask>0."""
     m = mask > 0
     return (pred[m] - gt[m]).abs().mean()
+
+
+def sliding_window_inference(inputs, roi_size, sw_batch_size, predictor, overlap=0.25):
+    """MONAI 0.7 monai.inferers.sliding_window_inference with mode="constant" (call site
+    train_light_linked_model.py:152-153), restated from the published algorithm: scan interval int(roi*(1-overlap)) (the roi
+    itself on an axis that fits one window), dense_patch_slices origins with the last window pulled back inside the volume,
+    predictions summed with unit importance and divided by the visit count.  Volumes smaller than the roi (MONAI pads them)
+    are not covered.  PARITY UNPINNED: MONAI is absent from the authoring container."""
+    import math
+    image_size = tuple(inputs.shape[2:])
+    starts = []
+    for size, roi in zip(image_size, roi_size):
+        assert roi <= size
+        interval = roi if roi == size else max(1, int(roi * (1 - overlap)))
+        num = int(math.ceil(float(size) / interval))
+        first = None
+        for d in range(num):
+            if d * interval + roi >= size:
+                first = d
+                break
+        count = first + 1 if first is not None else 1
+        axis = []
+        for i in range(count):
+            st = i * interval
+            st -= max(st + roi - size, 0)
+            axis.append(st)
+        starts.append(axis)
+    slices = [(z, y, x) for z in starts[0] for y in starts[1] for x in starts[2]]
+    num_win, total = len(slices), len(slices) * inputs.shape[0]
+    out = cnt = None
+    for g0 in range(0, total, sw_batch_size):
+        idxs = list(range(g0, min(g0 + sw_batch_size, total)))
+        data = torch.cat([inputs[i // num_win:i // num_win + 1, :, slices[i % num_win][0]:slices[i % num_win][0] + roi_size[0],
+                                 slices[i % num_win][1]:slices[i % num_win][1] + roi_size[1],
+                                 slices[i % num_win][2]:slices[i % num_win][2] + roi_size[2]] for i in idxs])
+        prob = predictor(data)
+        if out is None:
+            out = torch.zeros((inputs.shape[0], prob.shape[1]) + image_size, dtype=prob.dtype)
+            cnt = torch.zeros_like(out)
+        for k, i in enumerate(idxs):
+            z, y, x = slices[i % num_win]
+            out[i // num_win, :, z:z + roi_size[0], y:y + roi_size[1], x:x + roi_size[2]] += prob[k]
+            cnt[i // num_win, :, z:z + roi_size[0], y:y + roi_size[1], x:x + roi_size[2]] += 1
+    return out / cnt

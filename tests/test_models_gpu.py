@@ -319,3 +319,36 @@ def test_losses_and_dose_metrics_against_reference_goldens():
         assert torch.equal(pp.cpu(), oracle.dose_postprocess(pred, mask))
     z = ops.masked_l1(torch.randn(100, device=dev), torch.randn(100, device=dev), torch.zeros(100, device=dev))
     assert z.item() == 0.0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_sliding_window_inference(dtype):
+    """sliding_window_inference(ct, roi, sw_batch 4, predictor) of train_light_linked_model.py:152-153 for a
+    volume larger than the segmentation crop (48 x 32 x 40 with a 32^3 crop: 2 x 1 x 2 overlapping windows per image, batch 2,
+    so the last window group is ragged) against the oracle's restatement of MONAI's algorithm driving the oracle network;
+    window layout against hand-computed origins; roi == volume degenerates to the plain forward."""
+    from dose_prediction_amd import cascade
+    from dose_prediction_amd.models import oar_transeg
+    dev = _dev()
+    assert cascade.window_starts((128, 128, 128), (96, 96, 96)) == [[0, 32]] * 3          # interval 72: windows at 0 and 128-96
+    assert cascade.window_starts((192, 192, 128), (96, 96, 96)) == [[0, 72, 96], [0, 72, 96], [0, 32]]
+    assert cascade.window_starts((96, 96, 96), (96, 96, 96)) == [[0]] * 3
+    _set(dtype)
+    try:
+        torch.manual_seed(11)
+        roi, vol = (32, 32, 32), (48, 32, 40)
+        seg = oar_transeg.Model(1, 8, roi, feature_size=4, hidden_size=48, mlp_dim=96, num_heads=12, pos_embed="perceptron").to(dev).eval()
+        ct = torch.randn((2, 1) + vol, generator=torch.Generator().manual_seed(6))
+        if dtype == torch.bfloat16:
+            ct = ct.bfloat16().float()
+        got = cascade.sliding_window_logits(seg, ct.to(dev), roi, sw_batch_size=3, overlap=0.25)
+        got = got.float().permute(0, 4, 1, 2, 3).cpu()
+        sd = {k: v.detach().cpu() for k, v in seg.state_dict().items()}
+        with torch.no_grad():
+            ref = oracle.sliding_window_inference(ct, roi, 3, lambda w: oracle.oar_transeg(sd, w, num_heads=12, training=False), overlap=0.25)
+        assert rel_err(got, ref) < (OUT_TOL if dtype == torch.float32 else 0.15)
+        one = cascade.sliding_window_logits(seg, ct[:, :, :32, :, :32].contiguous().to(dev), roi)
+        direct = seg.forward_ndhwc(cascade.to_ndhwc(ct[:, :, :32, :, :32].contiguous().to(dev)))
+        assert rel_err(one.float().cpu(), direct.float()[..., :one.shape[-1]].cpu()) < (1e-5 if dtype == torch.float32 else 2e-2)   # split-kd atomics: not bitwise
+    finally:
+        _set(torch.float32)
