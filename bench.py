@@ -148,10 +148,36 @@ def cpu_baseline(args):
     loss.backward()
     dt = time.time() - t0
     scale = (S / 128.0) ** 3
-    return {"value": scale / dt, "unit": "128^3-equivalent volumes/s (fwd+bwd)", "cores": threads, "kind": "port",
-            "sample": f"1 step (forward + GenLoss + backward, net_A frozen) of the fp32 CPU oracle on one {S}^3 volume: "
-                      f"{dt:.2f} s with {threads} torch threads on {cores} host cores; scaled by voxel count ({scale:.4f})",
-            "seconds": dt}
+    res = {"value": scale / dt, "unit": "128^3-equivalent volumes/s (fwd+bwd)", "cores": threads, "kind": "port",
+           "sample": f"1 step (forward + GenLoss + backward, net_A frozen) of the fp32 CPU oracle on one {S}^3 volume: "
+                     f"{dt:.2f} s with {threads} torch threads on {cores} host cores; scaled by voxel count ({scale:.4f})",
+           "seconds": dt}
+    # the oracle as the CHECKER of this very sample (rel-error on output [1][0] and dose-MAE in Gy): the HIP path runs
+    # the same weights and input in both storage modes; nothing of this is timed or shipped
+    try:
+        import dose_prediction_amd
+        dev = torch.device("cuda", torch.cuda.current_device())
+        ref = out[1][0].detach()
+        mask = gt[:, 1:2] > 0
+        chk = {}
+        for name, dt_ in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+            dose_prediction_amd.set_compute_dtype(dt_)
+            hip = dose_pyfer.Model(in_ch=9, out_ch=1, list_ch_A=[-1, 16, 32, 64, 128, 256], feature_size=16, img_size=shape,
+                                   num_layers=8, num_heads=6, act="mish")
+            hip.load_state_dict({k: v.detach() for k, v in sd.items()})
+            hip = hip.to(dev).train()
+            with torch.no_grad():
+                got = hip(x.to(dev))[1][0].float().cpu()
+            chk[name] = {"rel_err_max": float((got - ref).abs().max() / ref.abs().max()),
+                         "dose_mae_gy_vs_oracle": float(70.0 * (got - ref).abs()[mask].mean())}
+            del hip
+        res["check_vs_oracle"] = chk
+    except Exception as e:
+        res["check_vs_oracle"] = f"failed: {e!r}"
+    finally:
+        import dose_prediction_amd
+        dose_prediction_amd.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+    return res
 
 
 def pmc_traffic(kernel_prefix):
