@@ -477,3 +477,35 @@ extern "C" int dp_window_normalize(const float* acc, const float* cnt, void* out
   DP_DISPATCH(dtype, hipLaunchKernelGGL(k_window_normalize<T>, dim3(g), dim3(256), 0, STREAM, acc, cnt, (T*)out, ldo, rows, C));
   DP_CHECK_LAUNCH("window_normalize"); return 0;
 }
+
+// ------------------------------------------------------------------------------------------------ im2col for small volumes
+// col[row][tap * CinP + c] = x[n, od*s + kd*dil - pad, ...][c] (zero outside / for c >= Cin).  A few thousand output voxels
+// with hundreds of channels (the deepest C3D stages: 256 -> 256 at 8^3, stride-2 128 -> 256 at 16^3 -> 8^3) are a plain
+// GEMM with K = taps * Cin once gathered: the gathered matrix is a few MB, the generic per-tap gather kernel spent 0.2-0.4 ms
+// there.  One 16-byte chunk per thread.
+template <typename T>
+__global__ void k_im2col3d(const T* __restrict__ x, int ldx, T* __restrict__ col, int N, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int Cin, int CinP,
+                           int k, int stride, int pad, int dil) {
+  const int cg8 = CinP >> 3, taps = k * k * k;
+  const int64_t total = (int64_t)N * Do * Ho * Wo * taps * cg8;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int cg = (int)(i % cg8); int64_t t = i / cg8;
+    const int tap = (int)(t % taps); int64_t row = t / taps;
+    const int kw = tap % k, kh = (tap / k) % k, kd = tap / (k * k);
+    int64_t v = row; const int ow = (int)(v % Wo); v /= Wo; const int oh = (int)(v % Ho); v /= Ho; const int od = (int)(v % Do); const int n = (int)(v / Do);
+    const int id = od * stride + kd * dil - pad, ih = oh * stride + kh * dil - pad, iw = ow * stride + kw * dil - pad;
+    const int nv = min(8, Cin - cg * 8);
+    const bool ok = id >= 0 && id < Di && ih >= 0 && ih < Hi && iw >= 0 && iw < Wi && nv > 0;
+    Frag8<T> f = ok ? frag_load(x + ((((int64_t)n * Di + id) * Hi + ih) * Wi + iw) * ldx + cg * 8, nv) : frag_zero<T>();
+    frag_store<T>(col + (row * taps + tap) * CinP + cg * 8, f, 8);
+  }
+}
+extern "C" int dp_im2col3d(const void* x, int ldx, void* col, int N, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int Cin, int k, int stride, int pad,
+                           int dil, int dtype, void* stream) {
+  const int CinP = (Cin + 7) & ~7;
+  int64_t total = (int64_t)N * Do * Ho * Wo * k * k * k * (CinP / 8);
+  int g = grid_for(total, 256, 256 * 64);
+  DP_DISPATCH(dtype, hipLaunchKernelGGL(k_im2col3d<T>, dim3(g), dim3(256), 0, STREAM, (const T*)x, ldx, (T*)col, N, Di, Hi, Wi, Do, Ho, Wo, Cin, CinP, k,
+                                        stride, pad, dil));
+  DP_CHECK_LAUNCH("im2col3d"); return 0;
+}

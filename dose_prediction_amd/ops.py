@@ -315,6 +315,13 @@ class Conv3d(torch.autograd.Function):
         elif k == 1 and stride == 1 and pad == 0:
             wp = _pack_conv(weight, 0, x.dtype)
             gemm_nt(x, wp, y, bias=b32, M=rows, N=cout, K=cin, lda=ldx, ldb=wp.shape[-1], ldc=cout)
+        elif N * Do * Ho * Wo <= 16384 and cin >= 32 and N * Do * Ho * Wo * k ** 3 * cin <= (1 << 26):
+            # few output voxels, many channels (deep C3D stages): gather once, then ONE GEMM with K = taps * Cin
+            wp = _pack_conv(weight, 0, x.dtype)                  # [Cout][tap][CinP]
+            orow, kk = N * Do * Ho * Wo, wp.shape[1] * wp.shape[2]
+            col = torch.empty((orow, kk), dtype=x.dtype, device=x.device)
+            _lib.call("dp_im2col3d", _p(x), ldx, _p(col), N, Di, Hi, Wi, Do, Ho, Wo, cin, k, stride, pad, dil, _dt(x), _stream())
+            gemm_nt(col, wp, y, bias=b32, M=orow, N=cout, K=kk, lda=kk, ldb=kk, ldc=cout)
         else:
             wp = _pack_conv(weight, 0, x.dtype)
             _lib.call("dp_conv3d", _p(x), ldx, _p(wp), _p(b32), _p(y), cout, N, Di, Hi, Wi, Do, Ho, Wo, cin, cout,
@@ -365,7 +372,14 @@ class Conv3d(torch.autograd.Function):
             ws = torch.empty((wse,), dtype=torch.float32, device=x.device)
             _lib.call("dp_pointwise_wgrad_rows", _p(x), ldx, _p(gy), ldg, _p(gw), cin, _p(gb), _p(ws), grows, cin, cout, dtc, _stream())
             return gx, gw, gb, None, None, None
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and k == 1 and stride == 1 and pad == 0 and grows < 32768:
+            # pointwise conv over few voxels: dW[co][ci] = gy^T x, both k-major in memory (split over K to fill the chip)
+            tiles = -(-cout // 64) * -(-cin // 64)
+            sk = max(1, min(grows // 512, 256 // tiles))
+            gw2 = (torch.zeros if sk > 1 else torch.empty)((cout, cin), dtype=torch.float32, device=x.device)
+            _lib.call("dp_gemm_tn", _p(gy), ldg, _p(x), ldx, _p(gw2), cin, cout, cin, grows, sk, dtc, _stream())
+            gw = gw2.view(weight.shape)
+        elif ctx.needs_input_grad[1]:
             taps = k * k * k
             wse = 0
             if USE_TILED and (k > 1 or grows >= 32768):

@@ -196,6 +196,11 @@ int dp_adam_multi(const void* table, const int32_t* chunk_t, const int32_t* chun
 int dp_argmax_onehot(const void* logits, int ld, void* out, int ldo, int choff, int32_t* labels, int64_t rows, int C,
                      int dtype, void* stream);
 
+/* Gather for small-volume convolutions (c3d.py:16 at the 8^3 / 16^3 stages): col[row][tap*CinP + c] with CinP = Cin rounded
+ * up to 8, row = output voxel (n, od, oh, ow), zero padding.  conv = dp_gemm_nt(col, weights packed [Cout][tap][CinP]). */
+int dp_im2col3d(const void* x, int ldx, void* col, int N, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int Cin, int k, int stride,
+                int pad, int dil, int dtype, void* stream);
+
 /* ---- sliding-window stitching (MONAI sliding_window_inference, constant blending; train_light_linked_model.py:152-153) --
  * acc[n][z0+z][y0+y][x0+x][c] += win[z][y][x][c] (fp32, C channels dense), cnt[voxel] += 1 for one rz x ry x rx window of
  * image n; then out[row][c] = acc / cnt.  acc and cnt are zero-initialised by the caller. */

@@ -79,6 +79,9 @@ DTYPES = [torch.float32, torch.bfloat16]
     (1, 128, 64, 2, 6, 32, 3, 1, 1, 1, True),
     (2, 1, 16, 3, 9, 40, 3, 1, 1, 1, False),      # single input channel (OAR-TRANSEG encoder1: CT -> 16)
     (1, 3, 16, 2, 9, 32, 7, 1, 3, 1, True),
+    (2, 64, 32, 8, 8, 10, 3, 2, 1, 1, True),      # few voxels, many channels, stride 2: im2col + GEMM forward
+    (1, 40, 24, 6, 5, 7, 3, 1, 2, 2, False),      # same path with dilation and ragged channels
+    (1, 128, 1, 8, 8, 8, 1, 1, 0, 1, True),       # pointwise head over few voxels: TN-GEMM weight gradient
     (1, 16, 1, 32, 32, 40, 1, 1, 0, 1, True),     # deep-supervision head at >= 32768 voxels: row-stream forward + wgrad
     (2, 32, 3, 16, 32, 40, 1, 1, 0, 1, True),
     (1, 64, 2, 16, 32, 64, 1, 1, 0, 1, False),
