@@ -123,9 +123,12 @@ class conv_3_1(nn.Module):
 
     def forward(self, x):
         """x: tensor or (a, b) pair = virtual torch.cat (the two first convolutions then read the operands directly)."""
-        x3 = ops.norm_act(self.conv_3[0](x), "instance", act=self._act)
-        x7 = ops.norm_act(self.conv_7[0](x), "instance", act=self._act)
-        y = ops.conv3d(ops.cat((x3, x7)), self.conv[0].weight, self.conv[0].bias)
+        r3, r7 = self.conv_3[0](x), self.conv_7[0](x)
+        if r3.shape[-1] % 8 == 0:       # both branches normalised straight into the halves of the mixer's input (no cat copy)
+            x37 = ops.norm_act_cat(r3, r7, act=self._act)
+        else:
+            x37 = ops.cat((ops.norm_act(r3, "instance", act=self._act), ops.norm_act(r7, "instance", act=self._act)))
+        y = ops.conv3d(x37, self.conv[0].weight, self.conv[0].bias)
         return ops.norm_act(y, "instance", act=self._act)
 
 

@@ -596,6 +596,75 @@ def linear(x, weight, bias=None, splitk=1):
 
 
 # ------------------------------------------------------------------------------------------------ normalisation
+def _norm_forward(x, kind, gamma, beta, running_mean, running_var, training, res, act, eps, momentum, y_ptr, ldy):
+    """Statistics + fused normalise/affine/residual/activation of one NDHWC tensor into (y_ptr, row pitch ldy)."""
+    rows, C, ldx = rows_ld(x)
+    N = x.shape[0]
+    V = rows // N
+    L = _lib.lib()
+    dtc = _dt(x)
+    dev = x.device
+    use_batch_stats = kind == "instance" or training
+    if use_batch_stats:
+        nblk = L.dp_stats_nblk(V)
+        part = torch.empty((N, nblk, 2, C), dtype=torch.float32, device=dev)
+        groups = N if kind == "instance" else 1
+        mean = torch.empty((groups, C), dtype=torch.float32, device=dev)
+        rstd = torch.empty((groups, C), dtype=torch.float32, device=dev)
+        _lib.call("dp_stats_partial", _p(x), ldx, N, V, C, _p(part), dtc, _stream())
+        upd = kind == "batch" and training and running_mean is not None
+        _lib.call("dp_stats_finalize", _p(part), N, nblk, C, V, 1 if kind == "batch" else 0, float(eps), _p(mean), _p(rstd),
+                  _p(running_mean) if upd else 0, _p(running_var) if upd else 0, float(momentum), _stream())
+    else:   # eval-mode batch norm: running statistics
+        mean = running_mean.detach().reshape(1, C).float()
+        rstd = torch.empty((1, C), dtype=torch.float32, device=dev)
+        zero_part = torch.zeros((1, 1, 2, C), dtype=torch.float32, device=dev)
+        # rstd = 1/sqrt(var+eps) through the finalize kernel: feed sums s1=0, s2=var (count 1)
+        zero_part[0, 0, 1].copy_(running_var.detach())
+        dummy = torch.empty((1, C), dtype=torch.float32, device=dev)
+        _lib.call("dp_stats_finalize", _p(zero_part), 1, 1, C, 1, 1, float(eps), _p(dummy), _p(rstd), 0, 0, 0.0, _stream())
+    ssn = C if kind == "instance" else 0
+    g32 = None if gamma is None else gamma.detach()
+    b32 = None if beta is None else beta.detach()
+    ldr = rows_ld(res)[2] if res is not None else 0
+    _lib.call("dp_norm_act_fwd", _p(x), ldx, _p(mean), _p(rstd), ssn, _p(g32), _p(b32), _p(res), ldr, ACT[act],
+              y_ptr, ldy, N, V, C, dtc, _stream())
+    return mean, rstd, use_batch_stats, ssn
+
+
+def _norm_backward(x, mean, rstd, gamma, beta, res, kind, act, use_stats, ssn, gy_ptr, ldg, need_x, need_gb, need_res):
+    """Backward of _norm_forward for an upstream gradient at (gy_ptr, row pitch ldg) -> (gx, dgamma, dbeta, gres)."""
+    rows, C, ldx = rows_ld(x)
+    N = x.shape[0]
+    V = rows // N
+    L = _lib.lib()
+    dtc = _dt(x)
+    dev = x.device
+    ldr = rows_ld(res)[2] if res is not None else 0
+    g32 = None if gamma is None else gamma.detach()
+    b32 = None if beta is None else beta.detach()
+    nblk = L.dp_stats_nblk(V)
+    part = torch.empty((N, nblk, 2, C), dtype=torch.float32, device=dev)
+    groups = N if kind == "instance" else 1
+    s1 = torch.empty((groups, C), dtype=torch.float32, device=dev)
+    s2 = torch.empty((groups, C), dtype=torch.float32, device=dev)
+    dgamma = torch.zeros((C,), dtype=torch.float32, device=dev) if need_gb else None
+    dbeta = torch.zeros((C,), dtype=torch.float32, device=dev) if need_gb else None
+    if use_stats or need_gb:
+        _lib.call("dp_norm_act_bwd_partial", _p(x), ldx, gy_ptr, ldg, _p(mean), _p(rstd), ssn, _p(g32), _p(b32), _p(res), ldr,
+                  ACT[act], N, V, C, _p(part), dtc, _stream())
+        _lib.call("dp_norm_bwd_finalize", _p(part), N, nblk, C, 0 if kind == "instance" else 1, _p(s1), _p(s2),
+                  _p(dgamma), _p(dbeta), _stream())
+    gx = gres = None
+    if need_x or need_res:
+        gx = torch.empty(x.shape, dtype=x.dtype, device=dev) if need_x else None
+        gres = torch.empty(x.shape, dtype=x.dtype, device=dev) if need_res else None
+        cnt = V if kind == "instance" else N * V
+        _lib.call("dp_norm_act_bwd_apply", _p(x), ldx, gy_ptr, ldg, _p(mean), _p(rstd), ssn, _p(g32), _p(b32), _p(res), ldr,
+                  ACT[act], _p(s1), _p(s2), 1.0 / cnt, 1 if use_stats else 0, _p(gx), C, _p(gres), C, N, V, C, dtc, _stream())
+    return gx, dgamma, dbeta, gres
+
+
 class NormAct(torch.autograd.Function):
     """InstanceNorm3d / BatchNorm3d (+affine) (+residual) + activation, fused.
     kind: 'instance' | 'batch'.  For 'batch', running buffers are updated in place when training."""
@@ -604,42 +673,12 @@ class NormAct(torch.autograd.Function):
     def forward(ctx, x, kind, gamma, beta, running_mean, running_var, training, res, act, eps, momentum):
         _chk_dev(x)
         x = as_rows(x)
-        rows, C, ldx = rows_ld(x)
-        N = x.shape[0]
-        V = rows // N
-        L = _lib.lib()
-        dtc = _dt(x)
-        dev = x.device
-        use_batch_stats = kind == "instance" or training
-        if use_batch_stats:
-            nblk = L.dp_stats_nblk(V)
-            part = torch.empty((N, nblk, 2, C), dtype=torch.float32, device=dev)
-            groups = N if kind == "instance" else 1
-            mean = torch.empty((groups, C), dtype=torch.float32, device=dev)
-            rstd = torch.empty((groups, C), dtype=torch.float32, device=dev)
-            _lib.call("dp_stats_partial", _p(x), ldx, N, V, C, _p(part), dtc, _stream())
-            upd = kind == "batch" and training and running_mean is not None
-            _lib.call("dp_stats_finalize", _p(part), N, nblk, C, V, 1 if kind == "batch" else 0, float(eps), _p(mean), _p(rstd),
-                      _p(running_mean) if upd else 0, _p(running_var) if upd else 0, float(momentum), _stream())
-        else:   # eval-mode batch norm: running statistics
-            mean = running_mean.detach().reshape(1, C).float()
-            rstd = torch.empty((1, C), dtype=torch.float32, device=dev)
-            zero_part = torch.zeros((1, 1, 2, C), dtype=torch.float32, device=dev)
-            # rstd = 1/sqrt(var+eps) through the finalize kernel: feed sums s1=0, s2=var (count 1)
-            zero_part[0, 0, 1].copy_(running_var.detach())
-            dummy = torch.empty((1, C), dtype=torch.float32, device=dev)
-            _lib.call("dp_stats_finalize", _p(zero_part), 1, 1, C, 1, 1, float(eps), _p(dummy), _p(rstd), 0, 0, 0.0, _stream())
-        ssn = C if kind == "instance" else 0
-        g32 = None if gamma is None else gamma.detach()
-        b32 = None if beta is None else beta.detach()
+        C = x.shape[-1]
         if res is not None:
             res = as_rows(res)
-            ldr = rows_ld(res)[2]
-        else:
-            ldr = 0
-        y = torch.empty(x.shape, dtype=x.dtype, device=dev)
-        _lib.call("dp_norm_act_fwd", _p(x), ldx, _p(mean), _p(rstd), ssn, _p(g32), _p(b32), _p(res), ldr, ACT[act],
-                  _p(y), C, N, V, C, dtc, _stream())
+        y = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+        mean, rstd, use_batch_stats, ssn = _norm_forward(x, kind, gamma, beta, running_mean, running_var, training, res, act, eps,
+                                                         momentum, _p(y), C)
         ctx.save_for_backward(x, mean, rstd, gamma, beta, res)
         ctx.cfg = (kind, act, use_batch_stats, ssn)
         return y
@@ -649,39 +688,50 @@ class NormAct(torch.autograd.Function):
         x, mean, rstd, gamma, beta, res = ctx.saved_tensors
         kind, act, use_stats, ssn = ctx.cfg
         gy = as_rows(gy)
-        rows, C, ldx = rows_ld(x)
-        ldg = rows_ld(gy)[2]
-        N = x.shape[0]
-        V = rows // N
-        L = _lib.lib()
-        dtc = _dt(x)
-        dev = x.device
-        ldr = rows_ld(res)[2] if res is not None else 0
-        g32 = None if gamma is None else gamma.detach()
-        b32 = None if beta is None else beta.detach()
-        nblk = L.dp_stats_nblk(V)
-        part = torch.empty((N, nblk, 2, C), dtype=torch.float32, device=dev)
-        groups = N if kind == "instance" else 1
-        s1 = torch.empty((groups, C), dtype=torch.float32, device=dev)
-        s2 = torch.empty((groups, C), dtype=torch.float32, device=dev)
         need_gb = gamma is not None and (ctx.needs_input_grad[2] or ctx.needs_input_grad[3])
-        dgamma = torch.zeros((C,), dtype=torch.float32, device=dev) if need_gb else None
-        dbeta = torch.zeros((C,), dtype=torch.float32, device=dev) if need_gb else None
-        if use_stats or need_gb:
-            _lib.call("dp_norm_act_bwd_partial", _p(x), ldx, _p(gy), ldg, _p(mean), _p(rstd), ssn, _p(g32), _p(b32), _p(res), ldr,
-                      ACT[act], N, V, C, _p(part), dtc, _stream())
-            _lib.call("dp_norm_bwd_finalize", _p(part), N, nblk, C, 0 if kind == "instance" else 1, _p(s1), _p(s2),
-                      _p(dgamma), _p(dbeta), _stream())
-        gx = gres = None
-        need_x = ctx.needs_input_grad[0]
-        need_res = res is not None and ctx.needs_input_grad[7]
-        if need_x or need_res:
-            gx = torch.empty(x.shape, dtype=x.dtype, device=dev) if need_x else None
-            gres = torch.empty(x.shape, dtype=x.dtype, device=dev) if need_res else None
-            cnt = V if kind == "instance" else N * V
-            _lib.call("dp_norm_act_bwd_apply", _p(x), ldx, _p(gy), ldg, _p(mean), _p(rstd), ssn, _p(g32), _p(b32), _p(res), ldr,
-                      ACT[act], _p(s1), _p(s2), 1.0 / cnt, 1 if use_stats else 0, _p(gx), C, _p(gres), C, N, V, C, dtc, _stream())
+        gx, dgamma, dbeta, gres = _norm_backward(x, mean, rstd, gamma, beta, res, kind, act, use_stats, ssn, _p(gy), rows_ld(gy)[2],
+                                                 ctx.needs_input_grad[0], need_gb, res is not None and ctx.needs_input_grad[7])
         return gx, None, dgamma, dbeta, None, None, None, gres, None, None, None
+
+
+class NormActCat(torch.autograd.Function):
+    """cat((IN(xa) -> act, IN(xb) -> act), channels) in ONE tensor: each half is normalised straight into its channel slice of
+    the concatenated output (blocks_MDUNet.conv_3_1, 141-147: the 3^3 and 7^3 branches end in InstanceNorm3d + act and are then
+    concatenated for the 1^3 mixer), so no torch.cat copy exists; the backward reads the two slices of the upstream gradient in
+    place.  Non-affine instance normalisation only."""
+
+    @staticmethod
+    def forward(ctx, xa, xb, act, eps):
+        _chk_dev(xa, xb)
+        xa, xb = as_rows(xa), as_rows(xb)
+        ca, cb = xa.shape[-1], xb.shape[-1]
+        if xa.shape[:-1] != xb.shape[:-1] or (ca % 8) or (cb % 8):
+            raise ValueError("norm_act_cat: operands must share the voxel grid and have channel counts that are multiples of 8")
+        y = torch.empty(tuple(xa.shape[:-1]) + (ca + cb,), dtype=xa.dtype, device=xa.device)
+        ma, ra, _, ssa = _norm_forward(xa, "instance", None, None, None, None, True, None, act, eps, 0.1, _p(y), ca + cb)
+        mb, rb, _, ssb = _norm_forward(xb, "instance", None, None, None, None, True, None, act, eps, 0.1,
+                                       y.data_ptr() + ca * y.element_size(), ca + cb)
+        ctx.save_for_backward(xa, xb, ma, ra, mb, rb)
+        ctx.cfg = (act, ssa, ssb)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        xa, xb, ma, ra, mb, rb = ctx.saved_tensors
+        act, ssa, ssb = ctx.cfg
+        gy = as_rows(gy)
+        ldg, ca = rows_ld(gy)[2], xa.shape[-1]
+        ga = gb = None
+        if ctx.needs_input_grad[0]:
+            ga = _norm_backward(xa, ma, ra, None, None, None, "instance", act, True, ssa, _p(gy), ldg, True, False, False)[0]
+        if ctx.needs_input_grad[1]:
+            gb = _norm_backward(xb, mb, rb, None, None, None, "instance", act, True, ssb, gy.data_ptr() + ca * gy.element_size(), ldg,
+                                True, False, False)[0]
+        return ga, gb, None, None
+
+
+def norm_act_cat(xa, xb, act=None, eps=1e-5):
+    return NormActCat.apply(xa, xb, act, eps)
 
 
 def norm_act(x, kind, gamma=None, beta=None, running_mean=None, running_var=None, training=True, res=None, act=None,
