@@ -634,10 +634,13 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_tiled(const T* __restrict__ x,
                     (int64_t)g.H * g.W * max(max(g.ldx, g.ldx2), g.ldgy) < (1ll << 30);   // 32-bit offsets inside a plane
   // ---- tile iteration: (u, tw) pairs whose input depth slice exists
   struct Tile { int n, d, id, h0, w0, nchk, lpn; };
-  auto tile_ok = [&](int u) { const int d = (u / g.tiles_h) % g.D, id = d + kd - C::PAD; return id >= 0 && id < g.D; };
+  // A unit names the INPUT depth slice: the KS blocks (one per kd) that sweep the same unit range then stage the same x slab
+  // at the same time (and gy tiles KS steps apart), so that slab is fetched into the XCD's L2 once; enumerating output slices
+  // spread the KS uses of a slab over KS steps and the L2 could not hold them (3.4 GB fetched for 0.4 GB of operands).
+  auto tile_ok = [&](int u) { const int id = (u / g.tiles_h) % g.D, d = id - kd + C::PAD; return d >= 0 && d < g.D; };
   auto tile_of = [&](int u, int tw) {
     Tile t; const int th = u % g.tiles_h, nd = u / g.tiles_h;
-    t.d = nd % g.D; t.n = nd / g.D; t.id = t.d + kd - C::PAD; t.h0 = th * C::TH; t.w0 = tw * C::TW;
+    t.id = nd % g.D; t.n = nd / g.D; t.d = t.id - kd + C::PAD; t.h0 = th * C::TH; t.w0 = tw * C::TW;
     t.nchk = min(C::NCHK, (g.W - t.w0 + 15) >> 4);             // 16-voxel chunks that hold real output positions
     t.lpn = t.nchk * 16 + KS - 1;                                // slab positions actually read
     return t;
