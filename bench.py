@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optimizer", action="store_true")
     ap.add_argument("--cpu-size", type=int, default=64)
+    ap.add_argument("--cpu-steps", type=int, default=2, help="oracle steps timed for cpu_baseline (2 x ~6 s on the GPU box's host)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph (GPU-bound either way)")
     ap.add_argument("--torch-adam", action="store_true", help="use torch.optim.Adam instead of the fused HIP Adam")
     return ap.parse_args()
@@ -142,16 +143,20 @@ def cpu_baseline(args):
         sd[k] = v
     x = synth.dose_input(1, shape)
     gt = synth.dose_target(1, shape)
+    nstep = max(1, args.cpu_steps)
     t0 = time.time()
-    out = oracle.dose_pyfer(sd, x, num_layers=8, num_heads=6, act="mish", training=True)
-    loss = oracle.gen_loss(out, gt, 10, 1, casecade=True, freez=True)
-    loss.backward()
-    dt = time.time() - t0
+    for _ in range(nstep):
+        for v in sd.values():
+            v.grad = None
+        out = oracle.dose_pyfer(sd, x, num_layers=8, num_heads=6, act="mish", training=True)
+        loss = oracle.gen_loss(out, gt, 10, 1, casecade=True, freez=True)
+        loss.backward()
+    dt = (time.time() - t0) / nstep
     scale = (S / 128.0) ** 3
     res = {"value": scale / dt, "unit": "128^3-equivalent volumes/s (fwd+bwd)", "cores": threads, "kind": "port",
-           "sample": f"1 step (forward + GenLoss + backward, net_A frozen) of the fp32 CPU oracle on one {S}^3 volume: "
-                     f"{dt:.2f} s with {threads} torch threads on {cores} host cores; scaled by voxel count ({scale:.4f})",
-           "seconds": dt}
+           "sample": f"{nstep} step(s) (forward + GenLoss + backward, net_A frozen) of the fp32 CPU oracle on one {S}^3 volume: "
+                     f"{dt:.2f} s per step with {threads} torch threads on {cores} host cores; scaled by voxel count ({scale:.4f})",
+           "seconds": dt * nstep}
     # the oracle as the CHECKER of this very sample (rel-error on output [1][0] and dose-MAE in Gy): the HIP path runs
     # the same weights and input in both storage modes; nothing of this is timed or shipped
     try:
