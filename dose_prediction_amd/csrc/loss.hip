@@ -85,3 +85,34 @@ extern "C" int dp_dose_postprocess(const float* pred, const float* mask, float* 
   hipLaunchKernelGGL(k_dose_postprocess, dim3((unsigned)g), dim3(256), 0, STREAM, pred, mask, out, n, scale);
   DP_CHECK_LAUNCH("dose_postprocess"); return 0;
 }
+
+// Ground-truth pyramid of GenLoss (loss.py:56-66, 88-97): dose by F.interpolate(mode="trilinear", align_corners=True), the
+// possible-dose mask by mode="nearest-exact", both to (Do, Ho, Wo); fp32 single-channel volumes [N][D][H][W].
+__global__ void __launch_bounds__(256) k_resample_gt(const float* __restrict__ dose, const float* __restrict__ mask, float* __restrict__ odose,
+                                                     float* __restrict__ omask, int N, int Di, int Hi, int Wi, int Do, int Ho, int Wo) {
+  const int64_t total = (int64_t)N * Do * Ho * Wo;
+  const float sd = Do > 1 ? (float)(Di - 1) / (float)(Do - 1) : 0.f, sh = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f,
+              sw = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f;
+  const float nd = (float)Di / (float)Do, nh = (float)Hi / (float)Ho, nw = (float)Wi / (float)Wo;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t t = i; const int ow = (int)(t % Wo); t /= Wo; const int oh = (int)(t % Ho); t /= Ho; const int od = (int)(t % Do); const int n = (int)(t / Do);
+    const float* src = dose + (int64_t)n * Di * Hi * Wi;
+    const float fd = od * sd, fh = oh * sh, fw = ow * sw;
+    const int d0 = min((int)fd, Di - 1), h0 = min((int)fh, Hi - 1), w0 = min((int)fw, Wi - 1);
+    const int d1 = min(d0 + 1, Di - 1), h1 = min(h0 + 1, Hi - 1), w1 = min(w0 + 1, Wi - 1);
+    const float td = fd - d0, th = fh - h0, tw = fw - w0;
+    auto at = [&](int d, int h, int w) { return src[((int64_t)d * Hi + h) * Wi + w]; };
+    const float c00 = at(d0, h0, w0) * (1.f - tw) + at(d0, h0, w1) * tw, c01 = at(d0, h1, w0) * (1.f - tw) + at(d0, h1, w1) * tw;
+    const float c10 = at(d1, h0, w0) * (1.f - tw) + at(d1, h0, w1) * tw, c11 = at(d1, h1, w0) * (1.f - tw) + at(d1, h1, w1) * tw;
+    odose[i] = (c00 * (1.f - th) + c01 * th) * (1.f - td) + (c10 * (1.f - th) + c11 * th) * td;
+    const int md = min((int)floorf((od + 0.5f) * nd), Di - 1), mh = min((int)floorf((oh + 0.5f) * nh), Hi - 1), mw = min((int)floorf((ow + 0.5f) * nw), Wi - 1);
+    omask[i] = mask[(int64_t)n * Di * Hi * Wi + ((int64_t)md * Hi + mh) * Wi + mw];
+  }
+}
+extern "C" int dp_resample_gt(const float* dose, const float* mask, float* out_dose, float* out_mask, int N, int Di, int Hi, int Wi, int Do, int Ho,
+                              int Wo, void* stream) {
+  if (Do < 1 || Ho < 1 || Wo < 1) DP_FAIL("resample_gt: empty output");
+  int64_t total = (int64_t)N * Do * Ho * Wo, g = (total + 255) / 256; if (g > 16384) g = 16384;
+  hipLaunchKernelGGL(k_resample_gt, dim3((unsigned)g), dim3(256), 0, STREAM, dose, mask, out_dose, out_mask, N, Di, Hi, Wi, Do, Ho, Wo);
+  DP_CHECK_LAUNCH("resample_gt"); return 0;
+}

@@ -1,9 +1,21 @@
 """The reference's training losses (DosePrediction/Train/loss.py) on device for the benchmark / trainer harness
 (SURVEY.md section 8f row 1).  The masked means sum(|p-g|*m)/sum(m) are one fused HIP reduction each (ops.masked_l1:
-dp_masked_l1_fwd / _bwd) instead of boolean-mask indexing: same value, no dynamic shapes, no host synchronisation.  Only the
-ground-truth down-sampling (no gradient, a few MB) stays in torch."""
+dp_masked_l1_fwd / _bwd) instead of boolean-mask indexing: same value, no dynamic shapes, no host synchronisation; the
+ground-truth pyramid (trilinear align_corners dose, nearest-exact mask) is dp_resample_gt."""
 import torch
-import torch.nn.functional as F
+
+from . import _lib
+
+
+def _resample_gt(dose, mask, dims):
+    """(dose, mask) [B,1,D,H,W] fp32 -> the same at spatial size dims (loss.py:56-66)."""
+    B, _, D, H, W = dose.shape
+    dose, mask = dose.contiguous().float(), mask.contiguous().float()
+    od = torch.empty((B, 1) + tuple(dims), dtype=torch.float32, device=dose.device)
+    om = torch.empty_like(od)
+    _lib.call("dp_resample_gt", dose.data_ptr(), mask.data_ptr(), od.data_ptr(), om.data_ptr(), B, D, H, W, dims[0], dims[1], dims[2],
+              torch.cuda.current_stream().cuda_stream)
+    return od, om
 
 
 def _masked_l1(pred, gt, mask):
@@ -22,8 +34,7 @@ def gen_loss(predictions, gt, delta1=10.0, delta2=1.0, casecade=True, freez=True
     inter = predictions[1:]
     for i, pr in enumerate(inter, start=1):
         dims = tuple(s // (2 ** i) for s in size)
-        g = F.interpolate(dose, size=dims, mode="trilinear", align_corners=True)
-        m = F.interpolate(mask, size=dims, mode="nearest-exact")
+        g, m = _resample_gt(dose, mask, dims)
         l_ds = l_ds + _masked_l1(pr, g, m)
     l_ds = l_ds / max(1, len(inter))
     loss = delta1 * _masked_l1(predictions[0], dose, mask) + delta2 * l_ds

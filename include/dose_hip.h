@@ -219,6 +219,10 @@ int dp_masked_l1_fwd(const float* pred, const float* gt, const float* mask, int6
                      void* stream);
 int dp_masked_l1_bwd(const float* pred, const float* gt, const float* mask, const float* out3, const float* gup, float* gpred,
                      int64_t n, void* stream);
+/* Ground-truth pyramid of GenLoss (Train/loss.py:56-66, 88-97): dose resampled like F.interpolate(mode="trilinear",
+ * align_corners=True), mask like mode="nearest-exact"; fp32 single-channel volumes [N][D][H][W]. */
+int dp_resample_gt(const float* dose, const float* mask, float* out_dose, float* out_mask, int N, int Di, int Hi, int Wi, int Do, int Ho,
+                   int Wo, void* stream);
 /* out = (mask < 1 || pred < 0) ? 0 : scale * pred   (train_light_pyfer.py:166-172, scale = 70 Gy) */
 int dp_dose_postprocess(const float* pred, const float* mask, float* out, int64_t n, float scale, void* stream);
 
