@@ -147,7 +147,9 @@ __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, 
   const int v_lane = W16 ? (rg * RWO * 2 + (r >> 4)) * LP + (r & 15) : (rg * RWO) * LP + wc * 32 + r;
   // fast staging path: bf16, whole 16-channel chunks, 16-byte aligned voxel rows (block-uniform)
   constexpr int SU = STAGE_UNROLL;
-  const bool fast = SWZ && (g.Cin % 16 == 0) && (g.ldx % 8 == 0) && (((uintptr_t)x & 15) == 0) &&
+  // whole 16-channel chunks must EXIST in memory (row pitch), not be logical channels: channels >= Cin of a padded row meet
+  // zero packed weights (25 = 16 + 9 -> 16 + 16 channel rows of the first skip block take the fast path)
+  const bool fast = SWZ && (g.NCH * 16 <= (g.x2 ? g.csplit + g.ldx2 : g.ldx)) && (g.ldx % 8 == 0) && (((uintptr_t)x & 15) == 0) &&
                     (!g.x2 || ((g.csplit % 16 == 0) && (g.ldx2 % 8 == 0) && (((uintptr_t)g.x2 & 15) == 0))) &&
                     (int64_t)g.H * g.W * max(g.ldx, g.x2 ? g.ldx2 : 0) < (1ll << 30);
   const int lp_par = SWZ ? ((LP >> 3) & 1) : 0;
@@ -627,7 +629,9 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_tiled(const T* __restrict__ x,
 
   constexpr int XPV = C::XC / 8, GPV = C::GC / 8;
   // fast staging: bf16, whole channel tiles, 16-byte aligned voxel rows (block-uniform)
-  const bool fast = sizeof(T) == 2 && cbase_x + C::XC <= g.Cin && cbase_g + C::GC <= g.Cout && (g.ldx % 8 == 0) && (g.ldgy % 8 == 0) &&
+  // the channel tile must exist in memory (row pitch); gradients of channels >= Cin / Cout are computed and discarded below
+  const bool fast = sizeof(T) == 2 && cbase_x + C::XC <= (g.x2 ? g.csplit + g.ldx2 : g.ldx) && cbase_g + C::GC <= g.ldgy &&
+                    (g.ldx % 8 == 0) && (g.ldgy % 8 == 0) &&
                     (((uintptr_t)x & 15) == 0) && (((uintptr_t)gy & 15) == 0) &&
                     (!g.x2 || ((g.csplit % 8 == 0) && (g.ldx2 % 8 == 0) && (((uintptr_t)g.x2 & 15) == 0))) &&
                     (g.tiles_w == 1 || g.W % C::TW == 0) &&                   // one tile width per launch (piece coordinates are precomputed)
