@@ -461,6 +461,14 @@ extern "C" int dp_conv3d_tiled2(const void* x, int ldx, const void* x2, int ldx2
   g.x2 = x2; g.ldx2 = ldx2; g.csplit = csplit; g.y2 = y2; g.ldy2 = ldy2; g.osplit = osplit;
   int ygrid; bool w16; tiled_geometry(g, k, np, rw, nt, &ygrid, &w16);
   { const char* e = getenv("DP_DBG"); g.dbg = e ? atoi(e) : 0; }
+  if (getenv("DP_DEBUG_SLOW")) {      // report launches that will take the guarded (slow) staging path
+    int nch = (Cin + 15) / 16;
+    bool fast = dtype == DP_BF16 && nch * 16 <= (x2 ? csplit + ldx2 : ldx) && ldx % 8 == 0 && ((uintptr_t)x & 15) == 0 &&
+                (!x2 || (csplit % 16 == 0 && ldx2 % 8 == 0 && ((uintptr_t)x2 & 15) == 0));
+    bool wide = (ldy * 2) % 16 == 0 && ((uintptr_t)y & 15) == 0 && (!y2 || ((ldy2 * 2) % 16 == 0 && ((uintptr_t)y2 & 15) == 0 && osplit % 8 == 0));
+    if (!fast || !wide) fprintf(stderr, "[dp slow] conv3d_tiled k=%d Cin=%d Cout=%d %dx%dx%d ldx=%d ldx2=%d csplit=%d ldy=%d: staging %s, epilogue %s\n", k, Cin, Cout,
+                                D, H, W, ldx, ldx2, csplit, ldy, fast ? "fast" : "GUARDED", wide ? "wide" : "SCALAR");
+  }
   if (g.splitkd && !ws) DP_FAIL("conv3d_tiled: this shape needs the fp32 scratch (dp_conv3d_tiled_ws_elems)");
   if ((int64_t)N * D * g.tiles_h * g.tiles_w > 2000000000LL) DP_FAIL("conv3d_tiled: grid too large");
   int rc = 0;
@@ -900,6 +908,15 @@ extern "C" int dp_conv3d_wgrad_tiled2(const void* x, int ldx, const void* x2, in
   g.x2 = x2; g.ldx2 = ldx2; g.csplit = csplit;
   { const char* e = getenv("DP_DBG"); g.dbg = e ? atoi(e) : 0; }
   const int np = (Cout <= 16 && k > 1) ? 2 : 1, mp = (Cin <= 16 && k > 1) ? 2 : 1;
+  if (getenv("DP_DEBUG_SLOW")) {
+    int xc = mp == 2 ? 16 : 32, gc = np == 2 ? 16 : 32, tw = (dtype == DP_BF16 && mp == 2) ? 64 : 32;
+    int avail = x2 ? csplit + ldx2 : ldx;
+    bool fast = dtype == DP_BF16 && ((Cin + xc - 1) / xc) * xc <= avail && ((Cout + gc - 1) / gc) * gc <= ldgy && ldx % 8 == 0 && ldgy % 8 == 0 &&
+                ((uintptr_t)x & 15) == 0 && ((uintptr_t)gy & 15) == 0 && (!x2 || (csplit % 8 == 0 && ldx2 % 8 == 0 && ((uintptr_t)x2 & 15) == 0)) &&
+                (W <= tw || W % tw == 0);
+    if (!fast) fprintf(stderr, "[dp slow] wgrad_tiled k=%d Cin=%d Cout=%d %dx%dx%d ldx=%d ldx2=%d csplit=%d ldgy=%d: some channel tiles stage GUARDED\n", k, Cin, Cout,
+                       D, H, W, ldx, ldx2, csplit, ldgy);
+  }
   int rc = 0;
 #define GO(TT, KS_) do { if (np == 2 && mp == 2) rc = launch_wgt<TT, KS_, 2, 2>(x, gy, ws, g, s); else if (np == 2) rc = launch_wgt<TT, KS_, 2, 1>(x, gy, ws, g, s); \
                          else if (mp == 2) rc = launch_wgt<TT, KS_, 1, 2>(x, gy, ws, g, s); else rc = launch_wgt<TT, KS_, 1, 1>(x, gy, ws, g, s); } while (0)

@@ -3,6 +3,7 @@
 // All are HBM-bound row streams over NDHWC voxel rows: each thread owns one 8-channel (16 B bf16) chunk of a row,
 // keeps its per-channel constants in registers and walks the block's voxel range.
 #include "common.h"
+#include <stdlib.h>
 
 #define STREAM ((hipStream_t)stream)
 #define NT 256
@@ -330,7 +331,9 @@ __global__ void __launch_bounds__(NT) k_norm_act_bwd_apply(NormArgs a) {
 
 static inline int norm_fast(int C, int ldx, const void* x, int ldg, const void* gy, int ldr, const void* res, int ldy, const void* y, int ldgr, const void* gr) {
   auto ok = [](int ld, const void* p) { return p == nullptr || (ld % 8 == 0 && aligned16(p)); };
-  return (C % 8 == 0) && ok(ldx, x) && ok(ldg, gy) && ok(ldr, res) && ok(ldy, y) && ok(ldgr, gr);
+  const int f = (C % 8 == 0) && ok(ldx, x) && ok(ldg, gy) && ok(ldr, res) && ok(ldy, y) && ok(ldgr, gr);
+  if (!f && getenv("DP_DEBUG_SLOW")) fprintf(stderr, "[dp slow] norm row stream C=%d ldx=%d ldg=%d ldr=%d ldy=%d: guarded 8-element accesses\n", C, ldx, ldg, ldr, ldy);
+  return f;
 }
 
 extern "C" int dp_norm_act_fwd(const void* x, int ldx, const float* mean, const float* rstd, int ssn, const float* gamma, const float* beta,
