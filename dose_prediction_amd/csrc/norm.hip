@@ -87,12 +87,13 @@ __global__ void __launch_bounds__(NT) k_stats_partial(const T* __restrict__ x, i
   int64_t vs = v0 + g.r0;
   if (g.active && fast) {
     const T* xb = x + (int64_t)n * V * ld + g.cg * 8;
-    for (; vs + (RU - 1) * (int64_t)g.rpi < v1; vs += RU * g.rpi) {
-      float t[RU][8];
+    constexpr int RUS = 8;       // a pure read stream: 8 x 16 bytes in flight per thread
+    for (; vs + (RUS - 1) * (int64_t)g.rpi < v1; vs += RUS * g.rpi) {
+      float t[RUS][8];
 #pragma unroll
-      for (int u = 0; u < RU; u++) ld8(xb + (vs + u * g.rpi) * ld, t[u]);
+      for (int u = 0; u < RUS; u++) ld8(xb + (vs + u * g.rpi) * ld, t[u]);
 #pragma unroll
-      for (int u = 0; u < RU; u++)
+      for (int u = 0; u < RUS; u++)
 #pragma unroll
         for (int i = 0; i < 8; i++) { s1[i] += t[u][i]; s2[i] += t[u][i] * t[u][i]; }
     }

@@ -363,7 +363,7 @@ class Conv3d(torch.autograd.Function):
                 _lib.call("dp_conv3d", _p(gy), ldg, _p(wt), 0, _p(gx), cx, N, Do, Ho, Wo, Di, Hi, Wi, cout, cin,
                           k, stride, pad, dil, 1, dtc, _stream())
         wse = _lib.lib().dp_pointwise_wgrad_ws_elems(grows, cin, cout) if (
-            k == 1 and stride == 1 and pad == 0 and ctx.needs_input_grad[1] and grows >= 32768 and cout * cin <= 512) else 0
+            k == 1 and stride == 1 and pad == 0 and ctx.needs_input_grad[1] and grows >= 32768 and cout * cin <= 256) else 0
         if wse:
             # heads: a handful of channels over millions of voxels -> one HBM row stream gives dW and db together
             gw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)

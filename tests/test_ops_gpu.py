@@ -85,7 +85,7 @@ DTYPES = [torch.float32, torch.bfloat16]
     (1, 16, 1, 32, 32, 40, 1, 1, 0, 1, True),     # deep-supervision head at >= 32768 voxels: row-stream forward + wgrad
     (2, 32, 3, 16, 32, 40, 1, 1, 0, 1, True),
     (1, 64, 2, 16, 32, 64, 1, 1, 0, 1, False),
-    (1, 32, 16, 32, 32, 40, 1, 1, 0, 1, True),    # conv_3_1 mixer: 16 x 32 accumulators per row stream
+    (1, 32, 16, 32, 32, 40, 1, 1, 0, 1, True),    # conv_3_1 mixer (tiled k = 1 weight gradient)
     (1, 25, 16, 32, 32, 40, 1, 1, 0, 1, True),
 ])
 def test_conv3d(cfg, dtype):
