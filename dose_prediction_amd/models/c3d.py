@@ -9,9 +9,10 @@ from ..blocks import SingleConv, UpConv
 
 def to_ndhwc(x):
     """Boundary conversion: the trainer's NCDHW fp32 tensor (network_trainer.py:230) -> NDHWC compute dtype,
-    channels zero-padded to a multiple of 8 (16-byte voxel rows)."""
+    channels zero-padded to a multiple of 16 (whole 16-channel chunks for the tiled convolution's fast staging path; a
+    1-channel CT padded to 8 sent OAR-TRANSEG's first 3x3x3 layer through the guarded loads)."""
     c = x.shape[1]
-    return ops.ToNDHWC.apply(x, (c + 7) // 8 * 8, config.compute_dtype())
+    return ops.ToNDHWC.apply(x, (c + 15) // 16 * 16, config.compute_dtype())
 
 
 def from_ndhwc(x):
