@@ -18,8 +18,8 @@ __global__ void __launch_bounds__(256) k_gemm_nt(const T* __restrict__ A, int64_
                                                  float alpha, int out_f32, int splitk) {
   constexpr int BM = 32 * TI, BN = 32 * TJ, WMR = 16 * TI, WNR = 16 * TJ, LDP = BK + 8, CPR = BK / 8;   // CPR: 16-byte chunks per row
   constexpr int UA = BM * CPR / 256 > 0 ? BM * CPR / 256 : 1, UB = BN * CPR / 256 > 0 ? BN * CPR / 256 : 1;   // chunks per thread
-  __shared__ __attribute__((aligned(16))) T As[BM * LDP];
-  __shared__ __attribute__((aligned(16))) T Bs[BN * LDP];
+  __shared__ __attribute__((aligned(16))) T smem[(BM + BN) * LDP];
+  T* const As = smem; T* const Bs = smem + BM * LDP;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
   const int r = lane & 15, q = lane >> 4;
   const int m0 = blockIdx.x * (32 * TI), n0 = blockIdx.y * (32 * TJ);
@@ -39,14 +39,21 @@ __global__ void __launch_bounds__(256) k_gemm_nt(const T* __restrict__ A, int64_
   const int imax = min(TI, (M - m0 - wm * WMR + 15) / 16), jmax = min(TJ, (N - n0 - wn * WNR + 15) / 16);
   Frag8<T> ra[UA], rb[UB];
   // interior tiles of aligned operands: straight-line 16-byte loads (no per-chunk guards -> all of a stage's loads are in flight together)
-  const bool fast = (BM * CPR) % 256 == 0 && (BN * CPR) % 256 == 0 && m0 + BM <= M && n0 + BN <= N && K % BK == 0 &&
-                    ((lda | ldb) & 7) == 0 && (((uintptr_t)A | (uintptr_t)B) & 15) == 0 && ((sa0 | sa1 | sb0 | sb1) & 7) == 0;
+  const bool fast = (BM * CPR) % 256 == 0 && (BN * CPR) % 256 == 0 && 256 % CPR == 0 && m0 + BM <= M && n0 + BN <= N && K % BK == 0 &&
+                    ((lda | ldb) & 7) == 0 && (((uintptr_t)A | (uintptr_t)B) & 15) == 0 && ((sa0 | sa1 | sb0 | sb1) & 7) == 0 &&
+                    lda * BM < (1ll << 30) && ldb * BN < (1ll << 30);
+  // fast path addressing: a wave-uniform 64-bit tile base per K step + 32-bit lane offsets fixed for the launch (issuing the 8
+  // loads of a step used to cost ~500 cycles of 64-bit address arithmetic, a quarter of the step)
+  const int g_row0 = tid / CPR, g_kc0 = (tid % CPR) * 8, g_rstep = 256 / CPR;
+  const int offA = g_row0 * (int)lda + g_kc0, offB = g_row0 * (int)ldb + g_kc0, stepA = g_rstep * (int)lda, stepB = g_rstep * (int)ldb;
+  const T* const tileA = A + (int64_t)m0 * lda; const T* const tileB = B + (int64_t)n0 * ldb;
   auto gload = [&](int kt) {
     if (fast) {
+      const T* ab = tileA + kt * BK; const T* bb = tileB + kt * BK;
 #pragma unroll
-      for (int u = 0; u < UA; u++) { int c = tid + u * 256, row = c / CPR, kc = c % CPR; ra[u] = frag_ld_lds(A + (int64_t)(m0 + row) * lda + kt * BK + kc * 8); }
+      for (int u = 0; u < UA; u++) ra[u] = frag_ld_lds(ab + (offA + u * stepA));
 #pragma unroll
-      for (int u = 0; u < UB; u++) { int c = tid + u * 256, row = c / CPR, kc = c % CPR; rb[u] = frag_ld_lds(B + (int64_t)(n0 + row) * ldb + kt * BK + kc * 8); }
+      for (int u = 0; u < UB; u++) rb[u] = frag_ld_lds(bb + (offB + u * stepB));
       return;
     }
 #pragma unroll
@@ -79,23 +86,62 @@ __global__ void __launch_bounds__(256) k_gemm_nt(const T* __restrict__ A, int64_
     }
     __syncthreads();
     if (kt + 1 < kt1) gload(kt + 1);
+    // all fragment reads of the step are issued before its first MFMA: one LDS latency per step instead of one per 32-deep
+    // sub-step (reads + MFMAs took ~1000 cycles for 256 cycles of MFMA work)
+    constexpr int NSUB = BK / 32;
+    Frag8<T> fa[NSUB][TI], fb[NSUB][TJ];
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 32) {
-      Frag8<T> fa[TI], fb[TJ];
+    for (int ss = 0; ss < NSUB; ss++) {
 #pragma unroll
-      for (int i = 0; i < TI; i++) fa[i] = frag_ld_lds(As + (wm * WMR + i * 16 + r) * LDP + kk + q * 8);
+      for (int i = 0; i < TI; i++) fa[ss][i] = frag_ld_lds(As + (wm * WMR + i * 16 + r) * LDP + ss * 32 + q * 8);
 #pragma unroll
-      for (int j = 0; j < TJ; j++) fb[j] = frag_ld_lds(Bs + (wn * WNR + j * 16 + r) * LDP + kk + q * 8);
+      for (int j = 0; j < TJ; j++) fb[ss][j] = frag_ld_lds(Bs + (wn * WNR + j * 16 + r) * LDP + ss * 32 + q * 8);
+    }
+#pragma unroll
+    for (int ss = 0; ss < NSUB; ss++)
 #pragma unroll
       for (int i = 0; i < TI; i++) {
         if (i >= imax) continue;      // wave-uniform: skip MFMA tiles that lie wholly outside M x N (skinny problems)
 #pragma unroll
-        for (int j = 0; j < TJ; j++) if (j < jmax) acc[i][j] = mma16(fa[i], fb[j], acc[i][j]);
+        for (int j = 0; j < TJ; j++) if (j < jmax) acc[i][j] = mma16(fa[ss][i], fb[ss][j], acc[i][j]);
       }
-    }
   }
   // epilogue: C/D layout col = lane&15, row = 4*(lane>>4) + reg
   const int64_t coff = b0 * sc0 + b1 * sc1;
+  // Interior tiles with a T output: transpose through LDS and write whole 16-byte chunks (2-byte scattered stores took
+  // ~5800 cycles -- 30 % of a 1024 x 768 x 768 token GEMM).
+  constexpr int CP = BN + 8;                                    // padded tile pitch (elements): 16-byte rows, no 4-way bank conflict
+  constexpr int NPASS = (BM * CP <= (BM + BN) * LDP) ? 1 : 2;   // the two wave rows take turns when the whole tile does not fit
+  constexpr bool CAN_STAGE = sizeof(T) == 2 && (BM / NPASS) * CP <= (BM + BN) * LDP;
+  if (CAN_STAGE && !out_f32 && splitk == 1 && m0 + BM <= M && n0 + BN <= N && (ldc & 7) == 0 && ((sc0 | sc1) & 7) == 0 &&
+      (((uintptr_t)Cv) & 15) == 0) {
+    T* tile = smem;
+    T* Cb = (T*)Cv + coff + (int64_t)m0 * ldc + n0;
+    constexpr int PR = BM / NPASS;                              // rows per pass
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ps++) {
+      __syncthreads();                                          // operand tiles / previous pass no longer needed
+      if (NPASS == 1 || wm == ps) {
+        const int rbase = NPASS == 1 ? wm * WMR : 0;
+#pragma unroll
+        for (int j = 0; j < TJ; j++) {
+          const int col = wn * WNR + j * 16 + r;
+          const float bv = bias ? bias[n0 + col] : 0.f;
+#pragma unroll
+          for (int i = 0; i < TI; i++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) st_f(tile + (rbase + i * 16 + q * 4 + e) * CP + col, alpha * acc[i][j][e] + bv);
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < PR * BN / 8 / 256; u++) {
+        const int c = tid + u * 256, row = c / (BN / 8), cc = (c % (BN / 8)) * 8;
+        *(v4u*)(Cb + (int64_t)(ps * PR + row) * ldc + cc) = *(const v4u*)(tile + row * CP + cc);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < TJ; j++) {
     int col = n0 + wn * WNR + j * 16 + r;
