@@ -8,6 +8,12 @@
 #define STREAM ((hipStream_t)stream)
 // BK: k-depth of one LDS stage (32 or 64).  LDP = padded LDS row (elements): keeps 16-B alignment, breaks the power-of-two stride.
 
+#ifdef DP_GEMM_PROBE
+__device__ unsigned long long dp_gemm_probe[40];      // tools/gemm_probe.hip: s_memtime at block start, every K step, phases of step 2, loop end, block end
+#define PROBE(i) do { if (probe) dp_gemm_probe[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PROBE(i) do { } while (0)
+#endif
 // TI x TJ = MFMA tiles per wave in M / N: block tile = (2*TI*16) x (2*TJ*16): 128x128 (4,4) for big problems, 64x64 (2,2)
 // when a 128x128 grid would leave most of the 256 CUs idle (ViT token matrices: M = B*512).
 template <typename T, int TI, int TJ, int BK>
@@ -71,9 +77,15 @@ __global__ void __launch_bounds__(256) k_gemm_nt(const T* __restrict__ A, int64_
       rb[u] = (row < BN && gn < N && nv > 0) ? frag_load(B + (int64_t)gn * ldb + k, nv) : frag_zero<T>();
     }
   };
+#ifdef DP_GEMM_PROBE
+  const bool probe = blockIdx.x == gridDim.x / 2 && blockIdx.y == gridDim.y / 2 && blockIdx.z == 0 && tid == 0;
+#endif
+  PROBE(0);
   if (kt0 < kt1) gload(kt0);
   for (int kt = kt0; kt < kt1; kt++) {
+    if (kt - kt0 < 30) PROBE(1 + (kt - kt0));
     __syncthreads();
+    if (kt - kt0 == 2) PROBE(33);
 #pragma unroll
     for (int u = 0; u < UA; u++) {
       int c = tid + u * 256, row = c / CPR, kc = c % CPR;
@@ -85,7 +97,9 @@ __global__ void __launch_bounds__(256) k_gemm_nt(const T* __restrict__ A, int64_
       if (row < BN) frag_st_lds(Bs + row * LDP + kc * 8, rb[u]);
     }
     __syncthreads();
+    if (kt - kt0 == 2) PROBE(34);
     if (kt + 1 < kt1) gload(kt + 1);
+    if (kt - kt0 == 2) PROBE(35);
     // all fragment reads of the step are issued before its first MFMA: one LDS latency per step instead of one per 32-deep
     // sub-step (reads + MFMAs took ~1000 cycles for 256 cycles of MFMA work)
     constexpr int NSUB = BK / 32;
@@ -106,6 +120,7 @@ __global__ void __launch_bounds__(256) k_gemm_nt(const T* __restrict__ A, int64_
         for (int j = 0; j < TJ; j++) if (j < jmax) acc[i][j] = mma16(fa[ss][i], fb[ss][j], acc[i][j]);
       }
   }
+  PROBE(31);
   // epilogue: C/D layout col = lane&15, row = 4*(lane>>4) + reg
   const int64_t coff = b0 * sc0 + b1 * sc1;
   // Interior tiles with a T output: transpose through LDS and write whole 16-byte chunks (2-byte scattered stores took
@@ -140,6 +155,7 @@ __global__ void __launch_bounds__(256) k_gemm_nt(const T* __restrict__ A, int64_
         *(v4u*)(Cb + (int64_t)(ps * PR + row) * ldc + cc) = *(const v4u*)(tile + row * CP + cc);
       }
     }
+    PROBE(32);
     return;
   }
 #pragma unroll
