@@ -119,41 +119,9 @@ __global__ void k_patchify(const T* __restrict__ x, T* __restrict__ out, int B, 
     else { T* aw = const_cast<T*>(a); for (int c = 0; c < C; c++) aw[c] = o[c]; }
   }
 }
-// Forward patchify, output-centric: one aligned 16-byte chunk (8 consecutive elements of the token matrix) per thread, gathered
-// with scalar reads of the (cached) voxel rows.  With C = 25 the voxel-per-thread kernel above wrote 50-byte runs with 2-byte
-// stores at a 50-byte lane stride: 1.08 GB of partial-line writes for a 0.21 GB matrix.
-template <typename T>
-__global__ void k_patchify_chunks(const T* __restrict__ x, T* __restrict__ out, int B, int S0, int S1, int S2, int C, int ld, int p) {
-  const int f1 = S1 / p, f2 = S2 / p;
-  const int64_t ntok = (int64_t)(S0 / p) * f1 * f2, p3n = (int64_t)p * p * p, nchunk = (int64_t)B * ntok * p3n * C / 8;
-  for (int64_t ch = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; ch < nchunk; ch += (int64_t)gridDim.x * blockDim.x) {
-    int64_t i = (ch * 8) / C; int c = (int)(ch * 8 - i * C);
-    __attribute__((aligned(16))) T v[8];
-    const T* a = nullptr;
-    bool fresh = true;
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-      if (fresh) {
-        const int64_t pp = i % p3n, bt = i / p3n, tok = bt % ntok, b = bt / ntok;
-        const int p3 = (int)(pp % p), p2 = (int)((pp / p) % p), p1 = (int)(pp / ((int64_t)p * p));
-        const int t2 = (int)(tok % f2), t1 = (int)((tok / f2) % f1), t0 = (int)(tok / ((int64_t)f2 * f1));
-        a = x + ((((int64_t)b * S0 + t0 * p + p1) * S1 + t1 * p + p2) * S2 + t2 * p + p3) * ld;
-        fresh = false;
-      }
-      v[k] = a[c];
-      if (++c == C) { c = 0; i++; fresh = true; }
-    }
-    *(v4u*)(out + ch * 8) = *(const v4u*)v;
-  }
-}
 extern "C" int dp_patchify(const void* x, void* out, int B, int S0, int S1, int S2, int C, int ld, int p, int dtype, void* stream) {
   if (S0 % p || S1 % p || S2 % p) DP_FAIL("patchify: size not divisible by patch");
   int64_t total = (int64_t)B * S0 * S1 * S2;
-  if (dtype == DP_BF16 && (total * C) % 8 == 0 && (((uintptr_t)out) & 15) == 0) {
-    hipLaunchKernelGGL(k_patchify_chunks<bf16_t>, dim3(grid_for(total * C / 8, 256, 256 * 64)), dim3(256), 0, STREAM, (const bf16_t*)x, (bf16_t*)out,
-                       B, S0, S1, S2, C, ld, p);
-    DP_CHECK_LAUNCH("patchify"); return 0;
-  }
   DP_DISPATCH(dtype, hipLaunchKernelGGL((k_patchify<T, false>), dim3(grid_for(total, 256)), dim3(256), 0, STREAM, (const T*)x, (T*)out, B, S0, S1, S2, C, ld, p));
   DP_CHECK_LAUNCH("patchify"); return 0;
 }
