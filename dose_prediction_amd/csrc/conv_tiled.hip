@@ -891,7 +891,9 @@ static int launch_wgt(const void* x, const void* gy, float* ws, WgtGeom g, hipSt
   }
   int want = (ncu * occ) / (KS * zdim); if (want < 1) want = 1;
   int ydim = units < want ? units : want;
-  if (ydim >= 8) ydim &= ~7;                                       // multiple of 8: XCD-aware decode in the kernel
+  // multiple of 8 => XCD-aware decode in the kernel; only when rounding down idles <= 5 % of the block slots (the locality is
+  // worth a few per cent, an empty eighth of the chip is not)
+  if (ydim >= 8 && (ydim & 7) * 20 <= ydim) ydim &= ~7;
   g.ydim = ydim; g.zdim = zdim;
   dim3 grid(KS * ydim * zdim, 1, 1);
   hipLaunchKernelGGL(kern, grid, dim3(256), C::SMEM, s, (const T*)x, (const T*)gy, ws, g);
