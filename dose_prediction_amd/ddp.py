@@ -53,6 +53,10 @@ class GradAllReducer:
             for p, off, n in b:
                 self.where[p] = (bi, off, n)
         self.chunk = cap
+        # a bucket that is ONE large tensor (the 78.6 M-element patch-embedding weight) is reduced in place on its gradient: no
+        # pack / unpack copies on the tail of the backward pass
+        self.inplace = [len(b) == 1 and b[0][2] >= cap for b in self.buckets]
+        self.grad_ref = [None] * len(self.buckets)
         self._reset()
         self.handles = []
         for p in self.params:
@@ -73,6 +77,8 @@ class GradAllReducer:
 
     def _launch(self, bi):
         flat = self.flat[bi]
+        if self.inplace[bi] and self.grad_ref[bi] is not None:
+            flat = self.grad_ref[bi]
         self.launched[bi] = True
         n = flat.numel()
         for c0 in range(0, n, self.chunk):
@@ -87,7 +93,10 @@ class GradAllReducer:
             self.callback_queued = True
             torch.autograd.Variable._execution_engine.queue_callback(self._finish)
         bi, off, n = self.where[p]
-        self.flat[bi][off:off + n].copy_(p.grad.reshape(-1))
+        if self.inplace[bi] and p.grad.is_contiguous():
+            self.grad_ref[bi] = p.grad.view(-1)
+        else:
+            self.flat[bi][off:off + n].copy_(p.grad.reshape(-1))
         self.ready_mark(p)
         self.pending[bi] -= 1
         # launch in bucket order so every rank issues the same collective sequence
@@ -116,9 +125,12 @@ class GradAllReducer:
                 w.wait()
         for bi, b in enumerate(self.buckets):
             for p, off, n in b:
-                if getattr(p, "_dp_has_grad", False):
-                    p.grad.copy_(self.flat[bi][off:off + n].view_as(p.grad))
+                if getattr(p, "_dp_has_grad", False) and self.grad_ref[bi] is None:
+                    # the averaged gradient stays in the bucket: .grad becomes a view of it (no unpack copy); the optimizer
+                    # consumes it before the next backward pass refills the bucket
+                    p.grad = self.flat[bi][off:off + n].view_as(p)
                 p._dp_has_grad = False
+            self.grad_ref[bi] = None
         self._reset()
 
 
