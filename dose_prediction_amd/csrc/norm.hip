@@ -207,7 +207,7 @@ __global__ void __launch_bounds__(NT) k_norm_act_fwd(NormArgs a) {
 #pragma unroll
       for (int u = 0; u < RU; u++) {
 #pragma unroll
-        for (int i = 0; i < 8; i++) { float z = t[u][i] * sc[i] + sh[i]; if (res) z += rr[u][i]; t[u][i] = act_fwd(z, ACT); }
+        for (int i = 0; i < 8; i++) { float z = t[u][i] * sc[i] + sh[i]; if (res) z += rr[u][i]; t[u][i] = (ACT == DP_ACT_MISH && sizeof(T) == 2) ? mish_fwd_fast(z) : act_fwd(z, ACT); }
         st8(y + (nb + vs + u * g.rpi) * a.ldy + g.cg * 8, t[u]);
       }
     }
@@ -218,7 +218,7 @@ __global__ void __launch_bounds__(NT) k_norm_act_fwd(NormArgs a) {
     unpack8<T>(x + row * a.ldx + g.cg * 8, g.nv, t);
     if (res) unpack8<T>(res + row * a.ldr + g.cg * 8, g.nv, rr);
 #pragma unroll
-    for (int i = 0; i < 8; i++) { float z = t[i] * sc[i] + sh[i]; if (res) z += rr[i]; t[i] = act_fwd(z, ACT); }
+    for (int i = 0; i < 8; i++) { float z = t[i] * sc[i] + sh[i]; if (res) z += rr[i]; t[i] = (ACT == DP_ACT_MISH && sizeof(T) == 2) ? mish_fwd_fast(z) : act_fwd(z, ACT); }
     pack8(y + row * a.ldy + g.cg * 8, g.nv, t);
   }
 }
@@ -238,7 +238,7 @@ __global__ void __launch_bounds__(NT) k_norm_act_bwd_partial(NormArgs a) {
     for (int i = 0; i < 8; i++) {
       float xh = (t[i] - k.m[i]) * k.r[i];
       float z = xh * k.ga[i] + k.be[i]; if (res) z += rr[i];
-      float gg = d[i] * act_bwd(z, ACT);
+      float gg = d[i] * ((ACT == DP_ACT_MISH && sizeof(T) == 2) ? mish_bwd_fast(z) : act_bwd(z, ACT));
       s1[i] += gg; s2[i] += gg * xh;
     }
   };
@@ -287,7 +287,7 @@ __global__ void __launch_bounds__(NT) k_norm_act_bwd_apply(NormArgs a) {
     for (int i = 0; i < 8; i++) {
       float xh = (t[i] - k.m[i]) * k.r[i];
       float z = xh * k.ga[i] + k.be[i]; if (res) z += rr[i];
-      gg[i] = d[i] * act_bwd(z, ACT);
+      gg[i] = d[i] * ((ACT == DP_ACT_MISH && sizeof(T) == 2) ? mish_bwd_fast(z) : act_bwd(z, ACT));
       t[i] = k.ga[i] * k.r[i] * (gg[i] - a1[i] - xh * a2[i]);
     }
   };
