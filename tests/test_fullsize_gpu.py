@@ -143,3 +143,28 @@ def test_pyfer_training_steps_128_bf16():
         assert all(h == h and h < 1e4 for h in hist) and hist[-1] < hist[0], hist
     finally:
         dose_prediction_amd.set_compute_dtype(torch.float32)
+
+
+def test_pyfer_noncubic_192x192x128_step():
+    """BASELINE.json configs[4] geometry (192 x 192 x 128, 1 152 tokens, batch 1 per GPU) in bf16: one training step runs, every
+    output has the pyramid shape of dose_pyfer.py:360 and all gradients are finite (the reference's GenLoss.downSample assumes a cube;
+    the device loss resamples each axis on its own)."""
+    import dose_prediction_amd
+    from dose_prediction_amd import losses, synth
+    from dose_prediction_amd.models import dose_pyfer
+    dev = _dev()
+    dose_prediction_amd.set_compute_dtype(torch.bfloat16)
+    try:
+        torch.manual_seed(1)
+        sz = (192, 192, 128)
+        net = dose_pyfer.Model(in_ch=9, out_ch=1, list_ch_A=[-1, 16, 32, 64, 128, 256], feature_size=16, img_size=sz, num_layers=8,
+                               num_heads=6, act="mish").to(dev).train()
+        x, gt = synth.dose_input(1, sz).to(dev), synth.dose_target(1, sz).to(dev)
+        out = net(x)
+        assert [tuple(o.shape[2:]) for o in out[1]] == [sz, (96, 96, 64), (48, 48, 32), (24, 24, 16)] and out[0].shape == (1, 1) + sz
+        loss = losses.gen_loss(out, gt, 10.0, 1.0, casecade=True, freez=False)
+        loss.backward()
+        assert loss.item() == loss.item()
+        assert all(torch.isfinite(p.grad).all() for p in net.parameters() if p.grad is not None)
+    finally:
+        dose_prediction_amd.set_compute_dtype(torch.float32)
