@@ -368,8 +368,9 @@ __global__ void __launch_bounds__(256) k_norm_bwd_finalize(const float* __restri
   if (threadIdx.x >= cpb || c >= C) return;
   s1o[gidx * C + c] = (float)s1; s2o[gidx * C + c] = (float)s2;
   // dgamma / dbeta are sums over ALL samples: one add per statistics group (N is small)
-  if (dgamma) atomicAdd(dgamma + c, (float)s2);
-  if (dbeta) atomicAdd(dbeta + c, (float)s1);
+  // batch mode has ONE statistics group: its sums ARE dgamma / dbeta (plain store: the caller need not zero them)
+  if (dgamma) { if (batch_mode) dgamma[c] = (float)s2; else atomicAdd(dgamma + c, (float)s2); }
+  if (dbeta) { if (batch_mode) dbeta[c] = (float)s1; else atomicAdd(dbeta + c, (float)s1); }
 }
 extern "C" int dp_norm_bwd_finalize(const float* part, int N, int nblk, int C, int batch_mode, float* s1, float* s2, float* dgamma, float* dbeta, void* stream) {
   int cpb = pick_cpb(C);

@@ -191,7 +191,7 @@ def gemm_nt(A, B, out, bias=None, alpha=1.0, M=None, N=None, K=None, batch=(1, 1
 
 
 def colsum_into(gy2d_rows, ld, rows, C, db, dtype_code):
-    """db[c] += sum_rows gy[row][c]  (stats partial + finalize; no torch arithmetic)."""
+    """db[c] = sum_rows gy[row][c]  (stats partial + batch-mode finalize, which overwrites: db need not be initialised)."""
     L = _lib.lib()
     nblk = L.dp_stats_nblk(rows)
     es = 4 if dtype_code == 0 else 2
@@ -394,7 +394,7 @@ class Conv3d(torch.autograd.Function):
                 wgrad(x, ldx, gy, ldg, gw, (N, Di, Hi, Wi, Do, Ho, Wo), cin, cout, k, stride, pad, dil, 1, 0,
                       cin * taps, taps, 1, dtc)
         if has_bias and ctx.needs_input_grad[2]:
-            gb = torch.zeros((cout,), dtype=torch.float32, device=x.device)
+            gb = torch.empty((cout,), dtype=torch.float32, device=x.device)
             colsum_into(_p(gy), ldg, grows, cout, gb, dtc)
         return gx, gw, gb, None, None, None
 
@@ -454,7 +454,7 @@ class Conv3dCat(torch.autograd.Function):
             _lib.call("dp_conv3d_wgrad_tiled2", _p(xa), lda, _p(xb), ldb, ca, _p(gy), ldg, _p(gw), _p(ws), N, D, H, W, cin, cout, k,
                       cin * taps, taps, 1, dtc, _stream())
         if has_bias and ctx.needs_input_grad[3]:
-            gb = torch.zeros((cout,), dtype=torch.float32, device=xa.device)
+            gb = torch.empty((cout,), dtype=torch.float32, device=xa.device)
             colsum_into(_p(gy), ldg, grows, cout, gb, dtc)
         return gxa, gxb, gw, gb, None
 
@@ -586,7 +586,7 @@ class Linear(torch.autograd.Function):
                 gw = torch.zeros(weight.shape, dtype=torch.float32, device=x.device)
                 wgrad(x, ldx, gy, ldg, gw, (1, 1, 1, rows, 1, 1, rows), K, nout, 1, 1, 0, 1, 0, 0, K, 1, 0, dtc)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = torch.zeros((nout,), dtype=torch.float32, device=x.device)
+            gb = torch.empty((nout,), dtype=torch.float32, device=x.device)
             colsum_into(_p(gy), ldg, rows, nout, gb, dtc)
         return gx, gw, gb, None
 
@@ -648,8 +648,9 @@ def _norm_backward(x, mean, rstd, gamma, beta, res, kind, act, use_stats, ssn, g
     groups = N if kind == "instance" else 1
     s1 = torch.empty((groups, C), dtype=torch.float32, device=dev)
     s2 = torch.empty((groups, C), dtype=torch.float32, device=dev)
-    dgamma = torch.zeros((C,), dtype=torch.float32, device=dev) if need_gb else None
-    dbeta = torch.zeros((C,), dtype=torch.float32, device=dev) if need_gb else None
+    mk = torch.zeros if kind == "instance" else torch.empty          # instance mode accumulates over samples, batch mode overwrites
+    dgamma = mk((C,), dtype=torch.float32, device=dev) if need_gb else None
+    dbeta = mk((C,), dtype=torch.float32, device=dev) if need_gb else None
     if use_stats or need_gb:
         _lib.call("dp_norm_act_bwd_partial", _p(x), ldx, gy_ptr, ldg, _p(mean), _p(rstd), ssn, _p(g32), _p(b32), _p(res), ldr,
                   ACT[act], N, V, C, _p(part), dtc, _stream())
@@ -761,8 +762,8 @@ class LayerNorm(torch.autograd.Function):
         C = x.shape[-1]
         rows = x.numel() // C
         gx = torch.empty_like(x)
-        dg = torch.zeros((C,), dtype=torch.float32, device=x.device)
-        db = torch.zeros((C,), dtype=torch.float32, device=x.device)
+        dgb = torch.zeros((2, C), dtype=torch.float32, device=x.device)      # one fill for both (accumulated by atomics)
+        dg, db = dgb[0], dgb[1]
         _lib.call("dp_layernorm_bwd", _p(x), _p(gy), _p(gamma.detach()), _p(mean), _p(rstd), _p(gx), _p(dg), _p(db), rows, C,
                   _dt(x), _stream())
         return gx, dg, db, None

@@ -91,7 +91,8 @@ int dp_norm_act_fwd(const void* x, int ldx, const float* mean, const float* rstd
 int dp_norm_act_bwd_partial(const void* x, int ldx, const void* gy, int ldgy, const float* mean, const float* rstd,
                             int stat_stride_n, const float* gamma, const float* beta, const void* res, int ldr, int act,
                             int N, int64_t V, int C, float* part, int dtype, void* stream);
-/* combine partials: s1,s2 float [groups][C] (groups = N instance, 1 batch); dgamma/dbeta (+=) if non-NULL. */
+/* combine partials: s1,s2 float [groups][C] (groups = N instance, 1 batch); dgamma/dbeta if non-NULL: accumulated (+=, one
+ * add per sample) in instance mode, OVERWRITTEN in batch mode (one statistics group: no zero-fill needed). */
 int dp_norm_bwd_finalize(const float* part, int N, int nblk, int C, int batch_mode, float* s1, float* s2,
                          float* dgamma, float* dbeta, void* stream);
 /* backward pass 2: gx = gamma*rstd*(g - s1/M - xhat*s2/M) (use_stats) or gamma*rstd*g (eval BN);
