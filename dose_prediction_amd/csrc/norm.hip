@@ -121,10 +121,18 @@ __device__ __forceinline__ void combine_partials(const float* __restrict__ part,
   double a1 = 0, a2 = 0;
   if (c < C) {
     const int64_t total = (int64_t)(n1 - n0) * nblk;
-    for (int64_t b = r; b < total; b += rows) {
-      const float* p = part + ((int64_t)n0 * nblk + b) * 2 * C;
-      a1 += p[c]; a2 += p[C + c];
+    const float* p0 = part + (int64_t)n0 * nblk * 2 * C + c;
+    int64_t b = r;
+    // 8 partial rows per trip with all 16 loads issued before the first add: one thread walks up to 64 rows, and a load -> add
+    // chain paid one L2 round trip per row (these 10-us launches were almost pure latency)
+    for (; b + 7 * (int64_t)rows < total; b += 8 * (int64_t)rows) {
+      float u[8], v[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) { const float* p = p0 + (b + k * (int64_t)rows) * 2 * C; u[k] = p[0]; v[k] = p[C]; }
+#pragma unroll
+      for (int k = 0; k < 8; k++) { a1 += u[k]; a2 += v[k]; }
     }
+    for (; b < total; b += rows) { const float* p = p0 + b * 2 * C; a1 += p[0]; a2 += p[C]; }
   }
   red[t * 2] = a1; red[t * 2 + 1] = a2;
   __syncthreads();
