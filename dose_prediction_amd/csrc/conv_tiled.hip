@@ -24,6 +24,11 @@
 #endif
 #define STREAM ((hipStream_t)stream)
 typedef float v16f __attribute__((ext_vector_type(16)));
+// Scratch contract (dp_scratch_contract): 0 = the fp32 scratch `ws` of dp_conv3d_tiled* (split-kd) and dp_conv3d_wgrad_tiled* may hold
+// anything and is cleared with a memset launch per call; 1 = the caller guarantees it is all zero on entry, and the finish /
+// unpack kernels put zeros back while they read it (a persistent scratch buffer then never needs a memset).
+static int g_scratch_zeroed = 0;
+extern "C" int dp_scratch_contract(int zeroed) { g_scratch_zeroed = zeroed ? 1 : 0; return 0; }
 typedef unsigned v2u __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ v16f mma32(const Frag8<bf16_t>& a, const Frag8<bf16_t>& b, v16f c) {
@@ -376,13 +381,14 @@ __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, 
 
 // split-kd epilogue: y = T(ws + bias)
 template <typename T>
-__global__ void k_conv_split_finish(const float* __restrict__ ws, const float* __restrict__ bias, T* __restrict__ y, int64_t rows, int C, int ldy,
-                                    T* __restrict__ y2, int ldy2, int osplit) {
+__global__ void k_conv_split_finish(float* __restrict__ ws, const float* __restrict__ bias, T* __restrict__ y, int64_t rows, int C, int ldy,
+                                    T* __restrict__ y2, int ldy2, int osplit, int rezero) {
   int64_t total = rows * C;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     int64_t rrow = i / C; int c = (int)(i - rrow * C);
     T* dst = (y2 && c >= osplit) ? y2 + rrow * ldy2 + (c - osplit) : y + rrow * ldy + c;
     st_f(dst, ws[i] + (bias ? bias[c] : 0.f));
+    if (rezero) ws[i] = 0.f;
   }
 }
 
@@ -402,7 +408,7 @@ static int launch_tiled(const void* x, const void* wq, const float* bias, void* 
     fprintf(stderr, "[dp] conv_tiled KS=%d NPAIR=%d RW=%d NT=%d TWP=%d smem=%zu grid=%u x %u x %u occupancy(blocks/CU)=%d (%s)\n", KS, NPAIR, RW, NT, TWP, smem,
             grid.x, grid.y, grid.z, nb, hipGetErrorString(e));
   }
-  if (g.splitkd) {
+  if (g.splitkd && !g_scratch_zeroed) {
     hipError_t me = hipMemsetAsync(ws, 0, (size_t)g.N * g.D * g.H * g.W * g.Cout * sizeof(float), s);
     if (me != hipSuccess) { dp_set_error("conv3d_tiled: memset failed"); return 1; }
   }
@@ -410,7 +416,7 @@ static int launch_tiled(const void* x, const void* wq, const float* bias, void* 
   if (g.splitkd) {
     int64_t rows = (int64_t)g.N * g.D * g.H * g.W;
     int gb = (int)((rows * g.Cout + 255) / 256); if (gb > 4096) gb = 4096;
-    hipLaunchKernelGGL(k_conv_split_finish<T>, dim3(gb), dim3(256), 0, s, ws, bias, (T*)y, rows, g.Cout, g.ldy, (T*)g.y2, g.ldy2, g.osplit);
+    hipLaunchKernelGGL(k_conv_split_finish<T>, dim3(gb), dim3(256), 0, s, ws, bias, (T*)y, rows, g.Cout, g.ldy, (T*)g.y2, g.ldy2, g.osplit, g_scratch_zeroed);
   }
   return 0;
 }
@@ -838,8 +844,8 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_tiled(const T* __restrict__ x,
     }
 }
 
-__global__ void __launch_bounds__(256) k_wgrad_unpack(const float* __restrict__ dwt, float* __restrict__ dw, int taps, int Cin, int Cout, int64_t s_co, int64_t s_ci,
-                                                      int64_t s_tap) {
+__global__ void __launch_bounds__(256) k_wgrad_unpack(float* __restrict__ dwt, float* __restrict__ dw, int taps, int Cin, int Cout, int64_t s_co, int64_t s_ci,
+                                                      int64_t s_tap, int rezero) {
   // [tap][ci][co] scratch -> dw[co*s_co + ci*s_ci + tap*s_tap] as an LDS-tiled transpose of 32 taps x 32 (ci, co) pairs: reads are
   // 128-byte runs along co, writes 128-byte runs along the taps (either side alone is a 4-byte scatter: 207 us for 343 x 256 x 128).
   __shared__ float tile[32][33];
@@ -849,7 +855,9 @@ __global__ void __launch_bounds__(256) k_wgrad_unpack(const float* __restrict__ 
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     const int tap = tap0 + ty + 8 * r; const int64_t pr = pair0 + tx;
-    tile[ty + 8 * r][tx] = (tap < taps && pr < pairs) ? dwt[(int64_t)tap * pairs + pr] : 0.f;
+    const bool in = tap < taps && pr < pairs;
+    tile[ty + 8 * r][tx] = in ? dwt[(int64_t)tap * pairs + pr] : 0.f;
+    if (in && rezero) dwt[(int64_t)tap * pairs + pr] = 0.f;
   }
   __syncthreads();
 #pragma unroll
@@ -914,8 +922,10 @@ extern "C" int dp_conv3d_wgrad_tiled2(const void* x, int ldx, const void* x2, in
   if (k == 1 && H * (int64_t)D * N > 2000000000LL) DP_FAIL("wgrad_tiled: too many rows");
   hipStream_t s = STREAM;
   int taps = k * k * k;
-  hipError_t me = hipMemsetAsync(ws, 0, (size_t)taps * Cin * Cout * sizeof(float), s);
-  if (me != hipSuccess) DP_FAIL("wgrad_tiled: memset failed: %s", hipGetErrorString(me));
+  if (!g_scratch_zeroed) {
+    hipError_t me = hipMemsetAsync(ws, 0, (size_t)taps * Cin * Cout * sizeof(float), s);
+    if (me != hipSuccess) DP_FAIL("wgrad_tiled: memset failed: %s", hipGetErrorString(me));
+  }
   WgtGeom g; g.N = N; g.D = D; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.ldx = ldx; g.ldgy = ldgy;
   g.x2 = x2; g.ldx2 = ldx2; g.csplit = csplit;
   { const char* e = getenv("DP_DBG"); g.dbg = e ? atoi(e) : 0; }
@@ -940,6 +950,6 @@ extern "C" int dp_conv3d_wgrad_tiled2(const void* x, int ldx, const void* x2, in
   if (rc) return rc;
   DP_CHECK_LAUNCH("wgrad_tiled");
   int64_t pairs = (int64_t)Cin * Cout;
-  hipLaunchKernelGGL(k_wgrad_unpack, dim3((unsigned)((pairs + 31) / 32), (taps + 31) / 32), dim3(256), 0, s, ws, dw, taps, Cin, Cout, s_co, s_ci, s_tap);
+  hipLaunchKernelGGL(k_wgrad_unpack, dim3((unsigned)((pairs + 31) / 32), (taps + 31) / 32), dim3(256), 0, s, ws, dw, taps, Cin, Cout, s_co, s_ci, s_tap, g_scratch_zeroed);
   DP_CHECK_LAUNCH("wgrad_unpack"); return 0;
 }

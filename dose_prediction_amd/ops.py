@@ -111,11 +111,27 @@ def _tiled_elems(cin, cout, k, stride, pad, dil, W):
     return _lib.lib().dp_conv3d_tiled_weight_elems(cin, cout, k, stride, pad, dil, W)
 
 
+_ZERO_SCRATCH = {}
+
+
+def _zero_scratch(device, n):
+    """Persistent all-zero fp32 scratch for the kernels that accumulate with atomics (dp_scratch_contract(1): they get it zeroed and
+    hand it back zeroed, so no memset launch per call).  One buffer per device, grown on demand; single-stream use."""
+    L = _lib.lib()
+    key = (device.type, device.index)
+    buf = _ZERO_SCRATCH.get(key)
+    if buf is None or buf.numel() < n:
+        buf = torch.zeros((max(n, 1 << 22),), dtype=torch.float32, device=device)
+        _ZERO_SCRATCH[key] = buf
+        L.dp_scratch_contract(1)
+    return buf
+
+
 def _tiled_ws(like, N, D, H, W, cin, cout, k):
     n = _lib.lib().dp_conv3d_tiled_ws_elems(N, D, H, W, cin, cout, k)
     if n < 0:
         raise _lib.DoseHipError("conv3d_tiled: scratch too large")
-    return torch.empty((n,), dtype=torch.float32, device=like.device) if n else None
+    return _zero_scratch(like.device, n) if n else None
 
 
 def _pack_conv_tiled(w, tf, dtype, elems):
@@ -387,7 +403,7 @@ class Conv3d(torch.autograd.Function):
             # the tiled kernel overwrites dW; the generic one accumulates into it
             gw = (torch.empty if wse else torch.zeros)(weight.shape, dtype=torch.float32, device=x.device)
             if wse:
-                ws = torch.empty((wse,), dtype=torch.float32, device=x.device)
+                ws = _zero_scratch(x.device, wse)
                 _lib.call("dp_conv3d_wgrad_tiled", _p(x), ldx, _p(gy), ldg, _p(gw), _p(ws), N, Di, Hi, Wi, cin, cout, k,
                           cin * taps, taps, 1, dtc, _stream())
             else:
@@ -450,7 +466,7 @@ class Conv3dCat(torch.autograd.Function):
         if ctx.needs_input_grad[2]:
             gw = torch.empty(weight.shape, dtype=torch.float32, device=xa.device)      # overwritten by the tiled kernel
             taps = k * k * k
-            ws = torch.empty((taps * cin * cout,), dtype=torch.float32, device=xa.device)
+            ws = _zero_scratch(xa.device, taps * cin * cout)
             _lib.call("dp_conv3d_wgrad_tiled2", _p(xa), lda, _p(xb), ldb, ca, _p(gy), ldg, _p(gw), _p(ws), N, D, H, W, cin, cout, k,
                       cin * taps, taps, 1, dtc, _stream())
         if has_bias and ctx.needs_input_grad[3]:
@@ -516,7 +532,7 @@ class ConvTranspose2x(torch.autograd.Function):
             if wse:
                 # ONE pointwise weight gradient with 8*Cout "output channels" (column (abc, co) of the unshuffled gradient):
                 # x is read once instead of 8 times; the small fp32 result [(abc,co)][ci] is permuted into torch's [ci][co][abc]
-                ws = torch.empty((wse,), dtype=torch.float32, device=x.device)
+                ws = _zero_scratch(x.device, wse)
                 tmp = torch.empty((8 * cout, cin), dtype=torch.float32, device=x.device)
                 _lib.call("dp_conv3d_wgrad_tiled", _p(x), ldx, _p(gu), 8 * cout, _p(tmp), _p(ws), N, D, H, W, cin, 8 * cout, 1,
                           cin, 1, 0, dtc, _stream())

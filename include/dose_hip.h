@@ -202,6 +202,12 @@ int dp_argmax_onehot(const void* logits, int ld, void* out, int ldo, int choff, 
 int dp_im2col3d(const void* x, int ldx, void* col, int N, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int Cin, int k, int stride,
                 int pad, int dil, int dtype, void* stream);
 
+/* Scratch contract for the fp32 workspaces `ws` of dp_conv3d_tiled* (split-kd accumulation) and dp_conv3d_wgrad_tiled*:
+ * 0 (default) = ws may hold anything, each call clears it with a memset launch; 1 = the caller passes an all-zero ws and
+ * gets it back all zero (the finish / unpack kernels re-zero what they read), so a persistent scratch never needs a memset.
+ * Process-wide; the Python host side keeps one persistent zeroed buffer per device and selects 1. */
+int dp_scratch_contract(int zeroed);
+
 /* ---- sliding-window stitching (MONAI sliding_window_inference, constant blending; train_light_linked_model.py:152-153) --
  * acc[n][z0+z][y0+y][x0+x][c] += win[z][y][x][c] (fp32, C channels dense), cnt[voxel] += 1 for one rz x ry x rx window of
  * image n; then out[row][c] = acc / cnt.  acc and cnt are zero-initialised by the caller. */

@@ -59,7 +59,7 @@ def main():
                 gw = torch.zeros(w.shape, dtype=torch.float32, device=dev)
                 taps = k ** 3
                 wse = _lib.lib().dp_conv3d_wgrad_tiled_ws_elems(ci, co, k, 1, k // 2, 1, 1, S)
-                ws = torch.empty((wse,), dtype=torch.float32, device=dev)
+                ws = ops._zero_scratch(dev, wse)          # zero-in / zero-out scratch contract (dp_scratch_contract)
                 _lib.call("dp_conv3d_wgrad_tiled", x.data_ptr(), ci, gy.data_ptr(), co, gw.data_ptr(), ws.data_ptr(), N, S, S, S,
                           ci, co, k, ci * taps, taps, 1, 1 if dt == torch.bfloat16 else 0, torch.cuda.current_stream().cuda_stream)
             ms = timeit(wg)
