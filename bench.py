@@ -30,7 +30,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--size", type=int, nargs="+", default=[128])
     ap.add_argument("--batch", type=int, default=2, help="volumes per GPU")
     ap.add_argument("--model", default="pyfer", choices=["pyfer", "transeg"])
@@ -46,7 +46,7 @@ def parse():
 def build_model(args, shape, dev):
     import dose_prediction_amd
     from dose_prediction_amd.models import dose_pyfer, oar_transeg
-    dose_prediction_amd.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+    dose_prediction_amd.set_compute_dtype(args.dtype)
     torch.manual_seed(4321)
     if args.model == "pyfer":
         # hyper-parameters: DosePrediction/Train/train_light_pyfer.py:73-83
@@ -181,7 +181,7 @@ def cpu_baseline(args):
         res["check_vs_oracle"] = f"failed: {e!r}"
     finally:
         import dose_prediction_amd
-        dose_prediction_amd.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+        dose_prediction_amd.set_compute_dtype(args.dtype)
     return res
 
 
@@ -311,7 +311,7 @@ def main():
     final_loss = float(loss.detach())
     if rank == 0:
         prof = summarize_profile(records, prof_steps)
-        peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
+        peak = PEAK_BF16_TFLOPS if args.dtype in ("bf16", "fp16") else PEAK_F32_TFLOPS
         dom = prof.get("conv7x7x7_tiled", prof.get("conv7x7x7_generic", {"tflops": 0.0, "avg_launch_ms": 0.0, "launches_per_step": 0}))
         default_cfg = args.model == "pyfer" and args.dtype == "bf16" and tuple(shape) == (128, 128, 128) and B == 2
         traffic, traffic_src = pmc_traffic("k_conv_tiled<unsigned short, 7,") if default_cfg else (None, None)

@@ -55,10 +55,10 @@ def sliding_window_logits(seg_model, ct, roi_size, sw_batch_size=4, overlap=0.25
             cnt = torch.zeros((B, D, H, W), dtype=torch.float32, device=ct.device)
         for i, (n, z, y, x) in enumerate(grp):
             _lib.call("dp_window_accumulate", logits[i].data_ptr(), logits.stride(-2), acc.data_ptr(), cnt.data_ptr(), n, D, H, W,
-                      rz, ry, rx, z, y, x, C, 0 if dt == torch.float32 else 1, torch.cuda.current_stream().cuda_stream)
+                      rz, ry, rx, z, y, x, C, ops._DT[dt], torch.cuda.current_stream().cuda_stream)
     out = torch.empty((B, D, H, W, C), dtype=dt, device=ct.device)
     _lib.call("dp_window_normalize", acc.data_ptr(), cnt.data_ptr(), out.data_ptr(), C, B * D * H * W, C,
-              0 if dt == torch.float32 else 1, torch.cuda.current_stream().cuda_stream)
+              ops._DT[dt], torch.cuda.current_stream().cuda_stream)
     return out
 
 

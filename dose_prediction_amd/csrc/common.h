@@ -6,7 +6,9 @@
 #include "../../include/dose_hip.h"
 
 typedef unsigned short bf16_t;   // raw bf16 bits
+typedef _Float16 f16_t;          // IEEE half (the third storage type: BASELINE.json configs[4] trains in fp16)
 typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 typedef short v4s __attribute__((ext_vector_type(4)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef unsigned int v4u __attribute__((ext_vector_type(4)));
@@ -19,6 +21,7 @@ void dp_set_error(const char* fmt, ...);
 // Dispatch on the storage dtype: CALL is a statement using the type alias T.
 #define DP_DISPATCH(dtype, ...) do { if ((dtype) == DP_F32) { typedef float T; __VA_ARGS__; } \
     else if ((dtype) == DP_BF16) { typedef bf16_t T; __VA_ARGS__; } \
+    else if ((dtype) == DP_F16) { typedef f16_t T; __VA_ARGS__; } \
     else { DP_FAIL("bad dtype %d", (int)(dtype)); } } while (0)
 
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
@@ -30,15 +33,19 @@ __device__ __forceinline__ float ld_f(const float* p) { return *p; }
 __device__ __forceinline__ float ld_f(const bf16_t* p) { return bf2f(*p); }
 __device__ __forceinline__ void st_f(float* p, float v) { *p = v; }
 __device__ __forceinline__ void st_f(bf16_t* p, float v) { *p = f2bf(v); }
+__device__ __forceinline__ float ld_f(const f16_t* p) { return (float)*p; }
+__device__ __forceinline__ void st_f(f16_t* p, float v) { *p = (f16_t)v; }
 
 // 8 consecutive elements of T as a register fragment.
 template <typename T> struct Frag8;
 template <> struct Frag8<float> { float v[8]; };
 template <> struct Frag8<bf16_t> { v4u u; };   // 8 x bf16 in 4 dwords
+template <> struct Frag8<f16_t> { v4u u; };    // 8 x fp16 in 4 dwords (same register image; only the MFMA opcode and the converts differ)
 
 template <typename T> __device__ __forceinline__ Frag8<T> frag_zero();
 template <> __device__ __forceinline__ Frag8<float> frag_zero<float>() { Frag8<float> f; for (int i = 0; i < 8; i++) f.v[i] = 0.f; return f; }
 template <> __device__ __forceinline__ Frag8<bf16_t> frag_zero<bf16_t>() { Frag8<bf16_t> f; f.u = (v4u){0, 0, 0, 0}; return f; }
+template <> __device__ __forceinline__ Frag8<f16_t> frag_zero<f16_t>() { Frag8<f16_t> f; f.u = (v4u){0, 0, 0, 0}; return f; }
 
 // Guarded load of up to 8 consecutive elements (nvalid in [0,8]); vector path when full and 16B/32B aligned.
 __device__ __forceinline__ Frag8<float> frag_load(const float* p, int nvalid) {
@@ -62,24 +69,33 @@ __device__ __forceinline__ Frag8<bf16_t> frag_load(const bf16_t* p, int nvalid) 
   }
   return f;
 }
+__device__ __forceinline__ Frag8<f16_t> frag_load(const f16_t* p, int nvalid) {   // bit copy: identical to the bf16 path
+  Frag8<bf16_t> t = frag_load((const bf16_t*)p, nvalid);
+  Frag8<f16_t> f; f.u = t.u; return f;
+}
 // LDS store/load of a fragment (pointer must be 16B aligned for bf16, 16B for float halves)
 __device__ __forceinline__ void frag_st_lds(float* p, const Frag8<float>& f) {
   *(v4f*)p = (v4f){f.v[0], f.v[1], f.v[2], f.v[3]};
   *(v4f*)(p + 4) = (v4f){f.v[4], f.v[5], f.v[6], f.v[7]};
 }
 __device__ __forceinline__ void frag_st_lds(bf16_t* p, const Frag8<bf16_t>& f) { *(v4u*)p = f.u; }
+__device__ __forceinline__ void frag_st_lds(f16_t* p, const Frag8<f16_t>& f) { *(v4u*)p = f.u; }
 __device__ __forceinline__ Frag8<float> frag_ld_lds(const float* p) {
   Frag8<float> f; v4f a = *(const v4f*)p, b = *(const v4f*)(p + 4);
   f.v[0] = a[0]; f.v[1] = a[1]; f.v[2] = a[2]; f.v[3] = a[3]; f.v[4] = b[0]; f.v[5] = b[1]; f.v[6] = b[2]; f.v[7] = b[3];
   return f;
 }
 __device__ __forceinline__ Frag8<bf16_t> frag_ld_lds(const bf16_t* p) { Frag8<bf16_t> f; f.u = *(const v4u*)p; return f; }
+__device__ __forceinline__ Frag8<f16_t> frag_ld_lds(const f16_t* p) { Frag8<f16_t> f; f.u = *(const v4u*)p; return f; }
 
 // One K=32 MFMA step on 16x16 tiles: acc += A(16x32) * B(32x16).  Lane l holds, for row/col (l&15), the 8
 // k-values 8*(l>>4)+j.  bf16: one v_mfma_f32_16x16x32_bf16.  f32: 8 x v_mfma_f32_16x16x4_f32 (step j uses
 // element j of every lane's fragment => k = 8q+j for q=0..3; exact fp32 FMA chain).  Verified by tools/mfma_probe.hip.
 __device__ __forceinline__ v4f mma16(const Frag8<bf16_t>& a, const Frag8<bf16_t>& b, v4f c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, a.u), __builtin_bit_cast(v8bf, b.u), c, 0, 0, 0);
+}
+__device__ __forceinline__ v4f mma16(const Frag8<f16_t>& a, const Frag8<f16_t>& b, v4f c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h, a.u), __builtin_bit_cast(v8h, b.u), c, 0, 0, 0);
 }
 __device__ __forceinline__ v4f mma16(const Frag8<float>& a, const Frag8<float>& b, v4f c) {
 #pragma unroll
@@ -88,11 +104,12 @@ __device__ __forceinline__ v4f mma16(const Frag8<float>& a, const Frag8<float>& 
 }
 
 // two ds_read_b64_tr_b16 at a lane address and OFF elements further: 8 consecutive voxels (k) of one column
-template <int OFF>
-__device__ __forceinline__ Frag8<bf16_t> tr_pair(const bf16_t* a) {
+template <int OFF, typename T16>
+__device__ __forceinline__ Frag8<T16> tr_pair(const T16* a) {
+  static_assert(sizeof(T16) == 2, "transpose reads move 16-bit elements");
   v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)a);
   v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(a + OFF));
-  Frag8<bf16_t> f;
+  Frag8<T16> f;
   f.u[0] = (unsigned)(unsigned short)lo[0] | ((unsigned)(unsigned short)lo[1] << 16);
   f.u[1] = (unsigned)(unsigned short)lo[2] | ((unsigned)(unsigned short)lo[3] << 16);
   f.u[2] = (unsigned)(unsigned short)hi[0] | ((unsigned)(unsigned short)hi[1] << 16);

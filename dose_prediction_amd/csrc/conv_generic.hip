@@ -151,6 +151,19 @@ template <> __device__ __forceinline__ Frag8<bf16_t> ld_kmajor<bf16_t>(const bf1
   f.u[3] = (unsigned)(unsigned short)hi[2] | ((unsigned)(unsigned short)hi[3] << 16);
   return f;
 }
+template <> __device__ __forceinline__ Frag8<f16_t> ld_kmajor<f16_t>(const f16_t* tile, int ch0, int lane) {
+  constexpr int WG_ROW = WgCfg<f16_t>::ROW;
+  int q = lane >> 4, i16 = lane & 15, qq = i16 >> 2, p = i16 & 3;
+  const f16_t* a = tile + (8 * q + qq) * WG_ROW + ch0 + 4 * p;
+  v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)a);
+  v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(a + 4 * WG_ROW));
+  Frag8<f16_t> f;
+  f.u[0] = (unsigned)(unsigned short)lo[0] | ((unsigned)(unsigned short)lo[1] << 16);
+  f.u[1] = (unsigned)(unsigned short)lo[2] | ((unsigned)(unsigned short)lo[3] << 16);
+  f.u[2] = (unsigned)(unsigned short)hi[0] | ((unsigned)(unsigned short)hi[1] << 16);
+  f.u[3] = (unsigned)(unsigned short)hi[2] | ((unsigned)(unsigned short)hi[3] << 16);
+  return f;
+}
 template <> __device__ __forceinline__ Frag8<float> ld_kmajor<float>(const float* tile, int ch0, int lane) {
   constexpr int WG_ROW = WgCfg<float>::ROW;
   int q = lane >> 4, r = lane & 15; Frag8<float> f;
@@ -246,7 +259,7 @@ extern "C" int dp_conv3d_wgrad(const void* x, int ldx, const void* gy, int ldgy,
   WgGeom g = {N, Di, Hi, Wi, Do, Ho, Wo, Cin, Cout, k, stride, pad, dil, shift, gy_tap_choff, ldx, ldgy, s_co, s_ci, s_tap};
   int64_t Vtot = (int64_t)N * Do * Ho * Wo;
   int taps = k * k * k;
-  int cb = dtype == DP_BF16 ? WgCfg<bf16_t>::CB : WgCfg<float>::CB;
+  int cb = dtype != DP_F32 ? WgCfg<bf16_t>::CB : WgCfg<float>::CB;
   dim3 grid(cdiv(Vtot, WG_VOX), taps, cdiv(Cout, cb) * cdiv(Cin, cb));
   if (grid.y > 65535 || grid.z > 65535) DP_FAIL("wgrad: grid too large (taps %d)", taps);
   DP_DISPATCH(dtype, hipLaunchKernelGGL(k_wgrad_generic<T>, grid, dim3(256), 0, STREAM, (const T*)x, (const T*)gy, dw, g));

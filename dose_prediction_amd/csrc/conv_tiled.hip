@@ -34,6 +34,9 @@ typedef unsigned v2u __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v16f mma32(const Frag8<bf16_t>& a, const Frag8<bf16_t>& b, v16f c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, a.u), __builtin_bit_cast(v8bf, b.u), c, 0, 0, 0);
 }
+__device__ __forceinline__ v16f mma32(const Frag8<f16_t>& a, const Frag8<f16_t>& b, v16f c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, a.u), __builtin_bit_cast(v8h, b.u), c, 0, 0, 0);
+}
 __device__ __forceinline__ v16f mma32(const Frag8<float>& a, const Frag8<float>& b, v16f c) {
 #pragma unroll
   for (int j = 0; j < 8; j++) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[j], b.v[j], c, 0, 0, 0);
@@ -469,7 +472,7 @@ extern "C" int dp_conv3d_tiled2(const void* x, int ldx, const void* x2, int ldx2
   { const char* e = getenv("DP_DBG"); g.dbg = e ? atoi(e) : 0; }
   if (getenv("DP_DEBUG_SLOW")) {      // report launches that will take the guarded (slow) staging path
     int nch = (Cin + 15) / 16;
-    bool fast = dtype == DP_BF16 && nch * 16 <= (x2 ? csplit + ldx2 : ldx) && ldx % 8 == 0 && ((uintptr_t)x & 15) == 0 &&
+    bool fast = dtype != DP_F32 && nch * 16 <= (x2 ? csplit + ldx2 : ldx) && ldx % 8 == 0 && ((uintptr_t)x & 15) == 0 &&
                 (!x2 || (csplit % 16 == 0 && ldx2 % 8 == 0 && ((uintptr_t)x2 & 15) == 0));
     bool wide = (ldy * 2) % 16 == 0 && ((uintptr_t)y & 15) == 0 && (!y2 || ((ldy2 * 2) % 16 == 0 && ((uintptr_t)y2 & 15) == 0 && osplit % 8 == 0));
     if (!fast || !wide) fprintf(stderr, "[dp slow] conv3d_tiled k=%d Cin=%d Cout=%d %dx%dx%d ldx=%d ldx2=%d csplit=%d ldy=%d: staging %s, epilogue %s\n", k, Cin, Cout,
@@ -485,6 +488,7 @@ extern "C" int dp_conv3d_tiled2(const void* x, int ldx, const void* x2, int ldx2
 #define BYCFG(TT, KS_) do { if (np == 2) BYTW(TT, KS_, 2, 9, 1); else if (nt == 1) { if (w16) GO(TT, KS_, 1, 8, 1, 0); else BYTW(TT, KS_, 1, 8, 1); } \
                             else { if (w16) GO(TT, KS_, 1, 4, 2, 0); else BYTW(TT, KS_, 1, 4, 2); } } while (0)
   if (dtype == DP_BF16) { if (k == 7) BYCFG(bf16_t, 7); else BYCFG(bf16_t, 3); }
+  else if (dtype == DP_F16) { if (k == 7) BYCFG(f16_t, 7); else BYCFG(f16_t, 3); }
   else if (dtype == DP_F32) { if (k == 7) BYCFG(float, 7); else BYCFG(float, 3); }
   else DP_FAIL("conv3d_tiled: bad dtype");
 #undef BYCFG
@@ -538,14 +542,14 @@ struct WgtCfg {
 
 // k-major fragment of a [rows = voxels][pitch] LDS image: lane (col = lane&31, hh = lane>>5) gets, for column `colbase + (col&15)`,
 // the 8 voxels vox0(+shift for the upper 16 columns when SHIFT) + 8*hh .. +7.
-template <int PITCH>
-__device__ __forceinline__ Frag8<bf16_t> ld_kmajor32(const bf16_t* img, int vox_lo, int vox_hi, int col_lo, int col_hi, int lane) {
+template <int PITCH, typename T16> requires (sizeof(T16) == 2)
+__device__ __forceinline__ Frag8<T16> ld_kmajor32(const T16* img, int vox_lo, int vox_hi, int col_lo, int col_hi, int lane) {
   // lanes 16..31 / 48..63 (upper 16 columns) use (vox_hi, col_hi); the others (vox_lo, col_lo)
   const int upper = (lane >> 4) & 1, hh = lane >> 5, i16 = lane & 15, qq = i16 >> 2, p = i16 & 3;
-  const bf16_t* a = img + ((upper ? vox_hi : vox_lo) + 8 * hh + qq) * PITCH + (upper ? col_hi : col_lo) + 4 * p;
+  const T16* a = img + ((upper ? vox_hi : vox_lo) + 8 * hh + qq) * PITCH + (upper ? col_hi : col_lo) + 4 * p;
   v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)a);
   v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(a + 4 * PITCH));
-  Frag8<bf16_t> f;
+  Frag8<T16> f;
   f.u[0] = (unsigned)(unsigned short)lo[0] | ((unsigned)(unsigned short)lo[1] << 16);
   f.u[1] = (unsigned)(unsigned short)lo[2] | ((unsigned)(unsigned short)lo[3] << 16);
   f.u[2] = (unsigned)(unsigned short)hi[0] | ((unsigned)(unsigned short)hi[1] << 16);
@@ -569,9 +573,11 @@ __device__ __forceinline__ Frag8<float> ld_kmajor32(const float* img, int vox_lo
 // With M pairing the odd tap of a pair lives on the upper 16 columns, whose lanes simply READ their window one voxel later.
 template <typename T> struct Win16;
 template <> struct Win16<bf16_t> { unsigned w[8], wo[7]; };
+template <> struct Win16<f16_t> { unsigned w[8], wo[7]; };
 template <> struct Win16<float> { float w[16]; };
-__device__ __forceinline__ Win16<bf16_t> make_win(const Frag8<bf16_t>& a, const Frag8<bf16_t>& b) {
-  Win16<bf16_t> W;
+template <typename T16> requires (sizeof(T16) == 2)
+__device__ __forceinline__ Win16<T16> make_win(const Frag8<T16>& a, const Frag8<T16>& b) {
+  Win16<T16> W;
 #pragma unroll
   for (int r = 0; r < 4; r++) { W.w[r] = a.u[r]; W.w[4 + r] = b.u[r]; }
   return W;
@@ -584,15 +590,16 @@ __device__ __forceinline__ Win16<float> make_win(const Frag8<float>& a, const Fr
 }
 // the copy shifted by one voxel; called AFTER the MFMAs of the previous window have been issued, so that the LDS
 // latency of the window's loads is not exposed in front of them
-template <bool ODD> __device__ __forceinline__ void win_finish(Win16<bf16_t>& W) {
+template <bool ODD, typename T16> requires (sizeof(T16) == 2)
+__device__ __forceinline__ void win_finish(Win16<T16>& W) {
 #pragma unroll
   for (int r = 0; r < 7; r++) W.wo[r] = ODD ? __builtin_amdgcn_alignbit(W.w[r + 1], W.w[r], 16) : 0u;
 }
 template <bool ODD> __device__ __forceinline__ void win_finish(Win16<float>&) {}
 // fragment = voxels [S, S + 8) of the window (S compile-time)
-template <int S>
-__device__ __forceinline__ Frag8<bf16_t> win_frag(const Win16<bf16_t>& W) {
-  Frag8<bf16_t> f;
+template <int S, typename T16> requires (sizeof(T16) == 2)
+__device__ __forceinline__ Frag8<T16> win_frag(const Win16<T16>& W) {
+  Frag8<T16> f;
 #pragma unroll
   for (int r = 0; r < 4; r++) f.u[r] = (S & 1) ? W.wo[S / 2 + r] : W.w[S / 2 + r];
   return f;
@@ -765,11 +772,11 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_tiled(const T* __restrict__ x,
           it_c += C::WCH; if (it_c >= nchk) { it_c = chw; it_i++; }
           const int lr = i + (NPAIR == 2 ? 2 * jh : jh), vbase = lr * C::LP + 16 * c;
           if constexpr (sizeof(T) == 2) {
-            const bf16_t* ga = (const bf16_t*)gs + g_lane + (i * C::GRP + 16 * c * C::GC);
-            const bf16_t* xa = (const bf16_t*)xs + x_lane + vbase * C::XC;
-            fb = tr_pair<4 * C::GC>(ga);
-            r0 = tr_pair<4 * C::XC>(xa);
-            if (KS > 1) r1 = tr_pair<4 * C::XC>(xa + 8 * C::XC);                    // reads past a row end only feed unused window slots
+            const T* ga = gs + g_lane + (i * C::GRP + 16 * c * C::GC);
+            const T* xa = xs + x_lane + vbase * C::XC;
+            fb = tr_pair<4 * C::GC, T>(ga);
+            r0 = tr_pair<4 * C::XC, T>(xa);
+            if (KS > 1) r1 = tr_pair<4 * C::XC, T>(xa + 8 * C::XC);                    // reads past a row end only feed unused window slots
           } else {
             // gy rows are GRP apart: express the row offset in "voxels" of pitch GC (GRP is a multiple of GC)
             if (NPAIR == 2) fb = ld_kmajor32<C::GC>(gs, (i + 1) * (C::GRP / C::GC) + 16 * c, i * (C::GRP / C::GC) + 16 * c, 0, 0, lane);
@@ -931,10 +938,10 @@ extern "C" int dp_conv3d_wgrad_tiled2(const void* x, int ldx, const void* x2, in
   { const char* e = getenv("DP_DBG"); g.dbg = e ? atoi(e) : 0; }
   const int np = (Cout <= 16 && k > 1) ? 2 : 1, mp = (Cin <= 16 && k > 1) ? 2 : 1;
   if (getenv("DP_DEBUG_SLOW")) {
-    int xc = mp == 2 ? 16 : 32, gc = np == 2 ? 16 : 32, tw = (dtype == DP_BF16 && mp == 2) ? 64 : 32;
+    int xc = mp == 2 ? 16 : 32, gc = np == 2 ? 16 : 32, tw = (dtype != DP_F32 && mp == 2) ? 64 : 32;
     int avail = x2 ? csplit + ldx2 : ldx;
     (void)xc; (void)gc; (void)avail;
-    bool fast = dtype == DP_BF16 && ldx % 8 == 0 && ldgy % 8 == 0 &&
+    bool fast = dtype != DP_F32 && ldx % 8 == 0 && ldgy % 8 == 0 &&
                 ((uintptr_t)x & 15) == 0 && ((uintptr_t)gy & 15) == 0 && (!x2 || (csplit % 8 == 0 && ldx2 % 8 == 0 && ((uintptr_t)x2 & 15) == 0)) &&
                 (W <= tw || W % tw == 0);
     if (!fast) fprintf(stderr, "[dp slow] wgrad_tiled k=%d Cin=%d Cout=%d %dx%dx%d ldx=%d ldx2=%d csplit=%d ldgy=%d: some channel tiles stage GUARDED\n", k, Cin, Cout,
@@ -944,6 +951,7 @@ extern "C" int dp_conv3d_wgrad_tiled2(const void* x, int ldx, const void* x2, in
 #define GO(TT, KS_) do { if (np == 2 && mp == 2) rc = launch_wgt<TT, KS_, 2, 2>(x, gy, ws, g, s); else if (np == 2) rc = launch_wgt<TT, KS_, 2, 1>(x, gy, ws, g, s); \
                          else if (mp == 2) rc = launch_wgt<TT, KS_, 1, 2>(x, gy, ws, g, s); else rc = launch_wgt<TT, KS_, 1, 1>(x, gy, ws, g, s); } while (0)
   if (dtype == DP_BF16) { if (k == 7) GO(bf16_t, 7); else if (k == 3) GO(bf16_t, 3); else rc = launch_wgt<bf16_t, 1, 1, 1>(x, gy, ws, g, s); }
+  else if (dtype == DP_F16) { if (k == 7) GO(f16_t, 7); else if (k == 3) GO(f16_t, 3); else rc = launch_wgt<f16_t, 1, 1, 1>(x, gy, ws, g, s); }
   else if (dtype == DP_F32) { if (k == 7) GO(float, 7); else if (k == 3) GO(float, 3); else rc = launch_wgt<float, 1, 1, 1>(x, gy, ws, g, s); }
   else DP_FAIL("wgrad_tiled: bad dtype");
 #undef GO

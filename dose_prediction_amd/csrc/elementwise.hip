@@ -28,7 +28,18 @@ template <> __device__ __forceinline__ void frag_store<bf16_t>(bf16_t* p, const 
   if (nvalid >= 8 && ((uintptr_t)p & 15) == 0) { *(v4u*)p = f.u; }
   else { for (int i = 0; i < 8; i++) if (i < nvalid) p[i] = (bf16_t)((f.u[i >> 1] >> ((i & 1) * 16)) & 0xffff); }
 }
+template <> __device__ __forceinline__ void frag_store<f16_t>(f16_t* p, const Frag8<f16_t>& f, int nvalid) {
+  Frag8<bf16_t> t; t.u = f.u; frag_store<bf16_t>((bf16_t*)p, t, nvalid);        // bit copy
+}
 __device__ __forceinline__ void frag_unpack(const Frag8<float>& f, float* o) { for (int i = 0; i < 8; i++) o[i] = f.v[i]; }
+__device__ __forceinline__ void frag_unpack(const Frag8<f16_t>& f, float* o) {
+  const v8h h = __builtin_bit_cast(v8h, f.u);
+  for (int i = 0; i < 8; i++) o[i] = (float)h[i];
+}
+__device__ __forceinline__ void frag_pack(Frag8<f16_t>& f, const float* o) {
+  v8h h; for (int i = 0; i < 8; i++) h[i] = (f16_t)o[i];
+  f.u = __builtin_bit_cast(v4u, h);
+}
 __device__ __forceinline__ void frag_unpack(const Frag8<bf16_t>& f, float* o) {
   for (int i = 0; i < 4; i++) { o[2 * i] = __uint_as_float(f.u[i] << 16); o[2 * i + 1] = __uint_as_float(f.u[i] & 0xffff0000u); }
 }
@@ -93,6 +104,9 @@ extern "C" int dp_cast(const void* src, int sdt, void* dst, int ddt, int64_t n, 
   else if (sdt == DP_BF16 && ddt == DP_F32) hipLaunchKernelGGL((k_cast<bf16_t, float>), g, b, 0, STREAM, (const bf16_t*)src, (float*)dst, n);
   else if (sdt == DP_F32 && ddt == DP_F32) hipLaunchKernelGGL((k_cast<float, float>), g, b, 0, STREAM, (const float*)src, (float*)dst, n);
   else if (sdt == DP_BF16 && ddt == DP_BF16) hipLaunchKernelGGL((k_cast<bf16_t, bf16_t>), g, b, 0, STREAM, (const bf16_t*)src, (bf16_t*)dst, n);
+  else if (sdt == DP_F32 && ddt == DP_F16) hipLaunchKernelGGL((k_cast<float, f16_t>), g, b, 0, STREAM, (const float*)src, (f16_t*)dst, n);
+  else if (sdt == DP_F16 && ddt == DP_F32) hipLaunchKernelGGL((k_cast<f16_t, float>), g, b, 0, STREAM, (const f16_t*)src, (float*)dst, n);
+  else if (sdt == DP_F16 && ddt == DP_F16) hipLaunchKernelGGL((k_cast<f16_t, f16_t>), g, b, 0, STREAM, (const f16_t*)src, (f16_t*)dst, n);
   else DP_FAIL("cast: bad dtypes");
   DP_CHECK_LAUNCH("cast"); return 0;
 }

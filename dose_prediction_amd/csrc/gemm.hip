@@ -190,11 +190,14 @@ extern "C" int dp_gemm_nt(const void* A, int64_t lda, int64_t sa0, int64_t sa1, 
   dim3 g(cdiv(M, bm), cdiv(N, bn), nb0 * nb1 * splitk);
   if (g.y > 65535 || g.z > 65535) DP_FAIL("gemm_nt: grid too large");
   // bf16 and deep K: 64-deep LDS stages halve the number of barrier pairs (the token GEMMs are latency-, not MFMA-bound)
-  bool deep = dtype == DP_BF16 && K >= 256;
+  bool deep = dtype != DP_F32 && K >= 256;
 #define GEMM_ARGS g, dim3(256), 0, STREAM, (const T*)A, lda, sa0, sa1, (const T*)B, ldb, sb0, sb1, C, ldc, sc0, sc1, bias, M, N, K, nb1, alpha, out_f32, splitk
 #define GEMM_GO(TI_, TJ_, BK_) DP_DISPATCH(dtype, hipLaunchKernelGGL((k_gemm_nt<T, TI_, TJ_, BK_>), GEMM_ARGS))
-  if (deep) {   // bf16 only: the deeper stage keeps (BM + BN) * BK * 2 bytes of loads in flight per block
+  if (deep && dtype == DP_BF16) {   // 16-bit types only: the deeper stage keeps (BM + BN) * BK * 2 bytes of loads in flight per block
     typedef bf16_t T;
+    if (small) hipLaunchKernelGGL((k_gemm_nt<T, 2, 2, 128>), GEMM_ARGS); else hipLaunchKernelGGL((k_gemm_nt<T, 4, 4, 64>), GEMM_ARGS);
+  } else if (deep) {
+    typedef f16_t T;
     if (small) hipLaunchKernelGGL((k_gemm_nt<T, 2, 2, 128>), GEMM_ARGS); else hipLaunchKernelGGL((k_gemm_nt<T, 4, 4, 64>), GEMM_ARGS);
   } else if (small) GEMM_GO(2, 2, 32);
   else GEMM_GO(4, 4, 32);
@@ -239,7 +242,7 @@ __global__ void __launch_bounds__(256) k_gemm_tn(const T* __restrict__ A, int64_
   // lane part of the k-major fragment address: MFMA k group q = lane>>4 (8 consecutive k), column r = lane&15
   const int i16 = lane & 15, tr_lane = (8 * q + (i16 >> 2)) * LDPT + 4 * (i16 & 3);
   auto frag = [&](const T* img, int kk, int col0) {
-    if constexpr (sizeof(T) == 2) return tr_pair<4 * LDPT>((const bf16_t*)img + kk * LDPT + col0 + tr_lane);
+    if constexpr (sizeof(T) == 2) return tr_pair<4 * LDPT, T>(img + kk * LDPT + col0 + tr_lane);
     else { Frag8<float> f;
 #pragma unroll
       for (int j = 0; j < 8; j++) f.v[j] = img[(kk + 8 * q + j) * LDPT + col0 + r];

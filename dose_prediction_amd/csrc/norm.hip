@@ -24,6 +24,15 @@ template <> __device__ __forceinline__ void unpack8<bf16_t>(const bf16_t* p, int
   Frag8<bf16_t> f = frag_load(p, nv);
   for (int i = 0; i < 4; i++) { o[2 * i] = __uint_as_float(f.u[i] << 16); o[2 * i + 1] = __uint_as_float(f.u[i] & 0xffff0000u); }
 }
+template <> __device__ __forceinline__ void unpack8<f16_t>(const f16_t* p, int nv, float* o) {
+  Frag8<f16_t> f = frag_load(p, nv);
+  const v8h h = __builtin_bit_cast(v8h, f.u);
+  for (int i = 0; i < 8; i++) o[i] = (float)h[i];
+}
+__device__ __forceinline__ void pack8(f16_t* p, int nv, const float* o) {
+  if (nv >= 8 && ((uintptr_t)p & 15) == 0) { v8h h; for (int i = 0; i < 8; i++) h[i] = (f16_t)o[i]; *(v4u*)p = __builtin_bit_cast(v4u, h); }
+  else for (int i = 0; i < 8; i++) if (i < nv) p[i] = (f16_t)o[i];
+}
 __device__ __forceinline__ void pack8(float* p, int nv, const float* o) {
   if (nv >= 8 && ((uintptr_t)p & 15) == 0) { *(v4f*)p = (v4f){o[0], o[1], o[2], o[3]}; *(v4f*)(p + 4) = (v4f){o[4], o[5], o[6], o[7]}; }
   else for (int i = 0; i < 8; i++) if (i < nv) p[i] = o[i];
@@ -41,6 +50,17 @@ __device__ __forceinline__ void ld8(const bf16_t* p, float* o) {
   v4u u = *(const v4u*)p;
 #pragma unroll
   for (int i = 0; i < 4; i++) { o[2 * i] = __uint_as_float(u[i] << 16); o[2 * i + 1] = __uint_as_float(u[i] & 0xffff0000u); }
+}
+__device__ __forceinline__ void ld8(const f16_t* p, float* o) {
+  const v8h h = __builtin_bit_cast(v8h, *(const v4u*)p);
+#pragma unroll
+  for (int i = 0; i < 8; i++) o[i] = (float)h[i];
+}
+__device__ __forceinline__ void st8(f16_t* p, const float* o) {
+  v8h h;
+#pragma unroll
+  for (int i = 0; i < 8; i++) h[i] = (f16_t)o[i];
+  *(v4u*)p = __builtin_bit_cast(v4u, h);
 }
 __device__ __forceinline__ void st8(float* p, const float* o) { *(v4f*)p = (v4f){o[0], o[1], o[2], o[3]}; *(v4f*)(p + 4) = (v4f){o[4], o[5], o[6], o[7]}; }
 __device__ __forceinline__ void st8(bf16_t* p, const float* o) {

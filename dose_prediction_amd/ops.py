@@ -2,7 +2,7 @@
 
 Tensor conventions inside the HIP path
   * activations: 5-D ``[N, D, H, W, C]`` (NDHWC), last stride 1; a tensor may be a channel slice of a
-    wider buffer (row pitch ``ld`` = stride of W).  dtype float32 (parity mode) or bfloat16 (bench mode).
+    wider buffer (row pitch ``ld`` = stride of W).  dtype float32 (parity mode), bfloat16 (bench mode) or float16.
   * token matrices: 2-D/3-D ``[..., rows, C]`` contiguous.
   * parameters stay fp32 ``nn.Parameter``s in the reference's own shapes (state_dict compatible); kernels
     consume packed copies cached per (parameter version, dtype).  Weight gradients are produced in fp32.
@@ -15,7 +15,7 @@ import torch
 from . import _lib
 
 ACT = {None: 0, "none": 0, "relu": 1, "lrelu": 2, "mish": 3, "gelu": 4}
-_DT = {torch.float32: 0, torch.bfloat16: 1}
+_DT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
 
 
 def _stream():
@@ -30,7 +30,7 @@ def _dt(t):
     try:
         return _DT[t.dtype]
     except KeyError:
-        raise TypeError(f"HIP path supports float32/bfloat16 activations, got {t.dtype}")
+        raise TypeError(f"HIP path supports float32/bfloat16/float16 activations, got {t.dtype}")
 
 
 def _chk_dev(*ts):

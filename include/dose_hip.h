@@ -12,10 +12,11 @@
  *   - plain pointers are DEVICE pointers; `stream` is a hipStream_t passed as void*.
  *   - activations are NDHWC ("voxel rows"): element (n,d,h,w,c) at ((n*D+d)*H+h)*W+w)*ld + c, where
  *     `ld` >= C is the row pitch in elements (so a tensor may be a channel slice of a wider buffer).
- *   - dtype: DP_F32 (0) or DP_BF16 (1) selects the storage type T of activations / packed weights.
+ *   - dtype: DP_F32 (0), DP_BF16 (1) or DP_F16 (2) selects the storage type T of activations / packed weights.
  *     Accumulation and statistics are always fp32 (fp64 in the tiny finalize kernels).
  *     DP_F32 uses v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain) -- the parity mode;
- *     DP_BF16 uses v_mfma_f32_16x16x32_bf16 -- the benchmark mode.
+ *     DP_BF16 uses v_mfma_f32_16x16x32_bf16 -- the benchmark mode;
+ *     DP_F16 uses v_mfma_f32_16x16x32_f16 (BASELINE.json configs[4] trains in fp16).
  *   - every function returns 0 on success, non-zero on error; dp_last_error() gives the message.
  *   - no function allocates, frees or synchronises: workspaces are caller-provided.
  */
@@ -26,7 +27,7 @@
 extern "C" {
 #endif
 
-enum { DP_F32 = 0, DP_BF16 = 1 };
+enum { DP_F32 = 0, DP_BF16 = 1, DP_F16 = 2 };
 enum { DP_ACT_NONE = 0, DP_ACT_RELU = 1, DP_ACT_LRELU = 2, DP_ACT_MISH = 3, DP_ACT_GELU = 4 };
 
 const char* dp_last_error(void);

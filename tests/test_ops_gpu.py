@@ -3,6 +3,7 @@
 fp32 mode: exact-fp32 MFMA -> tolerance 2e-5 (relative L2) / 1e-4 (max-abs relative to max|ref|).
 bf16 mode: inputs are rounded to bf16 FIRST and the oracle is evaluated (in fp64) on the rounded inputs, so the only
 differences are fp32 accumulation order and the final rounding of outputs to bf16 (2^-9): tolerance 6e-3 rel-L2.
+fp16 mode: the same protocol with fp16 rounding (2^-12): tolerance 1e-3 rel-L2.
 """
 import math
 
@@ -14,7 +15,7 @@ from helpers import rel_l2, rel_err
 
 pytestmark = pytest.mark.gpu
 
-TOL = {torch.float32: (2e-5, 1e-4), torch.bfloat16: (6e-3, 2e-2)}
+TOL = {torch.float32: (2e-5, 1e-4), torch.bfloat16: (6e-3, 2e-2), torch.float16: (1e-3, 4e-3)}
 
 
 def _dev():
@@ -50,7 +51,7 @@ def check(name, got, ref, dtype, scale=1.0):
     assert e2 < tl2 * scale and em < tmax * scale, f"{name}: rel_l2={e2:.3e} rel_max={em:.3e} ({dtype})"
 
 
-DTYPES = [torch.float32, torch.bfloat16]
+DTYPES = [torch.float32, torch.bfloat16, torch.float16]
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -260,7 +261,7 @@ def test_attention(cfg, dtype):
     wh, woh, boh = (t.to(dev).requires_grad_(True) for t in (wqkv, wo, bo))
     yh = ops.linear(ops.attention(ops.linear(xh, wh), heads), woh, boh)
     yh.backward(r.to(dev, dtype))
-    s = 3.0 if dtype == torch.bfloat16 else 1.0     # intermediate qkv / P / O roundings in bf16
+    s = 3.0 if dtype != torch.float32 else 1.0     # intermediate qkv / P / O roundings in the 16-bit modes
     check("y", yh, yr, dtype, scale=s)
     check("gx", xh.grad, xr.grad, dtype, scale=s)
     check("gwqkv", wh.grad, wr.grad, dtype, scale=s)
@@ -393,6 +394,6 @@ def test_gemm_tn(cfg, dtype):
     ref = A[:, :M].double().t() @ B[:, :N].double()
     Ad, Bd = A.to(dev, dtype), B.to(dev, dtype)
     C = (torch.zeros if sk > 1 else torch.empty)((M, N), dtype=torch.float32, device=dev)
-    _lib.call("dp_gemm_tn", Ad.data_ptr(), lda, Bd.data_ptr(), ldb, C.data_ptr(), N, M, N, K, sk, 0 if dtype == torch.float32 else 1,
+    _lib.call("dp_gemm_tn", Ad.data_ptr(), lda, Bd.data_ptr(), ldb, C.data_ptr(), N, M, N, K, sk, {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}[dtype],
               torch.cuda.current_stream().cuda_stream)
     assert rel_l2(C.cpu().double(), ref) < (2e-5 if dtype == torch.float32 else 2e-5)   # inputs are pre-rounded: fp32 accumulation in both modes
