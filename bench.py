@@ -121,9 +121,68 @@ def summarize_profile(records, steps):
     return out
 
 
+def cpu_baseline_transeg(args):
+    """OAR-TRANSEG counterpart of cpu_baseline(): the oracle's forward + cross-entropy + backward at cpu_size^3, and the HIP path
+    checked on the same sample (logit rel-err, arg-max mismatch count -- SURVEY 8d)."""
+    import oracle
+    import dose_prediction_amd
+    from dose_prediction_amd.models import oar_transeg
+    cores = os.cpu_count() or 1
+    threads = min(cores, 128)
+    torch.set_num_threads(threads)
+    S = args.cpu_size
+    shape = (S, S, S)
+    torch.manual_seed(4321)
+    mk = lambda: oar_transeg.Model(in_channels=1, out_channels=8, img_size=shape, feature_size=16, hidden_size=768, mlp_dim=3072,  # noqa: E731
+                                   num_heads=12, pos_embed="perceptron", norm_name="instance", res_block=True, conv_block=True)
+    net = mk()
+    sd = {k: (v.detach().clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.detach().clone())
+          for k, v in net.state_dict().items()}
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn((1, 1) + shape, generator=g)
+    lab = torch.randint(0, 8, (1,) + shape, generator=g)
+    nstep = max(1, args.cpu_steps)
+    t0 = time.time()
+    for _ in range(nstep):
+        for v in sd.values():
+            v.grad = None
+        logits = oracle.oar_transeg(sd, x, num_heads=12, training=True)
+        torch.nn.functional.cross_entropy(logits, lab).backward()
+    dt = (time.time() - t0) / nstep
+    scale = (S / 128.0) ** 3
+    res = {"value": scale / dt, "unit": "128^3-equivalent volumes/s (fwd+bwd)", "cores": threads, "kind": "port",
+           "sample": f"{nstep} step(s) (forward + cross-entropy + backward) of the fp32 CPU oracle on one {S}^3 volume: {dt:.2f} s per step "
+                     f"with {threads} torch threads on {cores} host cores; scaled by voxel count ({scale:.4f})", "seconds": dt * nstep}
+    try:
+        dev = torch.device("cuda", torch.cuda.current_device())
+        ref = logits.detach()
+        top2 = ref.topk(2, dim=1).values
+        safe = (top2[:, 0] - top2[:, 1]) > 1e-3 * ref.abs().max()
+        chk = {}
+        for name in ("fp32", args.dtype) if args.dtype != "fp32" else ("fp32",):
+            dose_prediction_amd.set_compute_dtype(name)
+            hip = mk()
+            hip.load_state_dict({k: v.detach() for k, v in sd.items()})
+            hip = hip.to(dev).train()
+            with torch.no_grad():
+                got = hip(x.to(dev)).float().cpu()
+            mism = got.argmax(1) != ref.argmax(1)
+            chk[name] = {"rel_err_max": float((got - ref).abs().max() / ref.abs().max()), "argmax_mismatch": int(mism.sum()),
+                         "argmax_mismatch_off_near_ties": int((mism & safe).sum()), "voxels": int(mism.numel())}
+            del hip
+        res["check_vs_oracle"] = chk
+    except Exception as e:
+        res["check_vs_oracle"] = f"failed: {e!r}"
+    finally:
+        dose_prediction_amd.set_compute_dtype(args.dtype)
+    return res
+
+
 def cpu_baseline(args):
     """The CPU oracle (fp32 PyTorch-eager restatement, pinned to the reference by tests/golden) timed on the host cores:
     one forward+backward of the same network/loss at cpu_size^3, batch 1, reported in 128^3-volume equivalents."""
+    if args.model == "transeg":
+        return cpu_baseline_transeg(args)
     import oracle
     from dose_prediction_amd import synth
     from dose_prediction_amd.models import dose_pyfer
@@ -165,7 +224,7 @@ def cpu_baseline(args):
         ref = out[1][0].detach()
         mask = gt[:, 1:2] > 0
         chk = {}
-        for name, dt_ in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+        for name, dt_ in (("fp32", torch.float32), ("bf16", torch.bfloat16)) + ((("fp16", torch.float16),) if args.dtype == "fp16" else ()):
             dose_prediction_amd.set_compute_dtype(dt_)
             hip = dose_pyfer.Model(in_ch=9, out_ch=1, list_ch_A=[-1, 16, 32, 64, 128, 256], feature_size=16, img_size=shape,
                                    num_layers=8, num_heads=6, act="mish")
