@@ -33,7 +33,8 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--size", type=int, nargs="+", default=[128])
     ap.add_argument("--batch", type=int, default=2, help="volumes per GPU")
-    ap.add_argument("--model", default="pyfer", choices=["pyfer", "transeg"])
+    ap.add_argument("--model", default="pyfer", choices=["pyfer", "transeg", "cascade"],
+                    help="cascade = BASELINE.json configs[3]: frozen OAR-TRANSEG forward -> arg-max/one-hot glue -> DOSE-PYFER training step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optimizer", action="store_true")
     ap.add_argument("--cpu-size", type=int, default=64)
@@ -48,7 +49,7 @@ def build_model(args, shape, dev):
     from dose_prediction_amd.models import dose_pyfer, oar_transeg
     dose_prediction_amd.set_compute_dtype(args.dtype)
     torch.manual_seed(4321)
-    if args.model == "pyfer":
+    if args.model in ("pyfer", "cascade"):
         # hyper-parameters: DosePrediction/Train/train_light_pyfer.py:73-83
         net = dose_pyfer.Model(in_ch=9, out_ch=1, list_ch_A=[-1, 16, 32, 64, 128, 256], feature_size=16, img_size=shape,
                                num_layers=8, num_heads=6, act="mish", mode_multi_dec=True, multiS_conv=True)
@@ -297,7 +298,18 @@ def main():
         cls = torch.optim.Adam if args.torch_adam else FusedAdam
         opt = cls(params, lr=1e-4, weight_decay=3e-5, betas=(0.9, 0.999), eps=1e-8, amsgrad=True)
     B = args.batch
-    if args.model == "pyfer":
+    seg = None
+    if args.model == "cascade":
+        from dose_prediction_amd import cascade
+        from dose_prediction_amd.models import oar_transeg
+        torch.manual_seed(8765)
+        seg = oar_transeg.Model(in_channels=1, out_channels=8, img_size=shape, feature_size=16, hidden_size=768, mlp_dim=3072,
+                                num_heads=12, pos_embed="perceptron", norm_name="instance", res_block=True, conv_block=True).to(dev).eval()
+        full = synth.dose_input(B, shape, seed=1234 + rank).to(dev)
+        ct_in, ptv_in = full[:, 8:9].contiguous(), full[:, 0:1].contiguous()
+        gt = synth.dose_target(B, shape, seed=5678 + rank).to(dev)
+        x = None
+    elif args.model == "pyfer":
         x = synth.dose_input(B, shape, seed=1234 + rank).to(dev)
         gt = synth.dose_target(B, shape, seed=5678 + rank).to(dev)
     else:
@@ -310,8 +322,9 @@ def main():
         else:
             for p in params:
                 p.grad = None
-        out = net(x)
-        if args.model == "pyfer":
+        xin = cascade.cascade_structures(seg, ct_in, ptv_in)[0] if seg is not None else x
+        out = net(xin)
+        if args.model in ("pyfer", "cascade"):
             loss = losses.gen_loss(out, gt, 10.0, 1.0, casecade=True, freez=True)
         else:
             loss = torch.nn.functional.cross_entropy(out, gt)
@@ -375,13 +388,14 @@ def main():
         default_cfg = args.model == "pyfer" and args.dtype == "bf16" and tuple(shape) == (128, 128, 128) and B == 2
         traffic, traffic_src = pmc_traffic("k_conv_tiled<unsigned short, 7,") if default_cfg else (None, None)
         res = {
-            "metric": "128^3 CT volumes/sec (fwd+bwd)", "value": world * B * args.steps / dt, "unit": "volumes/s",
+            "metric": "128\u00b3 CT volumes/sec (fwd+bwd)", "value": world * B * args.steps / dt, "unit": "volumes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": ("DOSE-PYFER dose-only path (BASELINE.json configs[1])" if args.model == "pyfer"
+            "config": {"workload": ("End-to-end cascade TRANSEG -> PYFER (BASELINE.json configs[3], per-GPU batch)" if args.model == "cascade" else
+                                    "DOSE-PYFER dose-only path (BASELINE.json configs[1])" if args.model == "pyfer"
                                     else "OAR-TRANSEG segmentation path (BASELINE.json configs[2])"),
                        "volume": list(shape), "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
-                       "net_A_frozen": args.model == "pyfer", "optimizer_step_in_timed_region": opt is not None,
+                       "net_A_frozen": args.model in ("pyfer", "cascade"), "optimizer_step_in_timed_region": opt is not None,
                        "optimizer": (type(opt).__name__ + "(amsgrad)") if opt is not None else None,
                        "launch": "hipGraph replay" if graph is not None else "eager",
                        "final_loss": final_loss},

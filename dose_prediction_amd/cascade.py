@@ -71,6 +71,26 @@ def oar_masks(seg_model, ct):
 
 
 @torch.no_grad()
+def cascade_structures(seg_model, ct, ptv, reverse_axes=True, roi_size=None, sw_batch_size=4, overlap=0.25):
+    """The 9-channel PYFER input [B,9,D,H,W] fp32 of the linked model (train_light_linked_model.py:143-167) from a CT and a PTV
+    channel: OAR-TRANSEG (no grad) -> arg-max -> one-hot classes 1..7 -> axis reversal -> cat(ptv, oars, ct).  Used when the dose
+    network TRAINS on the segmentation network's masks (BASELINE.json configs[3], [4]); returns (structures, labels)."""
+    B = ct.shape[0]
+    if roi_size is not None and tuple(roi_size) != tuple(ct.shape[2:]):
+        logits = sliding_window_logits(seg_model, ct, tuple(roi_size), sw_batch_size, overlap)
+    else:
+        logits = seg_model.forward_ndhwc(to_ndhwc(ct))
+    D, H, W = logits.shape[1:4]
+    staged = torch.zeros((B, D, H, W, 16), dtype=config.compute_dtype(), device=ct.device)
+    labels = ops.argmax_onehot(logits, staged, choff=1, labels=True)
+    staged[..., 8:9] = to_ndhwc(ct)[..., :1]
+    if reverse_axes:
+        staged = staged.permute(0, 3, 2, 1, 4).contiguous()
+    staged[..., 0:1] = to_ndhwc(ptv)[..., :1]
+    return from_ndhwc(staged)[:, :9].float().contiguous(), labels
+
+
+@torch.no_grad()
 def cascade_forward(seg_model, dose_model, ct, ptv, possible_dose_mask=None, reverse_axes=True, roi_size=None,
                     sw_batch_size=4, overlap=0.25):
     """Returns (dose_gy [B,1,...] fp32 in Gy, labels).  ct, ptv: [B,1,D,H,W] fp32 on the GPU.  With reverse_axes the OAR masks

@@ -253,6 +253,9 @@ def test_cascade_glue():
         ref = oracle.dose_pyfer(sd_dose, structures, num_layers=4, num_heads=6, act="mish", training=False)[1][0]
     ref_gy = oracle.dose_postprocess(ref, mask)
     assert rel_err(dose_gy.cpu(), ref_gy) < OUT_TOL
+    # the training-time variant of the glue hands the same 9-channel tensor to the trainer (fp32 mode: exact)
+    st, lab2 = cascade.cascade_structures(seg, ct.to(dev), ptv.to(dev))
+    assert torch.equal(lab2.cpu(), labels.cpu()) and torch.equal(st.cpu(), structures)
 
 
 def test_activation_checkpointing():
