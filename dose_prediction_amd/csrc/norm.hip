@@ -507,7 +507,7 @@ extern "C" int dp_layernorm_fwd(const void* x, const float* gamma, const float* 
 extern "C" int dp_layernorm_bwd(const void* x, const void* gy, const float* gamma, const float* mean, const float* rstd, void* gx, float* dgamma,
                                 float* dbeta, int64_t rows, int C, int dtype, void* stream) {
   if (C <= 1024) {
-    int rpb = rows >= 4096 ? 16 : 8;
+    int rpb = rows >= 8192 ? 16 : (rows >= 2048 ? 8 : 4);          // token matrices (1024 rows): one row per wave, 256 blocks
     DP_DISPATCH(dtype, hipLaunchKernelGGL(k_layernorm_bwd_reg<T>, dim3(cdiv(rows, rpb)), dim3(256), 0, STREAM, (const T*)x, (const T*)gy, gamma,
                                           mean, rstd, (T*)gx, dgamma, dbeta, rows, C, rpb));
     DP_CHECK_LAUNCH("layernorm_bwd"); return 0;
