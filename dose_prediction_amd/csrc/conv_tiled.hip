@@ -851,6 +851,193 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_tiled(const T* __restrict__ x,
     }
 }
 
+// ================================================================================================ weight gradient, Cout <= 16
+// The 128^3-level layers have 16 output channels.  The kernel above fills the 32-wide N of a 32x32x16 MFMA with two kh taps
+// (and M with two kw taps when Cin <= 16): 49 taps occupy 64 tap slots, and the shifted tap costs a ninth accumulator row --
+// 32 % of the MFMA cycles are padding.  Here the MFMA is v_mfma_f32_16x16x32: M = 16 input channels, N = 16 output channels,
+// K = 32 voxels along W, ONE tap per MFMA and no padding at all.  Operand traffic stays low because (a) the x operand of all
+// KS kw taps of a (row, 32-voxel chunk) is ONE 16-voxel register window (two transpose-read pairs, shifts by v_alignbit /
+// register sub-ranges) and (b) a gy fragment (one transpose-read pair) feeds the KS taps of a kh: 12 LDS reads per 28 MFMAs.  A wave owns a kh subset (4 + 3 of 7, 2 + 1 of 3) of one 32-voxel chunk and keeps its nkh x KS accumulators
+// (4 VGPRs each) for the block's whole voxel share; staging, tile order, grid decode and the scratch layout are those of
+// k_wgrad_tiled.
+template <typename T, int KS>
+struct Wg16Cfg {
+  static constexpr int PAD = KS / 2, TH = 8, TW = 64, XC = 16, GC = 16;
+  static constexpr int LP = TW + KS - 1, LR = TH + KS - 1, GRP = TW * GC + 64;      // +128 B: gy rows on different banks
+  static constexpr int KPW = 2;                                                    // kh taps per wave (accumulators: KPW x KS x 4 VGPRs)
+  static constexpr size_t SMEM = ((size_t)LR * LP * XC + (size_t)TH * GRP) * sizeof(T);
+};
+
+template <typename T, int KS>
+__global__ void __launch_bounds__(256, 2) k_wgrad_cc16(const T* __restrict__ x, const T* __restrict__ gy, float* __restrict__ dwt, WgtGeom g) {
+  static_assert(sizeof(T) == 2, "16-bit storage types only");
+  using C = Wg16Cfg<T, KS>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* xs = (T*)smem_raw;
+  T* gs = xs + (size_t)C::LR * C::LP * C::XC;
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4;
+  int kd, mt, yb;
+  {
+    const int L = blockIdx.x, inner = KS * g.zdim;
+    if (g.ydim % 8 == 0) { const int xcd = L & 7, slot = L >> 3, c = slot % inner; yb = (slot / inner) * 8 + xcd; kd = c % KS; mt = c / KS; }
+    else { kd = L % KS; const int r = L / KS; yb = r % g.ydim; mt = r / g.ydim; }
+  }
+  // wave roles: kh0 / nkh = the wave's kh taps, [c_lo, c_hi) = its 32-voxel chunks of a tile row
+  const int kh0 = KS == 7 ? 2 * wv : 2 * (wv & 1), nkh = min(C::KPW, KS - kh0);
+  const int c_lo = KS == 7 ? 0 : (wv >> 1), c_hi = KS == 7 ? 2 : c_lo + 1;
+  const int units = g.N * g.D * g.tiles_h, per = (units + g.ydim - 1) / g.ydim;
+  const int u0 = yb * per, u1 = min(units, u0 + per);
+  const int cbase_x = mt * C::XC;
+  // lane part of the k-major (transposing) reads: k group q = lane>>4 holds voxels 8q..8q+7, lane&15 = channel
+  const int i16 = lane & 15, x_lane = (8 * q + (i16 >> 2)) * C::XC + 4 * (i16 & 3), g_lane = (8 * q + (i16 >> 2)) * C::GC + 4 * (i16 & 3);
+
+  v4f acc[C::KPW][KS];
+#pragma unroll
+  for (int a = 0; a < C::KPW; a++)
+#pragma unroll
+    for (int b = 0; b < KS; b++) acc[a][b] = (v4f){0.f, 0.f, 0.f, 0.f};
+
+  struct Tile { int n, d, id, h0, w0, nch; };
+  auto tile_ok = [&](int u) { const int id = (u / g.tiles_h) % g.D, d = id - kd + C::PAD; return d >= 0 && d < g.D; };
+  auto tile_of = [&](int u, int tw) {
+    Tile t; const int th = u % g.tiles_h, nd = u / g.tiles_h;
+    t.id = nd % g.D; t.n = nd / g.D; t.d = t.id - kd + C::PAD; t.h0 = th * C::TH; t.w0 = tw * C::TW;
+    t.nch = min(2, (g.W - t.w0 + 31) >> 5);
+    return t;
+  };
+  auto advance = [&](int& u, int& tw) { if (++tw >= g.tiles_w) { tw = 0; u++; while (u < u1 && !tile_ok(u)) u++; } };
+  int cu = u0, ctw = 0;
+  while (cu < u1 && !tile_ok(cu)) cu++;
+
+  // register-staged tiles (see k_wgrad_tiled): all 16-byte pieces of the next tile are in flight during the sweep
+  constexpr int XPV = 2, GPV = 2;
+  constexpr int PX = (C::LR * C::LP * XPV + 255) / 256, PG = (C::TH * C::TW * GPV + 255) / 256;
+  v4u rx[PX], rg[PG];
+  const int cpiece = cbase_x + (tid % XPV) * 8;
+  const bool xsecond = g.x2 && cpiece >= g.csplit;
+  const T* xsrc = (xsecond ? (const T*)g.x2 : x) + cpiece - (xsecond ? g.csplit : 0);
+  const int ldsrc = xsecond ? g.ldx2 : g.ldx;
+  const T* gsrc = gy + (tid % GPV) * 8;
+  const bool x_exists = cpiece + 8 <= (g.x2 ? g.csplit + g.ldx2 : g.ldx), g_exists = (tid % GPV) * 8 + 8 <= g.ldgy;
+  int pkx[PX], pkg[PG];
+  {
+    int lp = (tid / XPV) % C::LP, lr = (tid / XPV) / C::LP;
+#pragma unroll
+    for (int j = 0; j < PX; j++) {
+      pkx[j] = (j * 256 + tid < C::LR * C::LP * XPV) ? (lr << 16 | lp) : -1;
+      lp += 256 / XPV;
+#pragma unroll
+      for (int w_ = 0; w_ < (128 + C::LP - 1) / C::LP; w_++) if (lp >= C::LP) { lp -= C::LP; lr++; }
+    }
+#pragma unroll
+    for (int j = 0; j < PG; j++) { const int v = tid / GPV + j * (256 / GPV); pkg[j] = (v < C::TH * C::TW) ? ((v / C::TW) << 16 | (v % C::TW)) : -1; }
+  }
+  auto issue = [&](const Tile& t) {
+    const T* xplane = xsrc + (((int64_t)t.n * g.D + t.id) * g.H) * (int64_t)g.W * ldsrc;
+    const int ihb = t.h0 - C::PAD, iwb = t.w0 - C::PAD;
+#pragma unroll
+    for (int j = 0; j < PX; j++) {
+      const int ih = ihb + (pkx[j] >> 16), iw = iwb + (pkx[j] & 0xffff);
+      const bool ok = x_exists && pkx[j] >= 0 && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
+      v4u v = *(const v4u*)(xplane + (ok ? (ih * g.W + iw) * ldsrc : 0));
+      rx[j] = ok ? v : (v4u){0, 0, 0, 0};
+    }
+    const T* gplane = gsrc + (((int64_t)t.n * g.D + t.d) * g.H) * (int64_t)g.W * g.ldgy;
+#pragma unroll
+    for (int j = 0; j < PG; j++) {
+      const int oh = t.h0 + (pkg[j] >> 16), ow = t.w0 + (pkg[j] & 0xffff);
+      const bool ok = g_exists && pkg[j] >= 0 && oh < g.H && ow < g.W;
+      v4u v = *(const v4u*)(gplane + (ok ? (oh * g.W + ow) * g.ldgy : 0));
+      rg[j] = ok ? v : (v4u){0, 0, 0, 0};
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int j = 0; j < PX; j++)
+      if (pkx[j] >= 0) *(v4u*)(xs + ((pkx[j] >> 16) * C::LP + (pkx[j] & 0xffff)) * C::XC + (tid % XPV) * 8) = rx[j];
+#pragma unroll
+    for (int j = 0; j < PG; j++)
+      if (pkg[j] >= 0) *(v4u*)(gs + (pkg[j] >> 16) * C::GRP + (pkg[j] & 0xffff) * C::GC + (tid % GPV) * 8) = rg[j];
+  };
+  // sweep of one 32-voxel chunk of one tile: every x row rho is loaded once as a register window and meets the gy rows i = rho - kh
+  // of the wave's taps (wave-uniform predicates; the accumulator index kk is static)
+  auto sweep = [&](int chunk) {
+    const T* gb = gs + g_lane + 32 * chunk * C::GC;
+    const T* xb = xs + x_lane + 32 * chunk * C::XC;
+    // (a hand-pipelined variant -- next row's loads issued before this row's MFMAs, rolling gy registers -- measured 8 % slower:
+    // the second wave on the SIMD already hides the LDS latency and the register copies cost issue slots)
+#pragma unroll 1
+    for (int rho = kh0; rho < min(C::LR, kh0 + nkh - 1 + C::TH); rho++) {
+      Win16<T> W = make_win(tr_pair<4 * C::XC, T>(xb + rho * C::LP * C::XC), tr_pair<4 * C::XC, T>(xb + (rho * C::LP + 8) * C::XC));
+      win_finish<(KS > 1)>(W);
+#pragma unroll
+      for (int kk = 0; kk < C::KPW; kk++) {
+        const int i = rho - kh0 - kk;
+        if (kk >= nkh || i < 0 || i >= C::TH) continue;
+        const Frag8<T> gf = tr_pair<4 * C::GC, T>(gb + i * C::GRP);
+        [&]<int... KW>(std::integer_sequence<int, KW...>) {
+          ((acc[kk][KW] = mma16(win_frag<KW>(W), gf, acc[kk][KW])), ...);
+        }(std::make_integer_sequence<int, KS>{});
+      }
+    }
+  };
+  const bool fast = (g.ldx % 8 == 0) && (g.ldgy % 8 == 0) && (((uintptr_t)x & 15) == 0) && (((uintptr_t)gy & 15) == 0) &&
+                    (!g.x2 || ((g.csplit % 8 == 0) && (g.ldx2 % 8 == 0) && (((uintptr_t)g.x2 & 15) == 0)));
+  if (!fast) return;                                                // the launcher only selects this kernel for aligned operands
+  if (cu < u1) issue(tile_of(cu, ctw));
+  while (cu < u1) {
+    const Tile t = tile_of(cu, ctw);
+    lds_barrier();
+    commit();
+    int nu = cu, ntw = ctw; advance(nu, ntw);
+    if (nu < u1) issue(tile_of(nu, ntw));
+    lds_barrier();
+    if (nkh > 0)
+      for (int c = c_lo; c < min(c_hi, t.nch); c++) sweep(c);
+    cu = nu; ctw = ntw;
+  }
+  // C/D of the 16x16 MFMA: col (co) = lane&15, row (ci) = 4*(lane>>4) + e
+  const int co = lane & 15;
+  if (co >= g.Cout) return;
+#pragma unroll
+  for (int kk = 0; kk < C::KPW; kk++) {
+    if (kk >= nkh) continue;
+#pragma unroll
+    for (int kw = 0; kw < KS; kw++)
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const int ci = mt * 16 + 4 * q + e;
+        if (ci < g.Cin) atomicAdd(dwt + ((int64_t)((kd * KS + kh0 + kk) * KS + kw) * g.Cin + ci) * g.Cout + co, acc[kk][kw][e]);
+      }
+  }
+}
+
+template <typename T, int KS>
+static int launch_wg16(const void* x, const void* gy, float* ws, WgtGeom g, hipStream_t s) {
+  using C = Wg16Cfg<T, KS>;
+  auto kern = k_wgrad_cc16<T, KS>;
+  if (C::SMEM > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::SMEM);
+    if (e != hipSuccess) { dp_set_error("wgrad_cc16: cannot raise dynamic LDS to %zu: %s", C::SMEM, hipGetErrorString(e)); return 1; }
+  }
+  g.tiles_h = cdiv(g.H, C::TH); g.tiles_w = cdiv(g.W, C::TW);
+  g.MT = cdiv(g.Cin, C::XC); g.NTn = 1; g.KHG = 1;
+  int zdim = g.MT, units = g.N * g.D * g.tiles_h;
+  static int occ = 0, ncu = 0;
+  if (!occ) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)kern, 256, C::SMEM) != hipSuccess || occ < 1) occ = 2;
+    int dev = 0; hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount;
+    if (ncu < 1) ncu = 256;
+  }
+  int want = (ncu * occ) / (KS * zdim); if (want < 1) want = 1;
+  int ydim = units < want ? units : want;
+  if (ydim >= 8 && (ydim & 7) * 20 <= ydim) ydim &= ~7;
+  g.ydim = ydim; g.zdim = zdim;
+  hipLaunchKernelGGL(kern, dim3(KS * ydim * zdim), dim3(256), C::SMEM, s, (const T*)x, (const T*)gy, ws, g);
+  return 0;
+}
+
 __global__ void __launch_bounds__(256) k_wgrad_unpack(float* __restrict__ dwt, float* __restrict__ dw, int taps, int Cin, int Cout, int64_t s_co, int64_t s_ci,
                                                       int64_t s_tap, int rezero) {
   // [tap][ci][co] scratch -> dw[co*s_co + ci*s_ci + tap*s_tap] as an LDS-tiled transpose of 32 taps x 32 (ci, co) pairs: reads are
@@ -948,6 +1135,13 @@ extern "C" int dp_conv3d_wgrad_tiled2(const void* x, int ldx, const void* x2, in
                        D, H, W, ldx, ldx2, csplit, ldgy);
   }
   int rc = 0;
+  const bool aligned = ldx % 8 == 0 && ldgy % 8 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)gy & 15) == 0 &&
+                       (!x2 || (csplit % 8 == 0 && ldx2 % 8 == 0 && ((uintptr_t)x2 & 15) == 0)) &&
+                       (int64_t)H * W * (ldx > ldgy ? (ldx > ldx2 ? ldx : ldx2) : (ldgy > ldx2 ? ldgy : ldx2)) < (1ll << 30);
+  if (np == 2 && dtype != DP_F32 && aligned && !getenv("DP_NO_CC16")) {      // Cout <= 16: one tap per 16x16x32 MFMA, no tap-pairing padding
+    if (dtype == DP_BF16) rc = k == 7 ? launch_wg16<bf16_t, 7>(x, gy, ws, g, s) : launch_wg16<bf16_t, 3>(x, gy, ws, g, s);
+    else rc = k == 7 ? launch_wg16<f16_t, 7>(x, gy, ws, g, s) : launch_wg16<f16_t, 3>(x, gy, ws, g, s);
+  } else {
 #define GO(TT, KS_) do { if (np == 2 && mp == 2) rc = launch_wgt<TT, KS_, 2, 2>(x, gy, ws, g, s); else if (np == 2) rc = launch_wgt<TT, KS_, 2, 1>(x, gy, ws, g, s); \
                          else if (mp == 2) rc = launch_wgt<TT, KS_, 1, 2>(x, gy, ws, g, s); else rc = launch_wgt<TT, KS_, 1, 1>(x, gy, ws, g, s); } while (0)
   if (dtype == DP_BF16) { if (k == 7) GO(bf16_t, 7); else if (k == 3) GO(bf16_t, 3); else rc = launch_wgt<bf16_t, 1, 1, 1>(x, gy, ws, g, s); }
@@ -955,6 +1149,7 @@ extern "C" int dp_conv3d_wgrad_tiled2(const void* x, int ldx, const void* x2, in
   else if (dtype == DP_F32) { if (k == 7) GO(float, 7); else if (k == 3) GO(float, 3); else rc = launch_wgt<float, 1, 1, 1>(x, gy, ws, g, s); }
   else DP_FAIL("wgrad_tiled: bad dtype");
 #undef GO
+  }
   if (rc) return rc;
   DP_CHECK_LAUNCH("wgrad_tiled");
   int64_t pairs = (int64_t)Cin * Cout;
