@@ -860,18 +860,18 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_tiled(const T* __restrict__ x,
 // register sub-ranges) and (b) a gy fragment (one transpose-read pair) feeds the KS taps of a kh: 12 LDS reads per 28 MFMAs.  A wave owns a kh subset (4 + 3 of 7, 2 + 1 of 3) of one 32-voxel chunk and keeps its nkh x KS accumulators
 // (4 VGPRs each) for the block's whole voxel share; staging, tile order, grid decode and the scratch layout are those of
 // k_wgrad_tiled.
-template <typename T, int KS>
+template <typename T, int KS, int NT16>
 struct Wg16Cfg {
-  static constexpr int PAD = KS / 2, TH = 8, TW = 64, XC = 16, GC = 16;
+  static constexpr int PAD = KS / 2, TH = 8, TW = 64, XC = 16, GC = 16 * NT16;      // NT16 = 2: Cout in (16, 32], Cin <= 16
   static constexpr int LP = TW + KS - 1, LR = TH + KS - 1, GRP = TW * GC + 64;      // +128 B: gy rows on different banks
   static constexpr int KPW = 2;                                                    // kh taps per wave (accumulators: KPW x KS x 4 VGPRs)
   static constexpr size_t SMEM = ((size_t)LR * LP * XC + (size_t)TH * GRP) * sizeof(T);
 };
 
-template <typename T, int KS>
+template <typename T, int KS, int NT16>
 __global__ void __launch_bounds__(256, 2) k_wgrad_cc16(const T* __restrict__ x, const T* __restrict__ gy, float* __restrict__ dwt, WgtGeom g) {
   static_assert(sizeof(T) == 2, "16-bit storage types only");
-  using C = Wg16Cfg<T, KS>;
+  using C = Wg16Cfg<T, KS, NT16>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* xs = (T*)smem_raw;
   T* gs = xs + (size_t)C::LR * C::LP * C::XC;
@@ -891,11 +891,13 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_cc16(const T* __restrict__ x, 
   // lane part of the k-major (transposing) reads: k group q = lane>>4 holds voxels 8q..8q+7, lane&15 = channel
   const int i16 = lane & 15, x_lane = (8 * q + (i16 >> 2)) * C::XC + 4 * (i16 & 3), g_lane = (8 * q + (i16 >> 2)) * C::GC + 4 * (i16 & 3);
 
-  v4f acc[C::KPW][KS];
+  v4f acc[C::KPW][NT16][KS];
 #pragma unroll
   for (int a = 0; a < C::KPW; a++)
 #pragma unroll
-    for (int b = 0; b < KS; b++) acc[a][b] = (v4f){0.f, 0.f, 0.f, 0.f};
+    for (int n_ = 0; n_ < NT16; n_++)
+#pragma unroll
+      for (int b = 0; b < KS; b++) acc[a][n_][b] = (v4f){0.f, 0.f, 0.f, 0.f};
 
   struct Tile { int n, d, id, h0, w0, nch; };
   auto tile_ok = [&](int u) { const int id = (u / g.tiles_h) % g.D, d = id - kd + C::PAD; return d >= 0 && d < g.D; };
@@ -910,7 +912,7 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_cc16(const T* __restrict__ x, 
   while (cu < u1 && !tile_ok(cu)) cu++;
 
   // register-staged tiles (see k_wgrad_tiled): all 16-byte pieces of the next tile are in flight during the sweep
-  constexpr int XPV = 2, GPV = 2;
+  constexpr int XPV = 2, GPV = 2 * NT16;
   constexpr int PX = (C::LR * C::LP * XPV + 255) / 256, PG = (C::TH * C::TW * GPV + 255) / 256;
   v4u rx[PX], rg[PG];
   const int cpiece = cbase_x + (tid % XPV) * 8;
@@ -974,10 +976,13 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_cc16(const T* __restrict__ x, 
       for (int kk = 0; kk < C::KPW; kk++) {
         const int i = rho - kh0 - kk;
         if (kk >= nkh || i < 0 || i >= C::TH) continue;
-        const Frag8<T> gf = tr_pair<4 * C::GC, T>(gb + i * C::GRP);
-        [&]<int... KW>(std::integer_sequence<int, KW...>) {
-          ((acc[kk][KW] = mma16(win_frag<KW>(W), gf, acc[kk][KW])), ...);
-        }(std::make_integer_sequence<int, KS>{});
+#pragma unroll
+        for (int n_ = 0; n_ < NT16; n_++) {
+          const Frag8<T> gf = tr_pair<4 * C::GC, T>(gb + i * C::GRP + 16 * n_);
+          [&]<int... KW>(std::integer_sequence<int, KW...>) {
+            ((acc[kk][n_][KW] = mma16(win_frag<KW>(W), gf, acc[kk][n_][KW])), ...);
+          }(std::make_integer_sequence<int, KS>{});
+        }
       }
     }
   };
@@ -997,25 +1002,28 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_cc16(const T* __restrict__ x, 
     cu = nu; ctw = ntw;
   }
   // C/D of the 16x16 MFMA: col (co) = lane&15, row (ci) = 4*(lane>>4) + e
-  const int co = lane & 15;
-  if (co >= g.Cout) return;
 #pragma unroll
   for (int kk = 0; kk < C::KPW; kk++) {
     if (kk >= nkh) continue;
 #pragma unroll
-    for (int kw = 0; kw < KS; kw++)
+    for (int n_ = 0; n_ < NT16; n_++) {
+      const int co = 16 * n_ + (lane & 15);
+      if (co >= g.Cout) continue;
 #pragma unroll
-      for (int e = 0; e < 4; e++) {
-        const int ci = mt * 16 + 4 * q + e;
-        if (ci < g.Cin) atomicAdd(dwt + ((int64_t)((kd * KS + kh0 + kk) * KS + kw) * g.Cin + ci) * g.Cout + co, acc[kk][kw][e]);
-      }
+      for (int kw = 0; kw < KS; kw++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const int ci = mt * 16 + 4 * q + e;
+          if (ci < g.Cin) atomicAdd(dwt + ((int64_t)((kd * KS + kh0 + kk) * KS + kw) * g.Cin + ci) * g.Cout + co, acc[kk][n_][kw][e]);
+        }
+    }
   }
 }
 
-template <typename T, int KS>
+template <typename T, int KS, int NT16>
 static int launch_wg16(const void* x, const void* gy, float* ws, WgtGeom g, hipStream_t s) {
-  using C = Wg16Cfg<T, KS>;
-  auto kern = k_wgrad_cc16<T, KS>;
+  using C = Wg16Cfg<T, KS, NT16>;
+  auto kern = k_wgrad_cc16<T, KS, NT16>;
   if (C::SMEM > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::SMEM);
     if (e != hipSuccess) { dp_set_error("wgrad_cc16: cannot raise dynamic LDS to %zu: %s", C::SMEM, hipGetErrorString(e)); return 1; }
@@ -1138,9 +1146,13 @@ extern "C" int dp_conv3d_wgrad_tiled2(const void* x, int ldx, const void* x2, in
   const bool aligned = ldx % 8 == 0 && ldgy % 8 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)gy & 15) == 0 &&
                        (!x2 || (csplit % 8 == 0 && ldx2 % 8 == 0 && ((uintptr_t)x2 & 15) == 0)) &&
                        (int64_t)H * W * (ldx > ldgy ? (ldx > ldx2 ? ldx : ldx2) : (ldgy > ldx2 ? ldgy : ldx2)) < (1ll << 30);
-  if (np == 2 && dtype != DP_F32 && aligned && !getenv("DP_NO_CC16")) {      // Cout <= 16: one tap per 16x16x32 MFMA, no tap-pairing padding
-    if (dtype == DP_BF16) rc = k == 7 ? launch_wg16<bf16_t, 7>(x, gy, ws, g, s) : launch_wg16<bf16_t, 3>(x, gy, ws, g, s);
-    else rc = k == 7 ? launch_wg16<f16_t, 7>(x, gy, ws, g, s) : launch_wg16<f16_t, 3>(x, gy, ws, g, s);
+  const bool cc16 = k > 1 && dtype != DP_F32 && aligned && !getenv("DP_NO_CC16");
+  if (cc16 && np == 2) {                  // Cout <= 16: one tap per 16x16x32 MFMA, no tap-pairing padding
+    if (dtype == DP_BF16) rc = k == 7 ? launch_wg16<bf16_t, 7, 1>(x, gy, ws, g, s) : launch_wg16<bf16_t, 3, 1>(x, gy, ws, g, s);
+    else rc = k == 7 ? launch_wg16<f16_t, 7, 1>(x, gy, ws, g, s) : launch_wg16<f16_t, 3, 1>(x, gy, ws, g, s);
+  } else if (cc16 && mp == 2 && Cout <= 32) {   // Cin <= 16, Cout <= 32: two 16-wide N tiles share every x window (kw pairing wasted an eighth)
+    if (dtype == DP_BF16) rc = k == 7 ? launch_wg16<bf16_t, 7, 2>(x, gy, ws, g, s) : launch_wg16<bf16_t, 3, 2>(x, gy, ws, g, s);
+    else rc = k == 7 ? launch_wg16<f16_t, 7, 2>(x, gy, ws, g, s) : launch_wg16<f16_t, 3, 2>(x, gy, ws, g, s);
   } else {
 #define GO(TT, KS_) do { if (np == 2 && mp == 2) rc = launch_wgt<TT, KS_, 2, 2>(x, gy, ws, g, s); else if (np == 2) rc = launch_wgt<TT, KS_, 2, 1>(x, gy, ws, g, s); \
                          else if (mp == 2) rc = launch_wgt<TT, KS_, 1, 2>(x, gy, ws, g, s); else rc = launch_wgt<TT, KS_, 1, 1>(x, gy, ws, g, s); } while (0)
