@@ -9,6 +9,7 @@ Tensor conventions inside the HIP path
 PyTorch only provides device memory, the current stream and autograd bookkeeping here.
 """
 import math
+import os
 
 import torch
 
@@ -950,7 +951,51 @@ class Attention(torch.autograd.Function):
         return gqkv, None
 
 
+class FusedAttention(torch.autograd.Function):
+    """The same contraction as `Attention` in one launch forward (dp_attention_fwd) and three backward (dp_attention_bwd):
+    16-bit storage, head dim 64 or 128; only the per-row log-sum-exp is kept for backward, the N x N scores never exist."""
+
+    @staticmethod
+    def forward(ctx, qkv, heads):
+        _chk_dev(qkv)
+        qkv = qkv.contiguous()
+        B, N, H3 = qkv.shape
+        H = H3 // 3
+        d = H // heads
+        es = qkv.element_size()
+        base = qkv.data_ptr()
+        O = torch.empty((B, N, H), dtype=qkv.dtype, device=qkv.device)
+        lse = torch.empty((B * heads * ((N + 31) // 32 * 32),), dtype=torch.float32, device=qkv.device)
+        _lib.call("dp_attention_fwd", base, base + H * es, base + 2 * H * es, H3, _p(O), H, _p(lse), B, heads, N, d, float(d ** -0.5),
+                  _dt(qkv), _stream())
+        ctx.save_for_backward(qkv, O, lse)
+        ctx.heads = heads
+        return O
+
+    @staticmethod
+    def backward(ctx, gO):
+        qkv, O, lse = ctx.saved_tensors
+        heads = ctx.heads
+        gO = gO.contiguous()
+        B, N, H3 = qkv.shape
+        H = H3 // 3
+        d = H // heads
+        es = qkv.element_size()
+        base = qkv.data_ptr()
+        gqkv = torch.empty_like(qkv)
+        gb = gqkv.data_ptr()
+        delta = torch.empty_like(lse)
+        _lib.call("dp_attention_bwd", base, base + H * es, base + 2 * H * es, H3, _p(O), _p(gO), H, _p(lse), _p(delta), gb, gb + H * es,
+                  gb + 2 * H * es, H3, B, heads, N, d, float(d ** -0.5), _dt(qkv), _stream())
+        return gqkv, None
+
+
 def attention(qkv, heads):
+    """MONAI SABlock core on the packed qkv Linear output.  16-bit storage with head dim 64 / 128 (every configuration of
+    BASELINE.json) takes the fused kernels; fp32 (parity mode) and other head dims take MFMA GEMMs + row softmax."""
+    d = qkv.shape[-1] // 3 // heads
+    if qkv.dtype != torch.float32 and d in (64, 128) and not os.environ.get("DP_NO_FUSED_ATTN"):
+        return FusedAttention.apply(qkv, heads)
     return Attention.apply(qkv, heads)
 
 

@@ -70,6 +70,19 @@ int dp_gelu_bwd(const void* x, const void* gy, void* gx, int64_t n, int dtype, v
  * bwd: gs = scale * p * (gp - sum(gp*p)). */
 int dp_softmax_fwd(const void* s, void* p, int64_t rows, int cols, float scale, int dtype, void* stream);
 int dp_softmax_bwd(const void* p, const void* gp, void* gs, int64_t rows, int cols, float scale, int dtype, void* stream);
+/* Fused multi-head self-attention, 16-bit storage (DP_BF16 / DP_F16), head dim d in {64, 128}, any token count N.
+ * replaces: the whole of MONAI SABlock between its qkv Linear and out_proj (einops split "b h (qkv l d) -> qkv b l h d",
+ * softmax(q k^T * scale) v, merge "b h l d -> b l (h d)"); call sites dose_pyfer.py:55-67,129, oar_transeg.py:79-91,172
+ * (SURVEY.md §8b names dp_attention_{fwd,bwd}).  q, k, v point at head 0 of batch 0 inside a [B][N][ld] row-major tensor
+ * (for the packed qkv Linear output: ld = 3*heads*d, k = q + heads*d, v = q + 2*heads*d); head h starts h*d elements
+ * further.  o, go: [B][N][ldo] with the heads merged; dq/dk/dv: [B][N][ldg] laid out like q/k/v.  lse: float
+ * [B*heads*Np], Np = N rounded up to 32, base-2 log-sum-exp of the scaled scores, written by fwd and read by bwd; delta:
+ * float [B*heads*Np] scratch of bwd (rowsum(dO o O)); both 16-byte aligned.  The N x N scores are never stored.  fp32 storage: use dp_gemm_nt + dp_softmax_*. */
+int dp_attention_fwd(const void* q, const void* k, const void* v, int64_t ld, void* o, int64_t ldo, float* lse, int B, int heads, int N,
+                     int d, float scale, int dtype, void* stream);
+int dp_attention_bwd(const void* q, const void* k, const void* v, int64_t ld, const void* o, const void* go, int64_t ldo,
+                     const float* lse, float* delta, void* dq, void* dk, void* dv, int64_t ldg, int B, int heads, int N, int d,
+                     float scale, int dtype, void* stream);
 /* fp32 helpers for gradient buffers */
 int dp_fill_f32(float* p, float v, int64_t n, void* stream);
 

@@ -244,7 +244,8 @@ def test_layernorm_widths(C):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cfg", [(2, 64, 6, 128), (1, 512, 12, 64), (2, 8, 6, 8), (1, 144, 12, 4)])
+@pytest.mark.parametrize("cfg", [(2, 64, 6, 128), (1, 512, 12, 64), (2, 8, 6, 8), (1, 144, 12, 4), (2, 40, 6, 128), (1, 100, 12, 64),
+                                 (1, 1, 6, 64)])
 def test_attention(cfg, dtype):
     from dose_prediction_amd import ops
     dev = _dev()
@@ -266,6 +267,46 @@ def test_attention(cfg, dtype):
     check("gx", xh.grad, xr.grad, dtype, scale=s)
     check("gwqkv", wh.grad, wr.grad, dtype, scale=s)
     check("gwo", woh.grad, wor.grad, dtype, scale=s)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("cfg", [(2, 512, 12, 64), (2, 512, 6, 128), (1, 1152, 12, 64), (1, 1152, 6, 128), (3, 77, 6, 64)])
+def test_fused_attention_full_size(cfg, dtype):
+    """dp_attention_fwd/bwd at the token counts of BASELINE.json (512 @128^3, 1152 @192x192x128) and a ragged one, against the
+    float64 softmax(q k^T d^-1/2) v of the stored 16-bit qkv and against the unfused GEMM + softmax path of the same library."""
+    from dose_prediction_amd import ops
+    dev = _dev()
+    B, N, heads, d = cfg
+    H = heads * d
+    qkv = q(rnd((B, N, 3 * H), 11), dtype)
+    go = q(rnd((B, N, H), 12), dtype)
+    x = qkv.double().requires_grad_(True)
+    qq, kk, vv = (t.reshape(B, N, heads, d).permute(0, 2, 1, 3) for t in x.split(H, dim=2))
+    yr = (torch.softmax(qq @ kk.transpose(-1, -2) * d ** -0.5, -1) @ vv).permute(0, 2, 1, 3).reshape(B, N, H)
+    (yr * go.double()).sum().backward()
+    xf = qkv.to(dev, dtype).requires_grad_(True)
+    yf = ops.FusedAttention.apply(xf, heads)
+    yf.backward(go.to(dev, dtype))
+    xu = qkv.to(dev, dtype).requires_grad_(True)
+    yu = ops.Attention.apply(xu, heads)
+    yu.backward(go.to(dev, dtype))
+    check("y", yf, yr, dtype)
+    check("gqkv", xf.grad, x.grad, dtype, scale=2.0)
+    # the fused kernels keep P in fp32 until the second MFMA: never farther from the reference than the unfused path (+ slack)
+    yr = yr.detach()
+    ef, eu = rel_l2(yf.detach().double().cpu(), yr), rel_l2(yu.detach().double().cpu(), yr)
+    gf, gu = rel_l2(xf.grad.double().cpu(), x.grad), rel_l2(xu.grad.double().cpu(), x.grad)
+    assert ef <= 1.5 * eu + 1e-4 and gf <= 1.5 * gu + 1e-4, (ef, eu, gf, gu)
+
+
+def test_fused_attention_rejects_unsupported():
+    from dose_prediction_amd import _lib
+    dev = _dev()
+    t = torch.zeros(1024, device=dev)
+    with pytest.raises(_lib.DoseHipError):
+        _lib.call("dp_attention_fwd", t.data_ptr(), t.data_ptr(), t.data_ptr(), 96, t.data_ptr(), 32, t.data_ptr(), 1, 1, 4, 32, 1.0, 1, 0)
+    with pytest.raises(_lib.DoseHipError):
+        _lib.call("dp_attention_fwd", t.data_ptr(), t.data_ptr(), t.data_ptr(), 192, t.data_ptr(), 64, t.data_ptr(), 1, 1, 4, 64, 1.0, 0, 0)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
