@@ -316,7 +316,8 @@ class PatchEmbeddingBlock(nn.Module):
         tok = ops.patchify(x, self.in_channels, self.patch)
         rows = tok.shape[0] * tok.shape[1]
         # K = p^3*C is huge while M x N is small: split K so the GEMM fills the 256 CUs
-        splitk = max(1, min(32, (256 * 128 * 128) // max(1, rows * lin.out_features)))
+        # ... with 128x128 tiles in two full rounds (<= 512 blocks): 425 -> 283 us at 1024 x 768 x 102400
+        splitk = max(1, min(32, 480 // max(1, -(-rows // 128) * -(-lin.out_features // 128))))
         t = ops.linear(tok, lin.weight, lin.bias, splitk=splitk if tok.shape[-1] >= 4096 else 1)
         return ops.add_broadcast(t, self.position_embeddings)
 

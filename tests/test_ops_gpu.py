@@ -423,7 +423,8 @@ def test_conv3d_virtual_concat(cfg, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cfg", [(768, 96, 1024, 1), (100, 37, 200, 1), (64, 64, 2048, 4), (130, 70, 333, 2)])
+@pytest.mark.parametrize("cfg", [(768, 96, 1024, 1), (100, 37, 200, 1), (64, 64, 2048, 4), (130, 70, 333, 2), (768, 12800, 300, 1),
+                                 (700, 6000, 130, 2)])   # the last two: wide outputs (patch-embedding weight gradient shape class)
 def test_gemm_tn(cfg, dtype):
     """dp_gemm_tn: C = A^T B with k-major operands (weight gradients of row-major layers), ragged tiles and split-K."""
     from dose_prediction_amd import _lib
