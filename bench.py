@@ -276,7 +276,8 @@ def main():
     local = local % max(1, ndev)          # (gloo self-test: several ranks may share one GPU)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    ddp_on = world > 1 or (os.environ.get("DOSE_DDP_FORCE") and "RANK" in os.environ)   # FORCE: 1-rank self-test of the RCCL path
+    if ddp_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("DOSE_DDP_BACKEND", "nccl")      # nccl == RCCL on ROCm
         if backend == "nccl":
@@ -287,10 +288,10 @@ def main():
     from dose_prediction_amd import synth, losses, _lib
     from dose_prediction_amd.ddp import attach_gradient_allreduce
     net = build_model(args, shape, dev)
-    if world > 1:
+    if ddp_on:
         attach_gradient_allreduce(net, bucket_mb=32.0)
     params = [p for p in net.parameters() if p.requires_grad]
-    use_graph = (world == 1) and args.graph
+    use_graph = (not ddp_on) and args.graph
     from dose_prediction_amd.optim import FusedAdam
     # optimizer exactly as NetworkTrainer.set_optimizer builds it (network_trainer.py:120-125), as the fused HIP kernel
     opt = None
@@ -334,7 +335,7 @@ def main():
         return loss
 
     def sync():
-        if world > 1:
+        if ddp_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -376,7 +377,7 @@ def main():
             loss = step()
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if ddp_on:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
@@ -413,7 +414,7 @@ def main():
                 res["cpu_baseline"] = {"value": None, "unit": "volumes/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {e!r}"}
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if ddp_on:
         dist.barrier()
         dist.destroy_process_group()
 

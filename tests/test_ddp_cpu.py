@@ -39,7 +39,7 @@ def _worker(rank, world, port, out):
     torch.manual_seed(100 + rank)          # different initial weights per rank: the broadcast must fix that
     net = Net()
     keys_before = list(net.state_dict().keys())
-    attach_gradient_allreduce(net, bucket_mb=0.002)
+    red = attach_gradient_allreduce(net, bucket_mb=0.002)
     assert list(net.state_dict().keys()) == keys_before
     w0 = net.a.weight.detach().clone()
     res = {"w0": w0}
@@ -49,6 +49,15 @@ def _worker(rank, world, port, out):
         net(x).backward()
         res[f"g{step}"] = {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
         res[f"x{step}"] = x
+    # a step in which parameters that HAD gradients get none: their bucket slices must be exchanged as zeros again
+    net.zero_grad(set_to_none=True)
+    net.a(net.frozen(x)).sum().backward()
+    named = dict(net.named_parameters())
+    for name in ("b.weight", "bn.weight", "unused.weight"):
+        bi, off, n = red.where[named[name]]
+        assert not red.flat[bi][off:off + n].any(), name
+        assert named[name].grad is None, name
+    assert named["a.weight"].grad is not None
     res["sd"] = {k: v.clone() for k, v in net.state_dict().items()}
     out[rank] = res
     dist.barrier()

@@ -1,5 +1,5 @@
 import sys, os, collections, traceback, torch
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.argv=['x','--no-cpu-baseline']
 import bench
 from dose_prediction_amd import _lib, losses, synth
@@ -23,5 +23,10 @@ torch.zeros, torch.zeros_like = wrap(oz, "zeros"), wrap(ozl, "zeros_like")
 oz_ = torch.Tensor.zero_
 def zz(self): cnt["zero_ @ " + " <- ".join(f"{os.path.basename(s.filename)}:{s.lineno}" for s in reversed(traceback.extract_stack(limit=4)[:-1]))] += 1; return oz_(self)
 torch.Tensor.zero_ = zz
+oc_, ocl_ = torch.Tensor.copy_, torch.Tensor.clone
+def site(): return " <- ".join(f"{os.path.basename(s.filename)}:{s.lineno}" for s in reversed(traceback.extract_stack(limit=5)[:-2]))
+def cc(self, *a, **k): cnt["copy_ @ " + site()] += 1; return oc_(self, *a, **k)
+def cl(self, *a, **k): cnt["clone @ " + site()] += 1; return ocl_(self, *a, **k)
+torch.Tensor.copy_, torch.Tensor.clone = cc, cl
 step(); torch.cuda.synchronize()
-for k, v in cnt.most_common(25): print(v, k)
+for k, v in cnt.most_common(40): print(v, k)
