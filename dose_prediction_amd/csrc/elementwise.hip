@@ -49,25 +49,51 @@ __device__ __forceinline__ void frag_pack(Frag8<bf16_t>& f, const float* o) {
 }
 
 // ------------------------------------------------------------------------------------------------ layout
-template <typename T>
-__global__ void k_ncdhw_to_ndhwc(const float* __restrict__ src, T* __restrict__ dst, int N, int C, int64_t V, int ld, int cpad) {
-  int64_t total = (int64_t)N * V;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    int64_t n = i / V, v = i - n * V;
-    T* d = dst + i * ld;
-    const float* s = src + n * C * V + v;
+// Index arithmetic of the row kernels is done in 32 bits whenever the work fits (it always does for the volumes of this model):
+// a 64-bit divide per thread costs more than the 16 bytes the thread moves.
+template <typename T, typename I>
+__device__ __forceinline__ void ncdhw_to_ndhwc_body(const float* __restrict__ src, T* __restrict__ dst, I total, I V, int C, int ld, int cpad) {
+  bool vec = false;
+  if constexpr (sizeof(T) == 2) vec = (cpad & 7) == 0 && (ld & 7) == 0 && (((uintptr_t)dst) & 15) == 0;
+  for (I i = blockIdx.x * (I)blockDim.x + threadIdx.x; i < total; i += (I)gridDim.x * blockDim.x) {
+    const I n = i / V, v = i - n * V;
+    T* d = dst + (int64_t)i * ld;
+    const float* s = src + (int64_t)n * C * V + v;
+    if constexpr (sizeof(T) == 2) {
+      if (vec) {      // 8 channels -> one 16-byte store (2-byte scattered stores ran this conversion at 2.7 TB/s)
+        for (int c0 = 0; c0 < cpad; c0 += 8) {
+          float t[8];
+#pragma unroll
+          for (int j = 0; j < 8; j++) t[j] = (c0 + j < C) ? s[(int64_t)(c0 + j) * V] : 0.f;
+          Frag8<T> f; frag_pack(f, t);
+          *(v4u*)(d + c0) = f.u;
+        }
+        continue;
+      }
+    }
     for (int c = 0; c < cpad; c++) st_f(d + c, c < C ? s[(int64_t)c * V] : 0.f);
   }
 }
 template <typename T>
-__global__ void k_ndhwc_to_ncdhw(const T* __restrict__ src, float* __restrict__ dst, int N, int C, int64_t V, int ld, int acc) {
-  int64_t total = (int64_t)N * V;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    int64_t n = i / V, v = i - n * V;
-    const T* s = src + i * ld;
-    float* d = dst + n * C * V + v;
+__global__ void k_ncdhw_to_ndhwc(const float* __restrict__ src, T* __restrict__ dst, int N, int C, int64_t V, int ld, int cpad) {
+  const int64_t total = (int64_t)N * V;
+  if (total < (1ll << 31)) ncdhw_to_ndhwc_body<T, unsigned>(src, dst, (unsigned)total, (unsigned)V, C, ld, cpad);
+  else ncdhw_to_ndhwc_body<T, int64_t>(src, dst, total, V, C, ld, cpad);
+}
+template <typename T, typename I>
+__device__ __forceinline__ void ndhwc_to_ncdhw_body(const T* __restrict__ src, float* __restrict__ dst, I total, I V, int C, int ld, int acc) {
+  for (I i = blockIdx.x * (I)blockDim.x + threadIdx.x; i < total; i += (I)gridDim.x * blockDim.x) {
+    const I n = i / V, v = i - n * V;
+    const T* s = src + (int64_t)i * ld;
+    float* d = dst + (int64_t)n * C * V + v;
     for (int c = 0; c < C; c++) { float x = ld_f(s + c); if (acc) d[(int64_t)c * V] += x; else d[(int64_t)c * V] = x; }
   }
+}
+template <typename T>
+__global__ void k_ndhwc_to_ncdhw(const T* __restrict__ src, float* __restrict__ dst, int N, int C, int64_t V, int ld, int acc) {
+  const int64_t total = (int64_t)N * V;
+  if (total < (1ll << 31)) ndhwc_to_ncdhw_body<T, unsigned>(src, dst, (unsigned)total, (unsigned)V, C, ld, acc);
+  else ndhwc_to_ncdhw_body<T, int64_t>(src, dst, total, V, C, ld, acc);
 }
 extern "C" int dp_ncdhw_to_ndhwc(const float* src, void* dst, int N, int C, int64_t V, int ld, int cpad, int dtype, void* stream) {
   if (cpad < C || ld < cpad) DP_FAIL("ncdhw_to_ndhwc: need C <= cpad <= ld");
@@ -79,15 +105,66 @@ extern "C" int dp_ndhwc_to_ncdhw(const void* src, float* dst, int N, int C, int6
   DP_CHECK_LAUNCH("ndhwc_to_ncdhw"); return 0;
 }
 
+template <typename T, typename I>
+__device__ __forceinline__ void copy_rows_body(const T* __restrict__ src, int lds, T* __restrict__ dst, int ldd, I total, I cg8, int C) {
+  const I stride = (I)gridDim.x * blockDim.x;
+  for (I i0 = blockIdx.x * (I)blockDim.x + threadIdx.x; i0 < total; i0 += 4 * stride) {   // four 16-byte loads in flight per thread
+    Frag8<T> f[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const I i = i0 + u * stride;
+      if (i < total) { const I r = i / cg8; const int cg = (int)(i - r * cg8); f[u] = frag_load(src + (int64_t)r * lds + cg * 8, min(8, C - cg * 8)); }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const I i = i0 + u * stride;
+      if (i < total) { const I r = i / cg8; const int cg = (int)(i - r * cg8); frag_store<T>(dst + (int64_t)r * ldd + cg * 8, f[u], min(8, C - cg * 8)); }
+    }
+  }
+}
 template <typename T>
 __global__ void k_copy_rows(const T* __restrict__ src, int lds, T* __restrict__ dst, int ldd, int64_t rows, int C) {
-  int cg8 = (C + 7) >> 3;
-  int64_t total = rows * cg8;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    int64_t r = i / cg8; int cg = (int)(i - r * cg8); int nv = min(8, C - cg * 8);
-    Frag8<T> f = frag_load(src + r * lds + cg * 8, nv);
-    frag_store<T>(dst + r * ldd + cg * 8, f, nv);
+  const int cg8 = (C + 7) >> 3;
+  const int64_t total = rows * cg8;
+  if (total < (1ll << 31)) copy_rows_body<T, unsigned>(src, lds, dst, ldd, (unsigned)total, (unsigned)cg8, C);
+  else copy_rows_body<T, int64_t>(src, lds, dst, ldd, total, (int64_t)cg8, C);
+}
+// torch.cat of two row tensors in one pass: every destination row is written whole (two dp_copy_rows calls wrote alternating
+// 32-byte halves of each row and ran at 2.5 TB/s).
+template <typename T>
+__global__ void k_cat2_rows(const T* __restrict__ a, int lda, int Ca, const T* __restrict__ b, int ldb, int Cb, T* __restrict__ dst, int ldd,
+                            unsigned total, unsigned cg8, unsigned cga) {
+  const unsigned stride = gridDim.x * blockDim.x;
+  for (unsigned i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < total; i0 += 4 * stride) {
+    Frag8<T> f[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const unsigned i = i0 + u * stride;
+      if (i < total) {
+        const unsigned r = i / cg8, cg = i - r * cg8;
+        f[u] = cg < cga ? frag_load(a + (int64_t)r * lda + cg * 8, min(8, Ca - (int)cg * 8))
+                        : frag_load(b + (int64_t)r * ldb + (cg - cga) * 8, min(8, Cb - (int)(cg - cga) * 8));
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const unsigned i = i0 + u * stride;
+      if (i < total) {
+        const unsigned r = i / cg8, cg = i - r * cg8;
+        const int nv = cg < cga ? min(8, Ca - (int)cg * 8) : min(8, Cb - (int)(cg - cga) * 8);
+        frag_store<T>(dst + (int64_t)r * ldd + (cg < cga ? cg * 8 : Ca + (cg - cga) * 8), f[u], nv);
+      }
+    }
   }
+}
+extern "C" int dp_cat2_rows(const void* a, int lda, int Ca, const void* b, int ldb, int Cb, void* dst, int ldd, int64_t rows, int dtype, void* stream) {
+  if ((Ca & 7) || Ca <= 0 || Cb <= 0 || ldd < Ca + Cb) DP_FAIL("cat2_rows: first width must be a positive multiple of 8 (got %d) and ldd >= Ca + Cb", Ca);
+  const int cga = Ca / 8, cg8 = cga + (Cb + 7) / 8;
+  const int64_t total = rows * cg8;
+  if (total >= (1ll << 31)) DP_FAIL("cat2_rows: too many rows");
+  DP_DISPATCH(dtype, hipLaunchKernelGGL(k_cat2_rows<T>, dim3(grid_for(total, 256 * 4, 256 * 32)), dim3(256), 0, STREAM, (const T*)a, lda, Ca, (const T*)b,
+                                        ldb, Cb, (T*)dst, ldd, (unsigned)total, (unsigned)cg8, (unsigned)cga));
+  DP_CHECK_LAUNCH("cat2_rows"); return 0;
 }
 extern "C" int dp_copy_rows(const void* src, int lds, void* dst, int ldd, int64_t rows, int C, int dtype, void* stream) {
   DP_DISPATCH(dtype, hipLaunchKernelGGL(k_copy_rows<T>, dim3(grid_for(rows * ((C + 7) / 8), 256)), dim3(256), 0, STREAM, (const T*)src, lds, (T*)dst, ldd, rows, C));
@@ -118,31 +195,97 @@ extern "C" int dp_fill_f32(float* p, float v, int64_t n, void* stream) {
 }
 
 // patchify: one thread per (b, token, p1, p2, p3): C contiguous elements on both sides.
-template <typename T, bool INV>
-__global__ void k_patchify(const T* __restrict__ x, T* __restrict__ out, int B, int S0, int S1, int S2, int C, int ld, int p) {
-  int f0 = S0 / p, f1 = S1 / p, f2 = S2 / p;
-  int64_t ntok = (int64_t)f0 * f1 * f2, p3n = (int64_t)p * p * p;
-  int64_t total = (int64_t)B * ntok * p3n;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    int64_t pp = i % p3n, bt = i / p3n; int64_t tok = bt % ntok, b = bt / ntok;
-    int p3 = (int)(pp % p), p2 = (int)((pp / p) % p), p1 = (int)(pp / ((int64_t)p * p));
-    int t2 = (int)(tok % f2), t1 = (int)((tok / f2) % f1), t0 = (int)(tok / ((int64_t)f2 * f1));
-    int64_t vox = (((int64_t)b * S0 + t0 * p + p1) * S1 + t1 * p + p2) * S2 + t2 * p + p3;
-    const T* a = x + vox * ld; T* o = out + i * C;   // i == ((b*ntok+tok)*p3n + pp)
+template <typename T, bool INV, typename I>
+__device__ __forceinline__ void patchify_body(const T* __restrict__ x, T* __restrict__ out, I total, int S0, int S1, int S2, int C, int ld, int p) {
+  const I f1 = S1 / p, f2 = S2 / p, ntok = (I)(S0 / p) * f1 * f2, pu = p;
+  for (I i = blockIdx.x * (I)blockDim.x + threadIdx.x; i < total; i += (I)gridDim.x * blockDim.x) {
+    I t = i; const I q1 = t / pu; const int p3 = (int)(t - q1 * pu); t = q1;
+    const I q2 = t / pu; const int p2 = (int)(t - q2 * pu); t = q2;
+    const I bt = t / pu; const int p1 = (int)(t - bt * pu);
+    const I b = bt / ntok; I tok = bt - b * ntok;
+    const I r1 = tok / f2; const int t2 = (int)(tok - r1 * f2);
+    const I t0 = r1 / f1; const int t1 = (int)(r1 - t0 * f1);
+    const int64_t vox = (((int64_t)b * S0 + t0 * pu + p1) * S1 + t1 * p + p2) * S2 + t2 * p + p3;
+    const T* a = x + vox * ld; T* o = out + (int64_t)i * C;   // i == ((b*ntok+tok)*p^3 + pp)
     if (!INV) { for (int c = 0; c < C; c++) o[c] = a[c]; }
     else { T* aw = const_cast<T*>(a); for (int c = 0; c < C; c++) aw[c] = o[c]; }
   }
 }
+template <typename T, bool INV>
+__global__ void k_patchify(const T* __restrict__ x, T* __restrict__ out, int B, int S0, int S1, int S2, int C, int ld, int p) {
+  const int64_t total = (int64_t)B * S0 * S1 * S2;
+  if (total < (1ll << 31)) patchify_body<T, INV, unsigned>(x, out, (unsigned)total, S0, S1, S2, C, ld, p);
+  else patchify_body<T, INV, int64_t>(x, out, total, S0, S1, S2, C, ld, p);
+}
+// Fast path (16-bit storage): one wave per run of p voxels along W, i.e. per (b, token, p1, p2).  The run is contiguous on both
+// sides (p*ld elements in x, p*C in the token row), so it is moved with 16-byte accesses through a wave-private LDS strip; the
+// per-voxel kernel above issued 2*C two-byte accesses per voxel and ran at 1.5 TB/s.
+template <typename T, bool INV>
+__global__ void __launch_bounds__(256) k_patchify_runs(const T* __restrict__ x, T* __restrict__ out, int nruns, int S0, int S1, int S2, int C, int ld,
+                                                       int p, unsigned cmul) {
+  __shared__ __attribute__((aligned(16))) T strip[4][1024];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  T* ls = strip[wv];
+  const int f1 = S1 / p, f2 = S2 / p, ntok = (S0 / p) * f1 * f2, nin = p * ld / 8, nout = p * C / 8, cg8 = ld / 8;
+  for (int run = blockIdx.x * 4 + wv; run < nruns; run += gridDim.x * 4) {
+    int t = run; const int p2 = t % p; t /= p; const int p1 = t % p; t /= p;
+    const int tok = t % ntok, b = t / ntok, t2 = tok % f2, r1 = tok / f2, t1 = r1 % f1, t0 = r1 / f1;
+    const int64_t vox = (((int64_t)b * S0 + t0 * p + p1) * S1 + t1 * p + p2) * S2 + t2 * p;
+    const T* xr = x + vox * ld; T* orow = out + (int64_t)run * p * C;
+    if (!INV) {
+      for (int j = lane; j < nin; j += 64) *(v4u*)(ls + 8 * j) = *(const v4u*)(xr + 8 * j);
+      for (int j = lane; j < nout; j += 64) {
+        unsigned w[4];
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+          const unsigned i0 = 8 * j + e, v0 = (i0 * cmul) >> 20, i1 = i0 + 1, v1 = (i1 * cmul) >> 20;   // v = i / C (exact: i*C < 2^20)
+          const unsigned a = __builtin_bit_cast(unsigned short, ls[v0 * ld + (i0 - v0 * C)]), c = __builtin_bit_cast(unsigned short, ls[v1 * ld + (i1 - v1 * C)]);
+          w[e >> 1] = a | (c << 16);
+        }
+        *(v4u*)(orow + 8 * j) = (v4u){w[0], w[1], w[2], w[3]};
+      }
+    } else {   // token-row gradient -> voxel rows (pad channels zero)
+      T* xw = const_cast<T*>(xr);
+      for (int j = lane; j < nout; j += 64) *(v4u*)(ls + 8 * j) = *(const v4u*)(orow + 8 * j);
+      for (int j = lane; j < nin; j += 64) {
+        const int v = j / cg8, c0 = (j - v * cg8) * 8;
+        unsigned w[4];
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+          const unsigned a = (c0 + e < C) ? __builtin_bit_cast(unsigned short, ls[v * C + c0 + e]) : 0u;
+          const unsigned c = (c0 + e + 1 < C) ? __builtin_bit_cast(unsigned short, ls[v * C + c0 + e + 1]) : 0u;
+          w[e >> 1] = a | (c << 16);
+        }
+        *(v4u*)(xw + 8 * j) = (v4u){w[0], w[1], w[2], w[3]};
+      }
+    }
+  }
+}
+static bool patchify_fast(const void* x, const void* out, int B, int S0, int S1, int S2, int C, int ld, int p, int dtype) {
+  const int64_t nruns = (int64_t)B * (S0 / p) * (S1 / p) * (S2 / p) * p * p;
+  return dtype != DP_F32 && (ld & 7) == 0 && ((p * C) & 7) == 0 && p * ld <= 1024 && p * C <= 1024 && (int64_t)p * C * C < (1 << 20) && nruns < (1ll << 31) &&
+         ((((uintptr_t)x) | ((uintptr_t)out)) & 15) == 0;
+}
+template <bool INV>
+static void patchify_runs_launch(const void* x, void* out, int B, int S0, int S1, int S2, int C, int ld, int p, int dtype, hipStream_t st) {
+  const int nruns = B * (S0 / p) * (S1 / p) * (S2 / p) * p * p;
+  const unsigned cmul = ((1u << 20) + C - 1) / C;
+  const int grid = grid_for(nruns, 4, 256 * 32);
+  if (dtype == DP_BF16) hipLaunchKernelGGL((k_patchify_runs<bf16_t, INV>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)out, nruns, S0, S1, S2, C, ld, p, cmul);
+  else hipLaunchKernelGGL((k_patchify_runs<f16_t, INV>), dim3(grid), dim3(256), 0, st, (const f16_t*)x, (f16_t*)out, nruns, S0, S1, S2, C, ld, p, cmul);
+}
 extern "C" int dp_patchify(const void* x, void* out, int B, int S0, int S1, int S2, int C, int ld, int p, int dtype, void* stream) {
   if (S0 % p || S1 % p || S2 % p) DP_FAIL("patchify: size not divisible by patch");
   int64_t total = (int64_t)B * S0 * S1 * S2;
-  DP_DISPATCH(dtype, hipLaunchKernelGGL((k_patchify<T, false>), dim3(grid_for(total, 256)), dim3(256), 0, STREAM, (const T*)x, (T*)out, B, S0, S1, S2, C, ld, p));
+  if (patchify_fast(x, out, B, S0, S1, S2, C, ld, p, dtype)) patchify_runs_launch<false>(x, out, B, S0, S1, S2, C, ld, p, dtype, STREAM);
+  else DP_DISPATCH(dtype, hipLaunchKernelGGL((k_patchify<T, false>), dim3(grid_for(total, 256)), dim3(256), 0, STREAM, (const T*)x, (T*)out, B, S0, S1, S2, C, ld, p));
   DP_CHECK_LAUNCH("patchify"); return 0;
 }
 extern "C" int dp_unpatchify(const void* gout, void* gx, int B, int S0, int S1, int S2, int C, int ld, int p, int dtype, void* stream) {
   if (S0 % p || S1 % p || S2 % p) DP_FAIL("unpatchify: size not divisible by patch");
   int64_t total = (int64_t)B * S0 * S1 * S2;
-  DP_DISPATCH(dtype, hipLaunchKernelGGL((k_patchify<T, true>), dim3(grid_for(total, 256)), dim3(256), 0, STREAM, (const T*)gx, (T*)const_cast<void*>(gout), B, S0, S1, S2, C, ld, p));
+  if (patchify_fast(gx, gout, B, S0, S1, S2, C, ld, p, dtype)) patchify_runs_launch<true>(gx, const_cast<void*>(gout), B, S0, S1, S2, C, ld, p, dtype, STREAM);
+  else DP_DISPATCH(dtype, hipLaunchKernelGGL((k_patchify<T, true>), dim3(grid_for(total, 256)), dim3(256), 0, STREAM, (const T*)gx, (T*)const_cast<void*>(gout), B, S0, S1, S2, C, ld, p));
   DP_CHECK_LAUNCH("unpatchify"); return 0;
 }
 
@@ -186,29 +329,42 @@ __device__ __forceinline__ void tri_coord(int o, int n_in, int& i0, int& i1, flo
   i1 = i0 + 1 < n_in ? i0 + 1 : n_in - 1;
   f = s - (float)i0;
 }
-template <typename T>
-__global__ void k_trilinear_fwd(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, int N, int D, int H, int W, int C) {
-  int cg8 = (C + 7) >> 3;
-  int64_t OV = (int64_t)N * 8 * D * H * W, total = OV * cg8;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    int cg = (int)(i % cg8); int64_t ov = i / cg8;
-    int ow = (int)(ov % (2 * W)), oh = (int)((ov / (2 * W)) % (2 * H)), od = (int)((ov / ((int64_t)4 * W * H)) % (2 * D));
-    int64_t n = ov / ((int64_t)8 * W * H * D);
+template <typename T, typename I>
+__device__ __forceinline__ void trilinear_fwd_body(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, I total, I cg8, int D, int H, int W,
+                                                   int C) {
+  const I W2 = 2 * W, H2 = 2 * H, D2 = 2 * D;
+  for (I i = blockIdx.x * (I)blockDim.x + threadIdx.x; i < total; i += (I)gridDim.x * blockDim.x) {
+    const I ov = i / cg8; const int cg = (int)(i - ov * cg8);
+    I t = ov; const I q1 = t / W2; const int ow = (int)(t - q1 * W2); t = q1;
+    const I q2 = t / H2; const int oh = (int)(t - q2 * H2); t = q2;
+    const I n = t / D2; const int od = (int)(t - n * D2);
     int d0, d1, h0, h1, w0, w1; float fd, fh, fw;
     tri_coord(od, D, d0, d1, fd); tri_coord(oh, H, h0, h1, fh); tri_coord(ow, W, w0, w1, fw);
-    int nv = min(8, C - cg * 8);
+    const int nv = min(8, C - cg * 8);
+    Frag8<T> in[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int dd = (k & 4) ? d1 : d0, hh = (k & 2) ? h1 : h0, ww = (k & 1) ? w1 : w0;
+      in[k] = frag_load(x + ((((int64_t)n * D + dd) * H + hh) * W + ww) * ldx + cg * 8, nv);
+    }
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-      int dd = (k & 4) ? d1 : d0, hh = (k & 2) ? h1 : h0, ww = (k & 1) ? w1 : w0;
-      float wgt = ((k & 4) ? fd : 1.f - fd) * ((k & 2) ? fh : 1.f - fh) * ((k & 1) ? fw : 1.f - fw);
-      float t[8];
-      frag_unpack(frag_load(x + (((n * D + dd) * H + hh) * W + ww) * ldx + cg * 8, nv), t);
-      for (int j = 0; j < 8; j++) acc[j] += wgt * t[j];
+      const float wgt = ((k & 4) ? fd : 1.f - fd) * ((k & 2) ? fh : 1.f - fh) * ((k & 1) ? fw : 1.f - fw);
+      float tt[8];
+      frag_unpack(in[k], tt);
+      for (int j = 0; j < 8; j++) acc[j] += wgt * tt[j];
     }
     Frag8<T> f; frag_pack(f, acc);
-    frag_store<T>(y + ov * ldy + cg * 8, f, nv);
+    frag_store<T>(y + (int64_t)ov * ldy + cg * 8, f, nv);
   }
+}
+template <typename T>
+__global__ void k_trilinear_fwd(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, int N, int D, int H, int W, int C) {
+  const int cg8 = (C + 7) >> 3;
+  const int64_t total = (int64_t)N * 8 * D * H * W * cg8;
+  if (total < (1ll << 31)) trilinear_fwd_body<T, unsigned>(x, ldx, y, ldy, (unsigned)total, (unsigned)cg8, D, H, W, C);
+  else trilinear_fwd_body<T, int64_t>(x, ldx, y, ldy, total, (int64_t)cg8, D, H, W, C);
 }
 template <typename T>
 __global__ void k_trilinear_bwd(const T* __restrict__ gy, int ldgy, float* __restrict__ gx, int N, int D, int H, int W, int C) {

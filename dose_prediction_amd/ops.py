@@ -287,11 +287,15 @@ class Cat(torch.autograd.Function):
         xs = [as_rows(x) for x in xs]
         cs = [x.shape[-1] for x in xs]
         out = torch.empty(tuple(xs[0].shape[:-1]) + (sum(cs),), dtype=xs[0].dtype, device=xs[0].device)
-        off = 0
-        for x, c in zip(xs, cs):
-            rows, _, ld = rows_ld(x)
-            _lib.call("dp_copy_rows", _p(x), ld, out.data_ptr() + off * out.element_size(), out.shape[-1], rows, c, _dt(x), _stream())
-            off += c
+        if len(xs) == 2 and cs[0] % 8 == 0:
+            (rows, _, lda), (_, _, ldb) = rows_ld(xs[0]), rows_ld(xs[1])
+            _lib.call("dp_cat2_rows", _p(xs[0]), lda, cs[0], _p(xs[1]), ldb, cs[1], _p(out), out.shape[-1], rows, _dt(out), _stream())
+        else:
+            off = 0
+            for x, c in zip(xs, cs):
+                rows, _, ld = rows_ld(x)
+                _lib.call("dp_copy_rows", _p(x), ld, out.data_ptr() + off * out.element_size(), out.shape[-1], rows, c, _dt(x), _stream())
+                off += c
         ctx.cs = cs
         return out
 

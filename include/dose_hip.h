@@ -42,6 +42,9 @@ int dp_ndhwc_to_ncdhw(const void* src, float* dst, int N, int C, int64_t V, int 
 /* replaces: torch.cat(dim=1) (c3d.py:103-113, dose_pyfer.py:357, base_blocks.py:139, blocks_MDUNet.py:154):
  * copy rows x C channels from src (pitch lds) into dst (pitch ldd). */
 int dp_copy_rows(const void* src, int lds, void* dst, int ldd, int64_t rows, int C, int dtype, void* stream);
+/* torch.cat((a, b), dim=1) in one pass: dst row = [a row (Ca channels, Ca % 8 == 0) | b row (Cb channels)]; every
+ * destination row is written whole.  replaces: dose_pyfer.py:357 cat((out_net_A, x)), c3d.py:103-113. */
+int dp_cat2_rows(const void* a, int lda, int Ca, const void* b, int ldb, int Cb, void* dst, int ldd, int64_t rows, int dtype, void* stream);
 /* fp32 <-> T conversion of a flat array (weights, small vectors). */
 int dp_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream);
 /* replaces: einops Rearrange "b c (h p1)(w p2)(d p3) -> b (h w d)(p1 p2 p3 c)" in MONAI
