@@ -310,6 +310,24 @@ def test_fused_attention_rejects_unsupported():
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [(1000, 16, 16, 9, 16), (777, 8, 8, 24, 24), (4096, 32, 48, 5, 8), (3, 16, 16, 16, 16)])
+def test_cat_two_inputs(cfg, dtype):
+    """ops.cat of two row tensors (dp_cat2_rows, one pass) incl. sources that are channel slices of wider buffers; bit-exact."""
+    from dose_prediction_amd import ops
+    dev = _dev()
+    rows, ca, lda, cb, ldb = cfg
+    A = q(rnd((rows, lda), 1), dtype).to(dev, dtype)
+    B = q(rnd((rows, ldb), 2), dtype).to(dev, dtype)
+    a, b = A[:, :ca].requires_grad_(True), B[:, :cb].requires_grad_(True)
+    y = ops.cat((a, b))
+    ref = torch.cat((A[:, :ca], B[:, :cb]), dim=1)
+    assert torch.equal(y.reshape(rows, ca + cb), ref)
+    g = q(rnd((rows, ca + cb), 3), dtype).to(dev, dtype)
+    ga, gb = torch.autograd.grad(y, (a, b), g.view(y.shape))
+    assert torch.equal(ga.reshape(rows, ca), g[:, :ca]) and torch.equal(gb.reshape(rows, cb), g[:, ca:])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_patchify_posemb(dtype):
     from dose_prediction_amd import ops
     dev = _dev()
