@@ -290,24 +290,33 @@ extern "C" int dp_unpatchify(const void* gout, void* gx, int B, int S0, int S1, 
 }
 
 // pixel shuffle (2x2x2): src [V][8][C] <-> dst NDHWC(2D,2H,2W) pitch ldd
-template <typename T, bool INV>
-__global__ void k_pixel_shuffle2(const T* __restrict__ src, int lds, T* __restrict__ dst, int ldd, int N, int D, int H, int W, int C) {
-  int cg8 = (C + 7) >> 3;
-  int64_t V = (int64_t)N * D * H * W, total = V * 8 * cg8;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    int cg = (int)(i % cg8); int64_t r = i / cg8; int abc = (int)(r & 7); int64_t v = r >> 3;
-    int w = (int)(v % W), h = (int)((v / W) % H), d = (int)((v / ((int64_t)W * H)) % D); int64_t n = v / ((int64_t)W * H * D);
-    int a = abc >> 2, b = (abc >> 1) & 1, c = abc & 1;
-    int64_t ov = ((n * 2 * D + 2 * d + a) * 2 * H + 2 * h + b) * 2 * W + 2 * w + c;
-    int nv = min(8, C - cg * 8);
+template <typename T, bool INV, typename I>
+__device__ __forceinline__ void pixel_shuffle2_body(const T* __restrict__ src, int lds, T* __restrict__ dst, int ldd, I total, I cg8, int D, int H, int W,
+                                                    int C) {
+  const I Wu = W, Hu = H, Du = D;
+  for (I i = blockIdx.x * (I)blockDim.x + threadIdx.x; i < total; i += (I)gridDim.x * blockDim.x) {
+    const I r = i / cg8; const int cg = (int)(i - r * cg8), abc = (int)(r & 7); const I v = r >> 3;
+    I t = v; const I q1 = t / Wu; const int w = (int)(t - q1 * Wu); t = q1;
+    const I q2 = t / Hu; const int h = (int)(t - q2 * Hu); t = q2;
+    const I n = t / Du; const int d = (int)(t - n * Du);
+    const int a = abc >> 2, b = (abc >> 1) & 1, c = abc & 1;
+    const int64_t ov = (((int64_t)n * 2 * D + 2 * d + a) * 2 * H + 2 * h + b) * 2 * W + 2 * w + c;
+    const int nv = min(8, C - cg * 8);
     if (!INV) {  // src compact [v][abc][C] -> dst big (pitch ldd)
-      Frag8<T> f = frag_load(src + (v * 8 + abc) * C + cg * 8, nv);
+      Frag8<T> f = frag_load(src + ((int64_t)v * 8 + abc) * C + cg * 8, nv);
       frag_store<T>(dst + ov * ldd + cg * 8, f, nv);
     } else {     // src big (pitch lds) -> dst compact
       Frag8<T> f = frag_load(src + ov * lds + cg * 8, nv);
-      frag_store<T>(dst + (v * 8 + abc) * C + cg * 8, f, nv);
+      frag_store<T>(dst + ((int64_t)v * 8 + abc) * C + cg * 8, f, nv);
     }
   }
+}
+template <typename T, bool INV>
+__global__ void k_pixel_shuffle2(const T* __restrict__ src, int lds, T* __restrict__ dst, int ldd, int N, int D, int H, int W, int C) {
+  const int cg8 = (C + 7) >> 3;
+  const int64_t total = (int64_t)N * D * H * W * 8 * cg8;
+  if (total < (1ll << 31)) pixel_shuffle2_body<T, INV, unsigned>(src, lds, dst, ldd, (unsigned)total, (unsigned)cg8, D, H, W, C);
+  else pixel_shuffle2_body<T, INV, int64_t>(src, lds, dst, ldd, total, (int64_t)cg8, D, H, W, C);
 }
 extern "C" int dp_pixel_shuffle2(const void* src, void* dst, int N, int D, int H, int W, int C, int ldd, int dtype, void* stream) {
   int64_t total = (int64_t)N * D * H * W * 8 * ((C + 7) / 8);
