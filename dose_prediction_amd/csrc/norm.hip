@@ -209,15 +209,21 @@ struct NormArgs {
   const void* x; int ldx; const void* gy; int ldgy; const float* mean; const float* rstd; int ssn; const float* gamma; const float* beta;
   const void* res; int ldr; void* y; int ldy; void* gres; int ldgres; const float* s1; const float* s2; float inv_count; int use_stats;
   int64_t V; int C; int rpb; int nblk; float* part; int fast;
+  // forward only: second row source for channels >= csplit (normalise-into-concat in ONE pass, whole output rows per wave)
+  const void* x2; int ldx2; const float* mean2; const float* rstd2; int ssn2; int csplit;
 };
 
 template <typename T, int ACT>
 __global__ void __launch_bounds__(NT) k_norm_act_fwd(NormArgs a) {
-  const T* x = (const T*)a.x; const T* res = (const T*)a.res; T* y = (T*)a.y;
+  const T* res = (const T*)a.res; T* y = (T*)a.y;
   const int b = blockIdx.x, n = blockIdx.y;
   RowGeom g = row_geom(a.C);
   if (!g.active) return;
-  NormConst k = load_consts(a.mean, a.rstd, n * a.ssn, a.gamma, a.beta, g.cg * 8, g.nv);
+  const bool second = a.x2 != nullptr && g.cg * 8 >= a.csplit;      // this thread's 8-channel chunk comes from the second source
+  const T* x = second ? (const T*)a.x2 : (const T*)a.x;
+  const int ldx = second ? a.ldx2 : a.ldx, xoff = (second ? g.cg - (a.csplit >> 3) : g.cg) * 8;
+  NormConst k = second ? load_consts(a.mean2, a.rstd2, n * a.ssn2, nullptr, nullptr, xoff, g.nv)
+                       : load_consts(a.mean, a.rstd, n * a.ssn, a.gamma, a.beta, g.cg * 8, g.nv);
   float sc[8], sh[8];
 #pragma unroll
   for (int i = 0; i < 8; i++) { sc[i] = k.r[i] * k.ga[i]; sh[i] = k.be[i] - k.m[i] * sc[i]; }     // z = x*sc + sh
@@ -229,7 +235,7 @@ __global__ void __launch_bounds__(NT) k_norm_act_fwd(NormArgs a) {
 #pragma unroll
       for (int u = 0; u < RU; u++) {
         const int64_t row = nb + vs + u * g.rpi;
-        ld8(x + row * a.ldx + g.cg * 8, t[u]);
+        ld8(x + row * ldx + xoff, t[u]);
         if (res) ld8(res + row * a.ldr + g.cg * 8, rr[u]);
       }
 #pragma unroll
@@ -243,7 +249,7 @@ __global__ void __launch_bounds__(NT) k_norm_act_fwd(NormArgs a) {
   for (int64_t v = vs; v < v1; v += g.rpi) {
     const int64_t row = nb + v;
     float t[8], rr[8];
-    unpack8<T>(x + row * a.ldx + g.cg * 8, g.nv, t);
+    unpack8<T>(x + row * ldx + xoff, g.nv, t);
     if (res) unpack8<T>(res + row * a.ldr + g.cg * 8, g.nv, rr);
 #pragma unroll
     for (int i = 0; i < 8; i++) { float z = t[i] * sc[i] + sh[i]; if (res) z += rr[i]; t[i] = (ACT == DP_ACT_MISH && sizeof(T) == 2) ? mish_fwd_fast(z) : act_fwd(z, ACT); }
@@ -373,6 +379,17 @@ extern "C" int dp_norm_act_fwd(const void* x, int ldx, const float* mean, const 
   a.fast = norm_fast(C, ldx, x, 0, nullptr, ldr, res, ldy, y, 0, nullptr);
   NORM_LAUNCH(k_norm_act_fwd, a, dim3(a.nblk, N));
   DP_CHECK_LAUNCH("norm_act_fwd"); return 0;
+}
+extern "C" int dp_norm_act_cat_fwd(const void* xa, int lda, const float* mean_a, const float* rstd_a, int Ca, const void* xb, int ldb,
+                                   const float* mean_b, const float* rstd_b, int Cb, int act, void* y, int ldy, int N, int64_t V, int dtype,
+                                   void* stream) {
+  const int C = Ca + Cb;
+  if (C > 8 * NT || (Ca & 7) || (Cb & 7) || Ca <= 0 || Cb <= 0) DP_FAIL("norm_act_cat_fwd: channel counts must be positive multiples of 8 (%d, %d)", Ca, Cb);
+  NormArgs a = {}; a.x = xa; a.ldx = lda; a.mean = mean_a; a.rstd = rstd_a; a.ssn = Ca; a.x2 = xb; a.ldx2 = ldb; a.mean2 = mean_b; a.rstd2 = rstd_b;
+  a.ssn2 = Cb; a.csplit = Ca; a.y = y; a.ldy = ldy; a.V = V; a.C = C; a.rpb = rows_per_block(V); a.nblk = dp_stats_nblk(V);
+  a.fast = norm_fast(C, lda, xa, 0, nullptr, 0, nullptr, ldy, y, 0, nullptr) && norm_fast(C, ldb, xb, 0, nullptr, 0, nullptr, ldy, y, 0, nullptr);
+  NORM_LAUNCH(k_norm_act_fwd, a, dim3(a.nblk, N));
+  DP_CHECK_LAUNCH("norm_act_cat_fwd"); return 0;
 }
 extern "C" int dp_norm_act_bwd_partial(const void* x, int ldx, const void* gy, int ldgy, const float* mean, const float* rstd, int ssn,
                                        const float* gamma, const float* beta, const void* res, int ldr, int act, int N, int64_t V, int C,

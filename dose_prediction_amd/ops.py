@@ -617,7 +617,7 @@ def linear(x, weight, bias=None, splitk=1):
 
 
 # ------------------------------------------------------------------------------------------------ normalisation
-def _norm_forward(x, kind, gamma, beta, running_mean, running_var, training, res, act, eps, momentum, y_ptr, ldy):
+def _norm_forward(x, kind, gamma, beta, running_mean, running_var, training, res, act, eps, momentum, y_ptr, ldy, apply=True):
     """Statistics + fused normalise/affine/residual/activation of one NDHWC tensor into (y_ptr, row pitch ldy)."""
     rows, C, ldx = rows_ld(x)
     N = x.shape[0]
@@ -645,6 +645,8 @@ def _norm_forward(x, kind, gamma, beta, running_mean, running_var, training, res
         dummy = torch.empty((1, C), dtype=torch.float32, device=dev)
         _lib.call("dp_stats_finalize", _p(zero_part), 1, 1, C, 1, 1, float(eps), _p(dummy), _p(rstd), 0, 0, 0.0, _stream())
     ssn = C if kind == "instance" else 0
+    if not apply:       # statistics only (the caller normalises: norm_act_cat)
+        return mean, rstd, use_batch_stats, ssn
     g32 = None if gamma is None else gamma.detach()
     b32 = None if beta is None else beta.detach()
     ldr = rows_ld(res)[2] if res is not None else 0
@@ -730,9 +732,12 @@ class NormActCat(torch.autograd.Function):
         if xa.shape[:-1] != xb.shape[:-1] or (ca % 8) or (cb % 8):
             raise ValueError("norm_act_cat: operands must share the voxel grid and have channel counts that are multiples of 8")
         y = torch.empty(tuple(xa.shape[:-1]) + (ca + cb,), dtype=xa.dtype, device=xa.device)
-        ma, ra, _, ssa = _norm_forward(xa, "instance", None, None, None, None, True, None, act, eps, 0.1, _p(y), ca + cb)
-        mb, rb, _, ssb = _norm_forward(xb, "instance", None, None, None, None, True, None, act, eps, 0.1,
-                                       y.data_ptr() + ca * y.element_size(), ca + cb)
+        ma, ra, _, ssa = _norm_forward(xa, "instance", None, None, None, None, True, None, act, eps, 0.1, 0, 0, apply=False)
+        mb, rb, _, ssb = _norm_forward(xb, "instance", None, None, None, None, True, None, act, eps, 0.1, 0, 0, apply=False)
+        N = xa.shape[0]
+        # one pass over both sources: every 2*(ca+cb)-byte output row is written whole (two launches wrote alternating halves)
+        _lib.call("dp_norm_act_cat_fwd", _p(xa), rows_ld(xa)[2], _p(ma), _p(ra), ca, _p(xb), rows_ld(xb)[2], _p(mb), _p(rb), cb, ACT[act],
+                  _p(y), ca + cb, N, rows_ld(xa)[0] // N, _dt(xa), _stream())
         ctx.save_for_backward(xa, xb, ma, ra, mb, rb)
         ctx.cfg = (act, ssa, ssb)
         return y

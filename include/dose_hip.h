@@ -104,6 +104,11 @@ int dp_stats_finalize(const float* part, int N, int nblk, int C, int64_t V, int 
 int dp_norm_act_fwd(const void* x, int ldx, const float* mean, const float* rstd, int stat_stride_n,
                     const float* gamma, const float* beta, const void* res, int ldr, int act,
                     void* y, int ldy, int N, int64_t V, int C, int dtype, void* stream);
+/* cat((IN(xa) -> act, IN(xb) -> act), channels) written in ONE pass (blocks_MDUNet.conv_3_1, 141-147): non-affine instance
+ * statistics per source (mean / rstd: [N][Ca], [N][Cb]), y rows of Ca + Cb channels written whole. */
+int dp_norm_act_cat_fwd(const void* xa, int lda, const float* mean_a, const float* rstd_a, int Ca, const void* xb, int ldb,
+                        const float* mean_b, const float* rstd_b, int Cb, int act, void* y, int ldy, int N, int64_t V, int dtype,
+                        void* stream);
 /* backward pass 1: g = gy*act'(z); partials of sum(g) and sum(g*xhat): part float [N][nblk][2][C]. */
 int dp_norm_act_bwd_partial(const void* x, int ldx, const void* gy, int ldgy, const float* mean, const float* rstd,
                             int stat_stride_n, const float* gamma, const float* beta, const void* res, int ldr, int act,
