@@ -209,8 +209,9 @@ struct NormArgs {
   const void* x; int ldx; const void* gy; int ldgy; const float* mean; const float* rstd; int ssn; const float* gamma; const float* beta;
   const void* res; int ldr; void* y; int ldy; void* gres; int ldgres; const float* s1; const float* s2; float inv_count; int use_stats;
   int64_t V; int C; int rpb; int nblk; float* part; int fast;
-  // forward only: second row source for channels >= csplit (normalise-into-concat in ONE pass, whole output rows per wave)
-  const void* x2; int ldx2; const float* mean2; const float* rstd2; int ssn2; int csplit;
+  // second row source for channels >= csplit (normalise-into-concat and its backward in ONE pass over whole y / gy rows);
+  // backward: y2 / ldy2 = the second source's gx
+  const void* x2; int ldx2; const float* mean2; const float* rstd2; int ssn2; int csplit; void* y2; int ldy2;
 };
 
 template <typename T, int ACT>
@@ -260,10 +261,14 @@ __global__ void __launch_bounds__(NT) k_norm_act_fwd(NormArgs a) {
 template <typename T, int ACT>
 __global__ void __launch_bounds__(NT) k_norm_act_bwd_partial(NormArgs a) {
   __shared__ float red[NT * 16];
-  const T* x = (const T*)a.x; const T* gy = (const T*)a.gy; const T* res = (const T*)a.res;
+  const T* gy = (const T*)a.gy; const T* res = (const T*)a.res;
   const int b = blockIdx.x, n = blockIdx.y;
   RowGeom g = row_geom(a.C);
-  NormConst k = load_consts(a.mean, a.rstd, n * a.ssn, a.gamma, a.beta, g.cg * 8, g.active ? g.nv : 0);
+  const bool second = a.x2 != nullptr && g.cg * 8 >= a.csplit;
+  const T* x = second ? (const T*)a.x2 : (const T*)a.x;
+  const int ldx = second ? a.ldx2 : a.ldx, xoff = (second ? g.cg - (a.csplit >> 3) : g.cg) * 8;
+  NormConst k = second ? load_consts(a.mean2, a.rstd2, n * a.ssn2, nullptr, nullptr, xoff, g.active ? g.nv : 0)
+                       : load_consts(a.mean, a.rstd, n * a.ssn, a.gamma, a.beta, g.cg * 8, g.active ? g.nv : 0);
   const int64_t v0 = (int64_t)b * a.rpb, v1 = min(a.V, v0 + a.rpb), nb = (int64_t)n * a.V;
   float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int64_t vs = v0 + g.r0;
@@ -282,7 +287,7 @@ __global__ void __launch_bounds__(NT) k_norm_act_bwd_partial(NormArgs a) {
 #pragma unroll
       for (int u = 0; u < RU; u++) {
         const int64_t row = nb + vs + u * g.rpi;
-        ld8(x + row * a.ldx + g.cg * 8, t[u]); ld8(gy + row * a.ldgy + g.cg * 8, d[u]);
+        ld8(x + row * ldx + xoff, t[u]); ld8(gy + row * a.ldgy + g.cg * 8, d[u]);
         if (res) ld8(res + row * a.ldr + g.cg * 8, rr[u]);
       }
 #pragma unroll
@@ -292,7 +297,7 @@ __global__ void __launch_bounds__(NT) k_norm_act_bwd_partial(NormArgs a) {
   if (g.active) for (int64_t v = vs; v < v1; v += g.rpi) {
     const int64_t row = nb + v;
     float t[8], d[8], rr[8];
-    unpack8<T>(x + row * a.ldx + g.cg * 8, g.nv, t);
+    unpack8<T>(x + row * ldx + xoff, g.nv, t);
     unpack8<T>(gy + row * a.ldgy + g.cg * 8, g.nv, d);
     if (res) unpack8<T>(res + row * a.ldr + g.cg * 8, g.nv, rr);
     body(t, d, rr);
@@ -302,17 +307,23 @@ __global__ void __launch_bounds__(NT) k_norm_act_bwd_partial(NormArgs a) {
 
 template <typename T, int ACT>
 __global__ void __launch_bounds__(NT) k_norm_act_bwd_apply(NormArgs a) {
-  const T* x = (const T*)a.x; const T* gy = (const T*)a.gy; const T* res = (const T*)a.res; T* gx = (T*)a.y; T* gres = (T*)a.gres;
+  const T* gy = (const T*)a.gy; const T* res = (const T*)a.res; T* gres = (T*)a.gres;
   const int b = blockIdx.x, n = blockIdx.y;
   RowGeom g = row_geom(a.C);
   if (!g.active) return;
-  NormConst k = load_consts(a.mean, a.rstd, n * a.ssn, a.gamma, a.beta, g.cg * 8, g.nv);
+  const bool second = a.x2 != nullptr && g.cg * 8 >= a.csplit;
+  const T* x = second ? (const T*)a.x2 : (const T*)a.x;
+  T* gx = second ? (T*)a.y2 : (T*)a.y;
+  const int ldx = second ? a.ldx2 : a.ldx, ldgx = second ? a.ldy2 : a.ldy, xoff = (second ? g.cg - (a.csplit >> 3) : g.cg) * 8;
+  NormConst k = second ? load_consts(a.mean2, a.rstd2, n * a.ssn2, nullptr, nullptr, xoff, g.nv)
+                       : load_consts(a.mean, a.rstd, n * a.ssn, a.gamma, a.beta, g.cg * 8, g.nv);
+  const int sidx = a.x2 ? n * a.C : n * a.ssn;       // two-source mode: s1 / s2 are [N][Ca + Cb]
   float a1[8], a2[8];
 #pragma unroll
   for (int i = 0; i < 8; i++) {
     bool ok = a.use_stats && i < g.nv;
-    a1[i] = ok ? a.s1[n * a.ssn + g.cg * 8 + i] * a.inv_count : 0.f;
-    a2[i] = ok ? a.s2[n * a.ssn + g.cg * 8 + i] * a.inv_count : 0.f;
+    a1[i] = ok ? a.s1[sidx + g.cg * 8 + i] * a.inv_count : 0.f;
+    a2[i] = ok ? a.s2[sidx + g.cg * 8 + i] * a.inv_count : 0.f;
   }
   const int64_t v0 = (int64_t)b * a.rpb, v1 = min(a.V, v0 + a.rpb), nb = (int64_t)n * a.V;
   int64_t vs = v0 + g.r0;
@@ -331,14 +342,14 @@ __global__ void __launch_bounds__(NT) k_norm_act_bwd_apply(NormArgs a) {
 #pragma unroll
       for (int u = 0; u < RU; u++) {
         const int64_t row = nb + vs + u * g.rpi;
-        ld8(x + row * a.ldx + g.cg * 8, t[u]); ld8(gy + row * a.ldgy + g.cg * 8, d[u]);
+        ld8(x + row * ldx + xoff, t[u]); ld8(gy + row * a.ldgy + g.cg * 8, d[u]);
         if (res) ld8(res + row * a.ldr + g.cg * 8, rr[u]);
       }
 #pragma unroll
       for (int u = 0; u < RU; u++) {
         const int64_t row = nb + vs + u * g.rpi;
         body(t[u], d[u], rr[u], gg[u]);
-        if (gx) st8(gx + row * a.ldy + g.cg * 8, t[u]);
+        if (gx) st8(gx + row * ldgx + xoff, t[u]);
         if (gres) st8(gres + row * a.ldgres + g.cg * 8, gg[u]);
       }
     }
@@ -346,11 +357,11 @@ __global__ void __launch_bounds__(NT) k_norm_act_bwd_apply(NormArgs a) {
   for (int64_t v = vs; v < v1; v += g.rpi) {
     const int64_t row = nb + v;
     float t[8], d[8], rr[8], gg[8];
-    unpack8<T>(x + row * a.ldx + g.cg * 8, g.nv, t);
+    unpack8<T>(x + row * ldx + xoff, g.nv, t);
     unpack8<T>(gy + row * a.ldgy + g.cg * 8, g.nv, d);
     if (res) unpack8<T>(res + row * a.ldr + g.cg * 8, g.nv, rr);
     body(t, d, rr, gg);
-    if (gx) pack8(gx + row * a.ldy + g.cg * 8, g.nv, t);
+    if (gx) pack8(gx + row * ldgx + xoff, g.nv, t);
     if (gres) pack8(gres + row * a.ldgres + g.cg * 8, g.nv, gg);
   }
 }
@@ -400,6 +411,32 @@ extern "C" int dp_norm_act_bwd_partial(const void* x, int ldx, const void* gy, i
   a.fast = norm_fast(C, ldx, x, ldgy, gy, ldr, res, 0, nullptr, 0, nullptr);
   NORM_LAUNCH(k_norm_act_bwd_partial, a, dim3(a.nblk, N));
   DP_CHECK_LAUNCH("norm_act_bwd_partial"); return 0;
+}
+
+extern "C" int dp_norm_act_cat_bwd_partial(const void* xa, int lda, const float* mean_a, const float* rstd_a, int Ca, const void* xb, int ldb,
+                                           const float* mean_b, const float* rstd_b, int Cb, const void* gy, int ldgy, int act, int N, int64_t V,
+                                           float* part, int dtype, void* stream) {
+  const int C = Ca + Cb;
+  if (C > 8 * NT || (Ca & 7) || (Cb & 7) || Ca <= 0 || Cb <= 0) DP_FAIL("norm_act_cat_bwd_partial: channel counts must be positive multiples of 8");
+  NormArgs a = {}; a.x = xa; a.ldx = lda; a.mean = mean_a; a.rstd = rstd_a; a.ssn = Ca; a.x2 = xb; a.ldx2 = ldb; a.mean2 = mean_b; a.rstd2 = rstd_b;
+  a.ssn2 = Cb; a.csplit = Ca; a.gy = gy; a.ldgy = ldgy; a.V = V; a.C = C; a.rpb = rows_per_block(V); a.nblk = dp_stats_nblk(V); a.part = part;
+  a.fast = norm_fast(C, lda, xa, ldgy, gy, 0, nullptr, 0, nullptr, 0, nullptr) && norm_fast(C, ldb, xb, 0, nullptr, 0, nullptr, 0, nullptr, 0, nullptr);
+  NORM_LAUNCH(k_norm_act_bwd_partial, a, dim3(a.nblk, N));
+  DP_CHECK_LAUNCH("norm_act_cat_bwd_partial"); return 0;
+}
+extern "C" int dp_norm_act_cat_bwd_apply(const void* xa, int lda, const float* mean_a, const float* rstd_a, int Ca, const void* xb, int ldb,
+                                         const float* mean_b, const float* rstd_b, int Cb, const void* gy, int ldgy, int act, const float* s1,
+                                         const float* s2, float inv_count, void* gxa, int ldgxa, void* gxb, int ldgxb, int N, int64_t V, int dtype,
+                                         void* stream) {
+  const int C = Ca + Cb;
+  if (C > 8 * NT || (Ca & 7) || (Cb & 7) || Ca <= 0 || Cb <= 0) DP_FAIL("norm_act_cat_bwd_apply: channel counts must be positive multiples of 8");
+  if (!gxa || !gxb) DP_FAIL("norm_act_cat_bwd_apply: both gradients are produced");
+  NormArgs a = {}; a.x = xa; a.ldx = lda; a.mean = mean_a; a.rstd = rstd_a; a.ssn = Ca; a.x2 = xb; a.ldx2 = ldb; a.mean2 = mean_b; a.rstd2 = rstd_b;
+  a.ssn2 = Cb; a.csplit = Ca; a.gy = gy; a.ldgy = ldgy; a.y = gxa; a.ldy = ldgxa; a.y2 = gxb; a.ldy2 = ldgxb; a.s1 = s1; a.s2 = s2;
+  a.inv_count = inv_count; a.use_stats = 1; a.V = V; a.C = C; a.rpb = rows_per_block(V); a.nblk = dp_stats_nblk(V);
+  a.fast = norm_fast(C, lda, xa, ldgy, gy, 0, nullptr, ldgxa, gxa, 0, nullptr) && norm_fast(C, ldb, xb, 0, nullptr, 0, nullptr, ldgxb, gxb, 0, nullptr);
+  NORM_LAUNCH(k_norm_act_bwd_apply, a, dim3(a.nblk, N));
+  DP_CHECK_LAUNCH("norm_act_cat_bwd_apply"); return 0;
 }
 
 __global__ void __launch_bounds__(256) k_norm_bwd_finalize(const float* __restrict__ part, int N, int nblk, int C, int batch_mode, float* s1o, float* s2o,

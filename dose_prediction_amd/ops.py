@@ -749,6 +749,22 @@ class NormActCat(torch.autograd.Function):
         gy = as_rows(gy)
         ldg, ca = rows_ld(gy)[2], xa.shape[-1]
         ga = gb = None
+        if ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
+            # both halves in one pass over whole gradient rows (the per-half passes read 32-byte halves of 64-byte rows)
+            cb = xb.shape[-1]
+            N = xa.shape[0]
+            V = rows_ld(xa)[0] // N
+            dev, dtc = xa.device, _dt(xa)
+            nblk = _lib.lib().dp_stats_nblk(V)
+            part = torch.empty((N, nblk, 2, ca + cb), dtype=torch.float32, device=dev)
+            s12 = torch.empty((2, N, ca + cb), dtype=torch.float32, device=dev)
+            ga = torch.empty(xa.shape, dtype=xa.dtype, device=dev)
+            gb = torch.empty(xb.shape, dtype=xb.dtype, device=dev)
+            src = (_p(xa), rows_ld(xa)[2], _p(ma), _p(ra), ca, _p(xb), rows_ld(xb)[2], _p(mb), _p(rb), cb, _p(gy), ldg, ACT[act])
+            _lib.call("dp_norm_act_cat_bwd_partial", *src, N, V, _p(part), dtc, _stream())
+            _lib.call("dp_norm_bwd_finalize", _p(part), N, nblk, ca + cb, 0, _p(s12[0]), _p(s12[1]), 0, 0, _stream())
+            _lib.call("dp_norm_act_cat_bwd_apply", *src, _p(s12[0]), _p(s12[1]), 1.0 / V, _p(ga), ca, _p(gb), cb, N, V, dtc, _stream())
+            return ga, gb, None, None
         if ctx.needs_input_grad[0]:
             ga = _norm_backward(xa, ma, ra, None, None, None, "instance", act, True, ssa, _p(gy), ldg, True, False, False)[0]
         if ctx.needs_input_grad[1]:

@@ -109,6 +109,15 @@ int dp_norm_act_fwd(const void* x, int ldx, const float* mean, const float* rstd
 int dp_norm_act_cat_fwd(const void* xa, int lda, const float* mean_a, const float* rstd_a, int Ca, const void* xb, int ldb,
                         const float* mean_b, const float* rstd_b, int Cb, int act, void* y, int ldy, int N, int64_t V, int dtype,
                         void* stream);
+/* Backward of dp_norm_act_cat_fwd in one pass over whole gy rows.  part: float [N][nblk][2][Ca+Cb]; combine it with
+ * dp_norm_bwd_finalize(part, N, nblk, Ca+Cb, 0, s1, s2, NULL, NULL), then apply (inv_count = 1/V) -> gxa [.., Ca], gxb [.., Cb]. */
+int dp_norm_act_cat_bwd_partial(const void* xa, int lda, const float* mean_a, const float* rstd_a, int Ca, const void* xb, int ldb,
+                                const float* mean_b, const float* rstd_b, int Cb, const void* gy, int ldgy, int act, int N, int64_t V,
+                                float* part, int dtype, void* stream);
+int dp_norm_act_cat_bwd_apply(const void* xa, int lda, const float* mean_a, const float* rstd_a, int Ca, const void* xb, int ldb,
+                              const float* mean_b, const float* rstd_b, int Cb, const void* gy, int ldgy, int act, const float* s1,
+                              const float* s2, float inv_count, void* gxa, int ldgxa, void* gxb, int ldgxb, int N, int64_t V, int dtype,
+                              void* stream);
 /* backward pass 1: g = gy*act'(z); partials of sum(g) and sum(g*xhat): part float [N][nblk][2][C]. */
 int dp_norm_act_bwd_partial(const void* x, int ldx, const void* gy, int ldgy, const float* mean, const float* rstd,
                             int stat_stride_n, const float* gamma, const float* beta, const void* res, int ldr, int act,
