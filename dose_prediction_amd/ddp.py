@@ -55,6 +55,17 @@ class GradAllReducer:
                 self._index[p] = k
                 p._dp_slice_zero = True
         self.views = [[self.flat[bi][off:off + n].view_as(p) for p, off, n in b] for bi, b in enumerate(self.buckets)]
+        # the weight-gradient kernels write straight into the buckets (ops.GRAD_DEST): each backward pass hands out ONE fresh view
+        # per parameter (autograd adopts it as .grad, so the pack copy below has nothing to do for it); a second request in the
+        # same pass (a shared weight) gets a private tensor and is summed by autograd as usual
+        self._taken = set()
+        from . import ops
+        for bi, b in enumerate(self.buckets):
+            if self.inplace_candidate(b, cap):
+                continue
+            for p, off, n in b:
+                if p.is_cuda and p.dtype == torch.float32 and p.is_contiguous():
+                    ops.GRAD_DEST[p.data_ptr()] = self._dest(p, bi, off, n)
         self.chunk = cap
         # a bucket that is ONE large tensor (the 78.6 M-element patch-embedding weight) is reduced in place on its gradient: no
         # pack / unpack copies on the tail of the backward pass
@@ -64,6 +75,25 @@ class GradAllReducer:
         self.handles = []
         for p in self.params:
             p.register_post_accumulate_grad_hook(self._hook)
+
+    @staticmethod
+    def inplace_candidate(b, cap):
+        return len(b) == 1 and b[0][2] >= cap
+
+    def _dest(self, p, bi, off, n):
+        def take():
+            # a retained .grad (zero_grad(set_to_none=False)) aliases the slot: autograd would then add the slot to itself
+            if p in self._taken or p.grad is not None:
+                return None
+            self._taken.add(p)
+            return self.flat[bi][off:off + n].view_as(p)
+        return take
+
+    def close(self):
+        """Unregister the bucket slots from the weight-gradient kernels (the hooks stay: a closed reducer must not be used)."""
+        from . import ops
+        for p in self.params:
+            ops.GRAD_DEST.pop(p.data_ptr(), None)
 
     def _broadcast_state(self, module):
         """Rank 0's parameters and buffers (BatchNorm running statistics) to every rank."""
@@ -77,6 +107,7 @@ class GradAllReducer:
         self.launched = [False] * len(self.buckets)
         self.callback_queued = False
         self.work = []
+        self._taken = set()
 
     def _launch(self, bi):
         flat = self.flat[bi]
@@ -85,7 +116,8 @@ class GradAllReducer:
         else:
             # pack the whole bucket with one multi-tensor copy (a copy_ per parameter was ~230 launches and as many Python
             # round trips inside the backward pass: +3 ms per step before any byte moved)
-            have = [(v, p.grad) for (p, _, _), v in zip(self.buckets[bi], self.views[bi]) if getattr(p, "_dp_has_grad", False)]
+            have = [(v, p.grad) for (p, _, _), v in zip(self.buckets[bi], self.views[bi])
+                    if getattr(p, "_dp_has_grad", False) and p.grad.data_ptr() != v.data_ptr()]     # (already in place: written there)
             if have:
                 torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
         self.launched[bi] = True

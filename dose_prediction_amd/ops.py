@@ -128,6 +128,20 @@ def _zero_scratch(device, n):
     return buf
 
 
+# Weight-gradient destinations registered by the data-parallel reducer (dose_prediction_amd.ddp): parameter data_ptr -> callable
+# returning a fresh fp32 view of the parameter's slot in its flat all-reduce bucket (or None).  The weight-gradient kernels then
+# write straight into the bucket and autograd adopts the view as .grad, so no pack copy is needed before the exchange.
+GRAD_DEST = {}
+
+
+def _wgrad_buffer(weight, zero):
+    f = GRAD_DEST.get(weight.data_ptr()) if GRAD_DEST else None
+    buf = f() if f is not None else None
+    if buf is None:
+        return (torch.zeros if zero else torch.empty)(weight.shape, dtype=torch.float32, device=weight.device)
+    return buf.zero_() if zero else buf
+
+
 def _tiled_ws(like, N, D, H, W, cin, cout, k):
     n = _lib.lib().dp_conv3d_tiled_ws_elems(N, D, H, W, cin, cout, k)
     if n < 0:
@@ -387,7 +401,7 @@ class Conv3d(torch.autograd.Function):
             k == 1 and stride == 1 and pad == 0 and ctx.needs_input_grad[1] and grows >= 32768 and cout * cin <= 256) else 0
         if wse:
             # heads: a handful of channels over millions of voxels -> one HBM row stream gives dW and db together
-            gw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
+            gw = _wgrad_buffer(weight, False)
             want_b = has_bias and ctx.needs_input_grad[2]
             gb = torch.empty((cout,), dtype=torch.float32, device=x.device) if want_b else None
             ws = torch.empty((wse,), dtype=torch.float32, device=x.device)
@@ -397,16 +411,15 @@ class Conv3d(torch.autograd.Function):
             # pointwise conv over few voxels: dW[co][ci] = gy^T x, both k-major in memory (split over K to fill the chip)
             tiles = -(-cout // 64) * -(-cin // 64)
             sk = max(1, min(grows // 512, 256 // tiles))
-            gw2 = (torch.zeros if sk > 1 else torch.empty)((cout, cin), dtype=torch.float32, device=x.device)
-            _lib.call("dp_gemm_tn", _p(gy), ldg, _p(x), ldx, _p(gw2), cin, cout, cin, grows, sk, dtc, _stream())
-            gw = gw2.view(weight.shape)
+            gw = _wgrad_buffer(weight, sk > 1)
+            _lib.call("dp_gemm_tn", _p(gy), ldg, _p(x), ldx, _p(gw), cin, cout, cin, grows, sk, dtc, _stream())
         elif ctx.needs_input_grad[1]:
             taps = k * k * k
             wse = 0
             if USE_TILED and (k > 1 or grows >= 32768):
                 wse = _lib.lib().dp_conv3d_wgrad_tiled_ws_elems(cin, cout, k, stride, pad, dil, 1, Wo)
             # the tiled kernel overwrites dW; the generic one accumulates into it
-            gw = (torch.empty if wse else torch.zeros)(weight.shape, dtype=torch.float32, device=x.device)
+            gw = _wgrad_buffer(weight, not wse)
             if wse:
                 ws = _zero_scratch(x.device, wse)
                 _lib.call("dp_conv3d_wgrad_tiled", _p(x), ldx, _p(gy), ldg, _p(gw), _p(ws), N, Di, Hi, Wi, cin, cout, k,
@@ -469,7 +482,7 @@ class Conv3dCat(torch.autograd.Function):
             _lib.call("dp_conv3d_tiled2", _p(gy), ldg, 0, 0, 0, _p(wq), 0, _p(gxa), ca, _p(gxb), cbp, ca,
                       _p(_tiled_ws(xa, N, D, H, W, cout, cin, k)), N, D, H, W, cout, cin, k, dtc, _stream())
         if ctx.needs_input_grad[2]:
-            gw = torch.empty(weight.shape, dtype=torch.float32, device=xa.device)      # overwritten by the tiled kernel
+            gw = _wgrad_buffer(weight, False)      # overwritten by the tiled kernel
             taps = k * k * k
             ws = _zero_scratch(xa.device, taps * cin * cout)
             _lib.call("dp_conv3d_wgrad_tiled2", _p(xa), lda, _p(xb), ldb, ca, _p(gy), ldg, _p(gw), _p(ws), N, D, H, W, cin, cout, k,
@@ -552,7 +565,7 @@ class ConvTranspose2x(torch.autograd.Function):
                 gw = tmp.view(8, cout, cin).permute(2, 1, 0).contiguous().view(weight.shape)
             else:
                 # "tap" = abc selects the gy column block abc*Cout; x is not shifted
-                gw = torch.zeros(weight.shape, dtype=torch.float32, device=x.device)   # [Cin][Cout][8]
+                gw = _wgrad_buffer(weight, True)   # [Cin][Cout][8]
                 wgrad(x, ldx, gu, 8 * cout, gw, (1, 1, 1, rows, 1, 1, rows), cin, cout, 2, 1, 0, 1, 0, cout, 8, cout * 8, 1, dtc)
         return gx, gw
 
@@ -601,10 +614,10 @@ class Linear(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             if rows <= 16384:
                 # token matrices: dW[out][in] = gy^T x, both operands k-major (k = token rows) as they lie in memory
-                gw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
+                gw = _wgrad_buffer(weight, False)
                 _lib.call("dp_gemm_tn", _p(gy), ldg, _p(x), ldx, _p(gw), K, nout, K, rows, 1, dtc, _stream())
             else:
-                gw = torch.zeros(weight.shape, dtype=torch.float32, device=x.device)
+                gw = _wgrad_buffer(weight, True)
                 wgrad(x, ldx, gy, ldg, gw, (1, 1, 1, rows, 1, 1, rows), K, nout, 1, 1, 0, 1, 0, 0, K, 1, 0, dtc)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = torch.empty((nout,), dtype=torch.float32, device=x.device)

@@ -392,8 +392,13 @@ def test_gradient_allreduce_single_rank_rccl_is_identity():
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     try:
         net = build()
-        attach_gradient_allreduce(net, bucket_mb=0.05)          # small buckets: several packed ones and chunked big tensors
+        red = attach_gradient_allreduce(net, bucket_mb=0.05)    # small buckets: several packed ones and chunked big tensors
         got = grads(net)
+        from dose_prediction_amd import ops
+        n_direct = sum(1 for p in net.parameters() if p.grad is not None and p.data_ptr() in ops.GRAD_DEST)
+        assert n_direct > 20, n_direct          # conv / linear weight gradients are produced inside their bucket slots
+        red.close()
+        assert not ops.GRAD_DEST
     finally:
         dist.destroy_process_group()
     for step in ref:
