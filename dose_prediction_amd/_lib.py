@@ -24,9 +24,9 @@ def parse_header(path=HEADER):
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     src = re.sub(r"//[^\n]*", "", src)
     protos = {}
-    for m in re.finditer(r"(const\s+char\s*\*|int)\s+(dp_\w+)\s*\(([^)]*)\)\s*;", src):
+    for m in re.finditer(r"(const\s+char\s*\*|int64_t|int)\s+(dp_\w+)\s*\(([^)]*)\)\s*;", src):
         ret, name, args = m.group(1), m.group(2), m.group(3).strip()
-        restype = ctypes.c_char_p if "char" in ret else ctypes.c_int
+        restype = ctypes.c_char_p if "char" in ret else (ctypes.c_int64 if ret == "int64_t" else ctypes.c_int)
         argtypes, argnames = [], []
         if args and args != "void":
             for a in args.split(","):
