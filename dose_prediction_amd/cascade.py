@@ -70,6 +70,17 @@ def oar_masks(seg_model, ct):
     return labels, logits
 
 
+def _put_channel(staged, ch, vol):
+    """Write a [B,1,D,H,W] fp32 NCDHW volume into channel `ch` of an NDHWC staging buffer (one conversion pass; replaces a padded
+    to_ndhwc() of the volume followed by a strided single-channel copy)."""
+    B, _, D, H, W = vol.shape
+    if tuple(staged.shape[:4]) != (B, D, H, W):
+        raise ValueError(f"volume {tuple(vol.shape)} does not match the staging grid {tuple(staged.shape)}")
+    vol = vol.contiguous().float()
+    _lib.call("dp_ncdhw_to_ndhwc", vol.data_ptr(), staged.data_ptr() + ch * staged.element_size(), B, 1, D * H * W, staged.shape[-1], 1,
+              ops._dt(staged), ops._stream())
+
+
 @torch.no_grad()
 def cascade_structures(seg_model, ct, ptv, reverse_axes=True, roi_size=None, sw_batch_size=4, overlap=0.25):
     """The 9-channel PYFER input [B,9,D,H,W] fp32 of the linked model (train_light_linked_model.py:143-167) from a CT and a PTV
@@ -83,10 +94,10 @@ def cascade_structures(seg_model, ct, ptv, reverse_axes=True, roi_size=None, sw_
     D, H, W = logits.shape[1:4]
     staged = torch.zeros((B, D, H, W, 16), dtype=config.compute_dtype(), device=ct.device)
     labels = ops.argmax_onehot(logits, staged, choff=1, labels=True)
-    staged[..., 8:9] = to_ndhwc(ct)[..., :1]
+    _put_channel(staged, 8, ct)
     if reverse_axes:
         staged = staged.permute(0, 3, 2, 1, 4).contiguous()
-    staged[..., 0:1] = to_ndhwc(ptv)[..., :1]
+    _put_channel(staged, 0, ptv)
     return from_ndhwc(staged)[:, :9].float().contiguous(), labels
 
 
@@ -105,10 +116,10 @@ def cascade_forward(seg_model, dose_model, ct, ptv, possible_dose_mask=None, rev
     D, H, W = logits.shape[1:4]
     staged = torch.zeros((B, D, H, W, 16), dtype=dt, device=ct.device)   # channels: 0 PTV | 1..7 OARs | 8 CT | pad
     labels = ops.argmax_onehot(logits, staged, choff=1, labels=True)
-    staged[..., 8:9] = to_ndhwc(ct)[..., :1]
+    _put_channel(staged, 8, ct)
     if reverse_axes:
         staged = staged.permute(0, 3, 2, 1, 4).contiguous()              # (D,H,W) -> (W,H,D)
-    staged[..., 0:1] = to_ndhwc(ptv)[..., :1]
+    _put_channel(staged, 0, ptv)
     out_a = dose_model.net_A.forward_ndhwc(staged)
     outs = dose_model.net_B.forward_ndhwc(ops.cat((out_a, staged)), (out_a, staged))
     dose = from_ndhwc(outs[0])
