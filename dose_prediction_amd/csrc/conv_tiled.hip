@@ -100,6 +100,7 @@ extern "C" int dp_conv3d_tiled_weight_elems(int Cin, int Cout, int k, int stride
   int JH = np == 2 ? (k + 1) / 2 : k;
   return k * JH * k * ((Cin + 15) / 16) * ((Cout * np + 31) / 32) * 512;
 }
+extern "C" int dp_conv3d_tiled_npair(int Cout) { int rw, nt; return tiled_config(Cout, &rw, &nt); }
 extern "C" int dp_pack_conv_weight_tiled(const float* w, void* dst, int Cout, int Cin, int k, int transposed_flipped, int dtype, void* stream) {
   int rw, nt; int np = tiled_config(Cout, &rw, &nt);
   int JH = np == 2 ? (k + 1) / 2 : k;

@@ -1,0 +1,112 @@
+// Multi-tensor weight re-packing: ONE launch rebuilds every kernel-layout copy (bf16/fp16/fp32 packed weights) of the
+// parameters an optimizer step just changed.  The layouts are exactly those of the single-tensor pack entry points
+// (dp_pack_conv_weight, dp_pack_conv_weight_tiled, dp_cast + dp_copy_rows for Linear / ConvTranspose matrices); the
+// per-tensor launches cost ~600 launches per training step once the packs are (correctly) invalidated by every
+// optimizer.step() (network_trainer.py:185-213 calls it once per iteration).
+#include "common.h"
+
+#define STREAM ((hipStream_t)stream)
+#define PACK_CHUNK 8192          // destination elements per block (matrix-transpose tiles: 64 rows x 128 columns)
+
+enum { PK_CAST = 0, PK_MAT = 1, PK_MAT_T = 2, PK_CONV = 3, PK_CONV_TILED = 4, PK_TCONV = 5 };
+
+struct PackDesc { const float* src; void* dst; int64_t kind, a, b, c, d, e; };
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_pack_multi(const PackDesc* __restrict__ tab, const int* __restrict__ chunk_t,
+                                                    const int* __restrict__ chunk_i) {
+  const PackDesc P = tab[chunk_t[blockIdx.x]];
+  const unsigned ck = (unsigned)chunk_i[blockIdx.x];
+  const float* __restrict__ w = P.src;
+  T* __restrict__ dst = (T*)P.dst;
+  const int kind = (int)P.kind;
+  if (kind == PK_MAT_T) {
+    // dst[r][c] (rows a, valid columns b, pitch c) = src[c][r] (src is [b][a]); tile = 64 dst rows x 128 dst columns
+    __shared__ float tile[128][65];
+    const unsigned rows = (unsigned)P.a, cols = (unsigned)P.b, pitch = (unsigned)P.c;
+    const unsigned tc = (pitch + 127) / 128;
+    const unsigned r0 = (ck / tc) * 64, c0 = (ck % tc) * 128;
+    for (unsigned i = threadIdx.x; i < 128 * 64; i += 256) {
+      const unsigned sr = i >> 6, sc = i & 63;          // src row = dst col, src col = dst row
+      float v = 0.f;
+      if (c0 + sr < cols && r0 + sc < rows) v = w[(int64_t)(c0 + sr) * rows + r0 + sc];
+      tile[sr][sc] = v;
+    }
+    __syncthreads();
+    for (unsigned i = threadIdx.x; i < 64 * 128; i += 256) {
+      const unsigned dr = i >> 7, dc = i & 127;
+      if (r0 + dr < rows && c0 + dc < pitch) st_f(dst + (int64_t)(r0 + dr) * pitch + c0 + dc, tile[dc][dr]);
+    }
+    return;
+  }
+  const unsigned base = ck * PACK_CHUNK;
+  if (kind == PK_CAST) {
+    const unsigned n = (unsigned)P.a;
+    if (base + PACK_CHUNK <= n && (((uintptr_t)w | (uintptr_t)dst) & 15) == 0) {
+#pragma unroll
+      for (int j = 0; j < PACK_CHUNK / 1024; j++) {
+        const unsigned i = base + j * 1024 + threadIdx.x * 4;
+        const v4f v = *(const v4f*)(w + i);
+        st_f(dst + i, v[0]); st_f(dst + i + 1, v[1]); st_f(dst + i + 2, v[2]); st_f(dst + i + 3, v[3]);
+      }
+    } else {
+      for (unsigned i = base + threadIdx.x; i < min(n, base + PACK_CHUNK); i += 256) st_f(dst + i, w[i]);
+    }
+    return;
+  }
+  unsigned total;
+  if (kind == PK_MAT) total = (unsigned)(P.a * P.c);
+  else if (kind == PK_CONV) total = (unsigned)((P.d == 0 ? P.a : P.b) * P.c * ((( P.d == 0 ? P.b : P.a) + 7) & ~7));
+  else if (kind == PK_CONV_TILED) {
+    const int KS = (int)P.c, NP = (int)P.d;
+    total = (unsigned)(KS * (NP == 2 ? (KS + 1) / 2 : KS) * KS * ((P.b + 15) / 16) * ((P.a * NP + 31) / 32) * 512);
+  } else total = (unsigned)(P.d ? P.a * P.c : 8 * P.b * P.c);
+  const unsigned end = min(total, base + PACK_CHUNK);
+  for (unsigned i = base + threadIdx.x; i < end; i += 256) {
+    float v = 0.f;
+    if (kind == PK_MAT) {
+      const unsigned cols = (unsigned)P.b, pitch = (unsigned)P.c, r = i / pitch, c = i - r * pitch;
+      if (c < cols) v = w[(int64_t)r * cols + c];
+    } else if (kind == PK_CONV) {
+      // mode 0: dst[co][t][ciP] = w[co][ci][t]; mode 1: dst[ci][t][coP]; mode 2: dst[ci][T-1-t][coP]   (k_pack_w)
+      const unsigned Cout = (unsigned)P.a, Cin = (unsigned)P.b, taps = (unsigned)P.c; const int mode = (int)P.d;
+      const unsigned inner = mode == 0 ? Cin : Cout, innerP = (inner + 7) & ~7u;
+      const unsigned c = i % innerP, rt = i / innerP, t = rt % taps, row = rt / taps;
+      if (c < inner) {
+        const unsigned co = mode == 0 ? row : c, ci = mode == 0 ? c : row, ts = mode == 2 ? taps - 1 - t : t;
+        v = w[((int64_t)co * Cin + ci) * taps + ts];
+      }
+    } else if (kind == PK_CONV_TILED) {
+      // dst[kd][jh][kw][chunk][ntile][col 32][ci 16]   (k_pack_w_tiled)
+      const int Cout = (int)P.a, Cin = (int)P.b, KS = (int)P.c, NPAIR = (int)P.d, tf = (int)P.e;
+      const int JH = NPAIR == 2 ? (KS + 1) / 2 : KS, NCH = (Cin + 15) / 16, NTT = (Cout * NPAIR + 31) / 32, taps = KS * KS * KS;
+      const int c = (int)(i & 15), col = (int)((i >> 4) & 31); unsigned t = i >> 9;
+      const int nt = (int)(t % NTT); t /= NTT; const int ch = (int)(t % NCH); t /= NCH; const int kw = (int)(t % KS); t /= KS;
+      const int jh = (int)(t % JH), kd = (int)(t / JH);
+      int kh, co;
+      if (NPAIR == 2) { const int s = col >> 4; kh = 2 * jh + s; co = nt * 16 + (col & 15); }
+      else { kh = jh; co = nt * 32 + col; }
+      const int ci = ch * 16 + c;
+      if (kh < KS && co < Cout && ci < Cin) {
+        const int tap = (kd * KS + kh) * KS + kw;
+        v = tf ? w[((int64_t)ci * Cout + co) * taps + (taps - 1 - tap)] : w[((int64_t)co * Cin + ci) * taps + tap];
+      }
+    } else {   // PK_TCONV: w[ci][co][abc]; d == 0: dst[(abc, co)][ciP]; d != 0: dst[ci][(abc, co)P]
+      const unsigned cin = (unsigned)P.a, cout = (unsigned)P.b, pitch = (unsigned)P.c;
+      const unsigned r = i / pitch, c = i - r * pitch;
+      unsigned ci, q;
+      bool ok;
+      if (P.d == 0) { q = r; ci = c; ok = c < cin; } else { ci = r; q = c; ok = c < 8 * cout; }
+      if (ok) { const unsigned abc = q / cout, co = q - abc * cout; v = w[((int64_t)ci * cout + co) * 8 + abc]; }
+    }
+    st_f(dst + i, v);
+  }
+}
+
+extern "C" int dp_pack_chunk(void) { return PACK_CHUNK; }
+extern "C" int dp_pack_multi(const void* table, const int32_t* chunk_t, const int32_t* chunk_i, int nchunks, int dtype, void* stream) {
+  if (nchunks <= 0) return 0;
+  DP_DISPATCH(dtype, hipLaunchKernelGGL(k_pack_multi<T>, dim3(nchunks), dim3(256), 0, STREAM, (const PackDesc*)table,
+                                        (const int*)chunk_t, (const int*)chunk_i));
+  DP_CHECK_LAUNCH("pack_multi"); return 0;
+}

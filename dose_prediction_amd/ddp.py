@@ -97,9 +97,11 @@ class GradAllReducer:
 
     def _broadcast_state(self, module):
         """Rank 0's parameters and buffers (BatchNorm running statistics) to every rank."""
+        from . import ops
         with torch.no_grad():
             for t in list(module.parameters()) + list(module.buffers()):
                 dist.broadcast(t.data, 0, group=self.pg)
+        ops.invalidate_packs(module.parameters())     # written through .data: the version counters did not move
 
     def _reset(self):
         self.pending = [len(b) for b in self.buckets]

@@ -74,33 +74,95 @@ def new_act(like, shape, dtype=None):
 # ------------------------------------------------------------------------------------------------ packed-weight cache
 class _PackCache:
     """Packed (kernel-layout) copies of a parameter, stored ON the parameter object so that their lifetime is the
-    parameter's; an entry is rebuilt when the parameter's version counter, storage or device changed
-    (optimizer.step(), load_state_dict(), .to())."""
+    parameter's; an entry is rebuilt when the parameter's version counter, storage, device or pack generation changed
+    (optimizer.step(), load_state_dict(), .to()).  Updates that bypass autograd's version counter (FusedAdam writes through raw
+    pointers, the DDP broadcast through .data) MUST call refresh_packs() / invalidate_packs() on the parameters they touched.
 
-    def get(self, w, key, builder):
+    Entry: [tag, packed tensor, descriptor, used-since-last-refresh].  The descriptor (kind, a, b, c, d, e) is the dp_pack_multi
+    table row that rebuilds the copy in place; None = the copy aliases the parameter or can only be rebuilt by its builder."""
+
+    @staticmethod
+    def tag(w):
+        return (w._version, w.data_ptr(), w.device, w.__dict__.get("_dp_gen", 0))
+
+    def get(self, w, key, builder, desc=None):
         store = w.__dict__.setdefault("_dp_packs", {})
         ent = store.get(key)
-        tag = (w._version, w.data_ptr(), w.device)
+        tag = self.tag(w)
         if ent is None or ent[0] != tag:
-            ent = (tag, builder())
+            dst = builder()
+            ent = [tag, dst, desc(dst) if (desc is not None and w.is_contiguous()) else None, True]
             store[key] = ent
+        ent[3] = True
         return ent[1]
 
 
 _packs = _PackCache()
+_REPACK_PLANS = {}
+
+
+def invalidate_packs(params):
+    """Drop every packed copy of ``params`` (they are rebuilt lazily by the next forward)."""
+    for p in params:
+        p.__dict__.pop("_dp_packs", None)
+        p.__dict__["_dp_gen"] = p.__dict__.get("_dp_gen", 0) + 1
+
+
+def refresh_packs(params):
+    """Rebuild, in ONE launch per storage type (dp_pack_multi), every packed copy of ``params`` that was used since the last
+    refresh; called by FusedAdam.step() right after the update kernel, which changes the parameters through raw pointers
+    (p._version does not move).  Copies that were not used since the last refresh are dropped."""
+    L = _lib.lib()
+    chunk = L.dp_pack_chunk()
+    jobs = {}
+    for p in params:
+        store = p.__dict__.get("_dp_packs")
+        p.__dict__["_dp_gen"] = p.__dict__.get("_dp_gen", 0) + 1
+        if not store:
+            continue
+        tag = _packs.tag(p)
+        for key in list(store):
+            ent = store[key]
+            dst = ent[1]
+            if dst.data_ptr() == p.data_ptr():          # the "copy" is the parameter itself (fp32 row-major matrix)
+                ent[0] = tag
+                continue
+            if ent[2] is None or not ent[3] or ent[0][1:3] != tag[1:3]:
+                del store[key]
+                continue
+            ent[0], ent[3] = tag, False
+            jobs.setdefault((dst.dtype, dst.device), []).append((p, dst, ent[2]))
+    for (dtype, dev), lst in jobs.items():
+        pkey = (dtype, dev, tuple((p.data_ptr(), d.data_ptr()) for p, d, _ in lst))
+        plan = _REPACK_PLANS.get(pkey)
+        if plan is None:
+            rows, ct, ci = [], [], []
+            for t, (p, d, desc) in enumerate(lst):
+                kind, a, b, c = desc[0], desc[1], desc[2], desc[3]
+                rows.append((p.data_ptr(), d.data_ptr()) + tuple(desc))
+                n = (-(-a // 64)) * (-(-c // 128)) if kind == 2 else -(-d.numel() // chunk)
+                ct += [t] * n
+                ci += list(range(n))
+            plan = (torch.tensor(rows, dtype=torch.int64, device=dev), torch.tensor(ct, dtype=torch.int32, device=dev),
+                    torch.tensor(ci, dtype=torch.int32, device=dev), len(ct))
+            if len(_REPACK_PLANS) > 16:
+                _REPACK_PLANS.clear()
+            _REPACK_PLANS[pkey] = plan
+        _lib.call("dp_pack_multi", _p(plan[0]), _p(plan[1]), _p(plan[2]), plan[3], _DT[dtype], _stream())
 
 
 def _pack_conv(w, mode, dtype):
     """torch [Cout,Cin,k,k,k] fp32 -> packed T (see dp_pack_conv_weight)."""
+    cout, cin = w.shape[0], w.shape[1]
+    taps = w[0, 0].numel()
+
     def build():
-        cout, cin = w.shape[0], w.shape[1]
-        taps = w[0, 0].numel()
         rows, inner = (cout, cin) if mode == 0 else (cin, cout)
         dst = torch.empty((rows, taps, (inner + 7) // 8 * 8), dtype=dtype, device=w.device)
         wc = w.detach().contiguous()
         _lib.call("dp_pack_conv_weight", _p(wc), _p(dst), cout, cin, taps, mode, _DT[dtype], _stream())
         return dst
-    return _packs.get(w, ("conv", mode, dtype), build)
+    return _packs.get(w, ("conv", mode, dtype), build, lambda dst: (3, cout, cin, taps, mode, 0))
 
 
 USE_TILED = True
@@ -117,9 +179,10 @@ _ZERO_SCRATCH = {}
 
 def _zero_scratch(device, n):
     """Persistent all-zero fp32 scratch for the kernels that accumulate with atomics (dp_scratch_contract(1): they get it zeroed and
-    hand it back zeroed, so no memset launch per call).  One buffer per device, grown on demand; single-stream use."""
+    hand it back zeroed, so no memset launch per call).  One buffer per (device, stream), grown on demand: two streams issuing
+    atomically-accumulating kernels concurrently never share a scratch."""
     L = _lib.lib()
-    key = (device.type, device.index)
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
     buf = _ZERO_SCRATCH.get(key)
     if buf is None or buf.numel() < n:
         buf = torch.zeros((max(n, 1 << 22),), dtype=torch.float32, device=device)
@@ -160,7 +223,10 @@ def _pack_conv_tiled(w, tf, dtype, elems):
         else:
             _lib.call("dp_pack_conv_weight_tiled", _p(wc), _p(dst), cout, cin, k, 0, _DT[dtype], _stream())
         return dst
-    return _packs.get(w, ("conv_tiled", tf, dtype, elems), build)
+    k = w.shape[2]
+    co, ci = (w.shape[1], w.shape[0]) if tf else (w.shape[0], w.shape[1])      # roles in the convolution being computed
+    return _packs.get(w, ("conv_tiled", tf, dtype, elems), build,
+                      lambda dst: (4, co, ci, k, _lib.lib().dp_conv3d_tiled_npair(co), 1 if tf else 0))
 
 
 def _pack_tconv(w, transposed, dtype):
@@ -177,7 +243,8 @@ def _pack_tconv(w, transposed, dtype):
         _lib.call("dp_cast", _p(m), 0, _p(tmp), _DT[dtype], m.numel(), _stream())
         _lib.call("dp_copy_rows", _p(tmp), m.shape[1], _p(dst), dst.shape[1], m.shape[0], m.shape[1], _DT[dtype], _stream())
         return dst
-    return _packs.get(w, ("tconv", transposed, dtype), build)
+    return _packs.get(w, ("tconv", transposed, dtype), build,
+                      lambda dst: (5, w.shape[0], w.shape[1], dst.shape[1], 1 if transposed else 0, 0))
 
 
 def _pack_mat(w, transposed, dtype):
@@ -193,7 +260,13 @@ def _pack_mat(w, transposed, dtype):
         _lib.call("dp_cast", _p(m), 0, _p(tmp), _DT[dtype], m.numel(), _stream())
         _lib.call("dp_copy_rows", _p(tmp), m.shape[1], _p(dst), dst.shape[1], m.shape[0], m.shape[1], _DT[dtype], _stream())
         return dst
-    return _packs.get(w, ("mat", transposed, dtype), build)
+    def desc(dst):
+        if transposed:
+            return (2, w.shape[1], w.shape[0], dst.shape[1], 0, 0)
+        if dst.shape[1] == w.shape[1]:
+            return (0, w.numel(), 0, 0, 0, 0)
+        return (1, w.shape[0], w.shape[1], dst.shape[1], 0, 0)
+    return _packs.get(w, ("mat", transposed, dtype), build, desc)
 
 
 def _cast_vec(v, dtype):

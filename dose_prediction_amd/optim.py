@@ -1,18 +1,28 @@
 """Fused Adam for the HIP path: drop-in for the optimizer NetworkTrainer.set_optimizer builds
 (network_trainer.py:120-125: optim.Adam(params, lr, weight_decay=3e-5, betas=(0.9, 0.999), eps=1e-8, amsgrad=True)).
-One kernel launch per step over all parameters (dp_adam_multi); same update rule and state names as torch.optim.Adam."""
-import numpy as np
+One kernel launch per step over all parameters (dp_adam_multi) plus ONE launch that rebuilds the kernel-layout copies of the
+updated weights (dp_pack_multi); same update rule and state names as torch.optim.Adam, and its state_dict()s load either way
+(network_trainer.py:340-363 saves / restores `optimizer_state_dict`)."""
 import torch
 
 from . import _lib
 
 
 class FusedAdam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False):
+    """capturable=True keeps the step count on the device (state['step'] is a 0-dim int32 device tensor shared by a group's
+    parameters), so that a step captured in a HIP graph replays with the right bias corrections."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False, capturable=False):
         if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1) or weight_decay < 0:
             raise ValueError("invalid Adam hyper-parameter")
-        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad))
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad, capturable=capturable))
         self._plans = {}
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        for g in self.param_groups:
+            g.setdefault("amsgrad", False)
+            g.setdefault("capturable", False)
 
     def _plan(self, gi, plist):
         key = (gi, tuple(id(p) for p in plist))
@@ -30,8 +40,14 @@ class FusedAdam(torch.optim.Optimizer):
             self._plans[key] = plan
         return plan
 
+    @staticmethod
+    def _step_value(s):
+        """state['step'] as written by this class (int), by torch.optim.Adam (0-dim float tensor) or by capturable mode."""
+        return int(s.item()) if torch.is_tensor(s) else int(s)
+
     @torch.no_grad()
     def step(self, closure=None):
+        from . import ops
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -40,32 +56,50 @@ class FusedAdam(torch.optim.Optimizer):
             plist = [p for p in group["params"] if p.grad is not None]
             if not plist:
                 continue
+            capt = bool(group.get("capturable", False))
             for p in plist:
                 if not p.is_cuda or p.dtype != torch.float32 or p.grad.dtype != torch.float32:
                     raise _lib.DoseHipError("FusedAdam needs fp32 CUDA/HIP parameters and gradients")
                 st = self.state[p]
-                if len(st) == 0:
+                if "exp_avg" not in st:
                     st["step"] = 0
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    st["max_exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format) if group["amsgrad"] else None
+                if group["amsgrad"] and st.get("max_exp_avg_sq") is None:
+                    st["max_exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 if not p.is_contiguous() or not p.grad.is_contiguous():
                     raise _lib.DoseHipError("FusedAdam needs contiguous parameters / gradients")
-            steps = {self.state[p]["step"] for p in plist}
-            if len(steps) != 1:
-                raise _lib.DoseHipError("FusedAdam: parameters of one group must share the step count")
-            step = steps.pop() + 1
             ct, ci, nchunks, host, devtab = self._plan(gi, plist)
             h = host.numpy()
             for t, p in enumerate(plist):
                 st = self.state[p]
-                vm = st["max_exp_avg_sq"]
+                vm = st.get("max_exp_avg_sq") if group["amsgrad"] else None
                 h[t] = (p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
                         vm.data_ptr() if vm is not None else 0, p.numel())
-                st["step"] = step
             devtab.copy_(host, non_blocking=True)
             b1, b2 = group["betas"]
-            _lib.call("dp_adam_multi", devtab.data_ptr(), ct.data_ptr(), ci.data_ptr(), nchunks, float(group["lr"]), float(b1), float(b2),
-                      float(group["eps"]), float(group["weight_decay"]), int(step), 1 if group["amsgrad"] else 0,
-                      torch.cuda.current_stream().cuda_stream)
+            stream = torch.cuda.current_stream().cuda_stream
+            if capt:
+                sdev = self.state[plist[0]]["step"]
+                if not (torch.is_tensor(sdev) and sdev.is_cuda and sdev.dtype == torch.int32):
+                    # (before any capture) one shared device counter per group, initialised from the host-side counts
+                    steps = {self._step_value(self.state[p]["step"]) for p in plist}
+                    if len(steps) != 1:
+                        raise _lib.DoseHipError("FusedAdam: parameters of one group must share the step count")
+                    sdev = torch.full((), steps.pop(), dtype=torch.int32, device=plist[0].device)
+                for p in plist:
+                    self.state[p]["step"] = sdev
+                _lib.call("dp_adam_multi_dev", devtab.data_ptr(), ct.data_ptr(), ci.data_ptr(), nchunks, float(group["lr"]), float(b1),
+                          float(b2), float(group["eps"]), float(group["weight_decay"]), sdev.data_ptr(), 1 if group["amsgrad"] else 0, stream)
+            else:
+                steps = {self._step_value(self.state[p]["step"]) for p in plist}
+                if len(steps) != 1:
+                    raise _lib.DoseHipError("FusedAdam: parameters of one group must share the step count")
+                step = steps.pop() + 1
+                for p in plist:
+                    self.state[p]["step"] = step
+                _lib.call("dp_adam_multi", devtab.data_ptr(), ct.data_ptr(), ci.data_ptr(), nchunks, float(group["lr"]), float(b1), float(b2),
+                          float(group["eps"]), float(group["weight_decay"]), int(step), 1 if group["amsgrad"] else 0, stream)
+            # the kernel wrote the parameters through raw pointers (p._version did not move): rebuild their packed copies now
+            ops.refresh_packs(plist)
         return loss

@@ -221,6 +221,25 @@ int dp_adam_chunk(void);
 int dp_adam_multi(const void* table, const int32_t* chunk_t, const int32_t* chunk_i, int nchunks, double lr, double beta1, double beta2,
                   double eps, double weight_decay, int step, int amsgrad, void* stream);
 
+/* Capturable variant: *step_dev (device int32, the number of updates done so far) is incremented by the call and the bias
+ * corrections are computed from it on the device, so a captured HIP graph replays a correct Adam step. */
+int dp_adam_multi_dev(const void* table, const int32_t* chunk_t, const int32_t* chunk_i, int nchunks, double lr, double beta1, double beta2,
+                      double eps, double weight_decay, int32_t* step_dev, int amsgrad, void* stream);
+
+/* ---- packed-weight refresh after optimizer.step() (network_trainer.py:213) ----------------------------------------------
+ * The kernels read kernel-layout copies of the fp32 nn.Parameters; ONE launch rebuilds all copies of the parameters a step
+ * changed.  table: device array of {const float* src; void* dst; int64_t kind, a, b, c, d, e}:
+ *   kind 0 cast: dst[i] = src[i], i < a;                       kind 1 matrix: dst[r][c] = src[r*b + c] (a rows, pitch c, zero pad);
+ *   kind 2 transposed matrix: dst[r][c] = src[c*a + r] (a rows, b valid columns, pitch c);
+ *   kind 3 = dp_pack_conv_weight(Cout=a, Cin=b, taps=c, mode=d);
+ *   kind 4 = dp_pack_conv_weight_tiled(Cout=a, Cin=b, k=c, NPAIR=d (dp_conv3d_tiled_npair), transposed_flipped=e);
+ *   kind 5 ConvTranspose3d(k2,s2) weight [Cin=a][Cout=b][8] -> d == 0: [(abc,co)][pitch c over ci], d != 0: [ci][pitch c over (abc,co)].
+ * chunk_t/chunk_i map each block to (table row, chunk); a chunk is dp_pack_chunk() destination elements, for kind 2 one
+ * 64-row x 128-column destination tile (row-major tile index).  All destinations share the storage type `dtype`. */
+int dp_pack_chunk(void);
+int dp_conv3d_tiled_npair(int Cout);
+int dp_pack_multi(const void* table, const int32_t* chunk_t, const int32_t* chunk_i, int nchunks, int dtype, void* stream);
+
 /* ---- cascade glue ----------------------------------------------------------------------------- */
 /* replaces: AsDiscrete(argmax=True, to_onehot=True) + channel concat (train_light_linked_model.py:157-167):
  * logits NDHWC [rows][ld] (C classes) -> one-hot of the arg-max (first max wins, as torch.argmax) for classes

@@ -10,6 +10,9 @@ G2o OldModels conv_3_1                                                     OldMo
 G3  blocks_MDUNet.DualDilatedBlock                                        blocks_MDUNet.py:194-215
 G4  c3d.Model (two-U-Net cascade)                                         c3d.py:152-169
 G5  Train/loss.py Loss + GenLoss values and gradients                     loss.py:7-41,50-119
+G6  NetworkTrainer.run() of the reference's own network_trainer.py: one epoch x 3 iterations of c3d.Model with
+    Train/loss.py Loss on CPU fp32 -- per-iteration losses, learning rates, validation index, final weights, checkpoint /
+    optimizer-state / log structure                                       network_trainer.py:92-125,185-363
 G7  dose_pyfer.MainSubsetModel / dose_pyfer.Model / oar_transeg.Model wiring, through the
     test-only MONAI stand-in (tests/golden/monai_shim.py): pins the reference's WIRING only.
 """
@@ -234,6 +237,136 @@ def g5():
     save("g5_loss", **out)
 
 
+# --------------------------------------------------------------------------------------------- G6
+def pcg_tensor(shape, seed, kind="normal"):
+    """Inputs that are NOT stored: numpy PCG64 streams, regenerated identically by tests/helpers.pcg_tensor."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    n = int(np.prod(shape))
+    a = rng.standard_normal(n, dtype=np.float32) if kind == "normal" else rng.random(n, dtype=np.float32)
+    return torch.from_numpy(a.reshape(shape))
+
+
+def g6_data(shape=(64, 32, 32)):
+    """3 training batches (B=2) + 1 validation sample: Input [B,3,...] normal; GT = (dose uniform[0,1], mask = uniform > 0.5)."""
+    batches = []
+    for i in range(4):
+        B = 2 if i < 3 else 1
+        x = pcg_tensor((B, 3) + shape, 620 + i)
+        gt = torch.cat((pcg_tensor((B, 1) + shape, 630 + i, "uniform"), (pcg_tensor((B, 1) + shape, 640 + i, "uniform") > 0.5).float()), 1)
+        batches.append({"Input": x, "GT": gt})
+    return batches[:3], batches[3]
+
+
+def g6():
+    """The reference trainer itself (NetworkTrainer.run) on a tiny C3D cascade, CPU fp32 (the trainer casts inputs with
+    .float()).  Everything a drop-in network must reproduce when driven by that trainer is recorded.  Two runs: A = one
+    iteration (max_iter=1; after ONE Adam step from identical weights the update is lr*sign(g) wherever |g| >> eps, so the
+    weights are sharply defined), B = one epoch of three iterations (loss trajectory, learning rates, validation, bookkeeping)."""
+    import shutil
+    import tempfile
+    from NetworkTrainer.network_trainer import NetworkTrainer
+    from DosePrediction.Models.Networks.c3d import Model
+    from DosePrediction.Train.loss import Loss
+    chans = [-1, 4, 4, 8, 8, 8]
+    torch.manual_seed(0)
+    net0 = Model(3, 1, chans, chans)
+    randomize(net0, 61)
+    sd0 = {k: v.clone() for k, v in net0.state_dict().items()}
+    batches, val = g6_data()
+    xv, gtv = val["Input"], val["GT"]
+    base_loss = Loss(casecade=True)
+
+    def run_trainer(max_iter):
+        net = Model(3, 1, chans, chans)
+        net.load_state_dict(sd0)
+        out_dir = tempfile.mkdtemp(prefix="g6_")
+        losses = []
+
+        def loss_fn(output, target):
+            l = base_loss(output, target)
+            losses.append(float(l.detach()))
+            return l
+
+        def val_fn(tr):
+            with torch.no_grad():
+                pred = tr.setting.network(xv.to(tr.setting.device))
+            m = gtv[:, 1:2] > 0
+            return -float((pred[1][m] - gtv[:, 0:1][m]).abs().mean())
+
+        tr = NetworkTrainer()
+        tr.setting.project_name = "g6"
+        tr.setting.output_dir = out_dir
+        tr.setting.max_epoch = 1
+        if max_iter is not None:
+            tr.setting.max_iter = max_iter
+        tr.setting.train_loader = [{k: v.clone() for k, v in b.items()} for b in batches]
+        tr.setting.network = net
+        tr.setting.loss_function = loss_fn
+        tr.setting.online_evaluation_function_val = val_fn
+        tr.setting.lr_scheduler_update_on_iter = True
+        tr.set_GPU_device([-1])
+        tr.set_optimizer("Adam", {"lr": 1e-3})
+        tr.set_lr_scheduler("cosine", {"T_max": 10, "eta_min": 1e-7, "last_epoch": -1})
+        tr.run()
+        files = sorted(os.listdir(out_dir))
+        ck = torch.load(os.path.join(out_dir, "latest.pkl"), map_location="cpu", weights_only=False)
+        log_txt = open(os.path.join(out_dir, "log.txt")).read()
+        shutil.rmtree(out_dir)
+        return ck, losses, files, log_txt, net
+
+    def shadow64(n_iter):
+        """float64 shadow of the same sequence (the reference modules in double, plain loop): Adam normalises every gradient by
+        its own magnitude, so round-off-level gradients take lr-sized steps of random sign and the fp32 trajectory is only
+        defined up to |fp32 - fp64|; the tests take their tolerance from this pair."""
+        net64 = Model(3, 1, chans, chans)
+        net64.load_state_dict(sd0)
+        net64.double().train()
+        opt64 = torch.optim.Adam(net64.parameters(), lr=1e-3, weight_decay=3e-5, betas=(0.9, 0.999), eps=1e-08, amsgrad=True)
+        sch64 = torch.optim.lr_scheduler.CosineAnnealingLR(opt64, T_max=10, eta_min=1e-7, last_epoch=-1)
+        l64 = []
+        for b in batches[:n_iter]:
+            opt64.zero_grad()
+            l = Loss(casecade=True)(net64(b["Input"].double()), b["GT"].double())
+            l.backward()
+            opt64.step()
+            sch64.step()
+            l64.append(float(l))
+        net64.eval()
+        with torch.no_grad():
+            pv = net64(xv.double())
+        mv = gtv[:, 1:2] > 0
+        return net64.state_dict(), l64, -float((pv[1][mv] - gtv[:, 0:1].double()[mv]).abs().mean())
+
+    ckA, lossesA, _, _, _ = run_trainer(1)
+    sdA64, _, valA64 = shadow64(1)
+    ck, losses, files, log_txt, net = run_trainer(None)
+    sd64, l64, val64 = shadow64(3)
+    log = ck["log"]
+    opt_sd = ck["optimizer_state_dict"]
+    log_lines = [l.strip().split("  ")[0][:24] for l in log_txt.splitlines()]
+    st0 = opt_sd["state"][0]
+    out = dict(
+        losses=np.array(losses), val_index=np.array(log.average_val_index), moving_train_loss=np.array(log.moving_train_loss),
+        average_train_loss=np.array(log.average_train_loss), log_iter=np.array(log.iter), log_epoch=np.array(log.epoch),
+        list_lr=np.array(log.list_lr_associate_iter, dtype=np.float64), end_lr=np.array(opt_sd["param_groups"][0]["lr"]),
+        list_train=np.array(log.list_average_train_loss_associate_iter, dtype=np.float64),
+        list_val=np.array(log.list_average_val_index_associate_iter, dtype=np.float64),
+        files=np.array(files), ckpt_keys=np.array(list(ck.keys())), log_attrs=np.array(sorted(vars(log).keys())),
+        opt_group_keys=np.array(sorted(k for k in opt_sd["param_groups"][0] if k != "params")),
+        opt_n_params=np.array(len(opt_sd["param_groups"][0]["params"])), opt_state_ids=np.array(sorted(opt_sd["state"].keys())),
+        opt_state_keys=np.array(sorted(st0.keys())), opt_step=np.array(float(st0["step"])),
+        sched_keys=np.array(sorted(ck["lr_scheduler_state_dict"].keys())), log_lines=np.array(log_lines),
+        losses_f64=np.array(l64), val_index_f64=np.array(val64),
+        lossA=np.array(lossesA), valA=np.array(ckA["log"].average_val_index), valA_f64=np.array(valA64),
+        iterA=np.array(ckA["log"].iter), stepA=np.array(float(ckA["optimizer_state_dict"]["state"][0]["step"])))
+    names = [n for n, _ in net.named_parameters()]
+    for pid in (sorted(opt_sd["state"].keys())[0], sorted(opt_sd["state"].keys())[-1]):
+        for k in ("exp_avg", "exp_avg_sq", "max_exp_avg_sq"):
+            out[f"optA/{names[pid]}/{k}"] = ckA["optimizer_state_dict"]["state"][pid][k]
+    save("g6_trainer", **out, **pack("sd0", sd0), **pack("sdA", ckA["network_state_dict"]), **pack("sdA_f64", sdA64),
+         **pack("sd1", ck["network_state_dict"]), **pack("sd1_f64", sd64))
+
+
 # --------------------------------------------------------------------------------------------- G7
 def g7():
     from DosePrediction.Models.Networks.dose_pyfer import MainSubsetModel, Model
@@ -287,6 +420,6 @@ def g7():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g7"]
+    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g7"]
     for w in which:
         globals()[w]()

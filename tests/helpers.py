@@ -63,3 +63,22 @@ def cmp_prefix(ours, gold):
         # analytically-zero gradient (e.g. a conv bias in front of a normalisation): absolute check
         return ours.norm().item() / max(1.0, gold.numel() ** 0.5)
     return rel_l2(ours, gold)
+
+
+def pcg_tensor(shape, seed, kind="normal"):
+    """Inputs that are not stored in fixtures: numpy PCG64 streams (mirrors make_golden.pcg_tensor)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    n = int(np.prod(shape))
+    a = rng.standard_normal(n, dtype=np.float32) if kind == "normal" else rng.random(n, dtype=np.float32)
+    return torch.from_numpy(a.reshape(shape))
+
+
+def g6_data(shape=(64, 32, 32)):
+    """Training batches and validation sample of the G6 trainer fixture (mirrors make_golden.g6_data)."""
+    batches = []
+    for i in range(4):
+        B = 2 if i < 3 else 1
+        x = pcg_tensor((B, 3) + shape, 620 + i)
+        gt = torch.cat((pcg_tensor((B, 1) + shape, 630 + i, "uniform"), (pcg_tensor((B, 1) + shape, 640 + i, "uniform") > 0.5).float()), 1)
+        batches.append({"Input": x, "GT": gt})
+    return batches[:3], batches[3]

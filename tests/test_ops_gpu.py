@@ -457,3 +457,149 @@ def test_gemm_tn(cfg, dtype):
     _lib.call("dp_gemm_tn", Ad.data_ptr(), lda, Bd.data_ptr(), ldb, C.data_ptr(), N, M, N, K, sk, {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}[dtype],
               torch.cuda.current_stream().cuda_stream)
     assert rel_l2(C.cpu().double(), ref) < (2e-5 if dtype == torch.float32 else 2e-5)   # inputs are pre-rounded: fp32 accumulation in both modes
+
+
+# ------------------------------------------------------------------------------------------------ packed weights follow the optimizer
+def _all_pack_users(dev, dtype):
+    """One parameter per pack layout with a closure that makes ops build (and use) its packed copies."""
+    from dose_prediction_amd import ops
+    mk = lambda shape, seed, s=0.2: torch.nn.Parameter((rnd(shape, seed) * s).to(dev))  # noqa: E731
+    x16 = ndhwc(rnd((1, 16, 4, 9, 32), 70)).to(dev).to(dtype).requires_grad_(True)
+    x24 = ndhwc(rnd((1, 24, 4, 9, 32), 71)).to(dev).to(dtype).requires_grad_(True)
+    x9 = ndhwc(rnd((1, 9, 6, 6, 6), 72)).to(dev).to(dtype).requires_grad_(True)
+    tok = rnd((2, 40, 96), 73).to(dev).to(dtype).requires_grad_(True)
+    tok2 = rnd((2, 40, 100), 74).to(dev).to(dtype).requires_grad_(True)
+    users = [
+        (mk((16, 16, 7, 7, 7), 1, 0.05), lambda w: ops.conv3d(x16, w, None, 1, 3, 1)),        # tiled, tap-paired (Cout <= 16)
+        (mk((40, 24, 3, 3, 3), 2), lambda w: ops.conv3d(x24, w, None, 1, 1, 1)),              # tiled, two N tiles, ragged channels
+        (mk((12, 9, 3, 3, 3), 3), lambda w: ops.conv3d(x9, w, None, 2, 1, 1)),                # generic (stride 2): modes 0 and 1
+        (mk((12, 9, 3, 3, 3), 4), lambda w: ops.conv3d(x9, w, None, 1, 2, 2)),                # generic dilated: modes 0 and 2
+        (mk((8, 16, 1, 1, 1), 5), lambda w: ops.conv3d(x16, w, None, 1, 0, 1)),               # pointwise
+        (mk((16, 12, 2, 2, 2), 6), lambda w: ops.conv_transpose2x(x16, w)),                   # ConvTranspose matrices
+        (mk((64, 96), 7), lambda w: ops.linear(tok, w)),                                      # Linear, no padding (cast)
+        (mk((30, 100), 8), lambda w: ops.linear(tok2, w)),                                    # Linear, padded both ways
+    ]
+    return users
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_pack_multi_matches_single_tensor_packs(dtype):
+    """ops.refresh_packs (ONE dp_pack_multi launch) rebuilds every packed copy bit-identically to the per-tensor pack entry
+    points it replaces, for every layout (conv generic modes 0-2, tiled / tiled transposed+flipped, tconv, Linear +/- transposed)."""
+    from dose_prediction_amd import ops
+    dev = _dev()
+    users = _all_pack_users(dev, dtype)
+    for w, f in users:
+        y = f(w)
+        y.backward(torch.ones_like(y))
+    n_entries = 0
+    for w, f in users:
+        with torch.no_grad():
+            w.data.mul_(-1.7).add_(0.01)         # through .data: the version counter does not move, exactly like the fused optimizer
+        stale = {k: e[1].clone() for k, e in w._dp_packs.items()}
+        ops.refresh_packs([w])
+        multi = {k: e[1].clone() for k, e in w._dp_packs.items()}
+        assert set(multi) == set(stale) and len(multi) >= 1
+        ops.invalidate_packs([w])                  # now the per-tensor builders
+        y = f(w)
+        y.backward(torch.ones_like(y))
+        for k, e in w._dp_packs.items():
+            if e[1].data_ptr() == w.data_ptr():
+                continue
+            n_entries += 1
+            assert torch.equal(e[1].view(torch.uint8), multi[k].view(torch.uint8)), (k, dtype)
+            assert not torch.equal(e[1].view(torch.uint8), stale[k].view(torch.uint8)), (k, dtype)
+    assert n_entries >= 14
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_fused_adam_step_reaches_the_packed_weights(dtype):
+    """FusedAdam writes parameters through raw pointers; the forward after step() must use the NEW weights
+    (== a forward with freshly packed weights), for conv / tconv / linear in 16-bit and fp32 storage."""
+    from dose_prediction_amd import ops
+    from dose_prediction_amd.optim import FusedAdam
+    dev = _dev()
+    users = _all_pack_users(dev, dtype)
+    opt = FusedAdam([w for w, _ in users], lr=5e-2, amsgrad=True)
+    before = []
+    for w, f in users:
+        y = f(w)
+        y.float().pow(2).sum().backward()
+        before.append(y.detach().float().clone())
+    opt.step()
+    for (w, f), y0 in zip(users, before):
+        y1 = f(w).detach().float()
+        ops.invalidate_packs([w])
+        y2 = f(w).detach().float()
+        assert torch.equal(y1, y2), "forward after FusedAdam.step() does not use freshly packed weights"
+        assert (y1 - y0).abs().max() > 1e-3 * y0.abs().max(), "forward did not change after the optimizer step"
+
+
+def test_fused_adam_state_dict_round_trips_with_torch_adam():
+    """NetworkTrainer saves / restores optimizer_state_dict (network_trainer.py:340-363): FusedAdam must resume from a
+    torch.optim.Adam checkpoint (tensor `step`s) and vice versa, and continue identically."""
+    from dose_prediction_amd.optim import FusedAdam
+    dev = _dev()
+    shapes = [(8, 4, 3, 3, 3), (8,), (40, 24)]
+    kw = dict(lr=1e-3, weight_decay=3e-5, betas=(0.9, 0.999), eps=1e-8, amsgrad=True)
+
+    def run(cls_a, cls_b):
+        pa = [rnd(s, 10 + i).to(dev).requires_grad_(True) for i, s in enumerate(shapes)]
+        pb = [p.detach().clone().requires_grad_(True) for p in pa]
+        oa, ob = cls_a(pa, **kw), cls_b(pb, **kw)
+        for it in range(2):
+            for i, p in enumerate(pa):
+                p.grad = rnd(p.shape, 100 * it + i).to(dev)
+            oa.step()
+        ob.load_state_dict(oa.state_dict())
+        with torch.no_grad():
+            for x, y in zip(pa, pb):
+                y.copy_(x)
+        for it in range(2, 4):
+            for i, (x, y) in enumerate(zip(pa, pb)):
+                g = rnd(x.shape, 100 * it + i).to(dev)
+                x.grad, y.grad = g.clone(), g.clone()
+            oa.step()
+            ob.step()
+        for x, y in zip(pa, pb):
+            assert rel_err(y.detach().cpu(), x.detach().cpu()) < 2e-6
+        assert FusedAdam._step_value(ob.state[pb[0]]["step"]) == 4
+
+    run(torch.optim.Adam, FusedAdam)
+    run(FusedAdam, torch.optim.Adam)
+    # without amsgrad the state carries no max_exp_avg_sq key (torch's Adam has none either)
+    p = rnd((5, 3), 1).to(dev).requires_grad_(True)
+    o = FusedAdam([p], lr=1e-3)
+    p.grad = torch.ones_like(p)
+    o.step()
+    assert "max_exp_avg_sq" not in o.state[p]
+
+
+def test_fused_adam_capturable_replays_correct_steps():
+    """a step captured in a HIP graph must keep advancing Adam's bias corrections (device-side step count)."""
+    from dose_prediction_amd.optim import FusedAdam
+    dev = _dev()
+    kw = dict(lr=1e-2, weight_decay=3e-5, betas=(0.9, 0.999), eps=1e-8, amsgrad=True)
+    p0 = rnd((300, 70), 1).to(dev)
+    g = rnd((300, 70), 2).to(dev)
+    a = p0.clone().requires_grad_(True)
+    b = p0.clone().requires_grad_(True)
+    oa, ob = torch.optim.Adam([a], **kw), FusedAdam([b], capturable=True, **kw)
+    a.grad, b.grad = g.clone(), g.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ob.step()                       # eager warm-up step (allocates state)
+    torch.cuda.current_stream().wait_stream(side)
+    oa.step()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        ob.step()
+    oa.step()                           # the capture pass itself is not executed...
+    graph.replay()                      # ...this replay is step 2
+    for _ in range(3):
+        oa.step()
+        graph.replay()
+    torch.cuda.synchronize()
+    assert int(ob.state[b]["step"].item()) == 5
+    assert rel_err(b.detach().cpu(), a.detach().cpu()) < 5e-6
