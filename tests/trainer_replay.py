@@ -113,4 +113,9 @@ class TrainerReplay:
             for status in self.log.save_status:
                 self.save_trainer(status)
             self.log.save_status = []
+            self._log('            Average train loss is             %12.12f,     best is           %12.12f\n' %
+                      (self.log.average_train_loss, self.log.best_average_train_loss), 'a')
+            self._log('            Average val evaluation index is   %12.12f,     best is           %12.12f\n' %
+                      (self.log.average_val_index, self.log.best_average_val_index), 'a')
+            self._log('    End lr is %12.12f, %12.12f\n' % (self.optimizer.param_groups[0]['lr'], self.optimizer.param_groups[-1]['lr']), 'a')
         self._log('===============================> End successfully\n', 'a')
