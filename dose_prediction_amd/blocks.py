@@ -8,7 +8,7 @@ hand-written HIP kernels through ``dose_prediction_amd.ops`` on NDHWC tensors.
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import config, ops
 
 
 def _act_name(act):
@@ -71,9 +71,11 @@ class _ConvNormActPair(nn.Module):
             conv, norm = self.conv[i], self.conv[i + 1]
             x = ops.conv3d(x, conv.weight, conv.bias, 1, conv.padding[0], conv.dilation[0])
             if self._norm == "batch":
-                x = ops.norm_act(x, "batch", norm.weight, norm.bias, norm.running_mean, norm.running_var,
+                upd = self.training and config.bn_updates_enabled()
+                x = ops.norm_act(x, "batch", norm.weight, norm.bias, norm.running_mean if (upd or not self.training) else None,
+                                 norm.running_var if (upd or not self.training) else None,
                                  training=self.training, act=self._act, eps=norm.eps, momentum=norm.momentum)
-                if self.training:
+                if upd:
                     norm.num_batches_tracked += 1
             else:
                 x = ops.norm_act(x, "instance", act=self._act, eps=norm.eps)

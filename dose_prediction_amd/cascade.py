@@ -26,7 +26,7 @@ def window_starts(image_size, roi_size, overlap=0.25):
     starts = []
     for size, roi in zip(image_size, roi_size):
         if roi > size:
-            raise ValueError(f"volume axis {size} is smaller than the segmentation crop {roi}: padding is not supported")
+            raise ValueError(f"volume axis {size} is smaller than the segmentation crop {roi}: pad it first (sliding_window_logits does)")
         interval = roi if roi == size else max(1, int(roi * (1 - overlap)))
         num = int(math.ceil(float(size) / interval))
         first = next((d for d in range(num) if d * interval + roi >= size), None)
@@ -41,6 +41,15 @@ def sliding_window_logits(seg_model, ct, roi_size, sw_batch_size=4, overlap=0.25
     seg_model is built for img_size == roi_size; windows run sw_batch_size at a time in image-major order like MONAI."""
     B, _, D, H, W = ct.shape
     rz, ry, rx = roi_size
+    pads = [(max(r - s, 0) // 2, max(r - s, 0) - max(r - s, 0) // 2) for s, r in zip((D, H, W), roi_size)]
+    if any(a or b for a, b in pads):
+        # an axis shorter than the crop: MONAI zero-pads diff // 2 in front, the rest behind (padding_mode="constant"), runs the
+        # windows on the padded volume and crops the stitched result back
+        (z0, z1), (y0, y1), (x0, x1) = pads
+        padded = torch.zeros((B, 1, D + z0 + z1, H + y0 + y1, W + x0 + x1), dtype=ct.dtype, device=ct.device)
+        padded[:, :, z0:z0 + D, y0:y0 + H, x0:x0 + W] = ct
+        full = sliding_window_logits(seg_model, padded, roi_size, sw_batch_size, overlap)
+        return full[:, z0:z0 + D, y0:y0 + H, x0:x0 + W].contiguous()
     sz, sy, sx = window_starts((D, H, W), roi_size, overlap)
     wins = [(n, z, y, x) for n in range(B) for z in sz for y in sy for x in sx]
     x_all = to_ndhwc(ct)

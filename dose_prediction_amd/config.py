@@ -21,3 +21,56 @@ def set_compute_dtype(dtype):
 
 def compute_dtype():
     return _compute_dtype
+
+
+_loss_scale = 1.0
+_checkpoint_decoder = False
+
+
+def set_loss_scale(scale):
+    """Static loss scale for 16-bit storage (fp16: BASELINE.json configs[4]).  The module boundary (ops.FromNDHWC.backward) multiplies
+    the incoming fp32 gradient by `scale` while converting it to the storage type, so every stored activation gradient is `scale`
+    times larger (out of the fp16 subnormal range); parameter gradients come out multiplied by `scale` and are divided again
+    inside FusedAdam (grad_scale defaults to this value) or with ops.unscale_grads(params) before any other optimizer.  1.0 = off."""
+    global _loss_scale
+    if not (scale > 0):
+        raise ValueError("loss scale must be positive")
+    _loss_scale = float(scale)
+
+
+def loss_scale():
+    return _loss_scale
+
+
+def set_activation_checkpointing(on):
+    """Recompute the four pyramid decoder blocks in the backward pass (torch.utils.checkpoint around each ModifiedUnetrUpBlock /
+    UnetrUpBlock of PyMSCDecoder): their 128^3..16^3 intermediates are the bulk of the saved activations (BASELINE.json configs[4])."""
+    global _checkpoint_decoder
+    _checkpoint_decoder = bool(on)
+
+
+def activation_checkpointing():
+    return _checkpoint_decoder
+
+
+_bn_updates = True
+
+
+class bn_buffer_updates:
+    """Context: whether training-mode BatchNorm layers update running_mean / running_var / num_batches_tracked (switched off while
+    an activation-checkpointed block is recomputed in the backward pass)."""
+
+    def __init__(self, on):
+        self.on = bool(on)
+
+    def __enter__(self):
+        global _bn_updates
+        self.prev, _bn_updates = _bn_updates, self.on
+
+    def __exit__(self, *a):
+        global _bn_updates
+        _bn_updates = self.prev
+
+
+def bn_updates_enabled():
+    return _bn_updates

@@ -13,14 +13,18 @@
 
 // flags: bit 0 = post-process the prediction first (p = (mask < 1 || p < 0) ? 0 : p)
 __global__ void __launch_bounds__(L1_BLOCK) k_masked_l1_partial(const float* __restrict__ pred, const float* __restrict__ gt, const float* __restrict__ mask,
-                                                                int64_t n, float* __restrict__ part, int flags) {
+                                                                int64_t n, float* __restrict__ part, int flags, float delta) {
   __shared__ float red[2][L1_BLOCK / 64];
   const int64_t base = (int64_t)blockIdx.x * L1_ELEMS, end = min(n, base + L1_ELEMS);
   float s = 0.f, c = 0.f;
   const bool vec = (((uintptr_t)pred | (uintptr_t)gt | (uintptr_t)mask) & 15) == 0;
   auto one = [&](float p, float g, float m) {
     if (flags & 1) p = (m < 1.f || p < 0.f) ? 0.f : p;
-    if (m > 0.f) { s += fabsf(p - g); c += 1.f; }
+    if (m > 0.f) {      // delta > 0: nn.HuberLoss(delta) element (loss.py:53), else |p - g|
+      const float a = fabsf(p - g);
+      s += delta > 0.f ? (a < delta ? 0.5f * a * a : delta * (a - 0.5f * delta)) : a;
+      c += 1.f;
+    }
   };
   if (vec) {
     const int64_t end4 = base + ((end - base) & ~(int64_t)3);       // base is a multiple of 4: whole float4 groups, then <= 3 tail elements
@@ -51,11 +55,14 @@ __global__ void __launch_bounds__(64) k_masked_l1_finish(const float* __restrict
 }
 // gpred = gup[0] * sign(p - g) * (mask > 0) / max(count, 1)
 __global__ void __launch_bounds__(256) k_masked_l1_bwd(const float* __restrict__ pred, const float* __restrict__ gt, const float* __restrict__ mask,
-                                                       const float* __restrict__ stats, const float* __restrict__ gup, float* __restrict__ gpred, int64_t n) {
+                                                       const float* __restrict__ stats, const float* __restrict__ gup, float* __restrict__ gpred, int64_t n,
+                                                       float delta) {
   const float sc = gup[0] / fmaxf(stats[1], 1.f);
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const float d = pred[i] - gt[i];
-    gpred[i] = mask[i] > 0.f ? (d > 0.f ? sc : (d < 0.f ? -sc : 0.f)) : 0.f;
+    float gsign = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+    if (delta > 0.f) gsign = fabsf(d) < delta ? d : delta * gsign;          // Huber: d inside the quadratic zone, +-delta outside
+    gpred[i] = mask[i] > 0.f ? sc * gsign : 0.f;
   }
 }
 __global__ void __launch_bounds__(256) k_dose_postprocess(const float* __restrict__ pred, const float* __restrict__ mask, float* __restrict__ out, int64_t n, float scale) {
@@ -66,19 +73,35 @@ __global__ void __launch_bounds__(256) k_dose_postprocess(const float* __restric
 }
 
 extern "C" int64_t dp_masked_l1_ws_elems(int64_t n) { return 2 * ((n + L1_ELEMS - 1) / L1_ELEMS); }
-extern "C" int dp_masked_l1_fwd(const float* pred, const float* gt, const float* mask, int64_t n, float* ws, float* out3, int postprocess, void* stream) {
+static int masked_fwd(const float* pred, const float* gt, const float* mask, int64_t n, float* ws, float* out3, int postprocess, float delta, void* stream) {
   if (n <= 0) DP_FAIL("masked_l1: empty tensor");
   int64_t nblk = (n + L1_ELEMS - 1) / L1_ELEMS;
   if (nblk > 2000000000LL) DP_FAIL("masked_l1: tensor too large");
-  hipLaunchKernelGGL(k_masked_l1_partial, dim3((unsigned)nblk), dim3(L1_BLOCK), 0, STREAM, pred, gt, mask, n, ws, postprocess ? 1 : 0);
+  hipLaunchKernelGGL(k_masked_l1_partial, dim3((unsigned)nblk), dim3(L1_BLOCK), 0, STREAM, pred, gt, mask, n, ws, postprocess ? 1 : 0, delta);
   hipLaunchKernelGGL(k_masked_l1_finish, dim3(1), dim3(64), 0, STREAM, (const float*)ws, (int)nblk, out3);
   DP_CHECK_LAUNCH("masked_l1_fwd"); return 0;
 }
+static int masked_bwd(const float* pred, const float* gt, const float* mask, const float* out3, const float* gup, float* gpred, int64_t n, float delta,
+                      void* stream) {
+  int64_t g = (n + 255) / 256; if (g > 16384) g = 16384;
+  hipLaunchKernelGGL(k_masked_l1_bwd, dim3((unsigned)g), dim3(256), 0, STREAM, pred, gt, mask, out3, gup, gpred, n, delta);
+  DP_CHECK_LAUNCH("masked_l1_bwd"); return 0;
+}
+extern "C" int dp_masked_l1_fwd(const float* pred, const float* gt, const float* mask, int64_t n, float* ws, float* out3, int postprocess, void* stream) {
+  return masked_fwd(pred, gt, mask, n, ws, out3, postprocess, 0.f, stream);
+}
 extern "C" int dp_masked_l1_bwd(const float* pred, const float* gt, const float* mask, const float* out3, const float* gup, float* gpred, int64_t n,
                                 void* stream) {
-  int64_t g = (n + 255) / 256; if (g > 16384) g = 16384;
-  hipLaunchKernelGGL(k_masked_l1_bwd, dim3((unsigned)g), dim3(256), 0, STREAM, pred, gt, mask, out3, gup, gpred, n);
-  DP_CHECK_LAUNCH("masked_l1_bwd"); return 0;
+  return masked_bwd(pred, gt, mask, out3, gup, gpred, n, 0.f, stream);
+}
+extern "C" int dp_masked_huber_fwd(const float* pred, const float* gt, const float* mask, int64_t n, float delta, float* ws, float* out3, void* stream) {
+  if (!(delta > 0.f)) DP_FAIL("masked_huber: delta must be > 0");
+  return masked_fwd(pred, gt, mask, n, ws, out3, 0, delta, stream);
+}
+extern "C" int dp_masked_huber_bwd(const float* pred, const float* gt, const float* mask, const float* out3, const float* gup, float* gpred, int64_t n,
+                                   float delta, void* stream) {
+  if (!(delta > 0.f)) DP_FAIL("masked_huber: delta must be > 0");
+  return masked_bwd(pred, gt, mask, out3, gup, gpred, n, delta, stream);
 }
 extern "C" int dp_dose_postprocess(const float* pred, const float* mask, float* out, int64_t n, float scale, void* stream) {
   int64_t g = (n + 255) / 256; if (g > 16384) g = 16384;

@@ -23,8 +23,22 @@ def _masked_l1(pred, gt, mask):
     return ops.masked_l1(pred, gt, mask)
 
 
-def gen_loss(predictions, gt, delta1=10.0, delta2=1.0, casecade=True, freez=True):
-    """GenLoss.forward(mode='train', huber=False), loss.py:69-107."""
+def _masked_huber(pred, gt, mask, delta=0.5):
+    from . import ops
+    return ops.masked_l1(pred, gt, mask, huber_delta=delta)
+
+
+def gen_loss_val(prediction, gt, huber=False):
+    """GenLoss.forward(mode != 'train'), loss.py:109-117: masked L1 (+ Huber(delta 0.5) when huber) of one prediction."""
+    dose, mask = gt[:, 0:1], gt[:, 1:2]
+    l1 = _masked_l1(prediction, dose, mask)
+    return _masked_huber(prediction, dose, mask) + l1 if huber else l1
+
+
+def gen_loss(predictions, gt, delta1=10.0, delta2=1.0, casecade=True, freez=True, huber=False, mode="train"):
+    """GenLoss.forward, loss.py:69-117 (mode='train': 69-107; any other mode: the validation branch on a single prediction)."""
+    if mode != "train":
+        return gen_loss_val(predictions, gt, huber)
     dose, mask = gt[:, 0:1], gt[:, 1:2]
     pred_a = None
     if casecade:
@@ -37,14 +51,17 @@ def gen_loss(predictions, gt, delta1=10.0, delta2=1.0, casecade=True, freez=True
         g, m = _resample_gt(dose, mask, dims)
         l_ds = l_ds + _masked_l1(pr, g, m)
     l_ds = l_ds / max(1, len(inter))
-    loss = delta1 * _masked_l1(predictions[0], dose, mask) + delta2 * l_ds
+    full = _masked_huber(predictions[0], dose, mask) if huber else _masked_l1(predictions[0], dose, mask)
+    loss = delta1 * full + delta2 * l_ds
     if casecade and not freez:
         loss = loss + 0.5 * _masked_l1(pred_a, dose, mask)
     return loss
 
 
-def l1_loss(pred, gt, freez=True):
-    """Loss.forward (cascade), loss.py:13-28."""
+def l1_loss(pred, gt, freez=True, casecade=True):
+    """Loss.forward, loss.py:13-39 (casecade=True: [pred_A, pred_B]; casecade=False: one prediction, 29-39)."""
     dose, mask = gt[:, 0:1], gt[:, 1:2]
+    if not casecade:
+        return _masked_l1(pred, dose, mask)
     lb = _masked_l1(pred[1] if not isinstance(pred[1], (list, tuple)) else pred[1][0], dose, mask)
     return lb if freez else 0.5 * _masked_l1(pred[0], dose, mask) + lb

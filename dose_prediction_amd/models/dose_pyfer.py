@@ -83,10 +83,25 @@ class PyMSCDecoder(nn.Module):
 
     def forward(self, out_encoder):
         e1, e2, e3, e4, e5 = out_encoder
-        dec4 = self.decoder4(e5, e4)
-        dec3 = self.decoder3(dec4, e3)
-        dec2 = self.decoder2(dec3, e2)
-        dec1 = self.decoder1(dec2, e1)
+        from .. import config
+        if config.activation_checkpointing() and torch.is_grad_enabled():
+            from torch.utils.checkpoint import checkpoint
+
+            def run(blk, a, b):
+                calls = []
+
+                def once(a_, b_):
+                    # the recomputation pass (second call) must not update the BatchNorm running statistics a second time
+                    calls.append(1)
+                    with config.bn_buffer_updates(len(calls) == 1):
+                        return blk(a_, b_)
+                return checkpoint(once, a, b, use_reentrant=False)
+        else:
+            run = lambda blk, a, b: blk(a, b)  # noqa: E731
+        dec4 = run(self.decoder4, e5, e4)
+        dec3 = run(self.decoder3, dec4, e3)
+        dec2 = run(self.decoder2, dec3, e2)
+        dec1 = run(self.decoder1, dec2, e1)
         return [dec1, dec2, dec3, dec4]
 
 

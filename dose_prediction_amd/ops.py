@@ -101,6 +101,15 @@ _packs = _PackCache()
 _REPACK_PLANS = {}
 
 
+def unscale_grads(params):
+    """Divide the gradients of ``params`` by config.loss_scale() in one multi-tensor pass (for optimizers other than FusedAdam,
+    which unscales inside its kernel)."""
+    from . import config
+    gs = [p.grad for p in params if p.grad is not None]
+    if gs and config.loss_scale() != 1.0:
+        torch._foreach_mul_(gs, 1.0 / config.loss_scale())
+
+
 def invalidate_packs(params):
     """Drop every packed copy of ``params`` (they are rebuilt lazily by the next forward)."""
     for p in params:
@@ -338,6 +347,9 @@ class ToNDHWC(torch.autograd.Function):
         sp = tuple(gy.shape[1:4])
         gx = torch.empty((N, ctx.C) + sp, dtype=torch.float32, device=gy.device)
         _lib.call("dp_ndhwc_to_ncdhw", _p(gy), _p(gx), N, ctx.C, rows // N, ld, 0, _dt(gy), _stream())
+        from . import config
+        if config.loss_scale() != 1.0 and gy.dtype != torch.float32:
+            gx = gx / config.loss_scale()
         return gx, None, None
 
 
@@ -359,6 +371,9 @@ class FromNDHWC(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         gy = gy.contiguous().float()
+        from . import config
+        if config.loss_scale() != 1.0 and ctx.dtype != torch.float32:
+            gy = gy * config.loss_scale()         # loss scaling enters the 16-bit domain here (config.set_loss_scale)
         N, C = gy.shape[:2]
         sp = tuple(gy.shape[2:])
         gx = torch.empty((N,) + sp + (C,), dtype=ctx.dtype, device=gy.device)
@@ -1184,11 +1199,12 @@ def argmax_onehot(logits, out=None, choff=0, labels=False):
 
 # ------------------------------------------------------------------------------------------------ loss / metrics
 class MaskedL1(torch.autograd.Function):
-    """mean |pred - gt| over mask > 0 (Train/loss.py:13-28, 69-107) without boolean indexing: dp_masked_l1_fwd / _bwd.
+    """mean |pred - gt| over mask > 0 (Train/loss.py:13-28, 69-107) without boolean indexing: dp_masked_l1_fwd / _bwd; with
+    huber_delta > 0 the element is nn.HuberLoss(delta)'s (loss.py:53: GenLoss(huber=True)), dp_masked_huber_fwd / _bwd.
     pred, gt, mask: fp32 device tensors of equal numel (any shape); returns a 0-dim fp32 tensor."""
 
     @staticmethod
-    def forward(ctx, pred, gt, mask):
+    def forward(ctx, pred, gt, mask, huber_delta):
         _chk_dev(pred, gt, mask)
         if pred.dtype != torch.float32:
             raise _lib.DoseHipError("masked_l1 takes the fp32 tensors of the module boundary")
@@ -1198,8 +1214,12 @@ class MaskedL1(torch.autograd.Function):
             raise ValueError("masked_l1: pred, gt and mask must have the same number of elements")
         ws = torch.empty((_lib.lib().dp_masked_l1_ws_elems(n),), dtype=torch.float32, device=pred.device)
         out = torch.empty((3,), dtype=torch.float32, device=pred.device)
-        _lib.call("dp_masked_l1_fwd", _p(pred), _p(gt), _p(mask), n, _p(ws), _p(out), 0, _stream())
+        if huber_delta > 0:
+            _lib.call("dp_masked_huber_fwd", _p(pred), _p(gt), _p(mask), n, float(huber_delta), _p(ws), _p(out), _stream())
+        else:
+            _lib.call("dp_masked_l1_fwd", _p(pred), _p(gt), _p(mask), n, _p(ws), _p(out), 0, _stream())
         ctx.save_for_backward(pred, gt, mask, out)
+        ctx.delta = float(huber_delta)
         return out[2]
 
     @staticmethod
@@ -1207,12 +1227,15 @@ class MaskedL1(torch.autograd.Function):
         pred, gt, mask, out = ctx.saved_tensors
         gp = torch.empty_like(pred)
         gup = g.contiguous().float().reshape(1)
-        _lib.call("dp_masked_l1_bwd", _p(pred), _p(gt), _p(mask), _p(out), _p(gup), _p(gp), pred.numel(), _stream())
-        return gp, None, None
+        if ctx.delta > 0:
+            _lib.call("dp_masked_huber_bwd", _p(pred), _p(gt), _p(mask), _p(out), _p(gup), _p(gp), pred.numel(), ctx.delta, _stream())
+        else:
+            _lib.call("dp_masked_l1_bwd", _p(pred), _p(gt), _p(mask), _p(out), _p(gup), _p(gp), pred.numel(), _stream())
+        return gp, None, None, None
 
 
-def masked_l1(pred, gt, mask):
-    return MaskedL1.apply(pred, gt, mask)
+def masked_l1(pred, gt, mask, huber_delta=0.0):
+    return MaskedL1.apply(pred, gt, mask, huber_delta)
 
 
 def dose_score(pred, gt, mask, scale=70.0):

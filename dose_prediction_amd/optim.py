@@ -12,11 +12,14 @@ class FusedAdam(torch.optim.Optimizer):
     """capturable=True keeps the step count on the device (state['step'] is a 0-dim int32 device tensor shared by a group's
     parameters), so that a step captured in a HIP graph replays with the right bias corrections."""
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False, capturable=False):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False, capturable=False,
+                 grad_scale=None):
         if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1) or weight_decay < 0:
             raise ValueError("invalid Adam hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad, capturable=capturable))
         self._plans = {}
+        # gradients arrive multiplied by this factor (config.set_loss_scale: fp16 training); None = follow the global setting
+        self.grad_scale = grad_scale
 
     def __setstate__(self, state):
         super().__setstate__(state)
@@ -79,6 +82,9 @@ class FusedAdam(torch.optim.Optimizer):
             devtab.copy_(host, non_blocking=True)
             b1, b2 = group["betas"]
             stream = torch.cuda.current_stream().cuda_stream
+            from . import config
+            gs = float(self.grad_scale if self.grad_scale is not None else config.loss_scale())
+            inv_gs = 1.0 / gs
             if capt:
                 sdev = self.state[plist[0]]["step"]
                 if not (torch.is_tensor(sdev) and sdev.is_cuda and sdev.dtype == torch.int32):
@@ -90,7 +96,7 @@ class FusedAdam(torch.optim.Optimizer):
                 for p in plist:
                     self.state[p]["step"] = sdev
                 _lib.call("dp_adam_multi_dev", devtab.data_ptr(), ct.data_ptr(), ci.data_ptr(), nchunks, float(group["lr"]), float(b1),
-                          float(b2), float(group["eps"]), float(group["weight_decay"]), sdev.data_ptr(), 1 if group["amsgrad"] else 0, stream)
+                          float(b2), float(group["eps"]), float(group["weight_decay"]), inv_gs, sdev.data_ptr(), 1 if group["amsgrad"] else 0, stream)
             else:
                 steps = {self._step_value(self.state[p]["step"]) for p in plist}
                 if len(steps) != 1:
@@ -99,7 +105,7 @@ class FusedAdam(torch.optim.Optimizer):
                 for p in plist:
                     self.state[p]["step"] = step
                 _lib.call("dp_adam_multi", devtab.data_ptr(), ct.data_ptr(), ci.data_ptr(), nchunks, float(group["lr"]), float(b1), float(b2),
-                          float(group["eps"]), float(group["weight_decay"]), int(step), 1 if group["amsgrad"] else 0, stream)
+                          float(group["eps"]), float(group["weight_decay"]), inv_gs, int(step), 1 if group["amsgrad"] else 0, stream)
             # the kernel wrote the parameters through raw pointers (p._version did not move): rebuild their packed copies now
             ops.refresh_packs(plist)
         return loss

@@ -216,15 +216,16 @@ int dp_conv3d_wgrad_tiled(const void* x, int ldx, const void* gy, int ldgy, floa
 /* ---- optimizer ------------------------------------------------------------ */
 /* replaces: optim.Adam(..., amsgrad=True).step() as built by NetworkTrainer.set_optimizer (network_trainer.py:120-125): one
  * launch over all parameter tensors.  table: device array of {float* p; const float* g; float* m; float* v; float* vmax;
- * int64_t n}; chunk_t/chunk_i map each block to (tensor, chunk of dp_adam_chunk() elements); step = count after this update. */
+ * int64_t n}; chunk_t/chunk_i map each block to (tensor, chunk of dp_adam_chunk() elements); step = count after this update.
+ * inv_grad_scale multiplies every gradient first (1 / loss scale when the backward pass ran on a scaled loss: fp16 storage). */
 int dp_adam_chunk(void);
 int dp_adam_multi(const void* table, const int32_t* chunk_t, const int32_t* chunk_i, int nchunks, double lr, double beta1, double beta2,
-                  double eps, double weight_decay, int step, int amsgrad, void* stream);
+                  double eps, double weight_decay, double inv_grad_scale, int step, int amsgrad, void* stream);
 
 /* Capturable variant: *step_dev (device int32, the number of updates done so far) is incremented by the call and the bias
  * corrections are computed from it on the device, so a captured HIP graph replays a correct Adam step. */
 int dp_adam_multi_dev(const void* table, const int32_t* chunk_t, const int32_t* chunk_i, int nchunks, double lr, double beta1, double beta2,
-                      double eps, double weight_decay, int32_t* step_dev, int amsgrad, void* stream);
+                      double eps, double weight_decay, double inv_grad_scale, int32_t* step_dev, int amsgrad, void* stream);
 
 /* ---- packed-weight refresh after optimizer.step() (network_trainer.py:213) ----------------------------------------------
  * The kernels read kernel-layout copies of the fp32 nn.Parameters; ONE launch rebuilds all copies of the parameters a step
@@ -276,6 +277,11 @@ int dp_masked_l1_fwd(const float* pred, const float* gt, const float* mask, int6
                      void* stream);
 int dp_masked_l1_bwd(const float* pred, const float* gt, const float* mask, const float* out3, const float* gup, float* gpred,
                      int64_t n, void* stream);
+/* GenLoss(huber=True) (Train/loss.py:53,100-103,112-115): nn.HuberLoss(reduction='mean', delta) over mask > 0: element
+ * 0.5 d^2 for |d| < delta, delta (|d| - delta / 2) otherwise; same out3 / ws / backward conventions as dp_masked_l1_*. */
+int dp_masked_huber_fwd(const float* pred, const float* gt, const float* mask, int64_t n, float delta, float* ws, float* out3, void* stream);
+int dp_masked_huber_bwd(const float* pred, const float* gt, const float* mask, const float* out3, const float* gup, float* gpred,
+                        int64_t n, float delta, void* stream);
 /* Ground-truth pyramid of GenLoss (Train/loss.py:56-66, 88-97): dose resampled like F.interpolate(mode="trilinear",
  * align_corners=True), mask like mode="nearest-exact"; fp32 single-channel volumes [N][D][H][W]. */
 int dp_resample_gt(const float* dose, const float* mask, float* out_dose, float* out_mask, int N, int Di, int Hi, int Wi, int Do, int Ho,

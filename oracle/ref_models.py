@@ -14,8 +14,8 @@ from . import ref_ops as R
 __all__ = [
     "single_conv", "base_unet", "c3d_model", "conv_block_3", "conv_block_7", "conv_3_1", "conv_3_1_old",
     "dilated_conv_block", "dual_dilated_block", "unet_res_block", "unet_basic_block", "unetr_pr_up_block",
-    "modified_unetr_up_block", "unetr_up_block", "vit", "vit_encoder", "main_subset_model", "dose_pyfer",
-    "oar_transeg", "loss_l1_masked", "gen_loss", "dose_postprocess", "dose_mae", "sliding_window_inference",
+    "modified_unetr_up_block", "unetr_up_block", "vit", "transformer_block", "vit_encoder", "main_subset_model", "dose_pyfer",
+    "oar_transeg", "loss_l1_masked", "loss_l1_plain", "gen_loss", "gen_loss_val", "dose_postprocess", "dose_mae", "sliding_window_inference",
 ]
 
 
@@ -47,6 +47,7 @@ def base_unet(sd, p, x):
 
 def c3d_model(sd, x):
     """c3d.Model cascade of two BaseUNets, c3d.py:152-169."""
+    x = R.store(x)
     a = base_unet(sd, "net_A.", x)
     b = base_unet(sd, "net_B.", torch.cat((a, x), dim=1))
     return [R.conv3d(a, sd["conv_out_A.weight"], sd["conv_out_A.bias"]),
@@ -126,7 +127,7 @@ def unet_res_block(sd, p, x):
     out = R.instance_norm(R.conv3d(out, sd[p + ".conv2.conv.weight"], padding=1))
     res = x
     if w1.shape[0] != w1.shape[1]:
-        res = R.instance_norm(R.conv3d(x, sd[p + ".conv3.conv.weight"]))
+        res = R.store(R.instance_norm(R.conv3d(x, sd[p + ".conv3.conv.weight"])))     # (a stored tensor in the HIP path)
     return R.activation(out + res, "lrelu")
 
 
@@ -146,22 +147,27 @@ def unetr_pr_up_block(sd, p, x, num_layer):
     return x
 
 
+def transformer_block(sd, b, t, num_heads):
+    """MONAI 0.7.0 TransformerBlock (pre-norm): t + SABlock(LayerNorm(t)); t + MLPBlock(LayerNorm(t)), MLP = Linear -> GELU(erf) ->
+    Linear, dropout 0.  Cross-checked against nn.TransformerEncoderLayer(norm_first=True) in tests/test_oracle_leaves_cpu.py."""
+    t = R.store(t + R.attention(R.layer_norm(t, sd[b + "norm1.weight"], sd[b + "norm1.bias"]),
+                                sd[b + "attn.qkv.weight"], sd[b + "attn.out_proj.weight"],
+                                sd[b + "attn.out_proj.bias"], num_heads))
+    h = R.layer_norm(t, sd[b + "norm2.weight"], sd[b + "norm2.bias"])
+    h = R.gelu(R.linear(h, sd[b + "mlp.linear1.weight"], sd[b + "mlp.linear1.bias"]))
+    return R.store(t + R.linear(h, sd[b + "mlp.linear2.weight"], sd[b + "mlp.linear2.bias"]))
+
+
 def vit(sd, p, x, num_layers, num_heads):
     """MONAI 0.7.0 ViT(pos_embed='perceptron', classification=False): patchify -> Linear ->
     + position_embeddings -> num_layers pre-norm TransformerBlocks -> LayerNorm.
     Returns (normed last state, [output of every block])."""
     t = R.linear(R.patchify(x), sd[p + "patch_embedding.patch_embeddings.1.weight"],
                  sd[p + "patch_embedding.patch_embeddings.1.bias"])
-    t = t + sd[p + "patch_embedding.position_embeddings"]
+    t = R.store(t + R.store_weight(sd[p + "patch_embedding.position_embeddings"]))
     hidden = []
     for i in range(num_layers):
-        b = f"{p}blocks.{i}."
-        t = t + R.attention(R.layer_norm(t, sd[b + "norm1.weight"], sd[b + "norm1.bias"]),
-                            sd[b + "attn.qkv.weight"], sd[b + "attn.out_proj.weight"],
-                            sd[b + "attn.out_proj.bias"], num_heads)
-        h = R.layer_norm(t, sd[b + "norm2.weight"], sd[b + "norm2.bias"])
-        h = R.gelu(R.linear(h, sd[b + "mlp.linear1.weight"], sd[b + "mlp.linear1.bias"]))
-        t = t + R.linear(h, sd[b + "mlp.linear2.weight"], sd[b + "mlp.linear2.bias"])
+        t = transformer_block(sd, f"{p}blocks.{i}.", t, num_heads)
         hidden.append(t)
     return R.layer_norm(t, sd[p + "norm.weight"], sd[p + "norm.bias"]), hidden
 
@@ -225,6 +231,7 @@ def main_subset_model(sd, p, x, num_layers, num_heads, act, training, mode_multi
 def dose_pyfer(sd, x, num_layers=8, num_heads=6, act="mish", training=True, mode_multi_dec=True,
                multiS_conv=True, bn_out=None):
     """dose_pyfer.Model.forward, 355-360: net_A -> cat(out_A, x) -> net_B; conv_out_A."""
+    x = R.store(x)          # (entry conversion NCDHW fp32 -> NDHWC storage type)
     a = base_unet(sd, "net_A.", x)
     outs = main_subset_model(sd, "net_B.", torch.cat((a, x), dim=1), num_layers, num_heads, act, training,
                              mode_multi_dec, multiS_conv, bn_out)
@@ -235,6 +242,7 @@ def dose_pyfer(sd, x, num_layers=8, num_heads=6, act="mish", training=True, mode
 def oar_transeg(sd, x, num_heads=12, training=True, bn_out=None, old=False):
     """oar_transeg.Model.forward, 171-185 (num_layers hard-coded 12, line 73; decoder act defaults to
     'relu', base_blocks.py:103).  ``old=True`` selects the OldModels TRANSEG decoder variant."""
+    x = R.store(x)
     feat = tuple(s // 16 for s in x.shape[2:])
     z, hidden = vit(sd, "vit.", x, 12, num_heads)
     e1 = unet_res_block(sd, "encoder1.layer", x)
@@ -255,8 +263,27 @@ def loss_l1_masked(pred, gt, freez=True):
     return lb if freez else 0.5 * (pred[0][mask] - dose[mask]).abs().mean() + lb
 
 
-def gen_loss(predictions, gt, delta1=10, delta2=1, casecade=True, freez=True):
-    """Train/loss.py GenLoss.forward mode='train', huber=False, 69-107: delta1 * masked L1 at full
+def _huber(p, g, delta=0.5):
+    """nn.HuberLoss(reduction='mean', delta=0.5) (loss.py:53)."""
+    d = (p - g).abs()
+    return torch.where(d < delta, 0.5 * d * d, delta * (d - 0.5 * delta)).mean()
+
+
+def loss_l1_plain(pred, gt):
+    """Train/loss.py Loss.forward with casecade=False, 29-39: one prediction, masked L1."""
+    dose, mask = gt[:, 0:1], gt[:, 1:2] > 0
+    return (pred[mask] - dose[mask]).abs().mean()
+
+
+def gen_loss_val(prediction, gt, huber=False):
+    """Train/loss.py GenLoss.forward mode != 'train', 109-117: masked L1 (+ Huber when huber=True) of ONE prediction."""
+    dose, mask = gt[:, 0:1], gt[:, 1:2] > 0
+    l1 = (prediction[mask] - dose[mask]).abs().mean()
+    return _huber(prediction[mask], dose[mask]) + l1 if huber else l1
+
+
+def gen_loss(predictions, gt, delta1=10, delta2=1, casecade=True, freez=True, huber=False):
+    """Train/loss.py GenLoss.forward mode='train', 69-107: delta1 * masked L1 (Huber delta 0.5 when huber=True) at full
     resolution + delta2 * mean of masked L1 at 1/2,1/4,1/8 resolution against trilinear
     (align_corners) down-sampled dose and nearest-exact down-sampled mask."""
     dose, mask = gt[:, 0:1], gt[:, 1:2]
@@ -272,7 +299,8 @@ def gen_loss(predictions, gt, delta1=10, delta2=1, casecade=True, freez=True):
         l_ds = l_ds + (pr[m] - g[m]).abs().mean()
     l_ds = l_ds / len(predictions[1:])
     m0 = mask > 0
-    loss = delta1 * (predictions[0][m0] - dose[m0]).abs().mean() + delta2 * l_ds
+    full = _huber(predictions[0][m0], dose[m0]) if huber else (predictions[0][m0] - dose[m0]).abs().mean()
+    loss = delta1 * full + delta2 * l_ds
     if casecade and not freez:
         loss = loss + 0.5 * (pred_a[m0] - dose[m0]).abs().mean()
     return loss
@@ -295,9 +323,16 @@ def sliding_window_inference(inputs, roi_size, sw_batch_size, predictor, overlap
     """MONAI 0.7 monai.inferers.sliding_window_inference with mode="constant" (call site
     train_light_linked_model.py:152-153), restated from the published algorithm: scan interval int(roi*(1-overlap)) (the roi
     itself on an axis that fits one window), dense_patch_slices origins with the last window pulled back inside the volume,
-    predictions summed with unit importance and divided by the visit count.  Volumes smaller than the roi (MONAI pads them)
-    are not covered.  PARITY UNPINNED: MONAI is absent from the authoring container."""
+    predictions summed with unit importance and divided by the visit count.  An axis shorter than the roi is zero-padded
+    (padding_mode="constant", cval 0) by diff // 2 in front and diff - diff // 2 behind, and the result is cropped back.
+    PARITY UNPINNED: MONAI is absent from the authoring container."""
     import math
+    orig = tuple(inputs.shape[2:])
+    pads = [(max(r - s_, 0) // 2, max(r - s_, 0) - max(r - s_, 0) // 2) for s_, r in zip(orig, roi_size)]
+    if any(a or b for a, b in pads):
+        inputs = torch.nn.functional.pad(inputs, (pads[2][0], pads[2][1], pads[1][0], pads[1][1], pads[0][0], pads[0][1]))
+        full = sliding_window_inference(inputs, roi_size, sw_batch_size, predictor, overlap)
+        return full[:, :, pads[0][0]:pads[0][0] + orig[0], pads[1][0]:pads[1][0] + orig[1], pads[2][0]:pads[2][0] + orig[2]]
     image_size = tuple(inputs.shape[2:])
     starts = []
     for size, roi in zip(image_size, roi_size):

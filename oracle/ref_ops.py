@@ -10,7 +10,7 @@ import torch.nn.functional as F
 
 __all__ = [
     "conv3d", "conv_transpose3d_k2s2", "instance_norm", "batch_norm", "layer_norm", "activation",
-    "trilinear_up2", "linear", "gelu", "attention", "patchify", "bf16_round",
+    "trilinear_up2", "linear", "gelu", "attention", "patchify", "bf16_round", "storage", "store", "store_weight",
 ]
 
 
@@ -19,15 +19,63 @@ def bf16_round(t):
     return t.to(torch.bfloat16).to(torch.float32)
 
 
+# ---------------------------------------------------------------------------------------------- 16-bit storage emulation
+# The HIP path in bf16 / fp16 mode keeps fp32 accumulators inside every kernel and rounds ONLY where a tensor is stored:
+# each op output (convolution, transposed convolution, Linear, fused norm(+residual)+activation, LayerNorm, GELU, residual
+# add, trilinear up-sampling, attention output and the attention probabilities fed to the P.V MFMA), the packed weight copies,
+# and the same points of the backward pass (gradients are stored in the same type).  `with storage(torch.bfloat16):` makes
+# the oracle round at exactly those points (in whatever precision it otherwise computes, fp32 or fp64), so that
+# err(oracle-with-storage vs fp64 oracle) is the error budget of the storage format itself -- what a correct 16-bit
+# implementation must show, no more (tests/test_precision_budget_gpu.py).
+_STORE = None
+
+
+class storage:
+    def __init__(self, dtype):
+        self.dtype = None if dtype in (None, torch.float32, torch.float64) else dtype
+
+    def __enter__(self):
+        global _STORE
+        self.prev, _STORE = _STORE, self.dtype
+        return self
+
+    def __exit__(self, *a):
+        global _STORE
+        _STORE = self.prev
+
+
+class _Store(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t, dt):
+        ctx.dt = dt
+        return t.to(dt).to(t.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(ctx.dt).to(g.dtype), None
+
+
+def store(t):
+    """A tensor written to HBM by the HIP path: rounded to the storage type (forward value and incoming gradient)."""
+    return t if _STORE is None else _Store.apply(t, _STORE)
+
+
+def store_weight(w):
+    """The packed 16-bit copy of an fp32 master weight (its gradient stays fp32: weight gradients are produced in fp32)."""
+    if _STORE is None:
+        return w
+    return w + (w.detach().to(_STORE).to(w.dtype) - w.detach())
+
+
 def conv3d(x, w, b=None, stride=1, padding=0, dilation=1):
     """nn.Conv3d (reference: c3d.py:16, blocks_MDUNet.py:68,102,146)."""
-    return F.conv3d(x, w, b, stride=stride, padding=padding, dilation=dilation)
+    return store(F.conv3d(x, store_weight(w), b, stride=stride, padding=padding, dilation=dilation))
 
 
 def conv_transpose3d_k2s2(x, w):
     """nn.ConvTranspose3d(kernel 2, stride 2, no bias) (reference: base_blocks.py:118-127 via
     MONAI get_conv_layer(is_transposed=True)).  w: [Cin, Cout, 2, 2, 2]."""
-    return F.conv_transpose3d(x, w, None, stride=2)
+    return store(F.conv_transpose3d(x, store_weight(w), None, stride=2))
 
 
 def instance_norm(x, weight=None, bias=None, eps=1e-5):
@@ -66,26 +114,27 @@ def layer_norm(x, weight, bias, eps=1e-5):
     """nn.LayerNorm over the last dim (MONAI TransformerBlock.norm1/norm2, ViT.norm)."""
     mean = x.mean(dim=-1, keepdim=True)
     var = x.var(dim=-1, unbiased=False, keepdim=True)
-    return (x - mean) * torch.rsqrt(var + eps) * weight + bias
+    return store((x - mean) * torch.rsqrt(var + eps) * weight + bias)
 
 
 def activation(x, kind):
-    """ReLU / LeakyReLU(0.01) / Mish / GELU(erf) / identity."""
+    """ReLU / LeakyReLU(0.01) / Mish / identity, applied to a normalised tensor (+ residual).  In the HIP path this is the
+    tail of the fused norm(+residual)+activation kernel, i.e. a storage point (instance_norm / batch_norm themselves are not)."""
     if kind in (None, "none"):
-        return x
+        return store(x)
     if kind == "relu":
-        return torch.clamp_min(x, 0)
+        return store(torch.clamp_min(x, 0))
     if kind == "lrelu":
-        return torch.where(x >= 0, x, 0.01 * x)
+        return store(torch.where(x >= 0, x, 0.01 * x))
     if kind == "mish":
-        return x * torch.tanh(F.softplus(x))
+        return store(x * torch.tanh(F.softplus(x)))
     if kind == "gelu":
         return gelu(x)
     raise ValueError(kind)
 
 
 def gelu(x):
-    return 0.5 * x * (1.0 + torch.erf(x / math.sqrt(2.0)))
+    return store(0.5 * x * (1.0 + torch.erf(x / math.sqrt(2.0))))
 
 
 def trilinear_up2(x):
@@ -106,12 +155,12 @@ def trilinear_up2(x):
         return t.index_select(axis, i0) * (1 - f) + t.index_select(axis, i1) * f
     for ax in (2, 3, 4):
         x = interp_axis(x, ax)
-    return x
+    return store(x)
 
 
 def linear(x, w, b=None):
-    y = x @ w.t()
-    return y if b is None else y + b
+    y = x @ store_weight(w).t()
+    return store(y if b is None else y + b)
 
 
 def attention(x, qkv_w, out_w, out_b, num_heads):
@@ -121,8 +170,8 @@ def attention(x, qkv_w, out_w, out_b, num_heads):
     d = H // num_heads
     qkv = linear(x, qkv_w).view(B, N, 3, num_heads, d).permute(2, 0, 3, 1, 4)  # qkv b l n d
     q, k, v = qkv[0], qkv[1], qkv[2]
-    att = torch.softmax((q @ k.transpose(-1, -2)) * (d ** -0.5), dim=-1)
-    o = (att @ v).permute(0, 2, 1, 3).reshape(B, N, H)
+    att = store(torch.softmax((q @ k.transpose(-1, -2)) * (d ** -0.5), dim=-1))      # (16-bit P operand of the P.V MFMA)
+    o = store((att @ v).permute(0, 2, 1, 3).reshape(B, N, H))
     return linear(o, out_w, out_b)
 
 

@@ -234,6 +234,22 @@ def g5():
         out[tag] = l
         out[tag + "/gpb0"] = pbs[0].grad
     out["gen_val"] = GenLoss(im_size=S)(pbs[0], gt, mode="val")
+    # the remaining branches: Huber in train / val mode (loss.py:100-103, 112-115) and Loss(casecade=False) (29-39)
+    for p in [pa] + pbs:
+        p.grad = None
+    l = GenLoss(im_size=S)([pa, pbs], gt, delta1=10, delta2=1, mode="train", casecade=True, freez=True, huber=True)
+    l.backward()
+    out["gen_huber"] = l
+    for i, p in enumerate(pbs):
+        out[f"gen_huber/gpb{i}"] = p.grad
+        p.grad = None
+    l = GenLoss(im_size=S)(pbs[0], gt, mode="val", huber=True)
+    l.backward()
+    out["gen_val_huber"], out["gen_val_huber/gpb0"] = l, pbs[0].grad
+    pbs[0].grad = None
+    l = Loss(casecade=False)(pbs[0], gt)
+    l.backward()
+    out["l1_plain"], out["l1_plain/gpb0"] = l, pbs[0].grad
     save("g5_loss", **out)
 
 

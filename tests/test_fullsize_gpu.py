@@ -168,3 +168,170 @@ def test_pyfer_noncubic_192x192x128_step():
         assert all(torch.isfinite(p.grad).all() for p in net.parameters() if p.grad is not None)
     finally:
         dose_prediction_amd.set_compute_dtype(torch.float32)
+
+
+# ------------------------------------------------------------------------------------------------ sampled oracle at production size
+# The property tests above never compare with the oracle at 2 x 128^3, where the tiled kernels take their production branches (XCD
+# renumbering, 32-bit plane offsets, grid-quantised weight gradient, split-kd, W16 tiles).  Here the ORACLE's convolution
+# (oracle.conv3d, float64) is evaluated on CPU-cropped receptive fields of sampled output voxels / on sampled weight-gradient taps.
+def _sample_conv_ref(x_cpu, w_cpu, bias_cpu, pos, k):
+    """oracle.conv3d at sampled output voxels: x_cpu NCDHW float64 (already padded by k//2), pos = [(n, d, h, w)] -> [len(pos), Cout]."""
+    import oracle
+    out = []
+    for n, d, h, w in pos:
+        patch = x_cpu[n:n + 1, :, d:d + k, h:h + k, w:w + k]
+        out.append(oracle.conv3d(patch, w_cpu, bias_cpu).reshape(-1))
+    return torch.stack(out)
+
+
+def _positions(N, D, H, W, count, seed):
+    g = torch.Generator().manual_seed(seed)
+    pos = [(int(torch.randint(0, N, (1,), generator=g)), int(torch.randint(0, D, (1,), generator=g)), int(torch.randint(0, H, (1,), generator=g)),
+            int(torch.randint(0, W, (1,), generator=g))) for _ in range(count)]
+    # corners, edges and tile seams (8-row / 32-position tiles, XCD slice boundaries at D/8) always included
+    edge = [0, 1, 7, 8, 15, 16, 31, 32, 63, 64]
+    for a in edge:
+        for n in range(N):
+            for (d, h, w) in ((a % D, 0, 0), (0, a % H, W - 1), (D - 1, H - 1, a % W), (a % D, a % H, a % W), (D - 1 - a % D, a % H, W - 1 - a % W)):
+                pos.append((n, d, h, w))
+    return pos
+
+
+SAMPLED = [
+    # (N, D, H, W, Cin (split ca | 0), Cout, k, dtype)
+    (2, 128, 128, 128, 16, 0, 16, 7, torch.bfloat16),      # 7^3 16->16 (tap-paired), the dominant launch
+    (2, 128, 128, 128, 32, 16, 16, 7, torch.bfloat16),     # 7^3 32->16 over a virtual concat (decoder1 first conv)
+    (2, 128, 128, 128, 16, 0, 16, 3, torch.bfloat16),      # 3^3 16->16 at the 128^3 level
+    (2, 128, 128, 128, 16, 0, 16, 7, torch.float32),       # the same launch geometry in the fp32 parity mode
+    (2, 16, 16, 16, 256, 0, 128, 7, torch.bfloat16),       # split-kd / W16 tiles (decoder4 at 16^3)
+    (2, 32, 32, 32, 128, 64, 64, 3, torch.bfloat16),       # two N tiles, virtual concat, 32^3
+]
+
+
+@pytest.mark.parametrize("cfg", SAMPLED)
+def test_conv_sampled_oracle_full_size(cfg):
+    """Forward, data gradient and weight gradient of the hot launches vs oracle.conv3d on >= 4096 sampled voxels / 256 taps."""
+    from dose_prediction_amd import ops
+    dev = _dev()
+    N, D, H, W, cin, ca, cout, k, dtype = cfg
+    big = D >= 128
+    nsample = 4096 if big else 1024
+    tol = 2e-5 if dtype == torch.float32 else 6e-3
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn((N, D, H, W, cin), generator=g).to(dtype)
+    w = (torch.randn((cout, cin, k, k, k), generator=g) * (cin * k ** 3) ** -0.5)
+    bias = 0.1 * torch.randn((cout,), generator=g)
+    r = torch.randn((N, D, H, W, cout), generator=g).to(dtype)
+    xd = x.to(dev).requires_grad_(True)
+    wd, bd = w.to(dev).requires_grad_(True), bias.to(dev).requires_grad_(True)
+    if ca:
+        xa, xb = xd[..., :ca].detach().contiguous().requires_grad_(True), xd[..., ca:].detach().contiguous().requires_grad_(True)
+        y = ops.conv3d((xa, xb), wd, bd, 1, k // 2, 1)
+    else:
+        y = ops.conv3d(xd, wd, bd, 1, k // 2, 1)
+    y.backward(r.to(dev))
+    torch.cuda.synchronize()
+    gx = torch.cat((xa.grad, xb.grad), -1) if ca else xd.grad
+    wq = w if dtype == torch.float32 else w.to(dtype).float()           # the kernels multiply by the 16-bit packed weights
+    p = k // 2
+    pos = _positions(N, D, H, W, nsample, 5)
+    idx = tuple(torch.tensor(c) for c in zip(*pos))
+    # forward
+    xp = torch.nn.functional.pad(x.double().permute(0, 4, 1, 2, 3), (p,) * 6)
+    ref = _sample_conv_ref(xp, wq.double(), bias.double(), pos, k)
+    got = y.detach().cpu().double()[idx]
+    scale = ref.abs().max()
+    assert (got - ref).abs().max() <= (tol if dtype == torch.float32 else 2 ** -8) * scale, ("fwd", ((got - ref).abs().max() / scale).item())
+    assert ((got - ref).norm() / ref.norm()).item() < tol
+    # data gradient = convolution of r with the transposed, flipped weights
+    rp = torch.nn.functional.pad(r.double().permute(0, 4, 1, 2, 3), (p,) * 6)
+    wt = wq.double().transpose(0, 1).flip(2, 3, 4).contiguous()
+    refg = _sample_conv_ref(rp, wt, None, pos, k)
+    gotg = gx.detach().cpu().double()[idx]
+    assert ((gotg - refg).norm() / refg.norm()).item() < tol, "dgrad"
+    assert (gotg - refg).abs().max() <= (tol if dtype == torch.float32 else 2 ** -8) * refg.abs().max() * 1.01
+    # weight gradient at sampled (co, ci, kd, kh, kw): full-volume reductions of shifted products, float64
+    gtap = torch.Generator().manual_seed(6)
+    taps = [(int(torch.randint(0, cout, (1,), generator=gtap)), int(torch.randint(0, cin, (1,), generator=gtap)),
+             int(torch.randint(0, k, (1,), generator=gtap)), int(torch.randint(0, k, (1,), generator=gtap)),
+             int(torch.randint(0, k, (1,), generator=gtap))) for _ in range(96 if big else 256)]
+    taps += [(0, 0, 0, 0, 0), (cout - 1, cin - 1, k - 1, k - 1, k - 1), (cout - 1, 0, 0, k - 1, 0), (0, cin - 1, k // 2, k // 2, k // 2)]
+    rd = r.double()
+    refw = []
+    for co, ci, kd, kh, kw in taps:
+        sl = xp[:, ci, kd:kd + D, kh:kh + H, kw:kw + W]
+        refw.append((sl * rd[..., co]).sum())
+    refw = torch.stack(refw)
+    gotw = torch.stack([wd.grad[t].double().cpu() for t in taps])
+    wtol = 5e-5 if dtype == torch.float32 else 2e-3      # (fp32 products of 16-bit operands are exact; only the fp32 accumulation order differs)
+    assert ((gotw - refw).norm() / refw.norm()).item() < wtol, ("wgrad", ((gotw - refw).norm() / refw.norm()).item())
+    # bias gradient: column sums of r
+    refb = rd.sum(dim=(0, 1, 2, 3))
+    assert ((bd.grad.double().cpu() - refb).norm() / refb.norm()).item() < 1e-4
+
+
+def test_c5_cascade_fp16_checkpointing_192x192x128():
+    """BASELINE.json configs[4] as ONE configuration (per-GPU share: batch 1): frozen OAR-TRANSEG sliding-window inference (roi 96^3,
+    overlap 0.25, sw_batch 4 -> 3 x 3 x 2 windows) -> arg-max / one-hot glue with axis reversal (train_light_linked_model.py:143-167)
+    -> DOSE-PYFER in fp16 storage with loss scaling and activation checkpointing of the four decoder blocks -> GenLoss -> backward
+    -> fused Adam; three steps.  Finite everywhere, the loss falls, checkpointing lowers the peak memory, BatchNorm counters advance
+    once per step (not twice: the recomputation must not update the running statistics)."""
+    import dose_prediction_amd
+    from dose_prediction_amd import cascade, losses, synth
+    from dose_prediction_amd.models import dose_pyfer, oar_transeg
+    from dose_prediction_amd.optim import FusedAdam
+    dev = _dev()
+    vol, roi = (192, 192, 128), (96, 96, 96)
+    dose_prediction_amd.set_compute_dtype(torch.float16)
+    dose_prediction_amd.set_loss_scale(1024.0)
+    try:
+        assert [len(a) for a in cascade.window_starts(vol, roi)] == [3, 3, 2]
+        torch.manual_seed(8765)
+        seg = oar_transeg.Model(in_channels=1, out_channels=8, img_size=roi, feature_size=16, hidden_size=768, mlp_dim=3072, num_heads=12,
+                                pos_embed="perceptron", norm_name="instance", res_block=True, conv_block=True).to(dev).eval()
+        torch.manual_seed(4321)
+        net = dose_pyfer.Model(in_ch=9, out_ch=1, list_ch_A=[-1, 16, 32, 64, 128, 256], feature_size=16, img_size=vol[::-1], num_layers=8,
+                               num_heads=6, act="mish").to(dev).train()
+        for n, p in net.named_parameters():
+            if "net_A" in n or "conv_out_A" in n:
+                p.requires_grad = False
+        opt = FusedAdam([p for p in net.parameters() if p.requires_grad], lr=1e-4, weight_decay=3e-5, amsgrad=True)
+        full = synth.dose_input(1, vol[::-1]).to(dev)                       # (dose-loader orientation W, H, D)
+        ct = full[:, 8:9].permute(0, 1, 4, 3, 2).contiguous()              # the segmentation loader's orientation
+        ptv = full[:, 0:1].contiguous()
+        gt = synth.dose_target(1, vol[::-1]).to(dev)
+        structures, labels = cascade.cascade_structures(seg, ct, ptv, roi_size=roi, sw_batch_size=4, overlap=0.25)
+        assert structures.shape == (1, 9) + vol[::-1] and labels.shape == (1,) + vol
+        assert torch.equal(structures[:, 8], full[:, 8]) and torch.equal(structures[:, 0], full[:, 0])      # CT / PTV pass through
+        onehot = structures[:, 1:8]
+        assert set(onehot.unique().tolist()) <= {0.0, 1.0} and float(onehot.sum(1).max()) <= 1.0
+        bn = [m for m in net.modules() if isinstance(m, torch.nn.BatchNorm3d)]
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            out = net(structures)
+            loss = losses.gen_loss(out, gt, 10.0, 1.0, casecade=True, freez=True)
+            loss.backward()
+            assert all(torch.isfinite(p.grad).all() for p in net.parameters() if p.grad is not None)
+            opt.step()
+            return loss.item()
+
+        peaks, hist = {}, []
+        for ckpt in (False, True):
+            dose_prediction_amd.set_activation_checkpointing(ckpt)
+            torch.cuda.synchronize()
+            torch.cuda.reset_peak_memory_stats()
+            n0 = int(bn[0].num_batches_tracked)
+            for _ in range(1 if not ckpt else 3):
+                hist.append(step())
+            torch.cuda.synchronize()
+            peaks[ckpt] = torch.cuda.max_memory_allocated() / 2 ** 30
+            assert int(bn[0].num_batches_tracked) - n0 == (1 if not ckpt else 3)
+        print(f"[c5] losses {hist}; peak memory {peaks[False]:.2f} GiB without / {peaks[True]:.2f} GiB with decoder checkpointing")
+        assert all(h == h and h < 1e4 for h in hist) and hist[-1] < hist[0], hist
+        assert peaks[True] < 0.85 * peaks[False], peaks
+        assert all(torch.isfinite(p).all() for p in net.parameters())
+    finally:
+        dose_prediction_amd.set_activation_checkpointing(False)
+        dose_prediction_amd.set_loss_scale(1.0)
+        dose_prediction_amd.set_compute_dtype(torch.float32)

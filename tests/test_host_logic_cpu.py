@@ -17,7 +17,7 @@ def test_window_layout_matches_monai_rules():
     except ValueError:
         pass
     else:
-        raise AssertionError("a volume smaller than the crop must be rejected (padding is not implemented)")
+        raise AssertionError("window_starts takes padded volumes only (sliding_window_logits pads)")
 
 
 def test_oracle_sliding_window_is_a_partition_of_unity():
@@ -30,3 +30,17 @@ def test_oracle_sliding_window_is_a_partition_of_unity():
     calls = []
     oracle.sliding_window_inference(x, (16, 16, 16), 4, lambda w: (calls.append(w.shape[0]), w)[1], overlap=0.25)
     assert calls == [4, 4]                                                                # 2 images x (2 x 1 x 2) windows, 4 at a time
+
+
+def test_oracle_sliding_window_pads_small_volumes():
+    """An axis shorter than the roi is zero-padded diff // 2 in front (MONAI padding_mode='constant') and cropped back: an identity
+    predictor returns the input, and a predictor that reports the window it was given sees the padded geometry."""
+    x = torch.randn(1, 2, 10, 16, 13, generator=torch.Generator().manual_seed(4))
+    seen = []
+    y = oracle.sliding_window_inference(x, (16, 16, 16), 2, lambda w: (seen.append(tuple(w.shape[2:])), w)[1], overlap=0.25)
+    assert torch.allclose(y, x, atol=1e-6) and seen == [(16, 16, 16)]
+    # the zero padding is visible to the predictor: window = [3 zeros | 10 voxels | 3 zeros] along the first axis, 1 | 13 | 2 along the last
+    y = oracle.sliding_window_inference(x, (16, 16, 16), 2, lambda w: w.abs().sum(dim=(2, 3, 4), keepdim=True).expand_as(w) * 0 +
+                                        (w[:, :, :3].abs().sum() + w[:, :, 13:].abs().sum() + w[..., :1].abs().sum() + w[..., 14:].abs().sum()),
+                                        overlap=0.25)
+    assert float(y.abs().max()) == 0.0

@@ -531,7 +531,9 @@ def test_fused_adam_step_reaches_the_packed_weights(dtype):
         y1 = f(w).detach().float()
         ops.invalidate_packs([w])
         y2 = f(w).detach().float()
-        assert torch.equal(y1, y2), "forward after FusedAdam.step() does not use freshly packed weights"
+        # (not bit-equal in fp32: the split-kd convolution accumulates with fp32 atomics; the packs themselves are compared bit for
+        #  bit in test_pack_multi_matches_single_tensor_packs)
+        assert (y1 - y2).abs().max() <= 1e-5 * y2.abs().max(), "forward after FusedAdam.step() does not use freshly packed weights"
         assert (y1 - y0).abs().max() > 1e-3 * y0.abs().max(), "forward did not change after the optimizer step"
 
 

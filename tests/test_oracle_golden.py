@@ -116,6 +116,25 @@ def test_g5_losses():
         assert cmp_prefix(pb0.grad, g[f"{tag}/gpb0"]) < 1e-5
 
 
+def test_g5_loss_branches_huber_val_plain():
+    """GenLoss(huber=True) in train and val mode, GenLoss val, Loss(casecade=False): loss.py:29-39, 100-103, 109-117."""
+    g = load_golden("g5_loss")
+    gt = g["gt"].double()
+    pbs = [g[f"pb{i}"].double().requires_grad_(True) for i in range(4)]
+    l = oracle.gen_loss([g["pa"].double(), pbs], gt, 10, 1, casecade=True, freez=True, huber=True)
+    assert abs(l.item() - g["gen_huber"].item()) < 1e-6 * abs(g["gen_huber"].item())
+    l.backward()
+    for i in range(4):
+        assert cmp_prefix(pbs[i].grad, g[f"gen_huber/gpb{i}"]) < 1e-6
+    for tag, fn in (("gen_val_huber", lambda p: oracle.gen_loss_val(p, gt, huber=True)), ("l1_plain", lambda p: oracle.loss_l1_plain(p, gt))):
+        pb0 = g["pb0"].double().requires_grad_(True)
+        l = fn(pb0)
+        assert abs(l.item() - g[tag].item()) < 1e-6 * abs(g[tag].item()), tag
+        l.backward()
+        assert cmp_prefix(pb0.grad, g[f"{tag}/gpb0"]) < 1e-6, tag
+    assert abs(oracle.gen_loss_val(g["pb0"].double(), gt).item() - g["gen_val"].item()) < 1e-6 * abs(g["gen_val"].item())
+
+
 def _subset_variant(tag, **kw):
     g = load_golden(f"g7_subset_{tag}")
     sd = _leafify(pcg_state_dict(g["keys"], g["shapes"], g["seed"]))
