@@ -30,8 +30,8 @@ class SingleConv(nn.Module):
     def forward(self, x):
         """x: an NDHWC tensor, or a pair (a, b) standing for torch.cat((a, b), channels) (virtual concat)."""
         conv, norm = self.single_conv[0], self.single_conv[1]
-        y = ops.conv3d(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0], conv.dilation[0])
-        return ops.norm_act(y, "instance", norm.weight, norm.bias, act="relu", eps=norm.eps)
+        y, st = ops.conv3d(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0], conv.dilation[0], stats=True, bias_grad_zero=True)
+        return ops.norm_act(y, "instance", norm.weight, norm.bias, act="relu", eps=norm.eps, stats=st)
 
 
 class UpConv(nn.Module):
@@ -46,8 +46,8 @@ class UpConv(nn.Module):
 
     def forward(self, x):
         conv, norm = self.conv[0], self.conv[1]
-        y = ops.conv3d(ops.trilinear_up2(x), conv.weight, conv.bias, 1, 1, 1)
-        return ops.norm_act(y, "instance", norm.weight, norm.bias, act="relu", eps=norm.eps)
+        y, st = ops.conv3d(ops.trilinear_up2(x), conv.weight, conv.bias, 1, 1, 1, stats=True, bias_grad_zero=True)
+        return ops.norm_act(y, "instance", norm.weight, norm.bias, act="relu", eps=norm.eps, stats=st)
 
 
 # ------------------------------------------------------------------------------------------------ blocks_MDUNet.py leaves
@@ -69,16 +69,19 @@ class _ConvNormActPair(nn.Module):
         (conv_3_1) applies right after this block; kept separate (it is a second normalisation)."""
         for i in (0, 3):
             conv, norm = self.conv[i], self.conv[i + 1]
-            x = ops.conv3d(x, conv.weight, conv.bias, 1, conv.padding[0], conv.dilation[0])
+            if self._norm == "batch" and not self.training:
+                x, st = ops.conv3d(x, conv.weight, conv.bias, 1, conv.padding[0], conv.dilation[0]), None
+            else:
+                x, st = ops.conv3d(x, conv.weight, conv.bias, 1, conv.padding[0], conv.dilation[0], stats=True, bias_grad_zero=True)
             if self._norm == "batch":
                 upd = self.training and config.bn_updates_enabled()
                 x = ops.norm_act(x, "batch", norm.weight, norm.bias, norm.running_mean if (upd or not self.training) else None,
                                  norm.running_var if (upd or not self.training) else None,
-                                 training=self.training, act=self._act, eps=norm.eps, momentum=norm.momentum)
+                                 training=self.training, act=self._act, eps=norm.eps, momentum=norm.momentum, stats=st)
                 if upd:
                     norm.num_batches_tracked += 1
             else:
-                x = ops.norm_act(x, "instance", act=self._act, eps=norm.eps)
+                x = ops.norm_act(x, "instance", act=self._act, eps=norm.eps, stats=st)
         return x
 
 
@@ -130,7 +133,7 @@ class conv_3_1(nn.Module):
             x37 = ops.norm_act_cat(r3, r7, act=self._act)
         else:
             x37 = ops.cat((ops.norm_act(r3, "instance", act=self._act), ops.norm_act(r7, "instance", act=self._act)))
-        y = ops.conv3d(x37, self.conv[0].weight, self.conv[0].bias)
+        y = ops.conv3d(x37, self.conv[0].weight, self.conv[0].bias, bias_grad_zero=True)
         return ops.norm_act(y, "instance", act=self._act)
 
 
@@ -169,7 +172,7 @@ class DualDilatedBlock(nn.Module):
         if isinstance(x, (tuple, list)):          # dilated convolutions take the generic kernel: materialise the concat once
             x = ops.cat(x)
         y = ops.cat((self.conv_3(x), self.conv_5(x), self.conv_7(x)))
-        y = ops.conv3d(y, self.conv[0].weight, self.conv[0].bias)
+        y = ops.conv3d(y, self.conv[0].weight, self.conv[0].bias, bias_grad_zero=True)
         return ops.norm_act(y, "instance", act=self._act)
 
 
@@ -195,11 +198,11 @@ def get_conv_layer(spatial_dims, in_channels, out_channels, kernel_size=3, strid
     return _Conv(nn.Conv3d(in_channels, out_channels, kernel_size, stride, pad, bias=bias))
 
 
-def _run_conv(layer, x):
+def _run_conv(layer, x, stats=False):
     c = layer.conv
     if isinstance(c, nn.ConvTranspose3d):
         return ops.conv_transpose2x(x, c.weight)
-    return ops.conv3d(x, c.weight, c.bias, c.stride[0], c.padding[0], c.dilation[0])
+    return ops.conv3d(x, c.weight, c.bias, c.stride[0], c.padding[0], c.dilation[0], stats=stats)
 
 
 class UnetResBlock(nn.Module):
@@ -217,12 +220,13 @@ class UnetResBlock(nn.Module):
 
     def forward(self, inp, inp_cat=None):
         """inp_cat: optional (a, b) pair with cat((a, b)) == inp, used by the 3x3x3 convolution (virtual concat)."""
-        out = ops.norm_act(_run_conv(self.conv1, inp_cat if inp_cat is not None else inp), "instance", act="lrelu")
-        out = _run_conv(self.conv2, out)
+        out, st = _run_conv(self.conv1, inp_cat if inp_cat is not None else inp, stats=True)
+        out = ops.norm_act(out, "instance", act="lrelu", stats=st)
+        out, st = _run_conv(self.conv2, out, stats=True)
         res = inp
         if self.downsample:
             res = ops.norm_act(_run_conv(self.conv3, inp), "instance")
-        return ops.norm_act(out, "instance", res=res, act="lrelu")        # IN(out) + res -> LeakyReLU, fused
+        return ops.norm_act(out, "instance", res=res, act="lrelu", stats=st)        # IN(out) + res -> LeakyReLU, fused
 
 
 class UnetBasicBlock(nn.Module):
@@ -237,8 +241,10 @@ class UnetBasicBlock(nn.Module):
 
     def forward(self, inp):
         """inp: tensor or (a, b) pair = virtual torch.cat."""
-        out = ops.norm_act(_run_conv(self.conv1, inp), "instance", act="lrelu")
-        return ops.norm_act(_run_conv(self.conv2, out), "instance", act="lrelu")
+        out, st = _run_conv(self.conv1, inp, stats=True)
+        out = ops.norm_act(out, "instance", act="lrelu", stats=st)
+        out, st = _run_conv(self.conv2, out, stats=True)
+        return ops.norm_act(out, "instance", act="lrelu", stats=st)
 
 
 class UnetrBasicBlock(nn.Module):
@@ -382,10 +388,16 @@ class ViT(nn.Module):
                 if m.bias is not None:
                     nn.init.zeros_(m.bias)
 
-    def forward(self, x):
+    def forward(self, x, events=None):
+        """events: optional list that receives one recorded HIP event per block output (the caller runs this method on a side
+        stream and lets consumers of hidden[i] wait for events[i] only: models.dose_pyfer.run_vit_beside)."""
         x = self.patch_embedding(x)
         hidden = []
         for blk in self.blocks:
             x = blk(x)
             hidden.append(x)
+            if events is not None:
+                ev = torch.cuda.Event()
+                ev.record()
+                events.append(ev)
         return ops.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps), hidden

@@ -74,3 +74,18 @@ class bn_buffer_updates:
 
 def bn_updates_enabled():
     return _bn_updates
+
+
+_vit_side_stream = os.environ.get("DOSE_HIP_SIDE_STREAM", "1") != "0"
+
+
+def set_vit_side_stream(on):
+    """Run the ViT branch of ViTEncoder / OAR-TRANSEG (small-grid, latency-bound token kernels) on a second HIP stream so that it
+    overlaps the independent full-chip 128^3 `skip1` / `encoder1` branch, forward and (through autograd's stream bookkeeping)
+    backward.  On by default; DOSE_HIP_SIDE_STREAM=0 or set_vit_side_stream(False) serialises everything on the current stream."""
+    global _vit_side_stream
+    _vit_side_stream = bool(on)
+
+
+def vit_side_stream():
+    return _vit_side_stream

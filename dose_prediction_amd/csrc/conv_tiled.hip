@@ -57,6 +57,12 @@ struct TiledGeom {
   // contiguous voxel rows of ONE tensor (a 32-channel row read 16 channels at a time touches every cache line twice and
   // held the L2 hit rate of the 32->16 7x7x7 layer at ~25 % against ~90 % for 16-channel inputs).
   const void* x2; void* y2; int ldx2, csplit, ldy2, osplit;
+  // Normalisation statistics of the OUTPUT, taken from the fp32 accumulators in the epilogue (the InstanceNorm / BatchNorm that
+  // follows every convolution of the path then needs no read pass over y, and its mean / variance are those of the unrounded
+  // values): block (n, d, tile_h, tile_w) writes its per-channel (sum, sum of squares) over the voxels it owns to
+  // stat_part[((n * stat_nblk + blk) * 2 + {0,1}) * Cout + c]; the partial rows are combined in fp64 by dp_stats_finalize.
+  // Only with the wide (16-byte) epilogue and without split-kd (dp_conv3d_tiled_stat_blocks tells).
+  float* stat_part; int stat_nblk; int wide;
 };
 
 // ---------------------------------------------------------------------------------------------- weight packing
@@ -288,8 +294,9 @@ __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, 
   __syncthreads();                                               // every wave is done reading the slab
   T* patch = slab + (wv & 3) * (2 * 32 * 32);                      // two alternating [32 positions][NC] patches per wave
   T* y2 = (T*)g.y2;
-  const bool wide = !g.splitkd && (g.ldy * (int)sizeof(T)) % 16 == 0 && (((uintptr_t)y & 15) == 0) &&
-                    (!y2 || ((g.ldy2 * (int)sizeof(T)) % 16 == 0 && (((uintptr_t)y2 & 15) == 0) && g.osplit % EPC == 0));
+  const bool wide = g.wide != 0;      // (host-computed: no split-kd, 16-byte aligned output rows)
+  const int dd = d, nn = n;
+  const int stat_blk = (dd * g.tiles_h + th) * g.tiles_w + tw;
   // destination of output channel c of voxel `vox` (virtual concat: channels >= osplit live in y2)
   auto out_ptr = [&](int64_t vox, int c) -> T* { return (y2 && c >= g.osplit) ? y2 + vox * g.ldy2 + (c - g.osplit) : y + vox * g.ldy + c; };
   auto store_tile = [&](const T* pt, int oh_lo, int nt_idx) {   // tile in `pt` as [32 positions][NC channels]; oh_lo: image row of position 0
@@ -314,9 +321,11 @@ __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, 
     const bool low = (lane & 16) == 0;
     const float bv = (bias && co < g.Cout) ? bias[co] : 0.f;
     if (wide) {
+      float st1 = 0.f, st2 = 0.f;
 #pragma unroll
       for (int t = 0; t < RWO; t++) {
         T* pp = patch + (t & 1) * (32 * NC);
+        const bool rowok = hw0 + t < g.H;
 #pragma unroll
         for (int k = 0; k < 8; k++) {
           // v_permlane16_swap: lanes 16-31 / 48-63 of the first operand <-> lanes 0-15 / 32-47 of the second.  The low lanes
@@ -326,10 +335,27 @@ __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, 
           const float v = (low ? acc[t][0][k] + __uint_as_float(sw[1]) : acc[t + 1][0][k + 8] + __uint_as_float(sw[0])) + bv;
           const int m = (k & 3) + 8 * (k >> 2) + 4 * hh + (low ? 0 : 16);
           st_f(pp + m * NC + co, v);
+          const float vs = (rowok && wbase_o + m < g.W) ? v : 0.f;      // branch-free: voxels outside the volume count as 0
+          st1 += vs; st2 += vs * vs;
         }
         __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier();
         store_tile(pp, hw0 + t, 0);
         __builtin_amdgcn_wave_barrier();
+      }
+      if (g.stat_part) {          // block-uniform
+        // lanes co, co+16, co+32, co+48 hold the same channel; then the four waves meet in LDS (the patches are dead)
+        st1 += __shfl_xor(st1, 16, 64); st2 += __shfl_xor(st2, 16, 64);
+        st1 += __shfl_xor(st1, 32, 64); st2 += __shfl_xor(st2, 32, 64);
+        __syncthreads();
+        float* sred = (float*)smem_raw;
+        if (lane < 16) { sred[(wv * 2) * 16 + lane] = st1; sred[(wv * 2 + 1) * 16 + lane] = st2; }
+        __syncthreads();
+        if (tid < 32) {
+          const int which = tid >> 4, c = tid & 15;
+          if (c < g.Cout)
+            g.stat_part[(((int64_t)nn * g.stat_nblk + stat_blk) * 2 + which) * g.Cout + c] =
+                (sred[(0 + which) * 16 + c] + sred[(2 + which) * 16 + c]) + (sred[(4 + which) * 16 + c] + sred[(6 + which) * 16 + c]);
+        }
       }
     } else {
 #pragma unroll
@@ -346,18 +372,46 @@ __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, 
       }
     }
   } else if (wide) {
+    float st1[NT], st2[NT];
 #pragma unroll
     for (int j = 0; j < NT; j++) {
       const int co = (nt0 + j) * 32 + r;
       const float bv = (bias && co < g.Cout) ? bias[co] : 0.f;
+      st1[j] = 0.f; st2[j] = 0.f;
 #pragma unroll
       for (int i = 0; i < RW; i++) {
         T* pp = patch + (i & 1) * (32 * NC);
 #pragma unroll
-        for (int e = 0; e < 16; e++) st_f(pp + ((e & 3) + 8 * (e >> 2) + 4 * hh) * NC + r, acc[i][j][e] + bv);
+        for (int e = 0; e < 16; e++) {
+          const int m = (e & 3) + 8 * (e >> 2) + 4 * hh;
+          const float v = acc[i][j][e] + bv;
+          st_f(pp + m * NC + r, v);
+          const int oh = W16 ? hw0 + 2 * i + (m >> 4) : hw0 + i, ow = W16 ? (m & 15) : wbase_o + m;
+          const float vs = (oh < g.H && ow < g.W) ? v : 0.f;
+          st1[j] += vs; st2[j] += vs * vs;
+        }
         __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier();
         store_tile(pp, W16 ? hw0 + 2 * i : hw0 + i, nt0 + j);
         __builtin_amdgcn_wave_barrier();
+      }
+    }
+    if (g.stat_part) {            // block-uniform
+      __syncthreads();
+      float* sred = (float*)smem_raw;            // [wave][j][which][32]
+#pragma unroll
+      for (int j = 0; j < NT; j++) {
+        const float a1 = st1[j] + __shfl_xor(st1[j], 32, 64), a2 = st2[j] + __shfl_xor(st2[j], 32, 64);   // the two position halves of a channel
+        if (lane < 32) { sred[((wv * NT + j) * 2) * 32 + lane] = a1; sred[((wv * NT + j) * 2 + 1) * 32 + lane] = a2; }
+      }
+      __syncthreads();
+      for (int o = tid; o < NT * 2 * 32; o += 256) {
+        const int c32 = o & 31, which = (o >> 5) & 1, j = o >> 6, c = (nt0 + j) * 32 + c32;
+        if (c < g.Cout) {
+          float sum = 0.f;
+#pragma unroll
+          for (int w4 = 0; w4 < 4; w4++) sum += sred[((w4 * NT + j) * 2 + which) * 32 + c32];
+          g.stat_part[(((int64_t)nn * g.stat_nblk + stat_blk) * 2 + which) * g.Cout + c] = sum;
+        }
       }
     }
   } else {
@@ -450,11 +504,35 @@ extern "C" int dp_conv3d_tiled_ws_elems(int N, int D, int H, int W, int Cin, int
   return e > 2000000000LL ? -1 : (int)e;
 }
 
+static bool tiled_wide(const TiledGeom& g, const void* y, int dtype) {
+  const int es = dtype == DP_F32 ? 4 : 2, epc = 16 / es;
+  return !g.splitkd && (g.ldy * es) % 16 == 0 && (((uintptr_t)y & 15) == 0) &&
+         (!g.y2 || ((g.ldy2 * es) % 16 == 0 && (((uintptr_t)g.y2 & 15) == 0) && g.osplit % epc == 0));
+}
+// Number of per-sample partial statistics rows dp_conv3d_tiled_stats writes for this shape (= D x output tiles), or 0 when the
+// launch cannot produce statistics (split-kd volumes, output rows that are not 16-byte aligned: the caller then runs dp_stats_partial).
+extern "C" int dp_conv3d_tiled_stat_blocks(int N, int D, int H, int W, int Cin, int Cout, int k, int ldy, int dtype) {
+  if (!tiled_applicable(Cin, Cout, k, 1, k / 2, 1, W)) return 0;
+  int rw, nt; int np = tiled_config(Cout, &rw, &nt);
+  TiledGeom g; g.N = N; g.D = D; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.dbg = 0; g.x2 = nullptr; g.y2 = nullptr; g.ldy = ldy;
+  int ygrid; bool w16; tiled_geometry(g, k, np, rw, nt, &ygrid, &w16);
+  if (!tiled_wide(g, nullptr, dtype)) return 0;
+  return D * g.tiles_h * g.tiles_w;
+}
 // Tiled convolution with weights packed by dp_pack_conv_weight_tiled.  Same-size output ("same" padding).
 // ws: fp32 scratch of dp_conv3d_tiled_ws_elems() elements (may be NULL when that is 0).
 extern "C" int dp_conv3d_tiled2(const void* x, int ldx, const void* x2, int ldx2, int csplit, const void* wq, const float* bias,
                                 void* y, int ldy, void* y2, int ldy2, int osplit, float* ws, int N, int D, int H, int W,
                                 int Cin, int Cout, int k, int dtype, void* stream);
+static int conv3d_tiled_impl(const void* x, int ldx, const void* x2, int ldx2, int csplit, const void* wq, const float* bias,
+                             void* y, int ldy, void* y2, int ldy2, int osplit, float* ws, float* stat_part, int N, int D, int H, int W,
+                             int Cin, int Cout, int k, int dtype, void* stream);
+extern "C" int dp_conv3d_tiled_stats(const void* x, int ldx, const void* x2, int ldx2, int csplit, const void* wq, const float* bias,
+                                     void* y, int ldy, float* ws, float* stat_part, int N, int D, int H, int W, int Cin, int Cout, int k,
+                                     int dtype, void* stream) {
+  if (!stat_part) DP_FAIL("conv3d_tiled_stats: stat_part is NULL");
+  return conv3d_tiled_impl(x, ldx, x2, ldx2, csplit, wq, bias, y, ldy, nullptr, 0, 0, ws, stat_part, N, D, H, W, Cin, Cout, k, dtype, stream);
+}
 extern "C" int dp_conv3d_tiled(const void* x, int ldx, const void* wq, const float* bias, void* y, int ldy, float* ws, int N, int D, int H, int W,
                                int Cin, int Cout, int k, int dtype, void* stream) {
   return dp_conv3d_tiled2(x, ldx, nullptr, 0, 0, wq, bias, y, ldy, nullptr, 0, 0, ws, N, D, H, W, Cin, Cout, k, dtype, stream);
@@ -462,6 +540,11 @@ extern "C" int dp_conv3d_tiled(const void* x, int ldx, const void* wq, const flo
 extern "C" int dp_conv3d_tiled2(const void* x, int ldx, const void* x2, int ldx2, int csplit, const void* wq, const float* bias,
                                 void* y, int ldy, void* y2, int ldy2, int osplit, float* ws, int N, int D, int H, int W,
                                 int Cin, int Cout, int k, int dtype, void* stream) {
+  return conv3d_tiled_impl(x, ldx, x2, ldx2, csplit, wq, bias, y, ldy, y2, ldy2, osplit, ws, nullptr, N, D, H, W, Cin, Cout, k, dtype, stream);
+}
+static int conv3d_tiled_impl(const void* x, int ldx, const void* x2, int ldx2, int csplit, const void* wq, const float* bias,
+                             void* y, int ldy, void* y2, int ldy2, int osplit, float* ws, float* stat_part, int N, int D, int H, int W,
+                             int Cin, int Cout, int k, int dtype, void* stream) {
   if (!tiled_applicable(Cin, Cout, k, 1, k / 2, 1, W)) DP_FAIL("conv3d_tiled: shape not supported");
   if (x2 && (csplit <= 0 || csplit >= Cin || csplit % 8)) DP_FAIL("conv3d_tiled: input split must be a multiple of 8 inside (0, Cin)");
   if (y2 && (osplit <= 0 || osplit >= Cout || osplit % 8)) DP_FAIL("conv3d_tiled: output split must be a multiple of 8 inside (0, Cout)");
@@ -470,6 +553,9 @@ extern "C" int dp_conv3d_tiled2(const void* x, int ldx, const void* x2, int ldx2
   g.N = N; g.D = D; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.ldx = ldx; g.ldy = ldy;
   g.x2 = x2; g.ldx2 = ldx2; g.csplit = csplit; g.y2 = y2; g.ldy2 = ldy2; g.osplit = osplit;
   int ygrid; bool w16; tiled_geometry(g, k, np, rw, nt, &ygrid, &w16);
+  g.wide = tiled_wide(g, y, dtype) ? 1 : 0;
+  g.stat_part = stat_part; g.stat_nblk = D * g.tiles_h * g.tiles_w;
+  if (stat_part && !g.wide) DP_FAIL("conv3d_tiled_stats: this launch cannot produce statistics (dp_conv3d_tiled_stat_blocks == 0)");
   { const char* e = getenv("DP_DBG"); g.dbg = e ? atoi(e) : 0; }
   if (getenv("DP_DEBUG_SLOW")) {      // report launches that will take the guarded (slow) staging path
     int nch = (Cin + 15) / 16;

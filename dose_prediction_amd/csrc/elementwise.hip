@@ -433,6 +433,20 @@ extern "C" int dp_add(const void* a, const void* b, void* y, int64_t n, int64_t 
   DP_DISPATCH(dtype, hipLaunchKernelGGL(k_add<T>, dim3(grid_for(n, 256)), dim3(256), 0, STREAM, (const T*)a, (const T*)b, (T*)y, n, period));
   DP_CHECK_LAUNCH("add"); return 0;
 }
+// out[i] (fp32) = sum_b g[b * per + i]: gradient of a parameter broadcast over the batch (position embeddings)
+template <typename T>
+__global__ void k_sum_batch(const T* __restrict__ g, float* __restrict__ out, int B, int64_t per) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < per; i += (int64_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int b = 0; b < B; b++) s += ld_f(g + b * per + i);
+    out[i] = s;
+  }
+}
+extern "C" int dp_sum_batch(const void* g, float* out, int B, int64_t per, int dtype, void* stream) {
+  if (B < 1 || per < 1) DP_FAIL("sum_batch: empty problem");
+  DP_DISPATCH(dtype, hipLaunchKernelGGL(k_sum_batch<T>, dim3(grid_for(per, 256)), dim3(256), 0, STREAM, (const T*)g, out, B, per));
+  DP_CHECK_LAUNCH("sum_batch"); return 0;
+}
 template <typename T, bool BWD>
 __global__ void k_gelu(const T* __restrict__ x, const T* __restrict__ gy, T* __restrict__ out, int64_t n) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {

@@ -7,24 +7,33 @@ unchanged ``NetworkTrainer.forward/backward`` (network_trainer.py:185-213) keep 
 time ``loss.backward()`` returns.
 
 Design for 8 x MI355X: gradients are packed in REVERSE registration order (approximately the order autograd produces
-them) into flat fp32 buckets; a bucket is all-reduced asynchronously as soon as its last gradient arrives, on RCCL's own
+them) into flat buckets; a bucket is all-reduced asynchronously as soon as its last gradient arrives, on RCCL's own
 stream, while the remaining backward kernels keep the compute stream busy.  The patch-embedding weight (78.6 M of
-162.6 M elements) is produced last and is given a bucket of its own, split in chunks, so its exchange starts
-immediately and the tail is one chunk long.  Parameters that receive no gradient in a step (MainSubsetModel.out,
-cls_token, UnetResBlock.conv3 when Cin == Cout, frozen net_A) are handled at the end-of-backward callback.
+162.6 M elements) is given a bucket of its own, split in chunks, and is reduced in place on its gradient.  The graph is
+static: parameters that received no gradient in the FIRST backward pass (MainSubsetModel.out, cls_token, UnetResBlock.conv3
+when Cin == Cout) are taken out of the buckets' arrival counts from the second pass on, so that they cannot hold back the
+in-order launches; should one of them receive a gradient later, or an expected gradient stay away, the end-of-backward
+callback still reduces everything (correct, just without overlap for that bucket).
+
+``grad_dtype=torch.bfloat16`` exchanges bf16 copies of the gradients (half the xGMI bytes: 325 MB instead of 650 MB per step for
+DOSE-PYFER); the fp32 ``.grad`` tensors are overwritten with the averaged values afterwards.
 """
 import torch
 import torch.distributed as dist
 
 
 class GradAllReducer:
-    def __init__(self, module, bucket_mb=32.0, process_group=None, broadcast=True):
+    def __init__(self, module, bucket_mb=32.0, process_group=None, broadcast=True, grad_dtype=torch.float32):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
+        if grad_dtype not in (torch.float32, torch.bfloat16, torch.float16):
+            raise ValueError("grad_dtype must be float32, bfloat16 or float16")
         self.pg = process_group
         self.world = dist.get_world_size(process_group)
         self.params = [p for p in module.parameters() if p.requires_grad]
         self.backend = dist.get_backend(process_group)
+        self.grad_dtype = grad_dtype
+        self.low = grad_dtype != torch.float32
         if broadcast:
             self._broadcast_state(module)
         cap = int(bucket_mb * (1 << 20) / 4)
@@ -48,31 +57,32 @@ class GradAllReducer:
         self.flat, self.where, self._index = [], {}, {}
         for bi, b in enumerate(self.buckets):
             total = sum(n for _, _, n in b)
-            dev, dt = b[0][0].device, torch.float32
-            self.flat.append(torch.zeros(total, dtype=dt, device=dev))
+            self.flat.append(torch.zeros(total, dtype=grad_dtype, device=b[0][0].device))
             for k, (p, off, n) in enumerate(b):
                 self.where[p] = (bi, off, n)
                 self._index[p] = k
                 p._dp_slice_zero = True
         self.views = [[self.flat[bi][off:off + n].view_as(p) for p, off, n in b] for bi, b in enumerate(self.buckets)]
-        # the weight-gradient kernels write straight into the buckets (ops.GRAD_DEST): each backward pass hands out ONE fresh view
-        # per parameter (autograd adopts it as .grad, so the pack copy below has nothing to do for it); a second request in the
-        # same pass (a shared weight) gets a private tensor and is summed by autograd as usual
-        self._taken = set()
-        from . import ops
-        for bi, b in enumerate(self.buckets):
-            if self.inplace_candidate(b, cap):
-                continue
-            for p, off, n in b:
-                if p.is_cuda and p.dtype == torch.float32 and p.is_contiguous():
-                    ops.GRAD_DEST[p.data_ptr()] = self._dest(p, bi, off, n)
         self.chunk = cap
         # a bucket that is ONE large tensor (the 78.6 M-element patch-embedding weight) is reduced in place on its gradient: no
-        # pack / unpack copies on the tail of the backward pass
-        self.inplace = [len(b) == 1 and b[0][2] >= cap for b in self.buckets]
+        # pack / unpack copies on the tail of the backward pass (fp32 exchange only)
+        self.inplace = [(not self.low) and self.inplace_candidate(b, cap) for b in self.buckets]
+        # fp32 exchange: the weight-gradient kernels write straight into the buckets (ops.GRAD_DEST): each backward pass hands out
+        # ONE fresh view per parameter (autograd adopts it as .grad, so the pack copy has nothing to do for it); a second request in
+        # the same pass (a shared weight) gets a private tensor and is summed by autograd as usual
+        self._taken = set()
+        from . import ops
+        if not self.low:
+            for bi, b in enumerate(self.buckets):
+                if self.inplace[bi]:
+                    continue
+                for p, off, n in b:
+                    if p.is_cuda and p.dtype == torch.float32 and p.is_contiguous():
+                        ops.GRAD_DEST[p.data_ptr()] = self._dest(p, bi, off, n)
         self.grad_ref = [None] * len(self.buckets)
+        self.no_grad = None          # parameters without a gradient in the first backward pass (static graph), set by _finish
+        self.stats = {"launched_in_backward": 0, "launched_at_end": 0}
         self._reset()
-        self.handles = []
         for p in self.params:
             p.register_post_accumulate_grad_hook(self._hook)
 
@@ -104,25 +114,34 @@ class GradAllReducer:
         ops.invalidate_packs(module.parameters())     # written through .data: the version counters did not move
 
     def _reset(self):
-        self.pending = [len(b) for b in self.buckets]
-        self.ready = [False] * len(self.buckets)
+        skip = self.no_grad or ()
+        self.pending = [sum(1 for p, _, _ in b if p not in skip) for b in self.buckets]
         self.launched = [False] * len(self.buckets)
         self.callback_queued = False
         self.work = []
         self._taken = set()
+        self._streams = []
 
-    def _launch(self, bi):
+    def _launch(self, bi, at_end=False):
         flat = self.flat[bi]
+        cur = torch.cuda.current_stream() if flat.is_cuda else None
+        if cur is not None:
+            # gradients of this bucket may have been produced on another stream (the ViT branch runs on a side stream): the
+            # collective is ordered after the current stream only, so make that one wait for the others first
+            for s in self._streams:
+                if s != cur:
+                    cur.wait_stream(s)
         if self.inplace[bi] and self.grad_ref[bi] is not None:
             flat = self.grad_ref[bi]
         else:
             # pack the whole bucket with one multi-tensor copy (a copy_ per parameter was ~230 launches and as many Python
-            # round trips inside the backward pass: +3 ms per step before any byte moved)
+            # round trips inside the backward pass: +3 ms per step before any byte moved); converts to grad_dtype on the way
             have = [(v, p.grad) for (p, _, _), v in zip(self.buckets[bi], self.views[bi])
                     if getattr(p, "_dp_has_grad", False) and p.grad.data_ptr() != v.data_ptr()]     # (already in place: written there)
             if have:
                 torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
         self.launched[bi] = True
+        self.stats["launched_at_end" if at_end else "launched_in_backward"] += 1
         n = flat.numel()
         for c0 in range(0, n, self.chunk):
             piece = flat[c0:min(n, c0 + self.chunk)]
@@ -138,7 +157,14 @@ class GradAllReducer:
         bi, off, n = self.where[p]
         if self.inplace[bi] and p.grad.is_contiguous():
             self.grad_ref[bi] = p.grad.view(-1)
-        self.ready_mark(p)
+        if p.is_cuda:
+            s = torch.cuda.current_stream()
+            if s not in self._streams:
+                self._streams.append(s)
+        p._dp_has_grad = True
+        p._dp_slice_zero = False
+        if self.no_grad is not None and p in self.no_grad:
+            return               # unexpected gradient of a parameter that had none in the first pass: handled by _finish
         self.pending[bi] -= 1
         # launch in bucket order so every rank issues the same collective sequence
         while True:
@@ -147,20 +173,22 @@ class GradAllReducer:
                 break
             self._launch(nxt)
 
-    def ready_mark(self, p):
-        p._dp_has_grad = True
-        p._dp_slice_zero = False
-
     def _finish(self):
+        if self.no_grad is None:
+            self.no_grad = {p for p in self.params if not getattr(p, "_dp_has_grad", False)}
         # parameters without a gradient this step contribute zeros (identical on every rank: same graph)
         for bi, b in enumerate(self.buckets):
+            late = [p for p, _, _ in b if p in self.no_grad and getattr(p, "_dp_has_grad", False)]
+            if self.launched[bi] and late:
+                raise RuntimeError("gradient all-reduce: a parameter that had no gradient in the first backward pass received one after "
+                                   "its bucket was exchanged; re-attach the reducer (the graph is assumed static)")
             if not self.launched[bi]:
                 for p, off, n in b:
                     # (the slice of a parameter that never receives a gradient stays zero from one step to the next)
                     if not getattr(p, "_dp_has_grad", False) and not getattr(p, "_dp_slice_zero", False):
                         self.flat[bi][off:off + n].zero_()
                         p._dp_slice_zero = True
-                self._launch(bi)
+                self._launch(bi, at_end=True)
         for w in self.work:
             if isinstance(w, tuple):
                 w[0].wait()
@@ -168,8 +196,13 @@ class GradAllReducer:
             else:
                 w.wait()
         for bi, b in enumerate(self.buckets):
+            if self.low:
+                # averaged bf16 / fp16 values back into the fp32 gradients (one multi-tensor pass per bucket)
+                have = [(p.grad, v) for (p, _, _), v in zip(b, self.views[bi]) if getattr(p, "_dp_has_grad", False)]
+                if have:
+                    torch._foreach_copy_([g for g, _ in have], [v for _, v in have])
             for p, off, n in b:
-                if getattr(p, "_dp_has_grad", False) and self.grad_ref[bi] is None:
+                if not self.low and getattr(p, "_dp_has_grad", False) and self.grad_ref[bi] is None:
                     # the averaged gradient stays in the bucket: .grad becomes a view of it (no unpack copy); the optimizer
                     # consumes it before the next backward pass refills the bucket
                     p.grad = self.views[bi][self._index[p]]
@@ -178,6 +211,6 @@ class GradAllReducer:
         self._reset()
 
 
-def attach_gradient_allreduce(module, bucket_mb=32.0, process_group=None, broadcast=True):
+def attach_gradient_allreduce(module, bucket_mb=32.0, process_group=None, broadcast=True, grad_dtype=torch.float32):
     """Install the bucketed RCCL gradient exchange on ``module`` in place and return the reducer."""
-    return GradAllReducer(module, bucket_mb, process_group, broadcast)
+    return GradAllReducer(module, bucket_mb, process_group, broadcast, grad_dtype)

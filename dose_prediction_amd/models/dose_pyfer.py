@@ -16,6 +16,59 @@ def ensure_tuple_rep(v, n):
     return tuple(v) if isinstance(v, (tuple, list)) else (v,) * n
 
 
+_SIDE_STREAMS = {}
+
+
+class _SideRun:
+    """Handle of a ViT forward running on the side stream: hidden(i) / final() make the CURRENT stream wait for exactly the
+    producer they need (a per-block event), and register the tensor with the allocator for that stream."""
+
+    def __init__(self, z, hidden, events, side, main):
+        self.z, self.hid, self.events, self.side, self.main = z, hidden, events, side, main
+
+    def hidden(self, i):
+        t = self.hid[i]
+        if self.side is not None:
+            self.main.wait_event(self.events[i])
+            t.record_stream(self.main)
+        return t
+
+    def final(self):
+        if self.side is not None:
+            self.main.wait_stream(self.side)
+            self.z.record_stream(self.main)
+        return self.z
+
+
+def run_vit_beside(vit, x_in, first=None):
+    """Start vit(x_in) on a second HIP stream (config.vit_side_stream) and return (_SideRun, first()).  `first` -- the 128^3 block
+    on the same input -- is ENQUEUED BEFORE the transformer although both start from the same point of the caller's stream: its
+    autograd nodes are then older than the transformer's, so the backward pass issues the whole transformer / patch-embedding
+    backward (48 % of the gradient bytes of the data-parallel exchange) before the 128^3 block's.  The transformer is ~200 small-grid,
+    latency-bound launches (1024 token rows), while the skip blocks that run meanwhile on the caller's stream are full-chip
+    kernels on 128^3 .. 16^3 volumes; skip block k only waits for the transformer layer it reads.  Autograd replays each node on
+    the stream of its forward pass, so the backward branches overlap the same way."""
+    from .. import config
+    if not (config.vit_side_stream() and x_in.is_cuda):
+        out = first() if first is not None else None
+        z, hidden = vit(x_in)
+        return _SideRun(z, hidden, None, None, None), out
+    main = torch.cuda.current_stream(x_in.device)
+    key = (x_in.device.index, main.cuda_stream)
+    side = _SIDE_STREAMS.get(key)
+    if side is None:
+        side = _SIDE_STREAMS[key] = torch.cuda.Stream(device=x_in.device)
+    fork = torch.cuda.Event()
+    fork.record(main)
+    out = first() if first is not None else None
+    side.wait_event(fork)
+    x_in.record_stream(side)
+    events = []
+    with torch.cuda.stream(side):
+        z, hidden = vit(x_in, events)
+    return _SideRun(z, hidden, events, side, main), out
+
+
 class ViTEncoder(nn.Module):
     """dose_pyfer.ViTEncoder (22-144)."""
 
@@ -55,12 +108,11 @@ class ViTEncoder(nn.Module):
     def forward(self, x_in, x_cat=None):
         """x_cat: optional (a, b) pair with cat((a, b)) == x_in (virtual concat for skip1's 3x3x3 convolution)."""
         i = self.num_layers // 4
-        z12, hidden_states_out = self.vit(x_in)
-        out_encoder_1 = self.skip1(x_in, x_cat)
-        out_encoder_2 = self.skip2(self.proj_feat(hidden_states_out[i]))
-        out_encoder_3 = self.skip3(self.proj_feat(hidden_states_out[i * 2]))
-        out_encoder_4 = self.skip4(self.proj_feat(hidden_states_out[i * 3]))
-        out_encoder_5 = self.proj_feat(z12)
+        run, out_encoder_1 = run_vit_beside(self.vit, x_in, lambda: self.skip1(x_in, x_cat))
+        out_encoder_2 = self.skip2(self.proj_feat(run.hidden(i)))
+        out_encoder_3 = self.skip3(self.proj_feat(run.hidden(i * 2)))
+        out_encoder_4 = self.skip4(self.proj_feat(run.hidden(i * 3)))
+        out_encoder_5 = self.proj_feat(run.final())
         return [out_encoder_1, out_encoder_2, out_encoder_3, out_encoder_4, out_encoder_5]
 
 

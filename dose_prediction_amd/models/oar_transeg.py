@@ -7,7 +7,7 @@ import torch.nn as nn
 from ..blocks import ViT, UnetrBasicBlock, UnetrPrUpBlock
 from .base_blocks import ModifiedUnetrUpBlock, ModifiedUnetOutBlock
 from .c3d import to_ndhwc, from_ndhwc
-from .dose_pyfer import ensure_tuple_rep
+from .dose_pyfer import ensure_tuple_rep, run_vit_beside
 
 
 class Model(nn.Module):
@@ -52,12 +52,11 @@ class Model(nn.Module):
         return x.view([x.size(0)] + self.proj_view_shape)       # free view in NDHWC (reference: 165-169)
 
     def forward_ndhwc(self, x_in):
-        x, hidden_states_out = self.vit(x_in)
-        enc1 = self.encoder1(x_in)
-        enc2 = self.encoder2(self.proj_feat(hidden_states_out[3]))
-        enc3 = self.encoder3(self.proj_feat(hidden_states_out[6]))
-        enc4 = self.encoder4(self.proj_feat(hidden_states_out[9]))
-        dec3 = self.decoder5(self.proj_feat(x), enc4)
+        run, enc1 = run_vit_beside(self.vit, x_in, lambda: self.encoder1(x_in))   # the transformer on a second HIP stream
+        enc2 = self.encoder2(self.proj_feat(run.hidden(3)))
+        enc3 = self.encoder3(self.proj_feat(run.hidden(6)))
+        enc4 = self.encoder4(self.proj_feat(run.hidden(9)))
+        dec3 = self.decoder5(self.proj_feat(run.final()), enc4)
         dec2 = self.decoder4(dec3, enc3)
         dec1 = self.decoder3(dec2, enc2)
         return self.out(self.decoder2(dec1, enc1))

@@ -419,7 +419,7 @@ class Conv3d(torch.autograd.Function):
     """nn.Conv3d forward / data-gradient / weight-gradient (c3d.py:16, blocks_MDUNet.py:68,102,146)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, dil):
+    def forward(ctx, x, weight, bias, stride, pad, dil, want_stats=False, bias_grad_zero=False):
         _chk_dev(x, weight)
         x = as_rows(x)
         rows, cx, ldx = rows_ld(x)
@@ -431,10 +431,18 @@ class Conv3d(torch.autograd.Function):
         y = torch.empty((N, Do, Ho, Wo, cout), dtype=x.dtype, device=x.device)
         b32 = None if bias is None else bias.detach()
         te = _tiled_elems(cin, cout, k, stride, pad, dil, Wi) if k > 1 else 0
+        part = None
         if te:
             wq = _pack_conv_tiled(weight, 0, x.dtype, te)
-            _lib.call("dp_conv3d_tiled", _p(x), ldx, _p(wq), _p(b32), _p(y), cout, _p(_tiled_ws(x, N, Di, Hi, Wi, cin, cout, k)),
-                      N, Di, Hi, Wi, cin, cout, k, _dt(x), _stream())
+            nblk = _lib.lib().dp_conv3d_tiled_stat_blocks(N, Di, Hi, Wi, cin, cout, k, cout, _dt(x)) if want_stats else 0
+            if nblk:
+                # the statistics of the normalisation that follows come out of the epilogue's fp32 accumulators
+                part = torch.empty((N, nblk, 2, cout), dtype=torch.float32, device=x.device)
+                _lib.call("dp_conv3d_tiled_stats", _p(x), ldx, 0, 0, 0, _p(wq), _p(b32), _p(y), cout, _p(_tiled_ws(x, N, Di, Hi, Wi, cin, cout, k)),
+                          _p(part), N, Di, Hi, Wi, cin, cout, k, _dt(x), _stream())
+            else:
+                _lib.call("dp_conv3d_tiled", _p(x), ldx, _p(wq), _p(b32), _p(y), cout, _p(_tiled_ws(x, N, Di, Hi, Wi, cin, cout, k)),
+                          N, Di, Hi, Wi, cin, cout, k, _dt(x), _stream())
         elif k == 1 and stride == 1 and pad == 0:
             wp = _pack_conv(weight, 0, x.dtype)
             gemm_nt(x, wp, y, bias=b32, M=rows, N=cout, K=cin, lda=ldx, ldb=wp.shape[-1], ldc=cout)
@@ -451,10 +459,16 @@ class Conv3d(torch.autograd.Function):
                       k, stride, pad, dil, 0, _dt(x), _stream())
         ctx.save_for_backward(x, weight)
         ctx.cfg = (stride, pad, dil, bias is not None)
+        ctx.bias_grad_zero = bias_grad_zero
+        if want_stats:
+            if part is None:
+                part = _stats_partial(y)
+            ctx.mark_non_differentiable(part)
+            return y, part
         return y
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, *unused):
         x, weight = ctx.saved_tensors
         stride, pad, dil, has_bias = ctx.cfg
         gy = as_rows(gy)
@@ -490,11 +504,13 @@ class Conv3d(torch.autograd.Function):
         if wse:
             # heads: a handful of channels over millions of voxels -> one HBM row stream gives dW and db together
             gw = _wgrad_buffer(weight, False)
-            want_b = has_bias and ctx.needs_input_grad[2]
+            want_b = has_bias and ctx.needs_input_grad[2] and not ctx.bias_grad_zero
             gb = torch.empty((cout,), dtype=torch.float32, device=x.device) if want_b else None
             ws = torch.empty((wse,), dtype=torch.float32, device=x.device)
             _lib.call("dp_pointwise_wgrad_rows", _p(x), ldx, _p(gy), ldg, _p(gw), cin, _p(gb), _p(ws), grows, cin, cout, dtc, _stream())
-            return gx, gw, gb, None, None, None
+            if has_bias and ctx.needs_input_grad[2] and ctx.bias_grad_zero:
+                gb = torch.zeros((cout,), dtype=torch.float32, device=x.device)
+            return gx, gw, gb, None, None, None, None, None
         if ctx.needs_input_grad[1] and k == 1 and stride == 1 and pad == 0 and grows < 32768:
             # pointwise conv over few voxels: dW[co][ci] = gy^T x, both k-major in memory (split over K to fill the chip)
             tiles = -(-cout // 64) * -(-cin // 64)
@@ -516,14 +532,36 @@ class Conv3d(torch.autograd.Function):
                 wgrad(x, ldx, gy, ldg, gw, (N, Di, Hi, Wi, Do, Ho, Wo), cin, cout, k, stride, pad, dil, 1, 0,
                       cin * taps, taps, 1, dtc)
         if has_bias and ctx.needs_input_grad[2]:
-            gb = torch.empty((cout,), dtype=torch.float32, device=x.device)
-            colsum_into(_p(gy), ldg, grows, cout, gb, dtc)
-        return gx, gw, gb, None, None, None
+            if ctx.bias_grad_zero:
+                # the output feeds a normalisation over batch statistics: sum_v d(loss)/dy[v][c] is identically zero (the reference
+                # accumulates pure round-off there), so no column-sum pass over gy is made
+                gb = torch.zeros((cout,), dtype=torch.float32, device=x.device)
+            else:
+                gb = torch.empty((cout,), dtype=torch.float32, device=x.device)
+                colsum_into(_p(gy), ldg, grows, cout, gb, dtc)
+        return gx, gw, gb, None, None, None, None, None
 
 
-def conv3d(x, weight, bias=None, stride=1, pad=0, dil=1):
+def _stats_partial(y):
+    """Per-block (sum, sum of squares) rows of an NDHWC tensor: [N, nblk, 2, C] fp32 (dp_stats_partial)."""
+    y = as_rows(y)
+    rows, C, ld = rows_ld(y)
+    N = y.shape[0]
+    V = rows // N
+    part = torch.empty((N, _lib.lib().dp_stats_nblk(V), 2, C), dtype=torch.float32, device=y.device)
+    _lib.call("dp_stats_partial", _p(y), ld, N, V, C, _p(part), _dt(y), _stream())
+    return part
+
+
+def conv3d(x, weight, bias=None, stride=1, pad=0, dil=1, stats=False, bias_grad_zero=False):
+    """stats=True: returns (y, part) where part [N, nblk, 2, Cout] are the partial normalisation statistics of y (taken from the
+    convolution's fp32 accumulators when the tiled kernel runs, otherwise by a statistics pass): hand it to norm_act(..., stats=part).
+    bias_grad_zero=True: the caller normalises y over batch statistics next (InstanceNorm, or BatchNorm in training mode), which
+    makes the bias gradient identically zero: it is returned as exact zeros instead of a column sum of round-off."""
     if isinstance(x, (tuple, list)):
-        return conv3d_cat(x[0], x[1], weight, bias, stride, pad, dil)
+        return conv3d_cat(x[0], x[1], weight, bias, stride, pad, dil, stats, bias_grad_zero)
+    if stats or bias_grad_zero:
+        return Conv3d.apply(x, weight, bias, stride, pad, dil, stats, bias_grad_zero)
     return Conv3d.apply(x, weight, bias, stride, pad, dil)
 
 
@@ -533,7 +571,7 @@ class Conv3dCat(torch.autograd.Function):
     Only built by conv3d_cat() for shapes the tiled kernels support (k in {3,7}, stride 1, "same" padding)."""
 
     @staticmethod
-    def forward(ctx, xa, xb, weight, bias, pad):
+    def forward(ctx, xa, xb, weight, bias, pad, want_stats=False, bias_grad_zero=False):
         _chk_dev(xa, xb, weight)
         xa, xb = as_rows(xa), as_rows(xb)
         _, ca, lda = rows_ld(xa)
@@ -543,14 +581,27 @@ class Conv3dCat(torch.autograd.Function):
         y = torch.empty((N, D, H, W, cout), dtype=xa.dtype, device=xa.device)
         wq = _pack_conv_tiled(weight, 0, xa.dtype, _tiled_elems(cin, cout, k, 1, pad, 1, W))
         b32 = None if bias is None else bias.detach()
-        _lib.call("dp_conv3d_tiled2", _p(xa), lda, _p(xb), ldb, ca, _p(wq), _p(b32), _p(y), cout, 0, 0, 0,
-                  _p(_tiled_ws(xa, N, D, H, W, cin, cout, k)), N, D, H, W, cin, cout, k, _dt(xa), _stream())
+        nblk = _lib.lib().dp_conv3d_tiled_stat_blocks(N, D, H, W, cin, cout, k, cout, _dt(xa)) if want_stats else 0
+        part = None
+        if nblk:
+            part = torch.empty((N, nblk, 2, cout), dtype=torch.float32, device=xa.device)
+            _lib.call("dp_conv3d_tiled_stats", _p(xa), lda, _p(xb), ldb, ca, _p(wq), _p(b32), _p(y), cout,
+                      _p(_tiled_ws(xa, N, D, H, W, cin, cout, k)), _p(part), N, D, H, W, cin, cout, k, _dt(xa), _stream())
+        else:
+            _lib.call("dp_conv3d_tiled2", _p(xa), lda, _p(xb), ldb, ca, _p(wq), _p(b32), _p(y), cout, 0, 0, 0,
+                      _p(_tiled_ws(xa, N, D, H, W, cin, cout, k)), N, D, H, W, cin, cout, k, _dt(xa), _stream())
         ctx.save_for_backward(xa, xb, weight)
         ctx.cfg = (pad, bias is not None)
+        ctx.bias_grad_zero = bias_grad_zero
+        if want_stats:
+            if part is None:
+                part = _stats_partial(y)
+            ctx.mark_non_differentiable(part)
+            return y, part
         return y
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, *unused):
         xa, xb, weight = ctx.saved_tensors
         pad, has_bias = ctx.cfg
         gy = as_rows(gy)
@@ -576,12 +627,15 @@ class Conv3dCat(torch.autograd.Function):
             _lib.call("dp_conv3d_wgrad_tiled2", _p(xa), lda, _p(xb), ldb, ca, _p(gy), ldg, _p(gw), _p(ws), N, D, H, W, cin, cout, k,
                       cin * taps, taps, 1, dtc, _stream())
         if has_bias and ctx.needs_input_grad[3]:
-            gb = torch.empty((cout,), dtype=torch.float32, device=xa.device)
-            colsum_into(_p(gy), ldg, grows, cout, gb, dtc)
-        return gxa, gxb, gw, gb, None
+            if ctx.bias_grad_zero:
+                gb = torch.zeros((cout,), dtype=torch.float32, device=xa.device)
+            else:
+                gb = torch.empty((cout,), dtype=torch.float32, device=xa.device)
+                colsum_into(_p(gy), ldg, grows, cout, gb, dtc)
+        return gxa, gxb, gw, gb, None, None, None
 
 
-def conv3d_cat(xa, xb, weight, bias=None, stride=1, pad=0, dil=1):
+def conv3d_cat(xa, xb, weight, bias=None, stride=1, pad=0, dil=1, stats=False, bias_grad_zero=False):
     """conv3d(cat((xa, xb), channels)): virtual concat when the tiled kernels support the shape, else a real cat."""
     cout, cin, k = weight.shape[0], weight.shape[1], weight.shape[2]
     ca, W = xa.shape[-1], xa.shape[3]
@@ -592,7 +646,9 @@ def conv3d_cat(xa, xb, weight, bias=None, stride=1, pad=0, dil=1):
         ok = bool(_tiled_elems(cin, cout, k, 1, pad, 1, W)) and bool(_tiled_elems(cout, cin, k, 1, k - 1 - pad, 1, W)) and \
             bool(L.dp_conv3d_wgrad_tiled_ws_elems(cin, cout, k, 1, pad, 1, 1, W))
     if not ok:
-        return Conv3d.apply(cat((xa, xb)), weight, bias, stride, pad, dil)
+        return conv3d(cat((xa, xb)), weight, bias, stride, pad, dil, stats, bias_grad_zero)
+    if stats or bias_grad_zero:
+        return Conv3dCat.apply(xa, xb, weight, bias, pad, stats, bias_grad_zero)
     return Conv3dCat.apply(xa, xb, weight, bias, pad)
 
 
@@ -718,8 +774,9 @@ def linear(x, weight, bias=None, splitk=1):
 
 
 # ------------------------------------------------------------------------------------------------ normalisation
-def _norm_forward(x, kind, gamma, beta, running_mean, running_var, training, res, act, eps, momentum, y_ptr, ldy, apply=True):
-    """Statistics + fused normalise/affine/residual/activation of one NDHWC tensor into (y_ptr, row pitch ldy)."""
+def _norm_forward(x, kind, gamma, beta, running_mean, running_var, training, res, act, eps, momentum, y_ptr, ldy, apply=True, part=None):
+    """Statistics + fused normalise/affine/residual/activation of one NDHWC tensor into (y_ptr, row pitch ldy).
+    part: partial statistics rows [N, nblk, 2, C] already produced by the convolution that wrote x (conv3d(..., stats=True))."""
     rows, C, ldx = rows_ld(x)
     N = x.shape[0]
     V = rows // N
@@ -728,12 +785,17 @@ def _norm_forward(x, kind, gamma, beta, running_mean, running_var, training, res
     dev = x.device
     use_batch_stats = kind == "instance" or training
     if use_batch_stats:
-        nblk = L.dp_stats_nblk(V)
-        part = torch.empty((N, nblk, 2, C), dtype=torch.float32, device=dev)
+        if part is not None:
+            if tuple(part.shape[::2]) != (N, 2) or part.shape[3] != C:
+                raise ValueError("norm_act: stats tensor does not belong to this input")
+            nblk = part.shape[1]
+        else:
+            nblk = L.dp_stats_nblk(V)
+            part = torch.empty((N, nblk, 2, C), dtype=torch.float32, device=dev)
+            _lib.call("dp_stats_partial", _p(x), ldx, N, V, C, _p(part), dtc, _stream())
         groups = N if kind == "instance" else 1
         mean = torch.empty((groups, C), dtype=torch.float32, device=dev)
         rstd = torch.empty((groups, C), dtype=torch.float32, device=dev)
-        _lib.call("dp_stats_partial", _p(x), ldx, N, V, C, _p(part), dtc, _stream())
         upd = kind == "batch" and training and running_mean is not None
         _lib.call("dp_stats_finalize", _p(part), N, nblk, C, V, 1 if kind == "batch" else 0, float(eps), _p(mean), _p(rstd),
                   _p(running_mean) if upd else 0, _p(running_var) if upd else 0, float(momentum), _stream())
@@ -795,7 +857,7 @@ class NormAct(torch.autograd.Function):
     kind: 'instance' | 'batch'.  For 'batch', running buffers are updated in place when training."""
 
     @staticmethod
-    def forward(ctx, x, kind, gamma, beta, running_mean, running_var, training, res, act, eps, momentum):
+    def forward(ctx, x, kind, gamma, beta, running_mean, running_var, training, res, act, eps, momentum, stats=None):
         _chk_dev(x)
         x = as_rows(x)
         C = x.shape[-1]
@@ -803,7 +865,7 @@ class NormAct(torch.autograd.Function):
             res = as_rows(res)
         y = torch.empty(x.shape, dtype=x.dtype, device=x.device)
         mean, rstd, use_batch_stats, ssn = _norm_forward(x, kind, gamma, beta, running_mean, running_var, training, res, act, eps,
-                                                         momentum, _p(y), C)
+                                                         momentum, _p(y), C, part=stats)
         ctx.save_for_backward(x, mean, rstd, gamma, beta, res)
         ctx.cfg = (kind, act, use_batch_stats, ssn)
         return y
@@ -816,7 +878,7 @@ class NormAct(torch.autograd.Function):
         need_gb = gamma is not None and (ctx.needs_input_grad[2] or ctx.needs_input_grad[3])
         gx, dgamma, dbeta, gres = _norm_backward(x, mean, rstd, gamma, beta, res, kind, act, use_stats, ssn, _p(gy), rows_ld(gy)[2],
                                                  ctx.needs_input_grad[0], need_gb, res is not None and ctx.needs_input_grad[7])
-        return gx, None, dgamma, dbeta, None, None, None, gres, None, None, None
+        return gx, None, dgamma, dbeta, None, None, None, gres, None, None, None, None
 
 
 class NormActCat(torch.autograd.Function):
@@ -826,15 +888,15 @@ class NormActCat(torch.autograd.Function):
     place.  Non-affine instance normalisation only."""
 
     @staticmethod
-    def forward(ctx, xa, xb, act, eps):
+    def forward(ctx, xa, xb, act, eps, stats_a=None, stats_b=None):
         _chk_dev(xa, xb)
         xa, xb = as_rows(xa), as_rows(xb)
         ca, cb = xa.shape[-1], xb.shape[-1]
         if xa.shape[:-1] != xb.shape[:-1] or (ca % 8) or (cb % 8):
             raise ValueError("norm_act_cat: operands must share the voxel grid and have channel counts that are multiples of 8")
         y = torch.empty(tuple(xa.shape[:-1]) + (ca + cb,), dtype=xa.dtype, device=xa.device)
-        ma, ra, _, ssa = _norm_forward(xa, "instance", None, None, None, None, True, None, act, eps, 0.1, 0, 0, apply=False)
-        mb, rb, _, ssb = _norm_forward(xb, "instance", None, None, None, None, True, None, act, eps, 0.1, 0, 0, apply=False)
+        ma, ra, _, ssa = _norm_forward(xa, "instance", None, None, None, None, True, None, act, eps, 0.1, 0, 0, apply=False, part=stats_a)
+        mb, rb, _, ssb = _norm_forward(xb, "instance", None, None, None, None, True, None, act, eps, 0.1, 0, 0, apply=False, part=stats_b)
         N = xa.shape[0]
         # one pass over both sources: every 2*(ca+cb)-byte output row is written whole (two launches wrote alternating halves)
         _lib.call("dp_norm_act_cat_fwd", _p(xa), rows_ld(xa)[2], _p(ma), _p(ra), ca, _p(xb), rows_ld(xb)[2], _p(mb), _p(rb), cb, ACT[act],
@@ -865,22 +927,25 @@ class NormActCat(torch.autograd.Function):
             _lib.call("dp_norm_act_cat_bwd_partial", *src, N, V, _p(part), dtc, _stream())
             _lib.call("dp_norm_bwd_finalize", _p(part), N, nblk, ca + cb, 0, _p(s12[0]), _p(s12[1]), 0, 0, _stream())
             _lib.call("dp_norm_act_cat_bwd_apply", *src, _p(s12[0]), _p(s12[1]), 1.0 / V, _p(ga), ca, _p(gb), cb, N, V, dtc, _stream())
-            return ga, gb, None, None
+            return ga, gb, None, None, None, None
         if ctx.needs_input_grad[0]:
             ga = _norm_backward(xa, ma, ra, None, None, None, "instance", act, True, ssa, _p(gy), ldg, True, False, False)[0]
         if ctx.needs_input_grad[1]:
             gb = _norm_backward(xb, mb, rb, None, None, None, "instance", act, True, ssb, gy.data_ptr() + ca * gy.element_size(), ldg,
                                 True, False, False)[0]
-        return ga, gb, None, None
+        return ga, gb, None, None, None, None
 
 
-def norm_act_cat(xa, xb, act=None, eps=1e-5):
-    return NormActCat.apply(xa, xb, act, eps)
+def norm_act_cat(xa, xb, act=None, eps=1e-5, stats_a=None, stats_b=None):
+    return NormActCat.apply(xa, xb, act, eps, stats_a, stats_b)
 
 
 def norm_act(x, kind, gamma=None, beta=None, running_mean=None, running_var=None, training=True, res=None, act=None,
-             eps=1e-5, momentum=0.1):
-    return NormAct.apply(x, kind, gamma, beta, running_mean, running_var, training, res, act, eps, momentum)
+             eps=1e-5, momentum=0.1, stats=None):
+    """stats: the partial-statistics tensor conv3d(..., stats=True) returned together with x (skips the statistics pass)."""
+    if kind == "batch" and not training:
+        stats = None
+    return NormAct.apply(x, kind, gamma, beta, running_mean, running_var, training, res, act, eps, momentum, stats)
 
 
 class LayerNorm(torch.autograd.Function):
@@ -955,16 +1020,8 @@ class AddBroadcast(torch.autograd.Function):
             for s in ctx.pshape:
                 per *= s
             B = g.numel() // per
-            gp = torch.zeros((per,), dtype=torch.float32, device=g.device)
-            # sum over the batch with the column-sum reduction: rows = B, "channels" = per  (chunked to <= 2048 cols)
-            # sum over the batch in fp32: B-1 elementwise adds (a column-sum launch per 2048 columns would be ~200 launches)
-            g32 = _cast_vec(g.view(B, per), torch.float32)
-            gp = g32[0]
-            for b in range(1, B):
-                nxt = torch.empty_like(gp)
-                _lib.call("dp_add", _p(gp), _p(g32[b]), _p(nxt), per, per, 0, _stream())
-                gp = nxt
-            gp = gp.clone().view(ctx.pshape) if B == 1 else gp.view(ctx.pshape)
+            gp = torch.empty(ctx.pshape, dtype=torch.float32, device=g.device)
+            _lib.call("dp_sum_batch", _p(g), _p(gp), B, per, _dt(g), _stream())      # fp32 sum over the batch, one pass
         return g, gp
 
 

@@ -66,6 +66,9 @@ int dp_transpose(const void* src, int64_t lds, int64_t sb0, int64_t sb1, void* d
 /* y = a + b (b broadcast with period `period` elements; period==n for plain add).
  * replaces: residual adds in MONAI TransformerBlock, `x + position_embeddings`. */
 int dp_add(const void* a, const void* b, void* y, int64_t n, int64_t period, int dtype, void* stream);
+/* out[i] (fp32) = sum over b < B of g[b * per + i]: gradient of `x + position_embeddings` (MONAI PatchEmbeddingBlock) w.r.t. the
+ * [1, N, hidden] parameter that is broadcast over the batch. */
+int dp_sum_batch(const void* g, float* out, int B, int64_t per, int dtype, void* stream);
 /* replaces: nn.GELU in MONAI MLPBlock; bwd: gx = gy * gelu'(x). */
 int dp_gelu_fwd(const void* x, void* y, int64_t n, int dtype, void* stream);
 int dp_gelu_bwd(const void* x, const void* gy, void* gx, int64_t n, int dtype, void* stream);
@@ -195,6 +198,16 @@ int dp_conv3d_tiled(const void* x, int ldx, const void* wq, const float* bias, v
 int dp_conv3d_tiled2(const void* x, int ldx, const void* x2, int ldx2, int csplit, const void* wq, const float* bias,
                      void* y, int ldy, void* y2, int ldy2, int osplit, float* ws, int N, int D, int H, int W,
                      int Cin, int Cout, int k, int dtype, void* stream);
+/* The same convolution (one output tensor) that ALSO leaves the normalisation statistics of its output, taken from the fp32
+ * accumulators: stat_part[((n * nblk + b) * 2 + {0: sum, 1: sum of squares}) * Cout + c] for the nblk =
+ * dp_conv3d_tiled_stat_blocks(...) blocks of sample n; feed it to dp_stats_finalize(part, N, nblk, Cout, D*H*W, ...) in place of
+ * dp_stats_partial's output.  replaces: the statistics pass of the nn.InstanceNorm3d / nn.BatchNorm3d that follows every
+ * convolution of the path (c3d.py:15-19, blocks_MDUNet.py:67-74,101-108).  dp_conv3d_tiled_stat_blocks returns 0 when the shape
+ * cannot produce statistics (split-kd volumes, unaligned output rows). */
+int dp_conv3d_tiled_stat_blocks(int N, int D, int H, int W, int Cin, int Cout, int k, int ldy, int dtype);
+int dp_conv3d_tiled_stats(const void* x, int ldx, const void* x2, int ldx2, int csplit, const void* wq, const float* bias,
+                          void* y, int ldy, float* ws, float* stat_part, int N, int D, int H, int W, int Cin, int Cout, int k,
+                          int dtype, void* stream);
 int dp_conv3d_wgrad_tiled2(const void* x, int ldx, const void* x2, int ldx2, int csplit, const void* gy, int ldgy, float* dw, float* ws,
                            int N, int D, int H, int W, int Cin, int Cout, int k, int64_t s_co, int64_t s_ci, int64_t s_tap, int dtype, void* stream);
 /* weight gradient (fp32, ACCUMULATES): for every tap t, co, ci:

@@ -32,23 +32,27 @@ class Net(nn.Module):
         return self.b(torch.relu(self.bn(self.a(self.frozen(x))))).sum()
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, grad_dtype=torch.float32):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from dose_prediction_amd.ddp import attach_gradient_allreduce
     torch.manual_seed(100 + rank)          # different initial weights per rank: the broadcast must fix that
     net = Net()
     keys_before = list(net.state_dict().keys())
-    red = attach_gradient_allreduce(net, bucket_mb=0.002)
+    red = attach_gradient_allreduce(net, bucket_mb=0.002, grad_dtype=grad_dtype)
     assert list(net.state_dict().keys()) == keys_before
     w0 = net.a.weight.detach().clone()
     res = {"w0": w0}
     for step in range(2):                  # two steps: bucket state must reset
         net.zero_grad(set_to_none=True)
         x = torch.randn(5, 8, generator=torch.Generator().manual_seed(7 + rank + 10 * step))
+        before = dict(red.stats)
         net(x).backward()
         res[f"g{step}"] = {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
         res[f"x{step}"] = x
+        res[f"launched{step}"] = (red.stats["launched_in_backward"] - before["launched_in_backward"],
+                                  red.stats["launched_at_end"] - before["launched_at_end"], len(red.buckets))
+    assert {k for k, p in net.named_parameters() if p in red.no_grad} == {"unused.weight", "unused.bias"}
     # a step in which parameters that HAD gradients get none: their bucket slices must be exchanged as zeros again
     net.zero_grad(set_to_none=True)
     net.a(net.frozen(x)).sum().backward()
@@ -89,3 +93,25 @@ def test_bucketed_allreduce_gloo():
             assert torch.allclose(r0[f"g{step}"][k], avg, rtol=1e-5, atol=1e-6), (step, k)
             assert torch.equal(r0[f"g{step}"][k], r1[f"g{step}"][k])
         assert "unused.weight" not in r0[f"g{step}"] and "frozen.weight" not in r0[f"g{step}"]
+    # overlap: `unused` is registered last, i.e. it sits in bucket 0, and never receives a gradient.  In the first pass
+    # the reducer cannot know that (bucket 0 waits until the end-of-backward callback, and every later bucket queues behind it);
+    # from the second pass on the gradient-less parameters are known and EVERY bucket is exchanged from the hooks, inside backward
+    in_bwd, at_end, nb = r0["launched1"]
+    assert nb >= 3 and in_bwd == nb and at_end == 0, r0["launched1"]
+    assert r0["launched0"][1] >= 1
+
+
+def test_bf16_gradient_buckets_gloo():
+    """grad_dtype=torch.bfloat16 halves the exchanged bytes; the averaged gradients equal the fp32 exchange up to one bf16
+    rounding of each rank's contribution (2^-9 relative), are identical on both ranks, and .grad stays fp32."""
+    world = 2
+    mgr = mp.Manager()
+    out16, out32 = mgr.dict(), mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), out16, torch.bfloat16), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), out32), nprocs=world, join=True)
+    for step in range(2):
+        for k, g32 in out32[0][f"g{step}"].items():
+            g16 = out16[0][f"g{step}"][k]
+            assert g16.dtype == torch.float32
+            assert torch.equal(g16, out16[1][f"g{step}"][k])
+            assert (g16 - g32).abs().max() <= 2 ** -7 * g32.abs().max() + 1e-12, (step, k)

@@ -302,7 +302,8 @@ def test_c5_cascade_fp16_checkpointing_192x192x128():
         gt = synth.dose_target(1, vol[::-1]).to(dev)
         structures, labels = cascade.cascade_structures(seg, ct, ptv, roi_size=roi, sw_batch_size=4, overlap=0.25)
         assert structures.shape == (1, 9) + vol[::-1] and labels.shape == (1,) + vol
-        assert torch.equal(structures[:, 8], full[:, 8]) and torch.equal(structures[:, 0], full[:, 0])      # CT / PTV pass through
+        # CT / PTV pass through (rounded once to the fp16 staging buffer)
+        assert torch.equal(structures[:, 8], full[:, 8].half().float()) and torch.equal(structures[:, 0], full[:, 0].half().float())
         onehot = structures[:, 1:8]
         assert set(onehot.unique().tolist()) <= {0.0, 1.0} and float(onehot.sum(1).max()) <= 1.0
         bn = [m for m in net.modules() if isinstance(m, torch.nn.BatchNorm3d)]

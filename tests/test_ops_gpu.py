@@ -5,6 +5,7 @@ bf16 mode: inputs are rounded to bf16 FIRST and the oracle is evaluated (in fp64
 differences are fp32 accumulation order and the final rounding of outputs to bf16 (2^-9): tolerance 6e-3 rel-L2.
 fp16 mode: the same protocol with fp16 rounding (2^-12): tolerance 1e-3 rel-L2.
 """
+import copy
 import math
 
 import pytest
@@ -553,7 +554,7 @@ def test_fused_adam_state_dict_round_trips_with_torch_adam():
             for i, p in enumerate(pa):
                 p.grad = rnd(p.shape, 100 * it + i).to(dev)
             oa.step()
-        ob.load_state_dict(oa.state_dict())
+        ob.load_state_dict(copy.deepcopy(oa.state_dict()))      # (state_dict() hands out references to the live state tensors)
         with torch.no_grad():
             for x, y in zip(pa, pb):
                 y.copy_(x)
@@ -605,3 +606,65 @@ def test_fused_adam_capturable_replays_correct_steps():
     torch.cuda.synchronize()
     assert int(ob.state[b]["step"].item()) == 5
     assert rel_err(b.detach().cpu(), a.detach().cpu()) < 5e-6
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [
+    # (N, Cin, ca (virtual-concat split or 0), Cout, D, H, W, k)
+    (2, 16, 0, 16, 5, 19, 70, 7),       # tap-paired epilogue, ragged H and W tiles
+    (1, 32, 16, 16, 4, 9, 130, 3),      # virtual concat, TWC = 4
+    (2, 16, 0, 32, 25, 61, 40, 3),      # NPAIR == 1, one N tile (>= 400 blocks: no split-kd), ragged H
+    (1, 24, 0, 72, 10, 78, 33, 3),      # two N tiles per block + a second channel block (grid.y), ragged Cout / H
+    (4, 32, 0, 64, 100, 16, 16, 3),     # W16 tiles (two image rows per MFMA tile)
+    (1, 128, 0, 64, 4, 8, 16, 7),       # split-kd volume: statistics fall back to the row pass
+    (1, 12, 0, 8, 6, 6, 6, 3)])         # too small for the tiled kernel: generic convolution + row pass
+def test_conv_epilogue_statistics(cfg, dtype):
+    """conv3d(..., stats=True): the per-block (sum, sum of squares) rows written by the convolution epilogue (from the fp32
+    accumulators) give the InstanceNorm / BatchNorm statistics of the output; checked through norm_act against the oracle's
+    conv -> norm -> act in float64, forward and backward, for both statistics modes."""
+    from dose_prediction_amd import ops
+    dev = _dev()
+    N, Cin, ca, Cout, D, H, W, k = cfg
+    x = q(rnd((N, Cin, D, H, W), 1), dtype)
+    w = q(rnd((Cout, Cin, k, k, k), 2, (Cin * k ** 3) ** -0.5), dtype)
+    b = 0.3 * rnd((Cout,), 3)
+    for kind in ("instance", "batch"):
+        xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+        yr = oracle.conv3d(xr, wr, b.double(), 1, k // 2, 1)
+        if kind == "instance":
+            zr = oracle.activation(oracle.instance_norm(yr), "relu")
+        else:
+            zr = oracle.activation(oracle.batch_norm(yr, torch.ones(Cout).double(), torch.zeros(Cout).double(), torch.zeros(Cout).double(),
+                                                     torch.ones(Cout).double(), True)[0], "relu")
+        r = rnd(zr.shape, 4)
+        zr.backward(r.double())
+        xd = ndhwc(x).to(dev).to(dtype).requires_grad_(True)
+        wd = w.to(dev).requires_grad_(True)
+        if ca:
+            xa, xb = xd[..., :ca].detach().contiguous().requires_grad_(True), xd[..., ca:].detach().contiguous().requires_grad_(True)
+            y, st = ops.conv3d((xa, xb), wd, b.to(dev), 1, k // 2, 1, stats=True)
+        else:
+            y, st = ops.conv3d(xd, wd, b.to(dev), 1, k // 2, 1, stats=True)
+        assert st.shape[0] == N and st.shape[2:] == (2, Cout) and not st.requires_grad
+        V = D * H * W
+        from dose_prediction_amd import _lib
+        from_epilogue = _lib.lib().dp_conv3d_tiled_stat_blocks(N, D, H, W, Cin, Cout, k, Cout, ops._DT[dtype]) > 0
+        assert from_epilogue == (D * H * W > 1000), "this configuration was meant to exercise the other statistics path"
+        if from_epilogue:
+            assert st.shape[1] == _lib.lib().dp_conv3d_tiled_stat_blocks(N, D, H, W, Cin, Cout, k, Cout, ops._DT[dtype])
+        # epilogue path: the partial rows add up to the sums of the UNROUNDED outputs (fp32 accumulators): 1e-5; the fall-back row
+        # pass reads the stored (rounded) tensor: rounding noise ~ 2^-9 / sqrt(V)
+        s = st.double().sum(1).cpu()
+        ref1, ref2 = yr.detach().sum(dim=(2, 3, 4)), (yr.detach() ** 2).sum(dim=(2, 3, 4))
+        std = (ref2 / V - (ref1 / V) ** 2).clamp_min(1e-12).sqrt()
+        tol = 1e-5 if (from_epilogue or dtype == torch.float32) else 5e-4
+        assert ((s[:, 0] - ref1).abs() / (V * std)).max() < tol
+        assert ((s[:, 1] - ref2).abs() / ref2).max() < tol
+        gam = torch.ones(Cout, device=dev)
+        z = ops.norm_act(y, kind, gam if kind == "batch" else None, torch.zeros(Cout, device=dev) if kind == "batch" else None,
+                         act="relu", stats=st)
+        check(f"stats {kind} fwd", ncdhw(z), zr, dtype, scale=2.0)
+        z.backward(ndhwc(r).to(dev).to(dtype))
+        gx = torch.cat((xa.grad, xb.grad), -1) if ca else xd.grad
+        check(f"stats {kind} gx", ncdhw(gx), xr.grad, dtype, scale=10.0)     # (conv -> norm -> relu chain: three rounded stages)
+        check(f"stats {kind} gw", wd.grad, wr.grad, dtype, scale=10.0)
