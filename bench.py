@@ -118,6 +118,10 @@ def summarize_profile(records, steps):
             # (x, ldx, x2, ldx2, csplit, wq, bias, y, ldy, y2, ldy2, osplit, ws, N, D, H, W, Cin, Cout, k, dtype, stream)
             N, D, H, W, Cin, Cout, k = a[13:20]
             fl, key = 2.0 * N * D * H * W * Cin * Cout * k ** 3, f"conv{k}x{k}x{k}_tiled"
+        elif name == "dp_conv3d_tiled_stats":
+            # (x, ldx, x2, ldx2, csplit, wq, bias, y, ldy, ws, stat_part, N, D, H, W, Cin, Cout, k, dtype, stream)
+            N, D, H, W, Cin, Cout, k = a[11:18]
+            fl, key = 2.0 * N * D * H * W * Cin * Cout * k ** 3, f"conv{k}x{k}x{k}_tiled"
         elif name == "dp_conv3d_wgrad_tiled2":
             # (x, ldx, x2, ldx2, csplit, gy, ldgy, dw, ws, N, D, H, W, Cin, Cout, k, ...)
             N, D, H, W, Cin, Cout, k = a[9:16]

@@ -67,7 +67,7 @@ def lib():
 # HIP events recorded on the stream the kernel is launched on (torch's current stream) and appended as
 # (name, args, start_event, end_event).
 PROFILE = None
-PROFILE_NAMES = ("dp_conv3d", "dp_conv3d_tiled", "dp_conv3d_tiled2", "dp_conv3d_wgrad", "dp_conv3d_wgrad_tiled", "dp_conv3d_wgrad_tiled2",
+PROFILE_NAMES = ("dp_conv3d", "dp_conv3d_tiled", "dp_conv3d_tiled2", "dp_conv3d_tiled_stats", "dp_conv3d_wgrad", "dp_conv3d_wgrad_tiled", "dp_conv3d_wgrad_tiled2",
                  "dp_gemm_nt", "dp_gemm_tn")
 
 

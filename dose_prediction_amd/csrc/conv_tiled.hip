@@ -238,23 +238,59 @@ __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, 
       // (row, tap) pair -- 1 KiB of LDS per 32-cycle MFMA per SIMD, i.e. exactly the CU's whole LDS bandwidth -- and held
       // the sweep near half the MFMA rate; row-outer needs ROWS reads for RW*JH MFMAs (15 for 36 with 7x7x7 pairs, 14 for 56
       // unpaired).  The JH weight fragments of the NEXT column are in flight (two named register sets) while this one runs.
-      auto do_kw = [&](int kw, auto jc, const Frag8<T>* bb) {
-        constexpr int j = decltype(jc)::value;
+      // The A rows are software-pipelined through THREE register sets: the reads of rows rho+1 and rho+2 are in flight while the
+      // MFMAs of row rho issue (a read -> s_waitcnt lgkmcnt(0) -> MFMA chain per row left the matrix pipe idle for most of every
+      // LDS round trip: ~2.4 MFMAs = 77 cycles of work per 100+ cycle read; the sweep alone ran at 43 % of the MFMA peak).  The last
+      // two steps of a column already request rows 0 and 1 of the next column (`pre_next`), so only the first column of a pass
+      // exposes the latency.  On entry fa[0], fa[1] hold (requests for) rows 0, 1 of column kw.
+      Frag8<T> fa[3];
+      auto a_addr = [&](int kw, int rho) -> const T* {
         const int v_tap = v_lane + kw;
         const int sw0 = SWZ ? (hh ^ ((v_tap >> 3) & 1)) : hh;
-        const int a_even = v_tap * CK + sw0 * 8, a_odd = v_tap * CK + (sw0 ^ lp_par) * 8;   // odd rows flip the half iff LP/8 is odd
+        return slab + v_tap * CK + (((rho & 1) ? (sw0 ^ lp_par) : sw0) * 8) + rho * LP * CK;   // odd rows flip the half iff LP/8 is odd
+      };
+      auto do_kw = [&](int kw, auto jc, const Frag8<T>* bb, bool pre_next) {
+        constexpr int j = decltype(jc)::value;
 #pragma unroll
         for (int rho = 0; rho < ROWS; rho++) {
-          Frag8<T> fa = frag_ld_lds(slab + ((rho & 1) ? a_odd : a_even) + rho * LP * CK);
+          const int nxt = rho + 2;
+          if (nxt < ROWS) fa[nxt % 3] = frag_ld_lds(a_addr(kw, nxt));
+          else if (pre_next) fa[nxt % 3] = frag_ld_lds(a_addr(kw + 1, nxt - ROWS));
+          __builtin_amdgcn_sched_barrier(0);          // the prefetch stays above this row's MFMAs
 #pragma unroll
           for (int jh = 0; jh < JH; jh++) {
             const int num = rho - TS * jh;
             if (num < 0 || num % RS != 0 || num / RS >= RW) continue;      // compile-time after unrolling
-            acc[num / RS][j] = mma32(fa, bb[jh], acc[num / RS][j]);
+            acc[num / RS][j] = mma32(fa[rho % 3], bb[jh], acc[num / RS][j]);
           }
-          if (rho & 1) __builtin_amdgcn_sched_barrier(0);   // at most two A rows in flight: hoisting all ROWS reads costs 4 VGPRs each and spills
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (ROWS % 3 != 0) {                            // next column's rows 0, 1 sit in slots ROWS % 3, (ROWS + 1) % 3: bring them to 0, 1
+          const Frag8<T> t0 = fa[ROWS % 3], t1 = fa[(ROWS + 1) % 3];
+          fa[0] = t0; fa[1] = t1;
         }
       };
+      auto do_kw_same = [&](int kw, auto jc, const Frag8<T>* bb) {      // as do_kw, but the column that follows is kw again (two N tiles)
+        constexpr int j = decltype(jc)::value;
+#pragma unroll
+        for (int rho = 0; rho < ROWS; rho++) {
+          const int nxt = rho + 2;
+          fa[nxt % 3] = frag_ld_lds(a_addr(kw, nxt < ROWS ? nxt : nxt - ROWS));
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int jh = 0; jh < JH; jh++) {
+            const int num = rho - TS * jh;
+            if (num < 0 || num % RS != 0 || num / RS >= RW) continue;
+            acc[num / RS][j] = mma32(fa[rho % 3], bb[jh], acc[num / RS][j]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (ROWS % 3 != 0) {
+          const Frag8<T> t0 = fa[ROWS % 3], t1 = fa[(ROWS + 1) % 3];
+          fa[0] = t0; fa[1] = t1;
+        }
+      };
+      fa[0] = frag_ld_lds(a_addr(0, 0)); fa[1] = frag_ld_lds(a_addr(0, 1));
       std::integral_constant<int, 0> J0;
       // sched_barrier: without it the scheduler sinks the prefetch loads down to their first use (to shorten live ranges)
       // and every column pays the full L2 latency.
@@ -262,20 +298,20 @@ __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, 
 #pragma unroll 1
         for (int kw = 0; kw < KS; kw += 2) {        // KS is odd: the pass ends on b0, which is free again at the next pass's top
           if (kw + 1 < KS) { load_bk(wbase, kw + 1, 0, b1); __builtin_amdgcn_sched_barrier(0); }
-          do_kw(kw, J0, b0);
+          do_kw(kw, J0, b0, kw + 1 < KS);
           if (kw + 1 < KS) {
             if (kw + 2 < KS) { load_bk(wbase, kw + 2, 0, b0); __builtin_amdgcn_sched_barrier(0); }
-            do_kw(kw + 1, J0, b1);
+            do_kw(kw + 1, J0, b1, kw + 2 < KS);
           }
         }
       } else {                                      // two N tiles: they alternate between the register sets (A rows are read once per tile)
         std::integral_constant<int, NT - 1> J1;
 #pragma unroll 1
-        for (int kw = 0; kw < KS; kw++) {
+        for (int kw = 0; kw < KS; kw++) {              // (the second N tile sweeps the same column again: its "next column" is kw itself)
           load_bk(wbase, kw, 1, b1); __builtin_amdgcn_sched_barrier(0);
-          do_kw(kw, J0, b0);
+          do_kw_same(kw, J0, b0);
           if (kw + 1 < KS) { load_bk(wbase, kw + 1, 0, b0); __builtin_amdgcn_sched_barrier(0); }
-          do_kw(kw, J1, b1);
+          do_kw(kw, J1, b1, kw + 1 < KS);
         }
       }
     }

@@ -613,15 +613,16 @@ def test_fused_adam_capturable_replays_correct_steps():
     # (N, Cin, ca (virtual-concat split or 0), Cout, D, H, W, k)
     (2, 16, 0, 16, 5, 19, 70, 7),       # tap-paired epilogue, ragged H and W tiles
     (1, 32, 16, 16, 4, 9, 130, 3),      # virtual concat, TWC = 4
-    (2, 16, 0, 32, 25, 61, 40, 3),      # NPAIR == 1, one N tile (>= 400 blocks: no split-kd), ragged H
-    (1, 24, 0, 72, 10, 78, 33, 3),      # two N tiles per block + a second channel block (grid.y), ragged Cout / H
+    (2, 16, 0, 32, 50, 61, 40, 3),      # NPAIR == 1, one N tile (>= 400 blocks: no split-kd), ragged H
+    (1, 24, 0, 72, 20, 78, 33, 3),      # two N tiles per block + a second channel block (grid.y), ragged Cout / H
     (4, 32, 0, 64, 100, 16, 16, 3),     # W16 tiles (two image rows per MFMA tile)
     (1, 128, 0, 64, 4, 8, 16, 7),       # split-kd volume: statistics fall back to the row pass
     (1, 12, 0, 8, 6, 6, 6, 3)])         # too small for the tiled kernel: generic convolution + row pass
 def test_conv_epilogue_statistics(cfg, dtype):
     """conv3d(..., stats=True): the per-block (sum, sum of squares) rows written by the convolution epilogue (from the fp32
     accumulators) give the InstanceNorm / BatchNorm statistics of the output; checked through norm_act against the oracle's
-    conv -> norm -> act in float64, forward and backward, for both statistics modes."""
+    conv -> norm -> act in float64, forward and backward, for both statistics modes.  (Mish, not ReLU: with millions of elements a few
+    normalised values land within round-off of 0, where ReLU's derivative jumps and the comparison would measure that instead.)"""
     from dose_prediction_amd import ops
     dev = _dev()
     N, Cin, ca, Cout, D, H, W, k = cfg
@@ -632,10 +633,10 @@ def test_conv_epilogue_statistics(cfg, dtype):
         xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
         yr = oracle.conv3d(xr, wr, b.double(), 1, k // 2, 1)
         if kind == "instance":
-            zr = oracle.activation(oracle.instance_norm(yr), "relu")
+            zr = oracle.activation(oracle.instance_norm(yr), "mish")
         else:
             zr = oracle.activation(oracle.batch_norm(yr, torch.ones(Cout).double(), torch.zeros(Cout).double(), torch.zeros(Cout).double(),
-                                                     torch.ones(Cout).double(), True)[0], "relu")
+                                                     torch.ones(Cout).double(), True)[0], "mish")
         r = rnd(zr.shape, 4)
         zr.backward(r.double())
         xd = ndhwc(x).to(dev).to(dtype).requires_grad_(True)
@@ -657,12 +658,12 @@ def test_conv_epilogue_statistics(cfg, dtype):
         s = st.double().sum(1).cpu()
         ref1, ref2 = yr.detach().sum(dim=(2, 3, 4)), (yr.detach() ** 2).sum(dim=(2, 3, 4))
         std = (ref2 / V - (ref1 / V) ** 2).clamp_min(1e-12).sqrt()
-        tol = 1e-5 if (from_epilogue or dtype == torch.float32) else 5e-4
+        tol = 1e-5 if (from_epilogue or dtype == torch.float32) else 2e-3
         assert ((s[:, 0] - ref1).abs() / (V * std)).max() < tol
         assert ((s[:, 1] - ref2).abs() / ref2).max() < tol
         gam = torch.ones(Cout, device=dev)
         z = ops.norm_act(y, kind, gam if kind == "batch" else None, torch.zeros(Cout, device=dev) if kind == "batch" else None,
-                         act="relu", stats=st)
+                         act="mish", stats=st)
         check(f"stats {kind} fwd", ncdhw(z), zr, dtype, scale=2.0)
         z.backward(ndhwc(r).to(dev).to(dtype))
         gx = torch.cat((xa.grad, xb.grad), -1) if ca else xd.grad
