@@ -179,5 +179,15 @@ __device__ __forceinline__ float act_bwd(float z, int act) {
   }
 }
 
+// conv_cc16.hip: 16x16x32-MFMA convolution for the Cout <= 16 layers at W >= 96 (chosen by shape alone, so that the packed-weight
+// layout is known from (Cin, Cout, k, W))
+bool cc16_applicable(int Cin, int Cout, int k, int W);
+int cc16_weight_elems(int Cin, int Cout, int k);
+int cc16_pack(const float* w, void* dst, int Cout, int Cin, int k, int tf, int dtype, hipStream_t s);
+int cc16_stat_blocks(int D, int H, int W);
+bool cc16_wide(const void* y, int ldy, const void* y2, int ldy2, int osplit, int dtype);
+int cc16_launch(const void* x, int ldx, const void* x2, int ldx2, int csplit, const void* wq, const float* bias, void* y, int ldy,
+                void* y2, int ldy2, int osplit, float* stat_part, int N, int D, int H, int W, int Cin, int Cout, int k, int dtype, hipStream_t s);
+
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline int roundup8(int c) { return (c + 7) & ~7; }

@@ -1,0 +1,319 @@
+// Convolution for the 16-output-channel layers at the full-resolution level (stride 1, "same" padding, k in {3, 7}, Cout <= 16,
+// W >= 96): forward and -- with transposed + flipped weights -- data gradient.  These are the largest launches of the network
+// (conv_block_7 / conv_block_3 of decoder1, blocks_MDUNet.py:64-78,98-112; UnetResBlock of skip1; C3D encoder1 / decoder1,
+// c3d.py:11-22).
+//
+// v_mfma_f32_16x16x32_bf16 (f32: 8 x v_mfma_f32_16x16x4_f32), one instruction = 16 output positions along W x 16 output channels
+// x K = 32 = TWO horizontal taps (kw = 2p, 2p+1) x one 16-channel chunk.  Against the 32x32x16 kernel of conv_tiled.hip, which for
+// Cout <= 16 pairs two VERTICAL taps in N and recombines them in the epilogue:
+//   * no extra accumulator row per wave (RW = 9 rows of MFMAs for 8 output rows there) and no recombination shuffles,
+//   * the pairing padding is 1/8 of the MFMAs for 7x7x7 either way, so the MFMA count falls by 8/9, and the 16x16x32 shape holds
+//     a higher clock under load (MI355X_MICROARCH.md, "Shape": 1.12-1.15 x the FLOP/s of 32x32x16 at equal cycles per FLOP),
+//   * an accumulator tile is 4 registers per 16 positions: 8 rows x 32 positions = 64 VGPRs per depth slice, so a block owns DT = 2
+//     output depth slices and every staged input slab serves both of them (7 + 1 slabs per 2 slices instead of 7 per slice for
+//     7x7x7, 2 instead of 3 for 3x3x3: the 3x3x3 layers are bound by exactly this re-staging).
+// LDS traffic stays low because one A fragment (16 positions of slab row rho, tap pair p) feeds the MFMAs of EVERY vertical tap kh
+// whose output row rho - kh is inside the tile: 1 ds_read_b128 per 4 MFMAs.
+//
+// Block = 4 waves side by side (32 positions each = two 16-position M tiles), 8 output rows, DT depth slices.  Slab layout,
+// swizzle, staging and the transposing epilogue are those of conv_tiled.hip.
+#include "common.h"
+#include <stdlib.h>
+
+#define STREAM ((hipStream_t)stream)
+
+struct Cc16Geom {
+  int N, D, H, W, Cin, Cout, ldx, ldy, NCH, tiles_h, tiles_w, dtiles;
+  const void* x2; int ldx2, csplit;       // virtual concat of the input (channels >= csplit come from x2)
+  float* stat_part; int stat_nblk;        // normalisation statistics of the output (see TiledGeom in conv_tiled.hip)
+  void* y2; int ldy2, osplit;             // output channels >= osplit go to y2 (data gradient of a virtual concat)
+  int wide;                               // 16-byte aligned output rows: transposing epilogue; else scalar stores
+  int dbg;                                // experiments only (env DP_DBG): bit 0 skip staging, bit 1 skip the MFMA sweep, bit 2 skip the epilogue
+};
+
+bool cc16_applicable(int Cin, int Cout, int k, int W) {
+  static int off = -1;
+  if (off < 0) { const char* e = getenv("DP_NO_CC16"); off = (e && atoi(e)) ? 1 : 0; }
+  return !off && (k == 3 || k == 7) && Cout >= 8 && Cout <= 16 && Cin >= 1 && W >= 96;
+}
+int cc16_weight_elems(int Cin, int Cout, int k) { return k * ((Cin + 15) / 16) * ((k + 1) / 2) * k * 512; }
+
+// dst[kd][chunk][kwp][kh][co 16][k 32], k < 16: tap kw = 2 kwp, ci = chunk*16 + k; k >= 16: kw = 2 kwp + 1, ci = chunk*16 + k - 16.
+// transposed_flipped: w'[co][ci][tap] = w[ci][co][taps-1-tap] (data gradient as a forward convolution).
+template <typename T>
+__global__ void k_pack_w_cc16(const float* __restrict__ w, T* __restrict__ dst, int Cout, int Cin, int KS, int tf) {
+  const int KWP = (KS + 1) / 2, NCH = (Cin + 15) / 16, taps = KS * KS * KS;
+  const int total = KS * NCH * KWP * KS * 512;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int k = i & 31, co = (i >> 5) & 15; int t = i >> 9;
+    const int kh = t % KS; t /= KS; const int kwp = t % KWP; t /= KWP; const int ch = t % NCH; const int kd = t / NCH;
+    const int kw = 2 * kwp + (k >> 4), ci = ch * 16 + (k & 15);
+    float v = 0.f;
+    if (kw < KS && co < Cout && ci < Cin) {
+      const int tap = (kd * KS + kh) * KS + kw;
+      v = tf ? w[((int64_t)ci * Cout + co) * taps + (taps - 1 - tap)] : w[((int64_t)co * Cin + ci) * taps + tap];
+    }
+    st_f(dst + i, v);
+  }
+}
+int cc16_pack(const float* w, void* dst, int Cout, int Cin, int k, int tf, int dtype, hipStream_t s) {
+  const int total = cc16_weight_elems(Cin, Cout, k);
+  int g = (total + 255) / 256; if (g > 8192) g = 8192;
+  DP_DISPATCH(dtype, hipLaunchKernelGGL(k_pack_w_cc16<T>, dim3(g), dim3(256), 0, s, w, (T*)dst, Cout, Cin, k, tf));
+  DP_CHECK_LAUNCH("pack_conv_weight_cc16"); return 0;
+}
+
+template <typename T, int KS, int DT>
+__global__ void __launch_bounds__(256, 2) k_conv_cc16(const T* __restrict__ x, const T* __restrict__ wq, const float* __restrict__ bias,
+                                                   T* __restrict__ y, Cc16Geom g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* slab = (T*)smem_raw;
+  constexpr int PAD = KS / 2, KWP = (KS + 1) / 2, RWO = 8, ROWS = RWO + KS - 1, CK = 16, TW = 128;
+  constexpr int LP = (TW + KS - 1 + 7) & ~7, LR = ROWS;
+  constexpr bool SWZ = sizeof(T) == 2;
+  constexpr int lp_par = SWZ ? ((LP >> 3) & 1) : 0;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 15, q = lane >> 4;
+  // XCD-aware block order (see conv_tiled.hip): every XCD owns a contiguous range of depth tiles
+  int b = blockIdx.x;
+  if ((gridDim.x & 7) == 0) b = (b & 7) * (gridDim.x >> 3) + (b >> 3);
+  const int tw = b % g.tiles_w; b /= g.tiles_w; const int th = b % g.tiles_h; b /= g.tiles_h; const int dt = b % g.dtiles; const int n = b / g.dtiles;
+  const int h0 = th * RWO, w0 = tw * TW, d0 = dt * DT;
+
+  v4f acc[DT][RWO][2];
+#pragma unroll
+  for (int a = 0; a < DT; a++)
+#pragma unroll
+    for (int i = 0; i < RWO; i++)
+#pragma unroll
+      for (int m = 0; m < 2; m++) acc[a][i][m] = (v4f){0.f, 0.f, 0.f, 0.f};
+
+  constexpr int pieces = LR * LP * 2;              // 8-channel pieces of the slab
+  constexpr int SU = 8;
+  const bool fast = SWZ && (g.NCH * 16 <= (g.x2 ? g.csplit + g.ldx2 : g.ldx)) && (g.ldx % 8 == 0) && (((uintptr_t)x & 15) == 0) &&
+                    (!g.x2 || ((g.csplit % 16 == 0) && (g.ldx2 % 8 == 0) && (((uintptr_t)g.x2 & 15) == 0))) &&
+                    (int64_t)g.H * g.W * max(g.ldx, g.x2 ? g.ldx2 : 0) < (1ll << 30);
+  const int st_half = tid & 1, st_lp0 = (tid >> 1) % LP, st_lr0 = (tid >> 1) / LP;
+  // A operand: lane (r, q) = position r of the M tile, k-group q: q < 2 -> left tap of the pair, q >= 2 -> right tap (one voxel
+  // further), q & 1 = which 8-channel half of the voxel
+  const int v_lane = wv * 32 + r + (q >> 1), hsel = q & 1;
+  const int lane_off = r * 32 + q * 8;             // B operand: output channel r, k-group q of the packed [16][32] tile
+  constexpr int WT = 512;                          // elements per (kwp, kh) weight tile
+
+  for (int z = d0 - PAD; z < d0 + DT + PAD; z++) {
+    if (z < 0 || z >= g.D) continue;               // block-uniform: the whole depth slice is zero padding
+    for (int ch = 0; ch < g.NCH; ch++) {
+      lds_barrier();                               // every wave is done with the previous slab
+      if (g.dbg & 1) {
+      } else if (fast) {
+        const bool second = g.x2 && ch * CK >= g.csplit;
+        const T* xsrc = second ? (const T*)g.x2 : x;
+        const int ldsrc = second ? g.ldx2 : g.ldx, c0 = ch * CK - (second ? g.csplit : 0);
+        const T* xplane = xsrc + (((int64_t)n * g.D + z) * g.H) * (int64_t)g.W * ldsrc + c0 + st_half * 8;
+        int lp = st_lp0, lr = st_lr0, v = tid >> 1;
+        for (int p0 = 0; p0 < pieces; p0 += 256 * SU) {
+          v4u buf[SU]; int vv[SU];
+#pragma unroll
+          for (int j = 0; j < SU; j++) {
+            const int ih = h0 - PAD + lr, iw = w0 - PAD + lp;
+            const bool ok = (p0 + j * 256 + tid < pieces) && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W;
+            v4u t = *(const v4u*)(xplane + (ok ? (ih * g.W + iw) * ldsrc : 0));
+            buf[j] = ok ? t : (v4u){0, 0, 0, 0};
+            vv[j] = (p0 + j * 256 + tid < pieces) ? v : -1;
+            v += 128; lp += 128;
+#pragma unroll
+            for (int c_ = 0; c_ < (128 + LP - 1) / LP; c_++) if (lp >= LP) { lp -= LP; lr++; }
+          }
+#pragma unroll
+          for (int j = 0; j < SU; j++)
+            if (vv[j] >= 0) *(v4u*)(slab + (int64_t)vv[j] * CK + (st_half ^ ((vv[j] >> 3) & 1)) * 8) = buf[j];
+        }
+      } else {
+        for (int p = tid; p < pieces; p += 256) {
+          int half = p & 1, v = p >> 1, lp = v % LP, lr = v / LP;
+          int ih = h0 - PAD + lr, iw = w0 - PAD + lp, c = ch * CK + half * 8;
+          int nv = g.Cin - c; nv = nv > 8 ? 8 : nv;
+          bool ok = ih >= 0 && ih < g.H && iw >= 0 && iw < g.W && nv > 0;
+          const bool second = g.x2 && c >= g.csplit;
+          if (!second && g.x2 && c + nv > g.csplit) nv = g.csplit - c;
+          const T* xsrc = second ? (const T*)g.x2 : x;
+          const int ldsrc = second ? g.ldx2 : g.ldx, cc = c - (second ? g.csplit : 0);
+          Frag8<T> f = ok ? frag_load(xsrc + ((((int64_t)n * g.D + z) * g.H + ih) * g.W + iw) * ldsrc + cc, nv) : frag_zero<T>();
+          frag_st_lds(slab + (int64_t)v * CK + (half ^ (SWZ ? ((v >> 3) & 1) : 0)) * 8, f);
+        }
+      }
+      lds_barrier();
+#pragma unroll
+      for (int od = 0; od < DT; od++) {
+        const int kd = z - (d0 + od) + PAD;
+        if (kd < 0 || kd >= KS || d0 + od >= g.D || (g.dbg & 2)) continue;        // block-uniform
+        const T* wbase = wq + ((int64_t)(kd * g.NCH + ch) * KWP) * KS * WT + lane_off;
+        Frag8<T> b0[KS], b1[KS];
+        auto load_b = [&](int kwp, Frag8<T>* bb) {
+#pragma unroll
+          for (int kh = 0; kh < KS; kh++) bb[kh] = frag_ld_lds(wbase + (kwp * KS + kh) * WT);
+        };
+        // A fragments pipelined through three register sets (two reads in flight while a row's MFMAs issue); step s = 2 rho + mt
+        Frag8<T> fa[3];
+        auto a_ptr = [&](int kwp, int s) -> const T* {
+          const int rho = s >> 1, mt = s & 1;
+          const int vk = v_lane + 2 * kwp;
+          const int hs = SWZ ? (hsel ^ ((vk >> 3) & 1) ^ ((rho & 1) ? lp_par : 0)) : hsel;
+          return slab + (vk + rho * LP + mt * 16) * CK + hs * 8;
+        };
+        auto do_pair = [&](int kwp, const Frag8<T>* bb, bool pre_next) {
+          constexpr int S = 2 * ROWS;
+#pragma unroll
+          for (int s = 0; s < S; s++) {
+            const int nx = s + 2;
+            if (nx < S) fa[nx % 3] = frag_ld_lds(a_ptr(kwp, nx));
+            else if (pre_next) fa[nx % 3] = frag_ld_lds(a_ptr(kwp + 1, nx - S));
+            __builtin_amdgcn_sched_barrier(0);
+            const int rho = s >> 1, mt = s & 1;
+#pragma unroll
+            for (int kh = 0; kh < KS; kh++) {
+              const int orow = rho - kh;
+              if (orow < 0 || orow >= RWO) continue;                 // compile-time after unrolling
+              acc[od][orow][mt] = mma16(fa[s % 3], bb[kh], acc[od][orow][mt]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          if (S % 3 != 0) { const Frag8<T> t0 = fa[S % 3], t1 = fa[(S + 1) % 3]; fa[0] = t0; fa[1] = t1; }
+        };
+        load_b(0, b0);
+        fa[0] = frag_ld_lds(a_ptr(0, 0)); fa[1] = frag_ld_lds(a_ptr(0, 1));
+        static_assert(KWP % 2 == 0, "tap pairs are swept two at a time");
+#pragma unroll 1
+        for (int kwp = 0; kwp < KWP; kwp += 2) {
+          load_b(kwp + 1, b1); __builtin_amdgcn_sched_barrier(0);
+          do_pair(kwp, b0, true);
+          if (kwp + 2 < KWP) { load_b(kwp + 2, b0); __builtin_amdgcn_sched_barrier(0); }
+          do_pair(kwp + 1, b1, kwp + 2 < KWP);
+        }
+      }
+    }
+  }
+
+  // epilogue.  C/D layout of the 16x16 MFMA: column (output channel) = lane & 15, row (position) = 4 * (lane >> 4) + e.
+  // Each wave transposes one output row (32 positions x 16 channels) through a private LDS patch and writes 16-byte chunks.
+  constexpr int NC = 16;
+  constexpr int EPC = 16 / (int)sizeof(T), CPP = NC / EPC, PASSES = 32 * CPP / 64;
+  if (g.dbg & 4) return;
+  __syncthreads();                                                // every wave is done reading the slab
+  T* patch = slab + wv * (2 * 32 * NC);
+  const float bv = (bias && r < g.Cout) ? bias[r] : 0.f;
+  const int wbase_o = w0 + wv * 32;
+  T* y2 = (T*)g.y2;
+  if (!g.wide) {                                                  // unaligned output rows: plain 2/4-byte stores (rare shapes)
+#pragma unroll
+    for (int od = 0; od < DT; od++)
+#pragma unroll
+      for (int t = 0; t < RWO; t++)
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            const int d = d0 + od, oh = h0 + t, ow = wbase_o + mt * 16 + 4 * q + e;
+            if (d < g.D && oh < g.H && ow < g.W && r < g.Cout) {
+              const int64_t vox = (((int64_t)n * g.D + d) * g.H + oh) * g.W + ow;
+              T* dst = (y2 && r >= g.osplit) ? y2 + vox * g.ldy2 + (r - g.osplit) : y + vox * g.ldy + r;
+              st_f(dst, acc[od][t][mt][e] + bv);
+            }
+          }
+    return;
+  }
+  float st1 = 0.f, st2 = 0.f;
+#pragma unroll
+  for (int od = 0; od < DT; od++) {
+    const int d = d0 + od;
+    if (d >= g.D) continue;
+    if (g.stat_part) { st1 = 0.f; st2 = 0.f; }
+#pragma unroll
+    for (int t = 0; t < RWO; t++) {
+      T* pp = patch + (t & 1) * (32 * NC);
+      const int oh = h0 + t;
+#pragma unroll
+      for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const int m = mt * 16 + 4 * q + e;
+          const float v = acc[od][t][mt][e] + bv;
+          st_f(pp + m * NC + r, v);
+          const float vs = (oh < g.H && wbase_o + m < g.W) ? v : 0.f;
+          st1 += vs; st2 += vs * vs;
+        }
+      __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int ps = 0; ps < PASSES; ps++) {
+        const int qq = ps * 64 + lane, m = qq / CPP, cc = (qq % CPP) * EPC;
+        const int ow = wbase_o + m;
+        if (oh < g.H && ow < g.W && cc < g.Cout) {
+          const int64_t vox = (((int64_t)n * g.D + d) * g.H + oh) * g.W + ow;
+          T* dst = (y2 && cc >= g.osplit) ? y2 + vox * g.ldy2 + (cc - g.osplit) : y + vox * g.ldy + cc;
+          if (cc + EPC <= g.Cout) *(v4u*)dst = *(const v4u*)(pp + m * NC + cc);
+          else for (int k = 0; k < EPC; k++) if (cc + k < g.Cout) dst[k] = pp[m * NC + cc + k];
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (g.stat_part) {          // block-uniform: per-channel (sum, sum of squares) of this block's voxels of depth slice d
+      float a1 = st1 + __shfl_xor(st1, 16, 64), a2 = st2 + __shfl_xor(st2, 16, 64);
+      a1 += __shfl_xor(a1, 32, 64); a2 += __shfl_xor(a2, 32, 64);
+      __syncthreads();
+      float* sred = (float*)(smem_raw + 4 * 2 * 32 * NC * sizeof(T));      // behind the four waves' patches
+      if (lane < 16) { sred[(wv * 2) * 16 + lane] = a1; sred[(wv * 2 + 1) * 16 + lane] = a2; }
+      __syncthreads();
+      if (tid < 32) {
+        const int which = tid >> 4, c = tid & 15;
+        if (c < g.Cout) {
+          const int blk = (d * g.tiles_h + th) * g.tiles_w + tw;
+          g.stat_part[(((int64_t)n * g.stat_nblk + blk) * 2 + which) * g.Cout + c] =
+              (sred[(0 + which) * 16 + c] + sred[(2 + which) * 16 + c]) + (sred[(4 + which) * 16 + c] + sred[(6 + which) * 16 + c]);
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+int cc16_stat_blocks(int D, int H, int W) { return D * cdiv(H, 8) * cdiv(W, 128); }
+
+template <typename T, int KS>
+static int cc16_go(const void* x, const void* wq, const float* bias, void* y, Cc16Geom g, hipStream_t s) {
+  // (fp32 fragments are twice as wide: one depth slice per block keeps the parity mode's register spills down)
+  constexpr int DT = sizeof(T) == 4 ? 1 : 2, ROWS = 8 + KS - 1, LP = (128 + KS - 1 + 7) & ~7;
+  size_t smem = (size_t)ROWS * LP * 16 * sizeof(T);
+  const size_t need = 4 * 2 * 32 * 16 * sizeof(T) + 8 * 16 * sizeof(float);      // epilogue patches + statistics scratch
+  if (smem < need) smem = need;
+  auto kern = k_conv_cc16<T, KS, DT>;
+  if (smem > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) { dp_set_error("conv_cc16: cannot raise dynamic LDS to %zu: %s", smem, hipGetErrorString(e)); return 1; }
+  }
+  g.dtiles = cdiv(g.D, DT);
+  const int64_t blocks = (int64_t)g.N * g.dtiles * g.tiles_h * g.tiles_w;
+  if (blocks > 2000000000LL) { dp_set_error("conv_cc16: grid too large"); return 1; }
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), smem, s, (const T*)x, (const T*)wq, bias, (T*)y, g);
+  return 0;
+}
+
+bool cc16_wide(const void* y, int ldy, const void* y2, int ldy2, int osplit, int dtype) {
+  const int es = dtype == DP_F32 ? 4 : 2, epc = 16 / es;
+  return (ldy * es) % 16 == 0 && (((uintptr_t)y & 15) == 0) && (!y2 || ((ldy2 * es) % 16 == 0 && (((uintptr_t)y2 & 15) == 0) && osplit % epc == 0));
+}
+int cc16_launch(const void* x, int ldx, const void* x2, int ldx2, int csplit, const void* wq, const float* bias, void* y, int ldy,
+                void* y2, int ldy2, int osplit, float* stat_part, int N, int D, int H, int W, int Cin, int Cout, int k, int dtype, hipStream_t s) {
+  Cc16Geom g;
+  { const char* e = getenv("DP_DBG"); g.dbg = e ? atoi(e) : 0; }
+  g.y2 = y2; g.ldy2 = ldy2; g.osplit = osplit; g.wide = cc16_wide(y, ldy, y2, ldy2, osplit, dtype) ? 1 : 0;
+  if (stat_part && !g.wide) { dp_set_error("conv_cc16: statistics need 16-byte aligned output rows"); return 1; }
+  g.N = N; g.D = D; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.ldx = ldx; g.ldy = ldy; g.NCH = (Cin + 15) / 16;
+  g.tiles_h = cdiv(H, 8); g.tiles_w = cdiv(W, 128); g.dtiles = 0;
+  g.x2 = x2; g.ldx2 = ldx2; g.csplit = csplit; g.stat_part = stat_part; g.stat_nblk = cc16_stat_blocks(D, H, W);
+  int rc = 0;
+  if (dtype == DP_BF16) rc = k == 7 ? cc16_go<bf16_t, 7>(x, wq, bias, y, g, s) : cc16_go<bf16_t, 3>(x, wq, bias, y, g, s);
+  else if (dtype == DP_F16) rc = k == 7 ? cc16_go<f16_t, 7>(x, wq, bias, y, g, s) : cc16_go<f16_t, 3>(x, wq, bias, y, g, s);
+  else if (dtype == DP_F32) rc = k == 7 ? cc16_go<float, 7>(x, wq, bias, y, g, s) : cc16_go<float, 3>(x, wq, bias, y, g, s);
+  else { dp_set_error("conv_cc16: bad dtype"); return 1; }
+  if (rc) return rc;
+  DP_CHECK_LAUNCH("conv_cc16"); return 0;
+}

@@ -100,8 +100,18 @@ static inline bool tiled_applicable(int Cin, int Cout, int k, int stride, int pa
   return (k == 3 || k == 7) && stride == 1 && dil == 1 && pad == k / 2 && W >= 16 && Cin >= 1 && Cout >= 8;
 }
 
+// 0: the shape takes the generic kernel; 1: k_conv_tiled layout (dp_pack_conv_weight_tiled); 2: k_conv_cc16 layout
+// (dp_pack_conv_weight_cc16).  A function of the shape alone, so the packed copies can be cached per (Cin, Cout, k, W class).
+extern "C" int dp_conv3d_tiled_layout(int Cin, int Cout, int k, int stride, int pad, int dil, int W) {
+  if (!tiled_applicable(Cin, Cout, k, stride, pad, dil, W)) return 0;
+  return cc16_applicable(Cin, Cout, k, W) ? 2 : 1;
+}
+extern "C" int dp_pack_conv_weight_cc16(const float* w, void* dst, int Cout, int Cin, int k, int transposed_flipped, int dtype, void* stream) {
+  return cc16_pack(w, dst, Cout, Cin, k, transposed_flipped, dtype, STREAM);
+}
 extern "C" int dp_conv3d_tiled_weight_elems(int Cin, int Cout, int k, int stride, int pad, int dil, int W) {
   if (!tiled_applicable(Cin, Cout, k, stride, pad, dil, W)) return 0;
+  if (cc16_applicable(Cin, Cout, k, W)) return cc16_weight_elems(Cin, Cout, k);
   int rw, nt; int np = tiled_config(Cout, &rw, &nt);
   int JH = np == 2 ? (k + 1) / 2 : k;
   return k * JH * k * ((Cin + 15) / 16) * ((Cout * np + 31) / 32) * 512;
@@ -532,6 +542,7 @@ static void tiled_geometry(TiledGeom& g, int k, int np, int rw, int nt, int* ygr
 // fp32 scratch elements dp_conv3d_tiled needs for this shape (0 = none)
 extern "C" int dp_conv3d_tiled_ws_elems(int N, int D, int H, int W, int Cin, int Cout, int k) {
   if (!tiled_applicable(Cin, Cout, k, 1, k / 2, 1, W)) return 0;
+  if (cc16_applicable(Cin, Cout, k, W)) return 0;
   int rw, nt; int np = tiled_config(Cout, &rw, &nt);
   TiledGeom g; g.N = N; g.D = D; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.dbg = 0; g.x2 = nullptr; g.y2 = nullptr;
   int ygrid; bool w16; tiled_geometry(g, k, np, rw, nt, &ygrid, &w16);
@@ -549,6 +560,7 @@ static bool tiled_wide(const TiledGeom& g, const void* y, int dtype) {
 // launch cannot produce statistics (split-kd volumes, output rows that are not 16-byte aligned: the caller then runs dp_stats_partial).
 extern "C" int dp_conv3d_tiled_stat_blocks(int N, int D, int H, int W, int Cin, int Cout, int k, int ldy, int dtype) {
   if (!tiled_applicable(Cin, Cout, k, 1, k / 2, 1, W)) return 0;
+  if (cc16_applicable(Cin, Cout, k, W)) return cc16_wide(nullptr, ldy, nullptr, 0, 0, dtype) ? cc16_stat_blocks(D, H, W) : 0;
   int rw, nt; int np = tiled_config(Cout, &rw, &nt);
   TiledGeom g; g.N = N; g.D = D; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.dbg = 0; g.x2 = nullptr; g.y2 = nullptr; g.ldy = ldy;
   int ygrid; bool w16; tiled_geometry(g, k, np, rw, nt, &ygrid, &w16);
@@ -584,6 +596,8 @@ static int conv3d_tiled_impl(const void* x, int ldx, const void* x2, int ldx2, i
   if (!tiled_applicable(Cin, Cout, k, 1, k / 2, 1, W)) DP_FAIL("conv3d_tiled: shape not supported");
   if (x2 && (csplit <= 0 || csplit >= Cin || csplit % 8)) DP_FAIL("conv3d_tiled: input split must be a multiple of 8 inside (0, Cin)");
   if (y2 && (osplit <= 0 || osplit >= Cout || osplit % 8)) DP_FAIL("conv3d_tiled: output split must be a multiple of 8 inside (0, Cout)");
+  if (cc16_applicable(Cin, Cout, k, W))
+    return cc16_launch(x, ldx, x2, ldx2, csplit, wq, bias, y, ldy, y2, ldy2, osplit, stat_part, N, D, H, W, Cin, Cout, k, dtype, STREAM);
   int rw, nt; int np = tiled_config(Cout, &rw, &nt);
   TiledGeom g;
   g.N = N; g.D = D; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.ldx = ldx; g.ldy = ldy;

@@ -8,7 +8,7 @@
 #define STREAM ((hipStream_t)stream)
 #define PACK_CHUNK 8192          // destination elements per block (matrix-transpose tiles: 64 rows x 128 columns)
 
-enum { PK_CAST = 0, PK_MAT = 1, PK_MAT_T = 2, PK_CONV = 3, PK_CONV_TILED = 4, PK_TCONV = 5 };
+enum { PK_CAST = 0, PK_MAT = 1, PK_MAT_T = 2, PK_CONV = 3, PK_CONV_TILED = 4, PK_TCONV = 5, PK_CONV_CC16 = 6 };
 
 struct PackDesc { const float* src; void* dst; int64_t kind, a, b, c, d, e; };
 
@@ -60,6 +60,9 @@ __global__ void __launch_bounds__(256) k_pack_multi(const PackDesc* __restrict__
   else if (kind == PK_CONV_TILED) {
     const int KS = (int)P.c, NP = (int)P.d;
     total = (unsigned)(KS * (NP == 2 ? (KS + 1) / 2 : KS) * KS * ((P.b + 15) / 16) * ((P.a * NP + 31) / 32) * 512);
+  } else if (kind == PK_CONV_CC16) {
+    const int KS = (int)P.c;
+    total = (unsigned)(KS * ((P.b + 15) / 16) * ((KS + 1) / 2) * KS * 512);
   } else total = (unsigned)(P.d ? P.a * P.c : 8 * P.b * P.c);
   const unsigned end = min(total, base + PACK_CHUNK);
   for (unsigned i = base + threadIdx.x; i < end; i += 256) {
@@ -88,6 +91,17 @@ __global__ void __launch_bounds__(256) k_pack_multi(const PackDesc* __restrict__
       else { kh = jh; co = nt * 32 + col; }
       const int ci = ch * 16 + c;
       if (kh < KS && co < Cout && ci < Cin) {
+        const int tap = (kd * KS + kh) * KS + kw;
+        v = tf ? w[((int64_t)ci * Cout + co) * taps + (taps - 1 - tap)] : w[((int64_t)co * Cin + ci) * taps + tap];
+      }
+    } else if (kind == PK_CONV_CC16) {
+      // dst[kd][chunk][kwp][kh][co 16][k 32]   (k_pack_w_cc16)
+      const int Cout = (int)P.a, Cin = (int)P.b, KS = (int)P.c, tf = (int)P.e;
+      const int KWP = (KS + 1) / 2, NCH = (Cin + 15) / 16, taps = KS * KS * KS;
+      const int k = (int)(i & 31), co = (int)((i >> 5) & 15); unsigned t = i >> 9;
+      const int kh = (int)(t % KS); t /= KS; const int kwp = (int)(t % KWP); t /= KWP; const int ch = (int)(t % NCH); const int kd = (int)(t / NCH);
+      const int kw = 2 * kwp + (k >> 4), ci = ch * 16 + (k & 15);
+      if (kw < KS && co < Cout && ci < Cin) {
         const int tap = (kd * KS + kh) * KS + kw;
         v = tf ? w[((int64_t)ci * Cout + co) * taps + (taps - 1 - tap)] : w[((int64_t)co * Cin + ci) * taps + tap];
       }

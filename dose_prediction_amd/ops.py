@@ -221,21 +221,25 @@ def _tiled_ws(like, N, D, H, W, cin, cout, k):
     return _zero_scratch(like.device, n) if n else None
 
 
-def _pack_conv_tiled(w, tf, dtype, elems):
-    """Weights for the LDS-tiled conv kernel (tf=1: transposed+flipped, i.e. the data-gradient convolution)."""
-    def build():
-        cout, cin, k = w.shape[0], w.shape[1], w.shape[2]
-        dst = torch.empty((elems,), dtype=dtype, device=w.device)
-        wc = w.detach().contiguous()
-        if tf:
-            _lib.call("dp_pack_conv_weight_tiled", _p(wc), _p(dst), cin, cout, k, 1, _DT[dtype], _stream())
-        else:
-            _lib.call("dp_pack_conv_weight_tiled", _p(wc), _p(dst), cout, cin, k, 0, _DT[dtype], _stream())
-        return dst
+def _pack_conv_tiled(w, tf, dtype, elems, W):
+    """Weights for the LDS-tiled conv kernels (tf=1: transposed+flipped, i.e. the data-gradient convolution); W = row length of
+    the volume the convolution runs on (selects the 32x32x16 or the 16x16x32 kernel's layout: dp_conv3d_tiled_layout)."""
     k = w.shape[2]
     co, ci = (w.shape[1], w.shape[0]) if tf else (w.shape[0], w.shape[1])      # roles in the convolution being computed
-    return _packs.get(w, ("conv_tiled", tf, dtype, elems), build,
-                      lambda dst: (4, co, ci, k, _lib.lib().dp_conv3d_tiled_npair(co), 1 if tf else 0))
+    layout = _lib.lib().dp_conv3d_tiled_layout(ci, co, k, 1, k // 2, 1, W)
+    fn = "dp_pack_conv_weight_cc16" if layout == 2 else "dp_pack_conv_weight_tiled"
+
+    def build():
+        dst = torch.empty((elems,), dtype=dtype, device=w.device)
+        wc = w.detach().contiguous()
+        _lib.call(fn, _p(wc), _p(dst), co, ci, k, 1 if tf else 0, _DT[dtype], _stream())
+        return dst
+
+    def desc(dst):
+        if layout == 2:
+            return (6, co, ci, k, 0, 1 if tf else 0)
+        return (4, co, ci, k, _lib.lib().dp_conv3d_tiled_npair(co), 1 if tf else 0)
+    return _packs.get(w, ("conv_tiled", tf, dtype, elems, layout), build, desc)
 
 
 def _pack_tconv(w, transposed, dtype):
@@ -433,7 +437,7 @@ class Conv3d(torch.autograd.Function):
         te = _tiled_elems(cin, cout, k, stride, pad, dil, Wi) if k > 1 else 0
         part = None
         if te:
-            wq = _pack_conv_tiled(weight, 0, x.dtype, te)
+            wq = _pack_conv_tiled(weight, 0, x.dtype, te, Wi)
             nblk = _lib.lib().dp_conv3d_tiled_stat_blocks(N, Di, Hi, Wi, cin, cout, k, cout, _dt(x)) if want_stats else 0
             if nblk:
                 # the statistics of the normalisation that follows come out of the epilogue's fp32 accumulators
@@ -488,7 +492,7 @@ class Conv3d(torch.autograd.Function):
                 gemm_nt(gy, wt, gx, M=grows, N=cin, K=cout, lda=ldg, ldb=wt.shape[-1], ldc=cx)
             elif stride == 1 and _tiled_elems(cout, cin, k, 1, dil * (k - 1) - pad, dil, Wo):
                 te = _tiled_elems(cout, cin, k, 1, dil * (k - 1) - pad, dil, Wo)
-                wq = _pack_conv_tiled(weight, 1, x.dtype, te)
+                wq = _pack_conv_tiled(weight, 1, x.dtype, te, Wo)
                 _lib.call("dp_conv3d_tiled", _p(gy), ldg, _p(wq), 0, _p(gx), cx, _p(_tiled_ws(x, N, Do, Ho, Wo, cout, cin, k)),
                           N, Do, Ho, Wo, cout, cin, k, dtc, _stream())
             elif stride == 1:
@@ -579,7 +583,7 @@ class Conv3dCat(torch.autograd.Function):
         N, D, H, W = xa.shape[:4]
         cout, cin, k = weight.shape[0], weight.shape[1], weight.shape[2]
         y = torch.empty((N, D, H, W, cout), dtype=xa.dtype, device=xa.device)
-        wq = _pack_conv_tiled(weight, 0, xa.dtype, _tiled_elems(cin, cout, k, 1, pad, 1, W))
+        wq = _pack_conv_tiled(weight, 0, xa.dtype, _tiled_elems(cin, cout, k, 1, pad, 1, W), W)
         b32 = None if bias is None else bias.detach()
         nblk = _lib.lib().dp_conv3d_tiled_stat_blocks(N, D, H, W, cin, cout, k, cout, _dt(xa)) if want_stats else 0
         part = None
@@ -617,7 +621,7 @@ class Conv3dCat(torch.autograd.Function):
             gxb = torch.empty((N, D, H, W, cbp), dtype=xa.dtype, device=xa.device)
             if cbp > cin - ca:
                 gxb.zero_()
-            wq = _pack_conv_tiled(weight, 1, xa.dtype, _tiled_elems(cout, cin, k, 1, k - 1 - pad, 1, W))
+            wq = _pack_conv_tiled(weight, 1, xa.dtype, _tiled_elems(cout, cin, k, 1, k - 1 - pad, 1, W), W)
             _lib.call("dp_conv3d_tiled2", _p(gy), ldg, 0, 0, 0, _p(wq), 0, _p(gxa), ca, _p(gxb), cbp, ca,
                       _p(_tiled_ws(xa, N, D, H, W, cout, cin, k)), N, D, H, W, cout, cin, k, dtc, _stream())
         if ctx.needs_input_grad[2]:

@@ -188,6 +188,11 @@ int dp_conv3d(const void* x, int ldx, const void* wp, const float* bias, void* y
  * shape and 0 when the shape must take dp_conv3d (NOT an error code).  Packed layout: see conv_tiled.hip. */
 int dp_conv3d_tiled_weight_elems(int Cin, int Cout, int k, int stride, int pad, int dil, int W);
 int dp_pack_conv_weight_tiled(const float* w, void* dst, int Cout, int Cin, int k, int transposed_flipped, int dtype, void* stream);
+/* Which LDS-tiled kernel (and packed-weight layout) a shape takes: 0 none (generic dp_conv3d), 1 the 32x32x16 kernel
+ * (dp_pack_conv_weight_tiled), 2 the 16x16x32 kernel for Cout <= 16 at W >= 96 (dp_pack_conv_weight_cc16; layout
+ * [kd][ci chunk][kw pair][kh][co 16][32 = two horizontal taps x 16 ci]).  dp_conv3d_tiled_weight_elems covers both. */
+int dp_conv3d_tiled_layout(int Cin, int Cout, int k, int stride, int pad, int dil, int W);
+int dp_pack_conv_weight_cc16(const float* w, void* dst, int Cout, int Cin, int k, int transposed_flipped, int dtype, void* stream);
 /* small volumes split the kd loop over blocks and accumulate in an fp32 scratch: dp_conv3d_tiled_ws_elems gives its size (0 = not needed). */
 int dp_conv3d_tiled_ws_elems(int N, int D, int H, int W, int Cin, int Cout, int k);
 int dp_conv3d_tiled(const void* x, int ldx, const void* wq, const float* bias, void* y, int ldy, float* ws, int N, int D, int H, int W,
@@ -247,6 +252,7 @@ int dp_adam_multi_dev(const void* table, const int32_t* chunk_t, const int32_t* 
  *   kind 2 transposed matrix: dst[r][c] = src[c*a + r] (a rows, b valid columns, pitch c);
  *   kind 3 = dp_pack_conv_weight(Cout=a, Cin=b, taps=c, mode=d);
  *   kind 4 = dp_pack_conv_weight_tiled(Cout=a, Cin=b, k=c, NPAIR=d (dp_conv3d_tiled_npair), transposed_flipped=e);
+ *   kind 6 = dp_pack_conv_weight_cc16(Cout=a, Cin=b, k=c, transposed_flipped=e);
  *   kind 5 ConvTranspose3d(k2,s2) weight [Cin=a][Cout=b][8] -> d == 0: [(abc,co)][pitch c over ci], d != 0: [ci][pitch c over (abc,co)].
  * chunk_t/chunk_i map each block to (table row, chunk); a chunk is dp_pack_chunk() destination elements, for kind 2 one
  * 64-row x 128-column destination tile (row-major tile index).  All destinations share the storage type `dtype`. */
