@@ -24,7 +24,7 @@ busy += ce - cs
 print(f"step span {1e-6 * (s1 - s0):.2f} ms, GPU busy {1e-6 * busy:.2f} ms, {len(sel)} kernels")
 c, n = collections.Counter(), collections.Counter()
 for s, e, nm in sel:
-    k = nm.split("(")[0][:70]
+    k = nm.replace("(anonymous namespace)::", "").split("(")[0][:70]
     c[k] += e - s
     n[k] += 1
 top = int(sys.argv[2]) if len(sys.argv) > 2 else 40
