@@ -1126,18 +1126,20 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_cc16(const T* __restrict__ x, 
   const bool fast = (g.ldx % 8 == 0) && (g.ldgy % 8 == 0) && (((uintptr_t)x & 15) == 0) && (((uintptr_t)gy & 15) == 0) &&
                     (!g.x2 || ((g.csplit % 8 == 0) && (g.ldx2 % 8 == 0) && (((uintptr_t)g.x2 & 15) == 0)));
   if (!fast) return;                                                // the launcher only selects this kernel for aligned operands
-  if (cu < u1) issue(tile_of(cu, ctw));
+  const bool dbg_nostage = g.dbg & 1, dbg_nosweep = g.dbg & 2;       // experiments only (env DP_DBG)
+  if (cu < u1 && !dbg_nostage) issue(tile_of(cu, ctw));
   while (cu < u1) {
     const Tile t = tile_of(cu, ctw);
     lds_barrier();
-    commit();
+    if (!dbg_nostage) commit();
     int nu = cu, ntw = ctw; advance(nu, ntw);
-    if (nu < u1) issue(tile_of(nu, ntw));
+    if (nu < u1 && !dbg_nostage) issue(tile_of(nu, ntw));
     lds_barrier();
-    if (nkh > 0)
+    if (nkh > 0 && !dbg_nosweep)
       for (int c = c_lo; c < min(c_hi, t.nch); c++) sweep(c);
     cu = nu; ctw = ntw;
   }
+  if (g.dbg & 4) return;
   // C/D of the 16x16 MFMA: col (co) = lane&15, row (ci) = 4*(lane>>4) + e
 #pragma unroll
   for (int kk = 0; kk < C::KPW; kk++) {
