@@ -1179,7 +1179,12 @@ static int launch_wg16(const void* x, const void* gy, float* ws, WgtGeom g, hipS
   }
   int want = (ncu * occ) / (KS * zdim); if (want < 1) want = 1;
   int ydim = units < want ? units : want;
-  if (ydim >= 8 && (ydim & 7) * 20 <= ydim) ydim &= ~7;
+  // multiple of 8 => XCD-aware decode in the kernel.  Experiment knob DP_WG_YDIM8: 1 = always round down, 2 = round up
+  static int y8 = -1;
+  if (y8 < 0) { const char* e = getenv("DP_WG_YDIM8"); y8 = e ? atoi(e) : 0; }
+  if (ydim >= 8 && y8 == 1) ydim &= ~7;
+  else if (ydim >= 8 && y8 == 2) ydim = (ydim + 7) & ~7;
+  else if (ydim >= 8 && (ydim & 7) * 20 <= ydim) ydim &= ~7;
   g.ydim = ydim; g.zdim = zdim;
   hipLaunchKernelGGL(kern, dim3(KS * ydim * zdim), dim3(256), C::SMEM, s, (const T*)x, (const T*)gy, ws, g);
   return 0;
