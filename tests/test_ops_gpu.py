@@ -80,6 +80,9 @@ DTYPES = [torch.float32, torch.bfloat16, torch.float16]
     (1, 9, 16, 4, 11, 36, 3, 1, 1, 1, True),
     (1, 128, 64, 2, 6, 32, 3, 1, 1, 1, True),
     (2, 1, 16, 3, 9, 40, 3, 1, 1, 1, False),      # single input channel (OAR-TRANSEG encoder1: CT -> 16)
+    (4, 128, 128, 12, 12, 12, 7, 1, 3, 1, True),  # 12^3 level of the 96^3 sliding-window crop (W < 16 tiles), batch of 4 windows
+    (2, 64, 32, 12, 12, 12, 3, 1, 1, 1, False),
+    (1, 16, 16, 10, 9, 12, 3, 1, 1, 1, True),     # W < 16 with the tap-paired (Cout <= 16) configuration
     (1, 3, 16, 2, 9, 32, 7, 1, 3, 1, True),
     (2, 64, 32, 8, 8, 10, 3, 2, 1, 1, True),      # few voxels, many channels, stride 2: im2col + GEMM forward
     (1, 40, 24, 6, 5, 7, 3, 1, 2, 2, False),      # same path with dilation and ragged channels
