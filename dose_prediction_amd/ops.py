@@ -206,6 +206,29 @@ def _zero_scratch(device, n):
 GRAD_DEST = {}
 
 
+_ZERO_POOL = {}
+
+
+def _zero_bias_grad(bias):
+    """An all-zero fp32 gradient for a bias whose gradient is identically zero (bias_grad_zero): a persistent per-parameter slice of
+    one zero buffer per device instead of a fill launch per layer and step.  Nothing ever writes a non-zero into it: optimizers only
+    read gradients, zero_grad / scaling / accumulating another such gradient leave zeros zero."""
+    dev = bias.device
+    pool = _ZERO_POOL.get(dev)
+    if pool is None:
+        pool = _ZERO_POOL[dev] = {"buf": torch.zeros((1 << 16,), dtype=torch.float32, device=dev), "used": 0, "slots": {}}
+    key = (bias.data_ptr(), bias.numel())
+    off = pool["slots"].get(key)
+    n = bias.numel()
+    if off is None:
+        if pool["used"] + n > pool["buf"].numel():
+            return torch.zeros(bias.shape, dtype=torch.float32, device=dev)
+        off = pool["slots"][key] = pool["used"]
+        pool["used"] += (n + 63) // 64 * 64
+    # a FRESH view object every time: autograd adopts it as .grad without a copy only if nobody else holds the tensor object
+    return pool["buf"][off:off + n].view(bias.shape)
+
+
 def _wgrad_buffer(weight, zero):
     f = GRAD_DEST.get(weight.data_ptr()) if GRAD_DEST else None
     buf = f() if f is not None else None
@@ -464,6 +487,7 @@ class Conv3d(torch.autograd.Function):
         ctx.save_for_backward(x, weight)
         ctx.cfg = (stride, pad, dil, bias is not None)
         ctx.bias_grad_zero = bias_grad_zero
+        ctx.bias_ref = bias if bias_grad_zero else None
         if want_stats:
             if part is None:
                 part = _stats_partial(y)
@@ -513,7 +537,7 @@ class Conv3d(torch.autograd.Function):
             ws = torch.empty((wse,), dtype=torch.float32, device=x.device)
             _lib.call("dp_pointwise_wgrad_rows", _p(x), ldx, _p(gy), ldg, _p(gw), cin, _p(gb), _p(ws), grows, cin, cout, dtc, _stream())
             if has_bias and ctx.needs_input_grad[2] and ctx.bias_grad_zero:
-                gb = torch.zeros((cout,), dtype=torch.float32, device=x.device)
+                gb = _zero_bias_grad(ctx.bias_ref)
             return gx, gw, gb, None, None, None, None, None
         if ctx.needs_input_grad[1] and k == 1 and stride == 1 and pad == 0 and grows < 32768:
             # pointwise conv over few voxels: dW[co][ci] = gy^T x, both k-major in memory (split over K to fill the chip)
@@ -539,7 +563,7 @@ class Conv3d(torch.autograd.Function):
             if ctx.bias_grad_zero:
                 # the output feeds a normalisation over batch statistics: sum_v d(loss)/dy[v][c] is identically zero (the reference
                 # accumulates pure round-off there), so no column-sum pass over gy is made
-                gb = torch.zeros((cout,), dtype=torch.float32, device=x.device)
+                gb = _zero_bias_grad(ctx.bias_ref)
             else:
                 gb = torch.empty((cout,), dtype=torch.float32, device=x.device)
                 colsum_into(_p(gy), ldg, grows, cout, gb, dtc)
@@ -597,6 +621,7 @@ class Conv3dCat(torch.autograd.Function):
         ctx.save_for_backward(xa, xb, weight)
         ctx.cfg = (pad, bias is not None)
         ctx.bias_grad_zero = bias_grad_zero
+        ctx.bias_ref = bias if bias_grad_zero else None
         if want_stats:
             if part is None:
                 part = _stats_partial(y)
@@ -632,7 +657,7 @@ class Conv3dCat(torch.autograd.Function):
                       cin * taps, taps, 1, dtc, _stream())
         if has_bias and ctx.needs_input_grad[3]:
             if ctx.bias_grad_zero:
-                gb = torch.zeros((cout,), dtype=torch.float32, device=xa.device)
+                gb = _zero_bias_grad(ctx.bias_ref)
             else:
                 gb = torch.empty((cout,), dtype=torch.float32, device=xa.device)
                 colsum_into(_p(gy), ldg, grows, cout, gb, dtc)
