@@ -379,8 +379,10 @@ def main():
         else:
             for p in params:
                 p.grad = None
-        xin = cascade.cascade_structures(seg, ct_in, ptv_in, roi_size=roi if args.roi else None)[0] if seg is not None else x
-        out = net(xin)
+        if seg is not None:     # cascade: the glue's NDHWC staging buffer goes straight into the dose network
+            out = net.forward_staged(cascade.cascade_structures(seg, ct_in, ptv_in, roi_size=roi if args.roi else None, staged=True)[0])
+        else:
+            out = net(x)
         if args.model in ("pyfer", "cascade"):
             loss = losses.gen_loss(out, gt, 10.0, 1.0, casecade=True, freez=True)
         else:
@@ -497,7 +499,7 @@ def main():
         }
         if fp32_leg is not None:
             res["fp32_mode"] = fp32_leg
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # (the host-side baseline is reported by the 1-GPU run only)
             try:
                 res["cpu_baseline"] = cpu_baseline(args)
             except Exception as e:   # the GPU numbers stay valid if the host leg fails

@@ -91,22 +91,26 @@ def _put_channel(staged, ch, vol):
 
 
 @torch.no_grad()
-def cascade_structures(seg_model, ct, ptv, reverse_axes=True, roi_size=None, sw_batch_size=4, overlap=0.25):
+def cascade_structures(seg_model, ct, ptv, reverse_axes=True, roi_size=None, sw_batch_size=4, overlap=0.25, staged=False):
     """The 9-channel PYFER input [B,9,D,H,W] fp32 of the linked model (train_light_linked_model.py:143-167) from a CT and a PTV
     channel: OAR-TRANSEG (no grad) -> arg-max -> one-hot classes 1..7 -> axis reversal -> cat(ptv, oars, ct).  Used when the dose
-    network TRAINS on the segmentation network's masks (BASELINE.json configs[3], [4]); returns (structures, labels)."""
+    network TRAINS on the segmentation network's masks (BASELINE.json configs[3], [4]); returns (structures, labels).
+    staged=True returns the NDHWC staging buffer itself (compute dtype, 16 channels) for dose_model.forward_staged()."""
     B = ct.shape[0]
     if roi_size is not None and tuple(roi_size) != tuple(ct.shape[2:]):
         logits = sliding_window_logits(seg_model, ct, tuple(roi_size), sw_batch_size, overlap)
     else:
         logits = seg_model.forward_ndhwc(to_ndhwc(ct))
     D, H, W = logits.shape[1:4]
+    staged_out = staged
     staged = torch.zeros((B, D, H, W, 16), dtype=config.compute_dtype(), device=ct.device)
     labels = ops.argmax_onehot(logits, staged, choff=1, labels=True)
     _put_channel(staged, 8, ct)
     if reverse_axes:
         staged = staged.permute(0, 3, 2, 1, 4).contiguous()
     _put_channel(staged, 0, ptv)
+    if staged_out:
+        return staged, labels
     return from_ndhwc(staged)[:, :9].float().contiguous(), labels
 
 

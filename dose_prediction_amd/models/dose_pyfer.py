@@ -204,7 +204,12 @@ class Model(nn.Module):
         self.conv_out_A = nn.Conv3d(list_ch_A[1], out_ch, kernel_size=1, padding=0, bias=True)
 
     def forward(self, x):
-        xh = to_ndhwc(x)
+        return self.forward_staged(to_ndhwc(x))
+
+    def forward_staged(self, xh):
+        """forward() on an input that already is NDHWC in the compute dtype with its 9 channels zero-padded to 16 (what
+        cascade.cascade_structures(..., staged=True) builds in place): saves the NDHWC -> NCDHW fp32 -> NDHWC round trip of the
+        cascade glue (train_light_linked_model.py:165-168 hands the concatenated structures straight to the dose network)."""
         out_net_A = self.net_A.forward_ndhwc(xh)
         out_net_B = self.net_B.forward_ndhwc(ops.cat((out_net_A, xh)), (out_net_A, xh))
         output_A = ops.conv3d(out_net_A, self.conv_out_A.weight, self.conv_out_A.bias)

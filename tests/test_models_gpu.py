@@ -233,6 +233,11 @@ def test_cascade_glue():
     # the training-time variant of the glue hands the same 9-channel tensor to the trainer (fp32 mode: exact)
     st, lab2 = cascade.cascade_structures(seg, ct.to(dev), ptv.to(dev))
     assert torch.equal(lab2.cpu(), labels.cpu()) and torch.equal(st.cpu(), structures)
+    # ... and the staged (NDHWC) form fed to forward_staged() gives the same dose as the NCDHW form through forward()
+    stg, _ = cascade.cascade_structures(seg, ct.to(dev), ptv.to(dev), staged=True)
+    with torch.no_grad():
+        a, b = dose(st)[1][0], dose.forward_staged(stg)[1][0]
+    assert rel_err(a.cpu(), b.cpu()) < 1e-5          # (split-kd atomics: not bitwise)
 
 
 def test_activation_checkpointing():
