@@ -318,6 +318,10 @@ class PatchEmbeddingBlock(nn.Module):
         lin = self.patch_embeddings[1]
         nn.init.trunc_normal_(lin.weight, mean=0.0, std=0.02, a=-2.0, b=2.0)
         nn.init.zeros_(lin.bias)
+        # the patch embedding is the transformer's first layer = its LAST backward node: once its gradient is in place, the grouped
+        # launch fills every transformer weight gradient recorded during the backward pass (ops.flush_deferred), still on the ViT stream
+        lin.bias.register_post_accumulate_grad_hook(ops.flush_deferred)
+        lin.weight.register_post_accumulate_grad_hook(ops.flush_deferred)
 
     def forward(self, x):
         lin = self.patch_embeddings[1]
@@ -326,7 +330,7 @@ class PatchEmbeddingBlock(nn.Module):
         # K = p^3*C is huge while M x N is small: split K so the GEMM fills the 256 CUs
         # ... with 128x128 tiles in two full rounds (<= 512 blocks): 425 -> 283 us at 1024 x 768 x 102400
         splitk = max(1, min(32, 480 // max(1, -(-rows // 128) * -(-lin.out_features // 128))))
-        t = ops.linear(tok, lin.weight, lin.bias, splitk=splitk if tok.shape[-1] >= 4096 else 1)
+        t = ops.linear(tok, lin.weight, lin.bias, splitk=splitk if tok.shape[-1] >= 4096 else 1, defer_wgrad=True)
         return ops.add_broadcast(t, self.position_embeddings)
 
 
@@ -338,8 +342,8 @@ class SABlock(nn.Module):
         self.qkv = nn.Linear(hidden_size, hidden_size * 3, bias=False)
 
     def forward(self, x):
-        o = ops.attention(ops.linear(x, self.qkv.weight), self.num_heads)
-        return ops.linear(o, self.out_proj.weight, self.out_proj.bias)
+        o = ops.attention(ops.linear(x, self.qkv.weight, defer_wgrad=True), self.num_heads)
+        return ops.linear(o, self.out_proj.weight, self.out_proj.bias, defer_wgrad=True)
 
 
 class MLPBlock(nn.Module):
@@ -350,7 +354,8 @@ class MLPBlock(nn.Module):
         self.fn = nn.GELU()
 
     def forward(self, x):
-        return ops.linear(ops.gelu(ops.linear(x, self.linear1.weight, self.linear1.bias)), self.linear2.weight, self.linear2.bias)
+        return ops.linear(ops.gelu(ops.linear(x, self.linear1.weight, self.linear1.bias, defer_wgrad=True)), self.linear2.weight,
+                          self.linear2.bias, defer_wgrad=True)
 
 
 class TransformerBlock(nn.Module):

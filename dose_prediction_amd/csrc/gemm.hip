@@ -211,14 +211,14 @@ extern "C" int dp_gemm_nt(const void* A, int64_t lda, int64_t sa0, int64_t sa1, 
 // gradient of a row-major layer looks like (dW[out][in] = gy^T x with k = token / voxel rows).  The 64-row k slabs are
 // staged as they lie; the MFMA fragments (8 consecutive k of one column per lane) come out of LDS through
 // ds_read_b64_tr_b16 (fp32: scalar column reads).  Replaces two k_transpose launches + k_gemm_nt per weight gradient.
+// One 64 x 64 output tile of C = A^T B (the body shared by k_gemm_tn and k_gemm_tn_grouped).  colsum != nullptr: the tile also
+// leaves colsum[m] = sum_k A[k][m] for its 64 columns m (the bias gradient of a Linear layer: A = gy), from the staged A tiles.
 template <typename T>
-__global__ void __launch_bounds__(256) k_gemm_tn(const T* __restrict__ A, int64_t lda, const T* __restrict__ B, int64_t ldb, float* __restrict__ C,
-                                                 int64_t ldc, int M, int N, int K, int splitk) {
+__device__ __forceinline__ void gemm_tn_tile(const T* __restrict__ A, int64_t lda, const T* __restrict__ B, int64_t ldb, float* __restrict__ C,
+                                             int64_t ldc, int M, int N, int K, int splitk, int m0, int n0, int ks, float* __restrict__ colsum,
+                                             T* As, T* Bs) {
   constexpr int BT = 64, BKT = 64, LDPT = BT + 8, CPRT = BT / 8, UT = BKT * CPRT / 256;     // 72-element LDS rows; 2 chunks per thread per operand
-  __shared__ __attribute__((aligned(16))) T As[BKT * LDPT];
-  __shared__ __attribute__((aligned(16))) T Bs[BKT * LDPT];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1, r = lane & 15, q = lane >> 4;
-  const int m0 = blockIdx.x * BT, n0 = blockIdx.y * BT, ks = blockIdx.z;
   const int ktiles = (K + BKT - 1) / BKT, per = (ktiles + splitk - 1) / splitk, kt0 = ks * per, kt1 = min(ktiles, kt0 + per);
   v4f acc[2][2];
 #pragma unroll
@@ -226,6 +226,7 @@ __global__ void __launch_bounds__(256) k_gemm_tn(const T* __restrict__ A, int64_
 #pragma unroll
     for (int j = 0; j < 2; j++) acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
   Frag8<T> ra[UT], rb[UT];
+  float csum = 0.f;
   const bool fast = m0 + BT <= M && n0 + BT <= N && ((lda | ldb) & 7) == 0 && (((uintptr_t)A | (uintptr_t)B) & 15) == 0;
   auto gload = [&](int kt) {
 #pragma unroll
@@ -258,6 +259,11 @@ __global__ void __launch_bounds__(256) k_gemm_tn(const T* __restrict__ A, int64_
     }
     __syncthreads();
     if (kt + 1 < kt1) gload(kt + 1);
+    if (colsum) {                                  // block-uniform: thread t adds rows (t >> 6) * 16 .. + 15 of column t & 63
+      const int cc = tid & 63, r0 = (tid >> 6) * 16;
+#pragma unroll
+      for (int rr = 0; rr < 16; rr++) csum += ld_f(As + (r0 + rr) * LDPT + cc);
+    }
 #pragma unroll
     for (int kk = 0; kk < BKT; kk += 32) {
       Frag8<T> fa[2], fb[2];
@@ -283,6 +289,36 @@ __global__ void __launch_bounds__(256) k_gemm_tn(const T* __restrict__ A, int64_
         if (splitk > 1) atomicAdd(C + (int64_t)row * ldc + col, acc[i][j][e]); else C[(int64_t)row * ldc + col] = acc[i][j][e];
       }
   }
+  if (colsum) {
+    __syncthreads();
+    float* red = (float*)As;
+    red[tid] = csum;
+    __syncthreads();
+    if (tid < 64 && m0 + tid < M) colsum[m0 + tid] = (red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]);
+  }
+}
+template <typename T>
+__global__ void __launch_bounds__(256) k_gemm_tn(const T* __restrict__ A, int64_t lda, const T* __restrict__ B, int64_t ldb, float* __restrict__ C,
+                                                 int64_t ldc, int M, int N, int K, int splitk) {
+  __shared__ __attribute__((aligned(16))) T As[64 * 72];
+  __shared__ __attribute__((aligned(16))) T Bs[64 * 72];
+  gemm_tn_tile<T>(A, lda, B, ldb, C, ldc, M, N, K, splitk, blockIdx.x * 64, blockIdx.y * 64, blockIdx.z, nullptr, As, Bs);
+}
+// Grouped form: ONE launch computes the weight (and bias) gradients of many Linear layers (the 8 transformer layers x 4 weights
+// + the patch embedding: every one a separate, latency-bound 25-us launch before).  table row p (12 x int64): A, B, C, colsum
+// pointers, lda, ldb, ldc, M, N, K, first tile id, tiles along M.  Tile ids are dealt problem-major, n-tile-major, m fastest.
+struct TnProblem { const void* A; const void* B; float* C; float* colsum; int64_t lda, ldb, ldc, M, N, K, tile0, tiles_m; };
+template <typename T>
+__global__ void __launch_bounds__(256) k_gemm_tn_grouped(const TnProblem* __restrict__ tab, int nprob) {
+  __shared__ __attribute__((aligned(16))) T As[64 * 72];
+  __shared__ __attribute__((aligned(16))) T Bs[64 * 72];
+  const int64_t bid = blockIdx.x;
+  int p = 0;
+  while (p + 1 < nprob && tab[p + 1].tile0 <= bid) p++;          // (uniform scalar loads; <= a few dozen problems)
+  const TnProblem P = tab[p];
+  const int t = (int)(bid - P.tile0), tm = (int)P.tiles_m, mi = t % tm, ni = t / tm;
+  gemm_tn_tile<T>((const T*)P.A, P.lda, (const T*)P.B, P.ldb, P.C, P.ldc, (int)P.M, (int)P.N, (int)P.K, 1, mi * 64, ni * 64, 0,
+                  (P.colsum && ni == 0) ? P.colsum : nullptr, As, Bs);
 }
 extern "C" int dp_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int M, int N, int K, int splitk,
                           int dtype, void* stream) {
@@ -292,4 +328,10 @@ extern "C" int dp_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb
   if (g.y > 65535 || g.z > 65535) DP_FAIL("gemm_tn: grid too large");
   DP_DISPATCH(dtype, hipLaunchKernelGGL(k_gemm_tn<T>, g, dim3(256), 0, STREAM, (const T*)A, lda, (const T*)B, ldb, C, ldc, M, N, K, splitk));
   DP_CHECK_LAUNCH("gemm_tn"); return 0;
+}
+extern "C" int dp_gemm_tn_grouped(const void* table, int nproblems, int64_t total_tiles, int dtype, void* stream) {
+  if (nproblems <= 0 || total_tiles <= 0) return 0;
+  if (total_tiles > 2000000000LL) DP_FAIL("gemm_tn_grouped: too many tiles");
+  DP_DISPATCH(dtype, hipLaunchKernelGGL(k_gemm_tn_grouped<T>, dim3((unsigned)total_tiles), dim3(256), 0, STREAM, (const TnProblem*)table, nproblems));
+  DP_CHECK_LAUNCH("gemm_tn_grouped"); return 0;
 }

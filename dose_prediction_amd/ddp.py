@@ -123,6 +123,8 @@ class GradAllReducer:
         self._streams = []
 
     def _launch(self, bi, at_end=False):
+        from . import ops
+        ops.flush_deferred()         # gradient tensors handed out unwritten (grouped Linear weight gradients) are filled first
         flat = self.flat[bi]
         cur = torch.cuda.current_stream() if flat.is_cuda else None
         if cur is not None:

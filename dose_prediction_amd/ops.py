@@ -747,11 +747,80 @@ def conv_transpose2x(x, weight):
     return ConvTranspose2x.apply(x, weight)
 
 
+# ------------------------------------------------------------------------------------------------ deferred weight gradients
+# The weight / bias gradients of the transformer's Linear layers are 33 separate TN GEMMs + 25 column sums per step, each a
+# latency-bound 5-25 us launch on 1024 token rows.  They feed nothing inside the backward pass, so a Linear created with
+# defer_wgrad=True only RECORDS its (gy, x, dW, db) and returns the (still unwritten) gradient tensors; ONE grouped launch
+# (dp_gemm_tn_grouped) fills all of them at the end of the backward pass, or earlier when somebody needs them (flush_deferred():
+# the data-parallel reducer before it packs a bucket, FusedAdam.step()).
+_DEFER = {"pending": [], "queued": False, "host": None, "rot": 0, "enabled": os.environ.get("DOSE_HIP_DEFER_WGRAD", "1") != "0"}
+
+
+def _defer_wgrad(gy, ldg, x, ldx, weight, bias, nout, nin, rows):
+    """(the PARAMETERS are recorded, not the gradient tensors handed to autograd: holding a second reference to those would make
+    AccumulateGrad clone them, and the grouped launch would then fill the orphaned originals; at flush time p.grad is the tensor
+    autograd kept)"""
+    ev = torch.cuda.Event()
+    ev.record()                                            # on the stream that produced gy (the ViT branch runs on a side stream)
+    _DEFER["pending"].append((gy, ldg, x, ldx, weight, bias, nout, nin, rows, ev, torch.cuda.current_stream()))
+    if not _DEFER["queued"]:
+        # (safety net: whatever is still pending at the end of the backward pass is flushed then)
+        torch.autograd.Variable._execution_engine.queue_callback(flush_deferred)
+        _DEFER["queued"] = True
+
+
+def flush_deferred(*_unused):
+    """Launch the grouped weight-gradient GEMM for everything recorded so far, on the stream that recorded it (the ViT branch's side
+    stream: the launch then overlaps the 128^3 branch's backward on the main stream), and make the current stream wait for it.
+    No-op when nothing is pending.  Also usable as a post-accumulate-grad hook (PatchEmbeddingBlock registers it on its weight: the
+    first layer of the transformer is its last backward node)."""
+    _DEFER["queued"] = False
+    pend, _DEFER["pending"] = _DEFER["pending"], []
+    cur = torch.cuda.current_stream() if (pend or _DEFER.get("last_stream") is not None) else None
+    by = {}
+    for e in pend:
+        by.setdefault((e[0].dtype, e[0].device, e[10]), []).append(e)
+    for (dtype, dev, st), lst in by.items():
+        rows_tab, tile0 = [], 0
+        for gy, ldg, x, ldx, weight, bias, nout, nin, rows, ev, _st in lst:
+            gw, gb = weight.grad, (None if bias is None else bias.grad)
+            if gw is None or (bias is not None and gb is None):
+                _DEFER["pending"].append((gy, ldg, x, ldx, weight, bias, nout, nin, rows, ev, st))    # not accumulated yet: next flush
+                continue
+            if gw.dtype != torch.float32 or not gw.is_contiguous() or (gb is not None and not gb.is_contiguous()):
+                raise _lib.DoseHipError("deferred weight gradient: the parameter's .grad is not a contiguous fp32 tensor")
+            tm, tn = -(-nout // 64), -(-nin // 64)
+            rows_tab.append((gy.data_ptr(), x.data_ptr(), gw.data_ptr(), 0 if gb is None else gb.data_ptr(), ldg, ldx, nin, nout, nin, rows, tile0, tm))
+            tile0 += tm * tn
+            for t in (gw, gb):
+                if t is not None:
+                    t.record_stream(st)
+        # table: rotating pinned host buffers (the async copy of the previous flush may still be reading the last one)
+        n = len(rows_tab)
+        if n == 0:
+            continue
+        if _DEFER["host"] is None or _DEFER["host"][0].shape[0] < n:
+            _DEFER["host"] = [torch.empty((max(n, 64), 12), dtype=torch.int64).pin_memory() for _ in range(4)]
+        host = _DEFER["host"][_DEFER["rot"] % 4]
+        _DEFER["rot"] += 1
+        host[:n] = torch.tensor(rows_tab, dtype=torch.int64)
+        with torch.cuda.stream(st):
+            tab = torch.empty((n, 12), dtype=torch.int64, device=dev)
+            tab.copy_(host[:n], non_blocking=True)
+            _lib.call("dp_gemm_tn_grouped", _p(tab), n, tile0, _DT[dtype], st.cuda_stream)
+        _DEFER["last_stream"] = st
+    last = _DEFER.get("last_stream")
+    if last is not None and cur is not None and last != cur:
+        cur.wait_stream(last)           # whoever asked for the flush reads the gradients on the current stream
+        if not pend:
+            _DEFER["last_stream"] = None
+
+
 class Linear(torch.autograd.Function):
     """nn.Linear on token rows (MONAI ViT blocks; patch embedding uses splitk)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, splitk):
+    def forward(ctx, x, weight, bias, splitk, defer_wgrad=False):
         _chk_dev(x, weight)
         x = as_rows(x)
         rows, K, ldx = rows_ld(x)
@@ -770,6 +839,8 @@ class Linear(torch.autograd.Function):
             gemm_nt(x, wp, y, bias=b32, M=rows, N=nout, K=K, lda=ldx, ldb=wp.shape[-1], ldc=nout)
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        ctx.bias_ref = bias if defer_wgrad else None
+        ctx.defer = defer_wgrad
         return y
 
     @staticmethod
@@ -784,6 +855,14 @@ class Linear(torch.autograd.Function):
             wt = _pack_mat(weight, True, x.dtype)            # [in][outP]
             gx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
             gemm_nt(gy, wt, gx, M=rows, N=K, K=nout, lda=ldg, ldb=wt.shape[-1], ldc=K)
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
+        if (ctx.defer and _DEFER["enabled"] and ctx.needs_input_grad[1] and rows <= 16384 and weight.grad is None
+                and (not want_b or ctx.bias_ref.grad is None)):
+            # recorded for the grouped launch at the end of the backward pass; dW and db are returned unwritten
+            gw = _wgrad_buffer(weight, False)
+            gb = torch.empty((nout,), dtype=torch.float32, device=x.device) if want_b else None
+            _defer_wgrad(gy, ldg, x, ldx, weight, ctx.bias_ref if want_b else None, nout, K, rows)
+            return gx, gw, gb, None, None
         if ctx.needs_input_grad[1]:
             if rows <= 16384:
                 # token matrices: dW[out][in] = gy^T x, both operands k-major (k = token rows) as they lie in memory
@@ -795,11 +874,13 @@ class Linear(torch.autograd.Function):
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = torch.empty((nout,), dtype=torch.float32, device=x.device)
             colsum_into(_p(gy), ldg, rows, nout, gb, dtc)
-        return gx, gw, gb, None
+        return gx, gw, gb, None, None
 
 
-def linear(x, weight, bias=None, splitk=1):
-    return Linear.apply(x, weight, bias, splitk)
+def linear(x, weight, bias=None, splitk=1, defer_wgrad=False):
+    """defer_wgrad=True (weights that are used once per forward pass and not shared): the weight / bias gradients are produced by
+    one grouped launch at the end of the backward pass instead of two to three small launches here."""
+    return Linear.apply(x, weight, bias, splitk, defer_wgrad)
 
 
 # ------------------------------------------------------------------------------------------------ normalisation

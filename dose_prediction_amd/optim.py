@@ -55,6 +55,7 @@ class FusedAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        ops.flush_deferred()          # (weight gradients recorded for the grouped launch: normally flushed at the end of backward)
         for gi, group in enumerate(self.param_groups):
             plist = [p for p in group["params"] if p.grad is not None]
             if not plist:
