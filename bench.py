@@ -13,6 +13,7 @@ import argparse
 import json
 import os
 import sys
+import math
 import time
 
 import torch
@@ -440,6 +441,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     final_loss = float(loss.detach())
+    if not math.isfinite(final_loss):
+        # a non-finite loss means the timed steps did not do the work the metric names: no line is better than a wrong one
+        raise SystemExit(f"[bench] non-finite loss after the timed steps ({final_loss}); refusing to report a throughput")
     peak_mem = torch.cuda.max_memory_allocated() / 2 ** 30
     # the tolerance-meeting mode, timed by the same harness: the identical step in fp32 storage / exact-fp32 MFMA
     fp32_leg = None

@@ -398,11 +398,19 @@ class ViT(nn.Module):
         stream and lets consumers of hidden[i] wait for events[i] only: models.dose_pyfer.run_vit_beside)."""
         x = self.patch_embedding(x)
         hidden = []
-        for blk in self.blocks:
-            x = blk(x)
+        if not self.blocks:
+            return ops.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps), hidden
+        # pre-norm blocks x = x + attn(norm1(x)); x = x + mlp(norm2(x)), with every residual add fused into the LayerNorm that reads
+        # its result (ops.add_layer_norm): norm2 of the same block, then norm1 of the next block (the final ViT.norm after the last)
+        first = self.blocks[0]
+        n = ops.layer_norm(x, first.norm1.weight, first.norm1.bias, first.norm1.eps)
+        for i, blk in enumerate(self.blocks):
+            x, n = ops.add_layer_norm(x, blk.attn(n), blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
+            nxt = self.blocks[i + 1].norm1 if i + 1 < len(self.blocks) else self.norm
+            x, n = ops.add_layer_norm(x, blk.mlp(n), nxt.weight, nxt.bias, nxt.eps)
             hidden.append(x)
             if events is not None:
                 ev = torch.cuda.Event()
                 ev.record()
                 events.append(ev)
-        return ops.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps), hidden
+        return n, hidden

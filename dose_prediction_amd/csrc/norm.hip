@@ -474,11 +474,18 @@ extern "C" int dp_norm_act_bwd_apply(const void* x, int ldx, const void* gy, int
 }
 
 // ---------------------------------------------------------------------------- LayerNorm: one wave per row
+// xb != nullptr: the row normalised is the STORED sum x + xb (rounded to T exactly as a separate add kernel would), which is also
+// written to `sum` -- the residual add of a pre-norm transformer block fused with the LayerNorm that follows it.
 template <typename T>
-__global__ void k_layernorm_fwd(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, T* __restrict__ y,
-                                float* __restrict__ mean, float* __restrict__ rstd, int64_t rows, int C, float eps) {
+__global__ void k_layernorm_fwd(const T* __restrict__ x, const T* __restrict__ xb, T* __restrict__ sum, const float* __restrict__ gamma,
+                                const float* __restrict__ beta, T* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd, int64_t rows,
+                                int C, float eps) {
   int lane = threadIdx.x & 63; int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
+  if (xb) {
+    for (int c = lane; c < C; c += 64) st_f(sum + row * C + c, ld_f(x + row * C + c) + ld_f(xb + row * C + c));
+    x = sum;          // (each lane re-reads only the columns it wrote itself)
+  }
   const T* a = x + row * C; T* o = y + row * C;
   float s = 0.f;
   for (int c = lane; c < C; c += 64) s += ld_f(a + c);
@@ -518,9 +525,9 @@ __global__ void k_layernorm_bwd(const T* __restrict__ x, const T* __restrict__ g
 // C <= 1024: every lane keeps its (up to 16) columns of the row in registers -> one read of x / gy per row, and the
 // dgamma / dbeta partials stay in registers over the wave's rows (no LDS atomics in the row loop).
 template <typename T>
-__global__ void __launch_bounds__(256) k_layernorm_bwd_reg(const T* __restrict__ x, const T* __restrict__ gy, const float* __restrict__ gamma,
-                                const float* __restrict__ mean, const float* __restrict__ rstd, T* __restrict__ gx, float* __restrict__ dgamma,
-                                float* __restrict__ dbeta, int64_t rows, int C, int rows_per_block) {
+__global__ void __launch_bounds__(256) k_layernorm_bwd_reg(const T* __restrict__ x, const T* __restrict__ gy, const T* __restrict__ gres,
+                                const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd, T* __restrict__ gx,
+                                float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t rows, int C, int rows_per_block) {
   __shared__ float sm[4][2][1024];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   float gam[16], ag[16], ab[16];
@@ -541,7 +548,8 @@ __global__ void __launch_bounds__(256) k_layernorm_bwd_reg(const T* __restrict__
 #pragma unroll
     for (int i = 0; i < 16; i++) {
       int c = lane + 64 * i;
-      if (c < C) st_f(o + c, r * (d[i] * gam[i] - s1 - xh[i] * s2));
+      // gres: the gradient that reaches the same tensor through the residual path (fused add + LayerNorm): one rounding, one store
+      if (c < C) st_f(o + c, r * (d[i] * gam[i] - s1 - xh[i] * s2) + (gres ? ld_f(gres + row * C + c) : 0.f));
       ag[i] += d[i] * xh[i]; ab[i] += d[i];
     }
   }
@@ -555,15 +563,23 @@ __global__ void __launch_bounds__(256) k_layernorm_bwd_reg(const T* __restrict__
 }
 extern "C" int dp_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int64_t rows, int C,
                                 float eps, int dtype, void* stream) {
-  DP_DISPATCH(dtype, hipLaunchKernelGGL(k_layernorm_fwd<T>, dim3(cdiv(rows, 4)), dim3(256), 0, STREAM, (const T*)x, gamma, beta, (T*)y, mean, rstd, rows, C, eps));
+  DP_DISPATCH(dtype, hipLaunchKernelGGL(k_layernorm_fwd<T>, dim3(cdiv(rows, 4)), dim3(256), 0, STREAM, (const T*)x, (const T*)nullptr, (T*)nullptr, gamma, beta,
+                                        (T*)y, mean, rstd, rows, C, eps));
   DP_CHECK_LAUNCH("layernorm_fwd"); return 0;
+}
+extern "C" int dp_add_layernorm_fwd(const void* a, const void* b, void* sum, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                                    int64_t rows, int C, float eps, int dtype, void* stream) {
+  if (!b || !sum) DP_FAIL("add_layernorm_fwd: operands missing");
+  DP_DISPATCH(dtype, hipLaunchKernelGGL(k_layernorm_fwd<T>, dim3(cdiv(rows, 4)), dim3(256), 0, STREAM, (const T*)a, (const T*)b, (T*)sum, gamma, beta,
+                                        (T*)y, mean, rstd, rows, C, eps));
+  DP_CHECK_LAUNCH("add_layernorm_fwd"); return 0;
 }
 extern "C" int dp_layernorm_bwd(const void* x, const void* gy, const float* gamma, const float* mean, const float* rstd, void* gx, float* dgamma,
                                 float* dbeta, int64_t rows, int C, int dtype, void* stream) {
   if (C <= 1024) {
     int rpb = rows >= 8192 ? 16 : (rows >= 2048 ? 8 : 4);          // token matrices (1024 rows): one row per wave, 256 blocks
-    DP_DISPATCH(dtype, hipLaunchKernelGGL(k_layernorm_bwd_reg<T>, dim3(cdiv(rows, rpb)), dim3(256), 0, STREAM, (const T*)x, (const T*)gy, gamma,
-                                          mean, rstd, (T*)gx, dgamma, dbeta, rows, C, rpb));
+    DP_DISPATCH(dtype, hipLaunchKernelGGL(k_layernorm_bwd_reg<T>, dim3(cdiv(rows, rpb)), dim3(256), 0, STREAM, (const T*)x, (const T*)gy, (const T*)nullptr,
+                                          gamma, mean, rstd, (T*)gx, dgamma, dbeta, rows, C, rpb));
     DP_CHECK_LAUNCH("layernorm_bwd"); return 0;
   }
   int rpb = 16;
@@ -571,4 +587,13 @@ extern "C" int dp_layernorm_bwd(const void* x, const void* gy, const float* gamm
   DP_DISPATCH(dtype, hipLaunchKernelGGL(k_layernorm_bwd<T>, dim3(cdiv(rows, rpb)), dim3(256), 2 * C * sizeof(float), STREAM, (const T*)x, (const T*)gy, gamma,
                                         mean, rstd, (T*)gx, dgamma, dbeta, rows, C, rpb));
   DP_CHECK_LAUNCH("layernorm_bwd"); return 0;
+}
+// backward of the fused residual add + LayerNorm: gx = gsum + LayerNorm'(gy)  (C <= 1024)
+extern "C" int dp_add_layernorm_bwd(const void* x, const void* gy, const void* gsum, const float* gamma, const float* mean, const float* rstd, void* gx,
+                                    float* dgamma, float* dbeta, int64_t rows, int C, int dtype, void* stream) {
+  if (C > 1024) DP_FAIL("add_layernorm_bwd: C > 1024 not supported");
+  int rpb = rows >= 8192 ? 16 : (rows >= 2048 ? 8 : 4);
+  DP_DISPATCH(dtype, hipLaunchKernelGGL(k_layernorm_bwd_reg<T>, dim3(cdiv(rows, rpb)), dim3(256), 0, STREAM, (const T*)x, (const T*)gy, (const T*)gsum,
+                                        gamma, mean, rstd, (T*)gx, dgamma, dbeta, rows, C, rpb));
+  DP_CHECK_LAUNCH("add_layernorm_bwd"); return 0;
 }

@@ -795,18 +795,29 @@ def flush_deferred(*_unused):
             for t in (gw, gb):
                 if t is not None:
                     t.record_stream(st)
-        # table: rotating pinned host buffers (the async copy of the previous flush may still be reading the last one)
+        # table: rotating pinned host buffers, each guarded by the event of the copy that last read it (the host thread runs several
+        # steps ahead of the GPU when nothing synchronises: an unguarded buffer is overwritten before its copy has executed)
         n = len(rows_tab)
         if n == 0:
             continue
-        if _DEFER["host"] is None or _DEFER["host"][0].shape[0] < n:
-            _DEFER["host"] = [torch.empty((max(n, 64), 12), dtype=torch.int64).pin_memory() for _ in range(4)]
-        host = _DEFER["host"][_DEFER["rot"] % 4]
+        if _DEFER["host"] is None or _DEFER["host"][0][0].shape[0] < n:
+            for _h, e in (_DEFER["host"] or ()):
+                if e is not None:
+                    e.synchronize()
+            _DEFER["host"] = [[torch.empty((max(n, 64), 12), dtype=torch.int64).pin_memory(), None] for _ in range(4)]
+        slot = _DEFER["host"][_DEFER["rot"] % 4]
         _DEFER["rot"] += 1
+        if slot[1] is not None and not torch.cuda.is_current_stream_capturing():     # (torch.cuda.graph synchronises on entry)
+            slot[1].synchronize()
+        host = slot[0]
         host[:n] = torch.tensor(rows_tab, dtype=torch.int64)
         with torch.cuda.stream(st):
             tab = torch.empty((n, 12), dtype=torch.int64, device=dev)
             tab.copy_(host[:n], non_blocking=True)
+            slot[1] = None
+            if not torch.cuda.is_current_stream_capturing():
+                slot[1] = torch.cuda.Event()
+                slot[1].record(st)
             _lib.call("dp_gemm_tn_grouped", _p(tab), n, tile0, _DT[dtype], st.cuda_stream)
         _DEFER["last_stream"] = st
     last = _DEFER.get("last_stream")
@@ -1089,6 +1100,52 @@ class LayerNorm(torch.autograd.Function):
 
 def layer_norm(x, gamma, beta, eps=1e-5):
     return LayerNorm.apply(x, gamma, beta, eps)
+
+
+class AddLayerNorm(torch.autograd.Function):
+    """(s, z) = (a + b, LayerNorm(a + b)): the residual add of a pre-norm transformer block fused with the LayerNorm that consumes it
+    (dp_add_layernorm_fwd / _bwd); the backward adds the residual-path gradient of s inside the LayerNorm backward kernel."""
+
+    @staticmethod
+    def forward(ctx, a, b, gamma, beta, eps):
+        _chk_dev(a, b)
+        a, b = a.contiguous(), b.contiguous()
+        C = a.shape[-1]
+        rows = a.numel() // C
+        s, z = torch.empty_like(a), torch.empty_like(a)
+        mean = torch.empty((rows,), dtype=torch.float32, device=a.device)
+        rstd = torch.empty((rows,), dtype=torch.float32, device=a.device)
+        _lib.call("dp_add_layernorm_fwd", _p(a), _p(b), _p(s), _p(gamma.detach()), _p(beta.detach()), _p(z), _p(mean), _p(rstd), rows, C,
+                  float(eps), _dt(a), _stream())
+        ctx.save_for_backward(s, gamma, mean, rstd)
+        return s, z
+
+    @staticmethod
+    def backward(ctx, gs, gz):
+        s, gamma, mean, rstd = ctx.saved_tensors
+        C = s.shape[-1]
+        rows = s.numel() // C
+        if gz is None:
+            return gs, gs, None, None, None
+        gz = gz.contiguous()
+        gs = None if gs is None else gs.contiguous()
+        gx = torch.empty_like(s)
+        dgb = torch.zeros((2, C), dtype=torch.float32, device=s.device)
+        if C <= 1024:
+            _lib.call("dp_add_layernorm_bwd", _p(s), _p(gz), _p(gs), _p(gamma.detach()), _p(mean), _p(rstd), _p(gx), _p(dgb[0]), _p(dgb[1]),
+                      rows, C, _dt(s), _stream())
+        else:
+            _lib.call("dp_layernorm_bwd", _p(s), _p(gz), _p(gamma.detach()), _p(mean), _p(rstd), _p(gx), _p(dgb[0]), _p(dgb[1]), rows, C,
+                      _dt(s), _stream())
+            if gs is not None:
+                out = torch.empty_like(gx)
+                _lib.call("dp_add", _p(gx), _p(gs), _p(out), gx.numel(), gx.numel(), _dt(gx), _stream())
+                gx = out
+        return gx, gx, dgb[0], dgb[1], None
+
+
+def add_layer_norm(a, b, gamma, beta, eps=1e-5):
+    return AddLayerNorm.apply(a, b, gamma, beta, eps)
 
 
 # ------------------------------------------------------------------------------------------------ elementwise

@@ -39,7 +39,8 @@ class FusedAdam(torch.optim.Optimizer):
                 ci += list(range(n))
             dev = plist[0].device
             plan = (torch.tensor(ct, dtype=torch.int32, device=dev), torch.tensor(ci, dtype=torch.int32, device=dev), len(ct),
-                    torch.empty((len(plist), 6), dtype=torch.int64).pin_memory(), torch.empty((len(plist), 6), dtype=torch.int64, device=dev))
+                    torch.empty((len(plist), 6), dtype=torch.int64).pin_memory(), torch.empty((len(plist), 6), dtype=torch.int64, device=dev),
+                    [None])
             self._plans[key] = plan
         return plan
 
@@ -73,7 +74,11 @@ class FusedAdam(torch.optim.Optimizer):
                     st["max_exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 if not p.is_contiguous() or not p.grad.is_contiguous():
                     raise _lib.DoseHipError("FusedAdam needs contiguous parameters / gradients")
-            ct, ci, nchunks, host, devtab = self._plan(gi, plist)
+            ct, ci, nchunks, host, devtab, copied = self._plan(gi, plist)
+            if copied[0] is not None and not torch.cuda.is_current_stream_capturing():     # (torch.cuda.graph synchronises on entry)
+                # the pinned table is rewritten below: the previous step's asynchronous copy out of it must have executed (the host
+                # thread may be several steps ahead of the GPU)
+                copied[0].synchronize()
             h = host.numpy()
             for t, p in enumerate(plist):
                 st = self.state[p]
@@ -81,6 +86,9 @@ class FusedAdam(torch.optim.Optimizer):
                 h[t] = (p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
                         vm.data_ptr() if vm is not None else 0, p.numel())
             devtab.copy_(host, non_blocking=True)
+            if not torch.cuda.is_current_stream_capturing():
+                copied[0] = torch.cuda.Event()
+                copied[0].record()
             b1, b2 = group["betas"]
             stream = torch.cuda.current_stream().cuda_stream
             from . import config

@@ -140,6 +140,13 @@ int dp_layernorm_fwd(const void* x, const float* gamma, const float* beta, void*
                      int64_t rows, int C, float eps, int dtype, void* stream);
 int dp_layernorm_bwd(const void* x, const void* gy, const float* gamma, const float* mean, const float* rstd,
                      void* gx, float* dgamma, float* dbeta, int64_t rows, int C, int dtype, void* stream);
+/* replaces: the residual add of a pre-norm MONAI TransformerBlock together with the LayerNorm that follows it
+ * (x = x + attn(...); norm2(x) / next block's norm1(x) / ViT.norm(x)): sum = a + b (stored, rounded to T), y = LayerNorm(sum).
+ * Backward: gx = gsum + LayerNorm'(gy) (gsum = the gradient reaching `sum` through the residual path, may be NULL; C <= 1024). */
+int dp_add_layernorm_fwd(const void* a, const void* b, void* sum, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                         int64_t rows, int C, float eps, int dtype, void* stream);
+int dp_add_layernorm_bwd(const void* x, const void* gy, const void* gsum, const float* gamma, const float* mean, const float* rstd,
+                         void* gx, float* dgamma, float* dbeta, int64_t rows, int C, int dtype, void* stream);
 
 /* ---- matrix products (MFMA) ------------------------------------------------------------------- */
 /* C[b0][b1][m][n] = alpha * sum_k A[..][m][k] * B[..][n][k] (+ bias[n]) ; "NT" GEMM, both operands k-contiguous.

@@ -242,6 +242,47 @@ def test_layernorm_gelu_add(dtype, C=768):
     check("gbeta", bh.grad, br.grad, dtype, scale=2.0)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C", [768, 48, 1000])
+def test_add_layernorm_fused(dtype, C):
+    """Fused residual add + LayerNorm (dp_add_layernorm_fwd/_bwd): the sum and the normalised output are BIT-identical to the separate
+    add and LayerNorm kernels (the sum is rounded to the storage type before the statistics); gradients against the fp64 oracle, with
+    both outputs used (the residual-path gradient is added inside the LayerNorm backward)."""
+    from dose_prediction_amd import ops
+    dev = _dev()
+    a, b = q(rnd((2, 37, C), 1) * 2 + 0.5, dtype), q(rnd((2, 37, C), 5), dtype)
+    g, be = 1 + 0.2 * rnd((C,), 2), 0.1 * rnd((C,), 3)
+    ar, br_, gr, ber = (t.double().requires_grad_(True) for t in (a, b, g, be))
+    sr = ar + br_
+    zr = oracle.layer_norm(sr, gr, ber)
+    r1, r2 = q(rnd(zr.shape, 4), dtype), q(rnd(zr.shape, 6), dtype)
+    ((zr * r1.double()).sum() + (sr * r2.double()).sum()).backward()
+    ah, bh = a.to(dev, dtype).requires_grad_(True), b.to(dev, dtype).requires_grad_(True)
+    gh, beh = g.to(dev).requires_grad_(True), be.to(dev).requires_grad_(True)
+    sh, zh = ops.add_layer_norm(ah, bh, gh, beh)
+    with torch.no_grad():
+        s0 = ops.add(ah, bh)
+        z0 = ops.layer_norm(s0, gh, beh)
+    assert torch.equal(sh, s0) and torch.equal(zh, z0)
+    torch.autograd.backward([sh, zh], [r2.to(dev, dtype), r1.to(dev, dtype)])
+    check("z", zh, zr, dtype, scale=2.0)
+    check("ga", ah.grad, ar.grad, dtype, scale=2.0)
+    assert torch.equal(ah.grad, bh.grad)
+    check("ggamma", gh.grad, gr.grad, dtype, scale=2.0)
+    check("gbeta", beh.grad, ber.grad, dtype, scale=2.0)
+    # only one of the two outputs used
+    for use in (0, 1):
+        a2, b2 = a.to(dev, dtype).requires_grad_(True), b.to(dev, dtype).requires_grad_(True)
+        out = ops.add_layer_norm(a2, b2, gh, beh)[use]
+        out.backward(r1.to(dev, dtype))
+        if use == 0:
+            assert torch.equal(a2.grad, r1.to(dev, dtype))
+        else:
+            a3 = s0.clone().requires_grad_(True)
+            ops.layer_norm(a3, gh, beh).backward(r1.to(dev, dtype))
+            assert torch.equal(a2.grad, a3.grad)
+
+
 @pytest.mark.parametrize("C", [48, 1000, 1536])
 def test_layernorm_widths(C):
     test_layernorm_gelu_add(torch.float32, C)
