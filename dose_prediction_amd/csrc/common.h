@@ -179,6 +179,16 @@ __device__ __forceinline__ float act_bwd(float z, int act) {
   }
 }
 
+// conv_wgrad_hk.hip: weight gradient of the <= 16-output-channel 7x7x7 layers with K along H (shares the tap-major scratch and the
+// unpack kernel of dp_conv3d_wgrad_tiled2, which dispatches to it)
+struct WgHkGeom {
+  int N, D, H, W, Cin, Cout, ldx, ldgy;
+  int tiles_h, tiles_w, MT, NTn, ydim;
+  const void* x2; int ldx2, csplit;   // virtual concat of the input
+};
+bool wgrad_hk_applicable(int Cout, int k, int H, int W, int dtype);
+int wgrad_hk_launch(const void* x, const void* gy, float* ws, const WgHkGeom& g, int k, int dtype, hipStream_t s);
+
 // conv_cc16.hip: 16x16x32-MFMA convolution for the Cout <= 16 layers at W >= 96 (chosen by shape alone, so that the packed-weight
 // layout is known from (Cin, Cout, k, W))
 bool cc16_applicable(int Cin, int Cout, int k, int W);

@@ -1288,7 +1288,12 @@ extern "C" int dp_conv3d_wgrad_tiled2(const void* x, int ldx, const void* x2, in
                        (!x2 || (csplit % 8 == 0 && ldx2 % 8 == 0 && ((uintptr_t)x2 & 15) == 0)) &&
                        (int64_t)H * W * (ldx > ldgy ? (ldx > ldx2 ? ldx : ldx2) : (ldgy > ldx2 ? ldgy : ldx2)) < (1ll << 30);
   const bool cc16 = k > 1 && dtype != DP_F32 && aligned && !getenv("DP_NO_CC16");
-  if (cc16 && np == 2) {                  // Cout <= 16: one tap per 16x16x32 MFMA, no tap-pairing padding
+  const bool hk_wide = getenv("DP_HK_NARROW") == nullptr;         // (experiments: restrict the K-along-H kernel to Cout <= 16)
+  if (k > 1 && dtype != DP_F32 && aligned && (np == 2 || hk_wide) && wgrad_hk_applicable(Cout, k, H, W, dtype)) {     // 7^3, planes >= 32 x 32: K along H (conv_wgrad_hk.hip)
+    WgHkGeom hg; hg.N = N; hg.D = D; hg.H = H; hg.W = W; hg.Cin = Cin; hg.Cout = Cout; hg.ldx = ldx; hg.ldgy = ldgy;
+    hg.tiles_h = hg.tiles_w = hg.MT = hg.NTn = hg.ydim = 0; hg.x2 = x2; hg.ldx2 = ldx2; hg.csplit = csplit;
+    rc = wgrad_hk_launch(x, gy, ws, hg, k, dtype, s);
+  } else if (cc16 && np == 2) {           // Cout <= 16: one tap per 16x16x32 MFMA, no tap-pairing padding
     if (dtype == DP_BF16) rc = k == 7 ? launch_wg16<bf16_t, 7, 1>(x, gy, ws, g, s) : launch_wg16<bf16_t, 3, 1>(x, gy, ws, g, s);
     else rc = k == 7 ? launch_wg16<f16_t, 7, 1>(x, gy, ws, g, s) : launch_wg16<f16_t, 3, 1>(x, gy, ws, g, s);
   } else if (cc16 && mp == 2 && Cout <= 32) {   // Cin <= 16, Cout <= 32: two 16-wide N tiles share every x window (kw pairing wasted an eighth)

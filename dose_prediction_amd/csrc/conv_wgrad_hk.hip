@@ -1,0 +1,218 @@
+// Weight gradient of the 7x7x7 convolutions on planes of at least 32 x 32 voxels, second generation: K along H.
+// One block = one kd, one tile of 16 input channels and one tile of 16 output channels (wider layers multiply the grid).
+//   dW[co][ci][kd][kh][kw] = sum_{n,d,h,w} gy[n,d,h,w,co] * x[n, d+kd-P, h+kh-P, w+kw-P, ci]        (stride 1, "same" padding)
+// v_mfma_f32_16x16x32: M = 16 input channels, N = 16 output channels, ONE tap per MFMA, K = 32 voxels of ONE COLUMN (32 consecutive
+// rows h of a fixed w).  k_wgrad_cc16 (conv_tiled.hip) lays K along W: its kw taps are register windows shifted by v_perm /
+// v_mov (22 VALU per 14 MFMAs) and its loop exposes three LDS latencies per row; PMC showed its waves issuing 40 % of the time and
+// the matrix pipe busy 35 %.  With K along H a kw (or kh) shift is just ANOTHER LDS ADDRESS of the same fragment shape:
+//   * the x fragment (rows r0+kh .. +31, column c) meets the gy fragments of columns c-kw, kw = 0..KS-1: a wave keeps the last KS
+//     gy fragments in a register ring and loads, per column step, ONE gy fragment and one x fragment per owned kh:
+//     6 transpose reads per 14 MFMAs (KS = 7, two kh per wave), no VALU at all;
+//   * the column loop is fully unrolled (static ring indices, static immediate offsets, ramp-up / ramp-down MFMAs removed at
+//     compile time) and the next step's fragments are requested before the current step's MFMAs;
+//   * k -> row map with bits 2 and 3 swapped and ODD row pitches (in voxels): the 32 lanes of a ds_read_b64_tr_b16 half touch 8
+//     consecutive rows = all 64 banks once (the natural map puts rows r and r+8 on the same banks: 2-way conflict).
+// Tiles: 32 rows x 32 columns of gy, (32+KS-1)^2 of x (halo factor 1.41 instead of 1.91 for the 8 x 64 tile), register-staged one
+// tile ahead as in k_wgrad_tiled; grid decode, scratch layout ([tap][ci][co] fp32, atomics) and the unpack kernel are shared with it.
+#include "common.h"
+#include <utility>
+
+namespace {
+
+template <typename T, int KS>
+struct HkCfg {
+  static constexpr int PAD = KS / 2, TH = 32, TW = 32, XC = 16, GC = 16;
+  static constexpr int LR = TH + KS - 1, LC = TW + KS - 1, LP = LC | 1, GP = TW + 1;      // odd pitches (voxels)
+  static constexpr int NKH = KS == 7 ? 2 : KS;                  // kh taps per wave
+  static constexpr int NG = (KS + NKH - 1) / NKH;               // kh groups (waves along kh)
+  static constexpr int NCW = 4 / NG, CW = TW / NCW;             // column chunks per tile / gy columns per wave
+  static constexpr int STEPS = CW + KS - 1;                     // x columns a wave walks over
+  static constexpr int RING = KS + 1;                           // gy fragments in registers (KS live + the one in flight)
+  static constexpr size_t SMEM = ((size_t)LR * LP * XC + (size_t)TH * GP * GC) * sizeof(T);
+};
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+
+template <typename T, int KS>
+__global__ void __launch_bounds__(256, 2) k_wgrad_hk(const T* __restrict__ x, const T* __restrict__ gy, float* __restrict__ dwt, WgHkGeom g) {
+  static_assert(sizeof(T) == 2, "16-bit storage types only");
+  using C = HkCfg<T, KS>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* xs = (T*)smem_raw;
+  T* gs = xs + (size_t)C::LR * C::LP * C::XC;
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4, i16 = lane & 15;
+  int kd, mt, nt, yb;
+  {
+    const int L = blockIdx.x, inner = KS * g.MT * g.NTn;
+    int c;
+    if (g.ydim % 8 == 0) { const int xcd = L & 7, slot = L >> 3; c = slot % inner; yb = (slot / inner) * 8 + xcd; }
+    else { c = L % inner; yb = L / inner; }
+    kd = c % KS; const int r = c / KS; mt = r % g.MT; nt = r / g.MT;
+  }
+  const int khg = wv % C::NG, cwi = wv / C::NG;
+  const int kh0 = khg * C::NKH, nkh = min(C::NKH, KS - kh0), g0 = cwi * C::CW;
+  const int per_plane = g.tiles_h * g.tiles_w, units = g.N * g.D * per_plane, per = (units + g.ydim - 1) / g.ydim;
+  const int u0 = yb * per, u1 = min(units, u0 + per);
+  // lane part of the transposing reads: k = 8q + j (+4 for the second read of a pair) sits on row 16(q>>1) + 4(q&1) + j (+8)
+  const int rowoff = 16 * (q >> 1) + 4 * (q & 1) + (i16 >> 2), c4 = 4 * (i16 & 3);
+  const T* const xb = xs + (rowoff + kh0) * C::LP * C::XC + g0 * C::XC + c4;
+  const T* const gb = gs + rowoff * C::GP * C::GC + g0 * C::GC + c4;
+
+  v4f acc[C::NKH][KS];
+#pragma unroll
+  for (int a = 0; a < C::NKH; a++)
+#pragma unroll
+    for (int b = 0; b < KS; b++) acc[a][b] = (v4f){0.f, 0.f, 0.f, 0.f};
+
+  struct Tile { int n, d, id, h0, w0; };
+  auto tile_ok = [&](int u) { const int id = (u / per_plane) % g.D, d = id - kd + C::PAD; return d >= 0 && d < g.D; };
+  auto tile_of = [&](int u) {
+    Tile t; const int tw = u % g.tiles_w, th = (u / g.tiles_w) % g.tiles_h, nd = u / per_plane;
+    t.id = nd % g.D; t.n = nd / g.D; t.d = t.id - kd + C::PAD; t.h0 = th * C::TH; t.w0 = tw * C::TW;
+    return t;
+  };
+  auto next_ok = [&](int u) { u++; while (u < u1 && !tile_ok(u)) u++; return u; };
+
+  // register-staged tiles: 16-byte pieces (8 channels), two per voxel
+  constexpr int PX = (C::LR * C::LC * 2 + 255) / 256, PG = C::TH * C::TW * 2 / 256;
+  v4u rx[PX], rg[PG];
+  const int piece = tid & 1, cpiece = mt * C::XC + piece * 8;
+  const bool xsecond = g.x2 && cpiece >= g.csplit;
+  const T* xsrc = (xsecond ? (const T*)g.x2 : x) + cpiece - (xsecond ? g.csplit : 0);
+  const int ldsrc = xsecond ? g.ldx2 : g.ldx;
+  const T* gsrc = gy + nt * C::GC + piece * 8;
+  const bool x_exists = cpiece + 8 <= (g.x2 ? g.csplit + g.ldx2 : g.ldx), g_exists = nt * C::GC + piece * 8 + 8 <= g.ldgy;
+  // x piece j of this thread: voxel j * 128 + tid / 2 of the LR x LC halo tile (recomputed where needed: a coordinate table in
+  // registers pushed the kernel over 256 VGPRs, and spilled coordinates serialise the global loads behind scratch reloads)
+  auto opaque = [](int v) { asm volatile("" : "+v"(v)); return v; };      // defeats loop-invariant hoisting of the coordinates
+  auto xvox = [&](int t2, int j, int& lr, int& lc) { const int v = j * 128 + t2; lr = v / C::LC; lc = v - lr * C::LC; return v < C::LR * C::LC; };
+  const int g_r = tid >> 6, g_c = (tid >> 1) & 31;       // gy piece j: row 4j + g_r, column g_c
+  auto issue = [&](const Tile& t) {
+    const T* xplane = xsrc + (((int64_t)t.n * g.D + t.id) * g.H) * (int64_t)g.W * ldsrc;
+    const int ihb = t.h0 - C::PAD, iwb = t.w0 - C::PAD, t2 = opaque(tid >> 1);
+#pragma unroll
+    for (int j = 0; j < PX; j++) {
+      int lr, lc; const bool in = xvox(t2, j, lr, lc);
+      const int ih = ihb + lr, iw = iwb + lc;
+      const bool ok = x_exists && in && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
+      v4u v = *(const v4u*)(xplane + (ok ? (ih * g.W + iw) * ldsrc : 0));
+      rx[j] = ok ? v : (v4u){0, 0, 0, 0};
+    }
+    const T* gplane = gsrc + (((int64_t)t.n * g.D + t.d) * g.H) * (int64_t)g.W * g.ldgy;
+#pragma unroll
+    for (int j = 0; j < PG; j++) {
+      const int oh = t.h0 + 4 * j + g_r, ow = t.w0 + g_c;
+      const bool ok = g_exists && oh < g.H && ow < g.W;
+      v4u v = *(const v4u*)(gplane + (ok ? (oh * g.W + ow) * g.ldgy : 0));
+      rg[j] = ok ? v : (v4u){0, 0, 0, 0};
+    }
+  };
+  auto commit = [&]() {
+    const int t2 = opaque(tid >> 1);
+#pragma unroll
+    for (int j = 0; j < PX; j++) {
+      int lr, lc;
+      if (xvox(t2, j, lr, lc)) *(v4u*)(xs + (lr * C::LP + lc) * C::XC + piece * 8) = rx[j];
+    }
+#pragma unroll
+    for (int j = 0; j < PG; j++) *(v4u*)(gs + ((4 * j + g_r) * C::GP + g_c) * C::GC + piece * 8) = rg[j];
+  };
+  // one tile: the wave walks over the STEPS x columns of its CW gy columns; everything below is static after unrolling
+  auto sweep = [&]<int NK>(std::integral_constant<int, NK>) {
+    Frag8<T> X[2][NK], G[C::RING];
+#pragma unroll
+    for (int kk = 0; kk < NK; kk++) X[0][kk] = tr_pair<8 * C::LP * C::XC, T>(xb + kk * C::LP * C::XC);
+    G[0] = tr_pair<8 * C::GP * C::GC, T>(gb);
+    static_for<0, C::STEPS>([&](auto cc_) {
+      constexpr int cc = decltype(cc_)::value, cur = cc & 1, nxt = cur ^ 1;
+      if constexpr (cc + 1 < C::STEPS) {
+#pragma unroll
+        for (int kk = 0; kk < NK; kk++) X[nxt][kk] = tr_pair<8 * C::LP * C::XC, T>(xb + (kk * C::LP + cc + 1) * C::XC);
+        if constexpr (cc + 1 < C::CW) G[(cc + 1) % C::RING] = tr_pair<8 * C::GP * C::GC, T>(gb + (cc + 1) * C::GC);
+      }
+      __builtin_amdgcn_sched_barrier(0);       // the next step's reads stay IN FRONT of this step's MFMAs (the scheduler sinks them to their use)
+      static_for<0, KS>([&](auto kw_) {
+        constexpr int kw = decltype(kw_)::value, gc = cc - kw;
+        if constexpr (gc >= 0 && gc < C::CW) {
+#pragma unroll
+          for (int kk = 0; kk < NK; kk++) acc[kk][kw] = mma16(X[cur][kk], G[gc % C::RING], acc[kk][kw]);
+        }
+      });
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+  const bool fast = (g.ldx % 8 == 0) && (g.ldgy % 8 == 0) && (((uintptr_t)x & 15) == 0) && (((uintptr_t)gy & 15) == 0) &&
+                    (!g.x2 || ((g.csplit % 8 == 0) && (g.ldx2 % 8 == 0) && (((uintptr_t)g.x2 & 15) == 0)));
+  if (!fast) return;                                                // the launcher only selects this kernel for aligned operands
+  int cu = u0;
+  while (cu < u1 && !tile_ok(cu)) cu++;
+  if (cu < u1) issue(tile_of(cu));
+  while (cu < u1) {
+    lds_barrier();
+    commit();
+    const int nu = next_ok(cu);
+    if (nu < u1) issue(tile_of(nu));
+    lds_barrier();
+    if (nkh == C::NKH) sweep(std::integral_constant<int, C::NKH>{});
+    else if constexpr (KS % C::NKH != 0) { if (nkh > 0) sweep(std::integral_constant<int, KS % C::NKH>{}); }
+    cu = nu;
+  }
+  // C/D of the 16x16 MFMA: col (co) = lane&15, row (ci) = 4*(lane>>4) + e
+#pragma unroll
+  for (int kk = 0; kk < C::NKH; kk++) {
+    if (kk >= nkh) continue;
+    const int co = nt * 16 + (lane & 15);
+    if (co >= g.Cout) continue;
+#pragma unroll
+    for (int kw = 0; kw < KS; kw++)
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const int ci = mt * 16 + 4 * q + e;
+        if (ci < g.Cin) atomicAdd(dwt + ((int64_t)((kd * KS + kh0 + kk) * KS + kw) * g.Cin + ci) * g.Cout + co, acc[kk][kw][e]);
+      }
+  }
+}
+
+template <typename T, int KS>
+int launch_hk(const void* x, const void* gy, float* ws, WgHkGeom g, hipStream_t s) {
+  using C = HkCfg<T, KS>;
+  auto kern = k_wgrad_hk<T, KS>;
+  static bool raised = false;
+  if (!raised) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::SMEM);
+    if (e != hipSuccess) { dp_set_error("wgrad_hk: cannot raise dynamic LDS to %zu: %s", C::SMEM, hipGetErrorString(e)); return 1; }
+    raised = true;
+  }
+  g.tiles_h = cdiv(g.H, C::TH); g.tiles_w = cdiv(g.W, C::TW);
+  g.MT = cdiv(g.Cin, C::XC); g.NTn = cdiv(g.Cout, C::GC);
+  const int units = g.N * g.D * g.tiles_h * g.tiles_w;
+  static int occ = 0, ncu = 0;
+  if (!occ) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)kern, 256, C::SMEM) != hipSuccess || occ < 1) occ = 1;
+    int dev = 0; hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount;
+    if (ncu < 1) ncu = 256;
+  }
+  int want = (ncu * occ) / (KS * g.MT * g.NTn); if (want < 1) want = 1;
+  int ydim = units < want ? units : want;
+  if (ydim >= 8 && (ydim & 7) * 20 <= ydim) ydim &= ~7;
+  g.ydim = ydim;
+  hipLaunchKernelGGL(kern, dim3(KS * ydim * g.MT * g.NTn), dim3(256), C::SMEM, s, (const T*)x, (const T*)gy, ws, g);
+  return 0;
+}
+
+}  // namespace
+
+bool wgrad_hk_applicable(int Cout, int k, int H, int W, int dtype) {
+  static const bool off = getenv("DP_NO_HK") != nullptr;
+  (void)Cout;
+  return !off && dtype != DP_F32 && k == 7 && H >= 32 && W >= 32;
+}
+
+int wgrad_hk_launch(const void* x, const void* gy, float* ws, const WgHkGeom& g, int k, int dtype, hipStream_t s) {
+  if (k != 7) { dp_set_error("wgrad_hk: kernel size %d not built", k); return 1; }
+  return dtype == DP_BF16 ? launch_hk<bf16_t, 7>(x, gy, ws, g, s) : launch_hk<f16_t, 7>(x, gy, ws, g, s);
+}
