@@ -7,9 +7,9 @@
 // the matrix pipe busy 35 %.  With K along H a kw (or kh) shift is just ANOTHER LDS ADDRESS of the same fragment shape:
 //   * the x fragment (rows r0+kh .. +31, column c) meets the gy fragments of columns c-kw, kw = 0..KS-1: a wave keeps the last KS
 //     gy fragments in a register ring and loads, per column step, ONE gy fragment and one x fragment per owned kh:
-//     6 transpose reads per 14 MFMAs (KS = 7, two kh per wave), no VALU at all;
+//     6 transpose reads per 13 MFMAs (KS = 7, two kh per wave; wave roles: RolePair / RoleLast below), no VALU at all;
 //   * the column loop is fully unrolled (static ring indices, static immediate offsets, ramp-up / ramp-down MFMAs removed at
-//     compile time) and the next step's fragments are requested before the current step's MFMAs;
+//     compile time) and every fragment is requested 6-13 MFMAs before its first use, into the registers its predecessor just left;
 //   * k -> row map with bits 2 and 3 swapped and ODD row pitches (in voxels): the 32 lanes of a ds_read_b64_tr_b16 half touch 8
 //     consecutive rows = all 64 banks once (the natural map puts rows r and r+8 on the same banks: 2-way conflict).
 // Tiles: 32 rows x 32 columns of gy, (32+KS-1)^2 of x (halo factor 1.41 instead of 1.91 for the 8 x 64 tile), register-staged one
@@ -23,17 +23,40 @@ template <typename T, int KS>
 struct HkCfg {
   static constexpr int PAD = KS / 2, TH = 32, TW = 32, XC = 16, GC = 16;
   static constexpr int LR = TH + KS - 1, LC = TW + KS - 1, LP = LC | 1, GP = TW + 1;      // odd pitches (voxels)
-  static constexpr int NKH = KS == 7 ? 2 : KS;                  // kh taps per wave
-  static constexpr int NG = (KS + NKH - 1) / NKH;               // kh groups (waves along kh)
-  static constexpr int NCW = 4 / NG, CW = TW / NCW;             // column chunks per tile / gy columns per wave
+  static constexpr int CW = TW;                                 // gy columns a wave walks over (every wave: the whole tile width)
   static constexpr int STEPS = CW + KS - 1;                     // x columns a wave walks over
-  static constexpr int RING = KS + 1;                           // gy fragments in registers (KS live + the one in flight)
   static constexpr size_t SMEM = ((size_t)LR * LP * XC + (size_t)TH * GP * GC) * sizeof(T);
 };
 
 template <int I, int N, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+
+// Tap sets of the four waves (KS = 7: 49 taps of one kd).  Rows = kh, one x fragment per row and column step; a row's kw mask
+// selects the taps the wave accumulates.  Two whole kh per wave leaves the fourth wave half idle (14 / 14 / 14 / 7 taps: 87.5 %);
+// here waves 0-2 hand the kw = 6 tap of their even kh to wave 3: 13 / 13 / 13 / 10 (94 %).
+struct RolePair {                         // waves 0..2: kh = 2w (kw 0..5) and 2w + 1 (all kw); rows relative to kh0 = 2w
+  static constexpr int NR = 2, NACC = 13;
+  static constexpr int row(int r) { return r; }
+  static constexpr unsigned mask(int r) { return r == 0 ? 0x3Fu : 0x7Fu; }
+  static constexpr bool dbuf(int) { return false; }
+};
+struct RoleLast {                         // wave 3: kh = 6 (all kw) and the kw = 6 taps of kh 0, 2, 4; absolute rows (kh0 = 0)
+  static constexpr int NR = 4, NACC = 10;
+  static constexpr int row(int r) { return r == 0 ? 6 : 2 * (r - 1); }
+  static constexpr unsigned mask(int r) { return r == 0 ? 0x7Fu : 0x40u; }
+  static constexpr bool dbuf(int r) { return r == 0; }          // (at most one double-buffered row per role)
+};
+template <typename R> constexpr int role_slot(int r, int kw) {     // accumulator index of tap (row r, kw)
+  int s = 0;
+  for (int i = 0; i < r; i++) s += __builtin_popcount(R::mask(i));
+  return s + __builtin_popcount(R::mask(r) & ((1u << kw) - 1u));
+}
+// does row r meet any live gy column at x column step cc?  (gy column = cc - kw, 0 <= . < CW)
+template <typename R> constexpr bool role_row_live(int r, int cc, int KS, int CW) {
+  for (int kw = 0; kw < KS; kw++) if ((R::mask(r) >> kw & 1u) && cc - kw >= 0 && cc - kw < CW) return true;
+  return false;
 }
 
 template <typename T, int KS>
@@ -52,8 +75,9 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_hk(const T* __restrict__ x, co
     else { c = L % inner; yb = L / inner; }
     kd = c % KS; const int r = c / KS; mt = r % g.MT; nt = r / g.MT;
   }
-  const int khg = wv % C::NG, cwi = wv / C::NG;
-  const int kh0 = khg * C::NKH, nkh = min(C::NKH, KS - kh0), g0 = cwi * C::CW;
+  static_assert(KS == 7, "wave roles are laid out for 7 x 7 x 7");
+  const bool last_role = wv == 3;
+  const int kh0 = last_role ? 0 : 2 * wv, g0 = 0;
   const int per_plane = g.tiles_h * g.tiles_w, units = g.N * g.D * per_plane, per = (units + g.ydim - 1) / g.ydim;
   const int u0 = yb * per, u1 = min(units, u0 + per);
   // lane part of the transposing reads: k = 8q + j (+4 for the second read of a pair) sits on row 16(q>>1) + 4(q&1) + j (+8)
@@ -61,11 +85,9 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_hk(const T* __restrict__ x, co
   const T* const xb = xs + (rowoff + kh0) * C::LP * C::XC + g0 * C::XC + c4;
   const T* const gb = gs + rowoff * C::GP * C::GC + g0 * C::GC + c4;
 
-  v4f acc[C::NKH][KS];
+  v4f acc[RolePair::NACC];
 #pragma unroll
-  for (int a = 0; a < C::NKH; a++)
-#pragma unroll
-    for (int b = 0; b < KS; b++) acc[a][b] = (v4f){0.f, 0.f, 0.f, 0.f};
+  for (int a = 0; a < RolePair::NACC; a++) acc[a] = (v4f){0.f, 0.f, 0.f, 0.f};
 
   struct Tile { int n, d, id, h0, w0; };
   auto tile_ok = [&](int u) { const int id = (u / per_plane) % g.D, d = id - kd + C::PAD; return d >= 0 && d < g.D; };
@@ -120,28 +142,46 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_hk(const T* __restrict__ x, co
 #pragma unroll
     for (int j = 0; j < PG; j++) *(v4u*)(gs + ((4 * j + g_r) * C::GP + g_c) * C::GC + piece * 8) = rg[j];
   };
-  // one tile: the wave walks over the STEPS x columns of its CW gy columns; everything below is static after unrolling
-  auto sweep = [&]<int NK>(std::integral_constant<int, NK>) {
-    Frag8<T> X[2][NK], G[C::RING];
-#pragma unroll
-    for (int kk = 0; kk < NK; kk++) X[0][kk] = tr_pair<8 * C::LP * C::XC, T>(xb + kk * C::LP * C::XC);
-    G[0] = tr_pair<8 * C::GP * C::GC, T>(gb);
-    static_for<0, C::STEPS>([&](auto cc_) {
-      constexpr int cc = decltype(cc_)::value, cur = cc & 1, nxt = cur ^ 1;
-      if constexpr (cc + 1 < C::STEPS) {
-#pragma unroll
-        for (int kk = 0; kk < NK; kk++) X[nxt][kk] = tr_pair<8 * C::LP * C::XC, T>(xb + (kk * C::LP + cc + 1) * C::XC);
-        if constexpr (cc + 1 < C::CW) G[(cc + 1) % C::RING] = tr_pair<8 * C::GP * C::GC, T>(gb + (cc + 1) * C::GC);
+  // one tile: the wave walks over the STEPS x columns of the tile's CW gy columns; everything below is static after unrolling.
+  // Software pipeline with (almost) no second buffers -- the kernel sits at the 256-VGPR limit of two waves per SIMD, and a
+  // spilled register costs an s_waitcnt vmcnt(0) in front of the tile prefetch: the gy fragment of column cc+1 is requested at
+  // the start of step cc (ring of KS+1), an x row requests its next column right after its own last MFMA of the step, i.e. the
+  // other rows' 6-9 MFMAs (100-150 cycles) before its first use; only RoleLast's 7-tap row, which has just three MFMAs of other
+  // rows behind it, keeps two buffers (that role has three accumulators fewer).
+  auto sweep = [&]<typename R>(R) {
+    Frag8<T> X[R::NR], Xd[2], G[KS + 1];
+    auto ldx = [&](auto r_, auto cc_) {
+      constexpr int r = decltype(r_)::value, cc = decltype(cc_)::value;
+      if constexpr (cc < C::STEPS && role_row_live<R>(r, cc, KS, C::CW)) {
+        const Frag8<T> f = tr_pair<8 * C::LP * C::XC, T>(xb + (R::row(r) * C::LP + cc) * C::XC);
+        if constexpr (R::dbuf(r)) Xd[cc & 1] = f; else X[r] = f;
       }
-      __builtin_amdgcn_sched_barrier(0);       // the next step's reads stay IN FRONT of this step's MFMAs (the scheduler sinks them to their use)
-      static_for<0, KS>([&](auto kw_) {
-        constexpr int kw = decltype(kw_)::value, gc = cc - kw;
-        if constexpr (gc >= 0 && gc < C::CW) {
-#pragma unroll
-          for (int kk = 0; kk < NK; kk++) acc[kk][kw] = mma16(X[cur][kk], G[gc % C::RING], acc[kk][kw]);
-        }
-      });
+    };
+    auto ldg = [&](auto gc_) {
+      constexpr int gc = decltype(gc_)::value;
+      if constexpr (gc < C::CW) G[gc % (KS + 1)] = tr_pair<8 * C::GP * C::GC, T>(gb + gc * C::GC);
+    };
+    static_for<0, R::NR>([&](auto r_) { ldx(r_, std::integral_constant<int, 0>{}); });
+    ldg(std::integral_constant<int, 0>{});
+    static_for<0, C::STEPS>([&](auto cc_) {
+      constexpr int cc = decltype(cc_)::value;
+      constexpr std::integral_constant<int, cc + 1> nx{};
+      ldg(nx);
+      static_for<0, R::NR>([&](auto r_) { if constexpr (R::dbuf(decltype(r_)::value)) ldx(r_, nx); });
       __builtin_amdgcn_sched_barrier(0);
+      static_for<0, R::NR>([&](auto r_) {
+        constexpr int r = decltype(r_)::value;
+        static_for<0, KS>([&](auto kw_) {
+          constexpr int kw = decltype(kw_)::value, gc = cc - kw;
+          if constexpr (gc >= 0 && gc < C::CW && (R::mask(r) >> kw & 1u)) {
+            constexpr int sl = role_slot<R>(r, kw);
+            acc[sl] = mma16(R::dbuf(r) ? Xd[cc & 1] : X[r], G[gc % (KS + 1)], acc[sl]);
+          }
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!R::dbuf(r)) ldx(r_, nx);
+        __builtin_amdgcn_sched_barrier(0);
+      });
     });
   };
   const bool fast = (g.ldx % 8 == 0) && (g.ldgy % 8 == 0) && (((uintptr_t)x & 15) == 0) && (((uintptr_t)gy & 15) == 0) &&
@@ -156,24 +196,30 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_hk(const T* __restrict__ x, co
     const int nu = next_ok(cu);
     if (nu < u1) issue(tile_of(nu));
     lds_barrier();
-    if (nkh == C::NKH) sweep(std::integral_constant<int, C::NKH>{});
-    else if constexpr (KS % C::NKH != 0) { if (nkh > 0) sweep(std::integral_constant<int, KS % C::NKH>{}); }
+    if (last_role) sweep(RoleLast{}); else sweep(RolePair{});
     cu = nu;
   }
   // C/D of the 16x16 MFMA: col (co) = lane&15, row (ci) = 4*(lane>>4) + e
+  const int co = nt * 16 + (lane & 15);
+  if (co >= g.Cout) return;
+  auto flush = [&]<typename R>(R) {
+    static_for<0, R::NR>([&](auto r_) {
+      constexpr int r = decltype(r_)::value;
+      static_for<0, KS>([&](auto kw_) {
+        constexpr int kw = decltype(kw_)::value;
+        if constexpr (R::mask(r) >> kw & 1u) {
+          constexpr int sl = role_slot<R>(r, kw);
+          const int kh = kh0 + R::row(r);
 #pragma unroll
-  for (int kk = 0; kk < C::NKH; kk++) {
-    if (kk >= nkh) continue;
-    const int co = nt * 16 + (lane & 15);
-    if (co >= g.Cout) continue;
-#pragma unroll
-    for (int kw = 0; kw < KS; kw++)
-#pragma unroll
-      for (int e = 0; e < 4; e++) {
-        const int ci = mt * 16 + 4 * q + e;
-        if (ci < g.Cin) atomicAdd(dwt + ((int64_t)((kd * KS + kh0 + kk) * KS + kw) * g.Cin + ci) * g.Cout + co, acc[kk][kw][e]);
-      }
-  }
+          for (int e = 0; e < 4; e++) {
+            const int ci = mt * 16 + 4 * q + e;
+            if (ci < g.Cin) atomicAdd(dwt + ((int64_t)((kd * KS + kh) * KS + kw) * g.Cin + ci) * g.Cout + co, acc[sl][e]);
+          }
+        }
+      });
+    });
+  };
+  if (last_role) flush(RoleLast{}); else flush(RolePair{});
 }
 
 template <typename T, int KS>
