@@ -354,8 +354,7 @@ class MLPBlock(nn.Module):
         self.fn = nn.GELU()
 
     def forward(self, x):
-        return ops.linear(ops.gelu(ops.linear(x, self.linear1.weight, self.linear1.bias, defer_wgrad=True)), self.linear2.weight,
-                          self.linear2.bias, defer_wgrad=True)
+        return ops.mlp(x, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias)
 
 
 class TransformerBlock(nn.Module):

@@ -21,7 +21,7 @@ __global__ void __launch_bounds__(256) k_gemm_nt(const T* __restrict__ A, int64_
                                                  const T* __restrict__ B, int64_t ldb, int64_t sb0, int64_t sb1,
                                                  void* __restrict__ Cv, int64_t ldc, int64_t sc0, int64_t sc1,
                                                  const float* __restrict__ bias, int M, int N, int K, int nb1,
-                                                 float alpha, int out_f32, int splitk) {
+                                                 float alpha, int out_f32, int splitk, T* __restrict__ aux, int64_t ldaux, int epi) {
   constexpr int BM = 32 * TI, BN = 32 * TJ, WMR = 16 * TI, WNR = 16 * TJ, LDP = BK + 8, CPR = BK / 8;   // CPR: 16-byte chunks per row
   constexpr int UA = BM * CPR / 256 > 0 ? BM * CPR / 256 : 1, UB = BN * CPR / 256 > 0 ? BN * CPR / 256 : 1;   // chunks per thread
   __shared__ __attribute__((aligned(16))) T smem[(BM + BN) * LDP];
@@ -145,10 +145,33 @@ __global__ void __launch_bounds__(256) k_gemm_nt(const T* __restrict__ A, int64_
 #pragma unroll
           for (int i = 0; i < TI; i++)
 #pragma unroll
-            for (int e = 0; e < 4; e++) st_f(tile + (rbase + i * 16 + q * 4 + e) * CP + col, alpha * acc[i][j][e] + bv);
+            for (int e = 0; e < 4; e++) {
+              float v = alpha * acc[i][j][e] + bv;
+              // epi 2: the product is the gradient of GELU's OUTPUT; aux holds the pre-activation (fc2 data gradient -> fc1 output gradient)
+              if (epi == 2) v *= act_bwd(ld_f(aux + (int64_t)(m0 + (NPASS == 1 ? 0 : ps * PR) + rbase + i * 16 + q * 4 + e) * ldaux + n0 + col), DP_ACT_GELU);
+              st_f(tile + (rbase + i * 16 + q * 4 + e) * CP + col, v);
+            }
         }
       }
       __syncthreads();
+      if (epi == 1) {
+        // fc1 + GELU: the tile holds the pre-activation rounded to T; it goes to aux as it is and to C through GELU -- the values
+        // a separate GELU kernel would read and write
+        T* Ab = aux + (int64_t)m0 * ldaux + n0;
+#pragma unroll
+        for (int u = 0; u < PR * BN / 8 / 256; u++) {
+          const int c = tid + u * 256, row = c / (BN / 8), cc = (c % (BN / 8)) * 8;
+          if constexpr (sizeof(T) == 2) {
+            union { v4u raw; T e[8]; } w;
+            w.raw = *(const v4u*)(tile + row * CP + cc);
+            *(v4u*)(Ab + (int64_t)(ps * PR + row) * ldaux + cc) = w.raw;
+#pragma unroll
+            for (int z = 0; z < 8; z++) st_f(&w.e[z], act_fwd(ld_f(&w.e[z]), DP_ACT_GELU));
+            *(v4u*)(Cb + (int64_t)(ps * PR + row) * ldc + cc) = w.raw;
+          }
+        }
+        continue;
+      }
 #pragma unroll
       for (int u = 0; u < PR * BN / 8 / 256; u++) {
         const int c = tid + u * 256, row = c / (BN / 8), cc = (c % (BN / 8)) * 8;
@@ -171,6 +194,8 @@ __global__ void __launch_bounds__(256) k_gemm_nt(const T* __restrict__ A, int64_
         if (row >= M) continue;
         float v = alpha * acc[i][j][e] + bv;
         int64_t idx = coff + (int64_t)row * ldc + col;
+        if (epi == 1) { T h; st_f(&h, v); aux[(int64_t)row * ldaux + col] = h; v = act_fwd(ld_f(&h), DP_ACT_GELU); }
+        else if (epi == 2) v *= act_bwd(ld_f(aux + (int64_t)row * ldaux + col), DP_ACT_GELU);
         if (out_f32) { if (splitk > 1) atomicAdd((float*)Cv + idx, v); else ((float*)Cv)[idx] = v; }
         else st_f((T*)Cv + idx, v);
       }
@@ -178,9 +203,9 @@ __global__ void __launch_bounds__(256) k_gemm_nt(const T* __restrict__ A, int64_
   }
 }
 
-extern "C" int dp_gemm_nt(const void* A, int64_t lda, int64_t sa0, int64_t sa1, const void* B, int64_t ldb, int64_t sb0, int64_t sb1,
-                          void* C, int64_t ldc, int64_t sc0, int64_t sc1, const float* bias, int M, int N, int K, int nb0, int nb1,
-                          float alpha, int out_f32, int splitk, int dtype, void* stream) {
+static int gemm_nt_impl(const void* A, int64_t lda, int64_t sa0, int64_t sa1, const void* B, int64_t ldb, int64_t sb0, int64_t sb1,
+                        void* C, int64_t ldc, int64_t sc0, int64_t sc1, const float* bias, int M, int N, int K, int nb0, int nb1,
+                        float alpha, int out_f32, int splitk, void* aux, int64_t ldaux, int epi, int dtype, void* stream) {
   if (M <= 0 || N <= 0 || K <= 0) DP_FAIL("gemm_nt: empty problem %d %d %d", M, N, K);
   if (splitk < 1) splitk = 1;
   if (splitk > 1 && !out_f32) DP_FAIL("gemm_nt: split-K needs fp32 (atomic) output");
@@ -191,7 +216,7 @@ extern "C" int dp_gemm_nt(const void* A, int64_t lda, int64_t sa0, int64_t sa1, 
   if (g.y > 65535 || g.z > 65535) DP_FAIL("gemm_nt: grid too large");
   // bf16 and deep K: 64-deep LDS stages halve the number of barrier pairs (the token GEMMs are latency-, not MFMA-bound)
   bool deep = dtype != DP_F32 && K >= 256;
-#define GEMM_ARGS g, dim3(256), 0, STREAM, (const T*)A, lda, sa0, sa1, (const T*)B, ldb, sb0, sb1, C, ldc, sc0, sc1, bias, M, N, K, nb1, alpha, out_f32, splitk
+#define GEMM_ARGS g, dim3(256), 0, STREAM, (const T*)A, lda, sa0, sa1, (const T*)B, ldb, sb0, sb1, C, ldc, sc0, sc1, bias, M, N, K, nb1, alpha, out_f32, splitk, (T*)aux, ldaux, epi
 #define GEMM_GO(TI_, TJ_, BK_) DP_DISPATCH(dtype, hipLaunchKernelGGL((k_gemm_nt<T, TI_, TJ_, BK_>), GEMM_ARGS))
   if (deep && dtype == DP_BF16) {   // 16-bit types only: the deeper stage keeps (BM + BN) * BK * 2 bytes of loads in flight per block
     typedef bf16_t T;
@@ -204,6 +229,20 @@ extern "C" int dp_gemm_nt(const void* A, int64_t lda, int64_t sa0, int64_t sa1, 
 #undef GEMM_ARGS
 #undef GEMM_GO
   DP_CHECK_LAUNCH("gemm_nt"); return 0;
+}
+extern "C" int dp_gemm_nt(const void* A, int64_t lda, int64_t sa0, int64_t sa1, const void* B, int64_t ldb, int64_t sb0, int64_t sb1,
+                          void* C, int64_t ldc, int64_t sc0, int64_t sc1, const float* bias, int M, int N, int K, int nb0, int nb1,
+                          float alpha, int out_f32, int splitk, int dtype, void* stream) {
+  return gemm_nt_impl(A, lda, sa0, sa1, B, ldb, sb0, sb1, C, ldc, sc0, sc1, bias, M, N, K, nb0, nb1, alpha, out_f32, splitk, nullptr, 0, 0, dtype, stream);
+}
+// Token GEMM with the transformer MLP's GELU in its epilogue (one matrix, storage-type output):
+//   mode 1: aux = A B^T + bias (pre-activation, kept for the backward pass), C = GELU(aux)
+//   mode 2: C = (A B^T) * GELU'(aux)             (the data gradient of the layer AFTER the GELU, taken through it)
+extern "C" int dp_gemm_nt_gelu(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const float* bias, void* aux,
+                               int64_t ldaux, int M, int N, int K, int mode, int dtype, void* stream) {
+  if (mode != 1 && mode != 2) DP_FAIL("gemm_nt_gelu: mode must be 1 (forward) or 2 (backward)");
+  if (!aux) DP_FAIL("gemm_nt_gelu: the pre-activation matrix is missing");
+  return gemm_nt_impl(A, lda, 0, 0, B, ldb, 0, 0, C, ldc, 0, 0, mode == 1 ? bias : nullptr, M, N, K, 1, 1, 1.f, 0, 1, aux, ldaux, mode, dtype, stream);
 }
 
 // ------------------------------------------------------------------------------------------------ TN GEMM

@@ -888,6 +888,73 @@ class Linear(torch.autograd.Function):
         return gx, gw, gb, None, None
 
 
+_FUSED_MLP = os.environ.get("DOSE_HIP_FUSED_MLP", "1") != "0"      # (A/B switch for experiments)
+
+
+class MLP(torch.autograd.Function):
+    """MONAI MLPBlock, linear2(GELU(linear1(x))), as ONE autograd node: the GELU is the epilogue of linear1's GEMM and its derivative
+    the epilogue of linear2's data-gradient GEMM (dp_gemm_nt_gelu), so neither the activation nor its gradient is a pass of its
+    own; the four weight / bias gradients join the grouped launch (flush_deferred).  16-bit storage types (fp32: composed ops)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        _chk_dev(x, w1, w2)
+        x = as_rows(x)
+        rows, K, ldx = rows_ld(x)
+        mid, nout = w1.shape[0], w2.shape[0]
+        w1p, w2p = _pack_mat(w1, False, x.dtype), _pack_mat(w2, False, x.dtype)
+        h = torch.empty(tuple(x.shape[:-1]) + (mid,), dtype=x.dtype, device=x.device)
+        a = torch.empty_like(h)
+        y = torch.empty(tuple(x.shape[:-1]) + (nout,), dtype=x.dtype, device=x.device)
+        _lib.call("dp_gemm_nt_gelu", _p(x), ldx, _p(w1p), w1p.shape[-1], _p(a), mid, _p(b1.detach()), _p(h), mid, rows, mid, K, 1, _dt(x),
+                  _stream())
+        gemm_nt(a, w2p, y, bias=b2.detach(), M=rows, N=nout, K=mid, lda=mid, ldb=w2p.shape[-1], ldc=nout)
+        ctx.save_for_backward(x, h, a, w1, w2)
+        ctx.params = (w1, b1, w2, b2)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, h, a, w1, w2 = ctx.saved_tensors
+        _, b1, _, b2 = ctx.params
+        gy = as_rows(gy)
+        rows, K, ldx = rows_ld(x)
+        _, nout, ldg = rows_ld(gy)
+        mid = w1.shape[0]
+        dtc = _dt(x)
+        # gh = (gy W2) * GELU'(h): the gradient with respect to linear1's output, in one GEMM
+        w2t = _pack_mat(w2, True, x.dtype)                      # [mid][outP]
+        gh = torch.empty_like(h)
+        _lib.call("dp_gemm_nt_gelu", _p(gy), ldg, _p(w2t), w2t.shape[-1], _p(gh), mid, 0, _p(h), mid, rows, mid, nout, 2, dtc, _stream())
+        gx = None
+        if ctx.needs_input_grad[0]:
+            w1t = _pack_mat(w1, True, x.dtype)                  # [in][midP]
+            gx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+            gemm_nt(gh, w1t, gx, M=rows, N=K, K=mid, lda=mid, ldb=w1t.shape[-1], ldc=K)
+        grads = []
+        for (w, b, g2, ldg2, inp, ldi, no, ni) in ((w1, b1, gh, mid, x, ldx, mid, K), (w2, b2, gy, ldg, a, mid, nout, mid)):
+            if _DEFER["enabled"] and rows <= 16384 and w.grad is None and b.grad is None:
+                gw = _wgrad_buffer(w, False)
+                gb = torch.empty((no,), dtype=torch.float32, device=x.device)
+                _defer_wgrad(g2, ldg2, inp, ldi, w, b, no, ni, rows)
+            else:
+                gw = _wgrad_buffer(w, False)
+                _lib.call("dp_gemm_tn", _p(g2), ldg2, _p(inp), ldi, _p(gw), ni, no, ni, rows, 1, dtc, _stream())
+                gb = torch.empty((no,), dtype=torch.float32, device=x.device)
+                colsum_into(_p(g2), ldg2, rows, no, gb, dtc)
+            grads += [gw, gb]
+        return gx, grads[0], grads[1], grads[2], grads[3]
+
+
+def mlp(x, w1, b1, w2, b2):
+    """linear2(GELU(linear1(x))) (MONAI MLPBlock, dropout 0)."""
+    if not _FUSED_MLP or x.dtype == torch.float32 or not (w1.requires_grad and w2.requires_grad and b1 is not None and b2 is not None
+                                         and b1.requires_grad and b2.requires_grad) or x.shape[-1] % 8 or w1.shape[0] % 8 \
+            or x.numel() // x.shape[-1] > 16384:
+        return linear(gelu(linear(x, w1, b1, defer_wgrad=True)), w2, b2, defer_wgrad=True)
+    return MLP.apply(x, w1, b1, w2, b2)
+
+
 def linear(x, weight, bias=None, splitk=1, defer_wgrad=False):
     """defer_wgrad=True (weights that are used once per forward pass and not shared): the weight / bias gradients are produced by
     one grouped launch at the end of the backward pass instead of two to three small launches here."""

@@ -156,6 +156,10 @@ int dp_add_layernorm_bwd(const void* x, const void* gy, const void* gsum, const 
 int dp_gemm_nt(const void* A, int64_t lda, int64_t sa0, int64_t sa1, const void* B, int64_t ldb, int64_t sb0, int64_t sb1,
                void* C, int64_t ldc, int64_t sc0, int64_t sc1, const float* bias, int M, int N, int K, int nb0, int nb1,
                float alpha, int out_f32, int splitk, int dtype, void* stream);
+/* replaces: MONAI MLPBlock's linear1 -> GELU (mode 1) and the gradient through that GELU inside linear2's data gradient (mode 2):
+ * mode 1: aux = A B^T + bias (pre-activation, storage type), C = GELU(aux);  mode 2: C = (A B^T) * GELU'(aux). */
+int dp_gemm_nt_gelu(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const float* bias, void* aux,
+                    int64_t ldaux, int M, int N, int K, int mode, int dtype, void* stream);
 /* C[m*ldc + n] (fp32) = sum_k A[k*lda + m] * B[k*ldb + n]  -- both operands k-major in memory: the weight gradient of
  * nn.Linear / ConvTranspose3d (autograd of MONAI's ViT blocks, base_blocks.py:118-127) dW = gy^T x with k = token or voxel
  * rows, without transposing either operand.  splitk > 1: K is split over blockIdx.z and C (pre-zeroed) is accumulated

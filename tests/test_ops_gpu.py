@@ -291,6 +291,44 @@ def test_add_layernorm_fused(dtype, C):
             assert torch.equal(a2.grad, a3.grad)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("cfg", [(2, 512, 768, 3072), (1, 37, 96, 200), (3, 64, 64, 256)])
+def test_mlp_fused_gelu_epilogues(cfg, dtype):
+    """ops.mlp = linear2(GELU(linear1(x))) with the GELU in linear1's GEMM epilogue and its derivative in linear2's data-gradient
+    epilogue (dp_gemm_nt_gelu).  Forward: the composed ops' values (the pre-activation is rounded to the storage type before the
+    GELU, as a separate kernel would read it).  Gradients: against the fp64 oracle, and not worse than the composed ops."""
+    from dose_prediction_amd import ops
+    dev = _dev()
+    B, N, H, M = cfg
+    x = q(rnd((B, N, H), 1), dtype)
+    w1, b1 = q(rnd((M, H), 2, H ** -0.5), dtype), 0.1 * rnd((M,), 3)
+    w2, b2 = q(rnd((H, M), 4, M ** -0.5), dtype), 0.1 * rnd((H,), 5)
+    r = q(rnd((B, N, H), 6), dtype)
+    ref = [t.double().requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+    yr = oracle.linear(oracle.gelu(oracle.linear(ref[0], ref[1], ref[2])), ref[3], ref[4])
+    (yr * r.double()).sum().backward()
+
+    def run(fused):
+        t = [x.to(dev, dtype).requires_grad_(True)] + [v.to(dev).requires_grad_(True) for v in (w1, b1, w2, b2)]
+        y = ops.mlp(*t) if fused else ops.linear(ops.gelu(ops.linear(t[0], t[1], t[2])), t[3], t[4])
+        y.backward(r.to(dev, dtype))
+        ops.flush_deferred()
+        torch.cuda.synchronize()
+        return y, t
+
+    yf, tf = run(True)
+    yc, tc = run(False)
+    # (same roundings as the composed ops; the compiler may contract the GELU polynomial differently in the two kernels, which can
+    # flip the last bit of a few activations, each of which reaches a row of outputs)
+    assert float((yf != yc).float().mean()) < 2e-2 and rel_l2(yf.cpu().double(), yc.cpu().double()) < 1e-3
+    s = 3.0
+    check("y", yf, yr, dtype, scale=s)
+    for name, a, c, g in zip(("gx", "gw1", "gb1", "gw2", "gb2"), tf, tc, ref):
+        check(name, a.grad, g.grad, dtype, scale=s)
+        ef, ec = rel_l2(a.grad.detach().cpu().double(), g.grad), rel_l2(c.grad.detach().cpu().double(), g.grad)
+        assert ef <= 1.5 * ec + 1e-6, (name, ef, ec)
+
+
 @pytest.mark.parametrize("C", [48, 1000, 1536])
 def test_layernorm_widths(C):
     test_layernorm_gelu_add(torch.float32, C)
