@@ -303,7 +303,8 @@ def pmc_traffic(kernel_prefix):
         return None, None
     try:
         ks = json.load(open(files[-1]))["kernels"]
-        sel = [v for k, v in ks.items() if kernel_prefix in k]
+        prefixes = (kernel_prefix,) if isinstance(kernel_prefix, str) else tuple(kernel_prefix)
+        sel = [v for k, v in ks.items() if any(p in k for p in prefixes)]
         n = sum(v["launches"] for v in sel)
         if not n:
             return None, None
@@ -478,7 +479,7 @@ def main():
         peak = PEAK_BF16_TFLOPS if args.dtype in ("bf16", "fp16") else PEAK_F32_TFLOPS
         dom = prof.get("conv7x7x7_tiled", prof.get("conv7x7x7_generic", {"tflops": 0.0, "avg_launch_ms": 0.0, "launches_per_step": 0}))
         default_cfg = args.model == "pyfer" and args.dtype == "bf16" and tuple(shape) == (128, 128, 128) and B == 2
-        traffic, traffic_src = pmc_traffic("k_conv_tiled<unsigned short, 7,") if default_cfg else (None, None)
+        traffic, traffic_src = pmc_traffic(("k_conv_tiled<unsigned short, 7,", "k_conv_cc16<unsigned short, 7,")) if default_cfg else (None, None)
         res = {
             "metric": "128\u00b3 CT volumes/sec (fwd+bwd)", "value": world * B * args.steps / dt, "unit": "volumes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
