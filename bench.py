@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--grad-dtype", default="fp32", choices=["fp32", "bf16"], help="dtype of the all-reduce buckets (N > 1)")
     ap.add_argument("--no-side-stream", action="store_true", help="run the ViT branch on the main stream (no second HIP stream)")
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the extra fp32-mode timing (default workload only)")
+    ap.add_argument("--own-stream", action="store_true", help="run the timed steps on a non-default (non-blocking) HIP stream")
     ap.add_argument("--fp32-steps", type=int, default=3)
     return ap.parse_args()
 
@@ -428,13 +429,18 @@ def main():
         except Exception as e:      # capture is an optimisation: fall back to eager launches
             print(f"[bench] HIP-graph capture failed ({e!r}); timing eager launches", file=sys.stderr)
             graph = None
+    import contextlib
+    own = torch.cuda.stream(side) if args.own_stream else contextlib.nullcontext()
+    if args.own_stream:
+        side.wait_stream(torch.cuda.current_stream())
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        if graph is not None:
-            graph.replay()
-            loss = static_loss
-        else:
-            loss = step()
+    with own:
+        for _ in range(args.steps):
+            if graph is not None:
+                graph.replay()
+                loss = static_loss
+            else:
+                loss = step()
     sync()
     dt = time.perf_counter() - t0
     if ddp_on:

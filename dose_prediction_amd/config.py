@@ -89,3 +89,20 @@ def set_vit_side_stream(on):
 
 def vit_side_stream():
     return _vit_side_stream
+
+
+_vit_cus = int(os.environ.get("DOSE_HIP_VIT_CUS", "0"))
+
+
+def set_vit_cus(n):
+    """Compute units reserved for the transformer branch while it runs beside the 128^3 block (0: both streams see the whole chip).
+    A multiple of 8 (the same number of CUs on each of the 8 XCDs); env DOSE_HIP_VIT_CUS."""
+    global _vit_cus
+    n = int(n)
+    if n < 0 or n % 8 or n > 128:
+        raise ValueError("vit_cus must be a multiple of 8 in [0, 128]")
+    _vit_cus = n
+
+
+def vit_cus():
+    return _vit_cus

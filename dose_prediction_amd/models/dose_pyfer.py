@@ -19,54 +19,109 @@ def ensure_tuple_rep(v, n):
 _SIDE_STREAMS = {}
 
 
+def _cu_stream(device, lo, hi, total=256):
+    """A HIP stream restricted to compute units [lo, hi) of the mask numbering (bit b = CU b/8 of XCD b%8: every XCD contributes
+    the same share); dp_stream_create_cu_mask."""
+    import ctypes
+    from .. import _lib
+    words = (ctypes.c_uint32 * (total // 32))()
+    for b in range(lo, hi):
+        words[b >> 5] |= 1 << (b & 31)
+    out = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        _lib.call("dp_stream_create_cu_mask", words, total // 32, ctypes.byref(out))
+    return torch.cuda.ExternalStream(out.value, device=device)
+
+
 class _SideRun:
     """Handle of a ViT forward running on the side stream: hidden(i) / final() make the CURRENT stream wait for exactly the
-    producer they need (a per-block event), and register the tensor with the allocator for that stream."""
+    producer they need (a per-block event), and register the tensor with the allocator for that stream.  With a CU partition
+    (`part` is not None) the consumers of the hidden states are meant to run inside `with run.beside():`, i.e. on the stream that
+    owns the other compute units, until final(*outs) joins everything back into the caller's stream."""
 
-    def __init__(self, z, hidden, events, side, main):
-        self.z, self.hid, self.events, self.side, self.main = z, hidden, events, side, main
+    def __init__(self, z, hidden, events, side, main, part=None):
+        self.z, self.hid, self.events, self.side, self.main, self.part = z, hidden, events, side, main, part
+
+    def beside(self):
+        import contextlib
+        return torch.cuda.stream(self.part) if self.part is not None else contextlib.nullcontext()
 
     def hidden(self, i):
         t = self.hid[i]
         if self.side is not None:
-            self.main.wait_event(self.events[i])
-            t.record_stream(self.main)
+            cur = torch.cuda.current_stream(t.device)
+            cur.wait_event(self.events[i])
+            t.record_stream(cur)
         return t
 
-    def final(self):
+    def final(self, *outs):
+        """The transformer's output on the caller's stream; `outs`: tensors produced inside beside() that the caller goes on to use."""
         if self.side is not None:
             self.main.wait_stream(self.side)
             self.z.record_stream(self.main)
+            if self.part is not None:
+                self.main.wait_stream(self.part)
+                _record_all(outs, self.main)
         return self.z
 
 
-def run_vit_beside(vit, x_in, first=None):
+def _record_all(out, stream):
+    if torch.is_tensor(out):
+        out.record_stream(stream)
+    elif isinstance(out, (list, tuple)):
+        for o in out:
+            _record_all(o, stream)
+
+
+def run_vit_beside(vit, x_in, first=None, first_inputs=()):
     """Start vit(x_in) on a second HIP stream (config.vit_side_stream) and return (_SideRun, first()).  `first` -- the 128^3 block
     on the same input -- is ENQUEUED BEFORE the transformer although both start from the same point of the caller's stream: its
     autograd nodes are then older than the transformer's, so the backward pass issues the whole transformer / patch-embedding
-    backward (48 % of the gradient bytes of the data-parallel exchange) before the 128^3 block's.  The transformer is ~200 small-grid,
+    backward (48 % of the gradient bytes of the data-parallel exchange) before the 128^3 block's.  The transformer is ~150 small-grid,
     latency-bound launches (1024 token rows), while the skip blocks that run meanwhile on the caller's stream are full-chip
     kernels on 128^3 .. 16^3 volumes; skip block k only waits for the transformer layer it reads.  Autograd replays each node on
-    the stream of its forward pass, so the backward branches overlap the same way."""
+    the stream of its forward pass, so the backward branches overlap the same way.
+
+    config.vit_cus() = V > 0: the two branches run on DISJOINT compute units -- the transformer on a stream masked to V CUs (V/8 per
+    XCD), `first` on a stream masked to the other 256 - V -- because on ordinary streams the transformer's workgroups only find free
+    CU slots at the tail of each full-chip kernel (kernel trace: the branch advances about one launch per main-stream kernel and its
+    backward pass ran with the main stream idle).  `first_inputs`: tensors `first` reads (allocator bookkeeping for its stream)."""
     from .. import config
     if not (config.vit_side_stream() and x_in.is_cuda):
         out = first() if first is not None else None
         z, hidden = vit(x_in)
         return _SideRun(z, hidden, None, None, None), out
     main = torch.cuda.current_stream(x_in.device)
-    key = (x_in.device.index, main.cuda_stream)
-    side = _SIDE_STREAMS.get(key)
-    if side is None:
-        side = _SIDE_STREAMS[key] = torch.cuda.Stream(device=x_in.device)
+    vcu = config.vit_cus()
+    key = (x_in.device.index, main.cuda_stream, vcu)
+    pair = _SIDE_STREAMS.get(key)
+    if pair is None:
+        if vcu > 0:
+            pair = (_cu_stream(x_in.device, 0, vcu), _cu_stream(x_in.device, vcu, 256))
+        else:
+            pair = (torch.cuda.Stream(device=x_in.device), None)
+        _SIDE_STREAMS[key] = pair
+    side, part = pair
     fork = torch.cuda.Event()
     fork.record(main)
-    out = first() if first is not None else None
+    out = None
+    if first is not None:
+        if part is not None and not torch.cuda.is_current_stream_capturing():
+            part.wait_event(fork)
+            for t in (x_in,) + tuple(first_inputs):
+                if torch.is_tensor(t):
+                    t.record_stream(part)
+            with torch.cuda.stream(part):
+                out = first()
+        else:
+            part = None
+            out = first()
     side.wait_event(fork)
     x_in.record_stream(side)
     events = []
     with torch.cuda.stream(side):
         z, hidden = vit(x_in, events)
-    return _SideRun(z, hidden, events, side, main), out
+    return _SideRun(z, hidden, events, side, main, part if first is not None else None), out
 
 
 class ViTEncoder(nn.Module):
@@ -108,11 +163,12 @@ class ViTEncoder(nn.Module):
     def forward(self, x_in, x_cat=None):
         """x_cat: optional (a, b) pair with cat((a, b)) == x_in (virtual concat for skip1's 3x3x3 convolution)."""
         i = self.num_layers // 4
-        run, out_encoder_1 = run_vit_beside(self.vit, x_in, lambda: self.skip1(x_in, x_cat))
-        out_encoder_2 = self.skip2(self.proj_feat(run.hidden(i)))
-        out_encoder_3 = self.skip3(self.proj_feat(run.hidden(i * 2)))
-        out_encoder_4 = self.skip4(self.proj_feat(run.hidden(i * 3)))
-        out_encoder_5 = self.proj_feat(run.final())
+        run, out_encoder_1 = run_vit_beside(self.vit, x_in, lambda: self.skip1(x_in, x_cat), x_cat or ())
+        with run.beside():
+            out_encoder_2 = self.skip2(self.proj_feat(run.hidden(i)))
+            out_encoder_3 = self.skip3(self.proj_feat(run.hidden(i * 2)))
+            out_encoder_4 = self.skip4(self.proj_feat(run.hidden(i * 3)))
+        out_encoder_5 = self.proj_feat(run.final(out_encoder_1, out_encoder_2, out_encoder_3, out_encoder_4))
         return [out_encoder_1, out_encoder_2, out_encoder_3, out_encoder_4, out_encoder_5]
 
 

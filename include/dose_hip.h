@@ -148,6 +148,11 @@ int dp_add_layernorm_fwd(const void* a, const void* b, void* sum, const float* g
 int dp_add_layernorm_bwd(const void* x, const void* gy, const void* gsum, const float* gamma, const float* mean, const float* rstd,
                          void* gx, float* dgamma, float* dbeta, int64_t rows, int C, int dtype, void* stream);
 
+/* ---- stream plumbing (no reference counterpart: the reference's two branches run one after the other on one stream) ----
+ * A stream restricted to the compute units whose bits are set in mask[0..nwords) (MI355X: bit b = CU b/8 of XCD b%8). */
+int dp_stream_create_cu_mask(const uint32_t* mask, int nwords, void** stream);
+int dp_stream_destroy(void* stream);
+
 /* ---- matrix products (MFMA) ------------------------------------------------------------------- */
 /* C[b0][b1][m][n] = alpha * sum_k A[..][m][k] * B[..][n][k] (+ bias[n]) ; "NT" GEMM, both operands k-contiguous.
  * replaces: nn.Linear (MONAI ViT), 1x1x1 nn.Conv3d (blocks_MDUNet.py:146, dose_pyfer.py:292,353), the GEMM half of

@@ -469,6 +469,43 @@ def test_vit_backward_is_issued_before_the_128_cube_branch():
         assert cmp_prefix(outs[True][1][n].cpu(), outs[False][1][n].cpu()) < 1e-4, n
 
 
+def test_cu_partitioned_branches_match_the_single_stream_result():
+    """config.set_vit_cus(V): the transformer on a stream masked to V compute units, the skip blocks on the complementary mask
+    (dp_stream_create_cu_mask).  Measured slower than ordinary streams for the benchmark and therefore off by
+    default; the path is kept correct: same outputs and gradients as the single-stream run, on the default AND on a user stream."""
+    import dose_prediction_amd
+    from dose_prediction_amd.models.dose_pyfer import MainSubsetModel
+    dev = _dev()
+    _set(torch.float32)
+    g = load_golden("g7_subset_multi")
+    outs = {}
+    user = torch.cuda.Stream()
+    for tag, side, vcu, stream in (("ref", False, 0, None), ("part", True, 32, None), ("part_user", True, 64, user)):
+        dose_prediction_amd.config.set_vit_side_stream(side)
+        dose_prediction_amd.config.set_vit_cus(vcu)
+        try:
+            net = MainSubsetModel(in_ch=5, out_ch=1, img_size=(32, 16, 16), feature_size=4, hidden_size=48, mlp_dim=96, num_heads=6,
+                                  num_layers=8, act="mish", mode_multi_dec=True, multiS_conv=True)
+            _load(net, pcg_state_dict(g["keys"], g["shapes"], g["seed"])).to(dev).train()
+            x, rs = g["x"].to(dev), [g[f"r{i}"].to(dev) for i in range(4)]
+            torch.cuda.synchronize()
+            import contextlib
+            with (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()):
+                o = net(x)
+                torch.autograd.backward(o, rs)
+            torch.cuda.synchronize()
+            outs[tag] = ([t.detach().clone() for t in o], {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None})
+        finally:
+            dose_prediction_amd.config.set_vit_side_stream(True)
+            dose_prediction_amd.config.set_vit_cus(0)
+    for tag in ("part", "part_user"):
+        for a, b in zip(outs[tag][0], outs["ref"][0]):
+            assert rel_err(a.cpu(), b.cpu()) < 1e-5, tag
+        assert outs[tag][1].keys() == outs["ref"][1].keys()
+        for n in outs["ref"][1]:
+            assert cmp_prefix(outs[tag][1][n].cpu(), outs["ref"][1][n].cpu()) < 1e-4, (tag, n)
+
+
 def test_host_running_ahead_of_the_gpu_does_not_corrupt_pointer_tables():
     """The fused Adam step and the grouped transformer weight-gradient launch read pointer tables that the host writes into PINNED
     buffers and copies asynchronously.  bench.py never synchronises between steps, so the host runs several steps ahead of the GPU;
