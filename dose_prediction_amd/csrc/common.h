@@ -97,10 +97,35 @@ __device__ __forceinline__ v4f mma16(const Frag8<bf16_t>& a, const Frag8<bf16_t>
 __device__ __forceinline__ v4f mma16(const Frag8<f16_t>& a, const Frag8<f16_t>& b, v4f c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h, a.u), __builtin_bit_cast(v8h, b.u), c, 0, 0, 0);
 }
+// EXPERIMENT, off (-DDP_F32_SPLIT): fp32 operands as two bf16 terms each (hi = bf16(v), lo = bf16(v - hi): 16 significand bits,
+// residual <= 2^-18 |v|): the product a b ~ ah bh + ah bl + al bh on the bf16 matrix pipe (three K = 32 instructions instead of
+// eight K = 4 fp32 ones, fp32 accumulation).  Relative error of a product ~3e-6 rms against 6e-8 for the exact chain; every fp32
+// parity test still passes, but the step only gains 184 -> 125 ms: splitting per MFMA costs ~60 VALU instructions per triple (it
+// belongs into the LDS staging, with pre-split weights), and the parity mode keeps the exact fp32 FMA chain.
+struct Split8 { v4u hi, lo; };
+__device__ __forceinline__ Split8 split_bf16(const Frag8<float>& f) {
+  Split8 s;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const float v0 = f.v[2 * r], v1 = f.v[2 * r + 1];
+    const bf16_t h0 = f2bf(v0), h1 = f2bf(v1);
+    const bf16_t l0 = f2bf(v0 - bf2f(h0)), l1 = f2bf(v1 - bf2f(h1));
+    s.hi[r] = (unsigned)h0 | ((unsigned)h1 << 16);
+    s.lo[r] = (unsigned)l0 | ((unsigned)l1 << 16);
+  }
+  return s;
+}
 __device__ __forceinline__ v4f mma16(const Frag8<float>& a, const Frag8<float>& b, v4f c) {
+#ifdef DP_F32_SPLIT
+  const Split8 sa = split_bf16(a), sb = split_bf16(b);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, sa.lo), __builtin_bit_cast(v8bf, sb.hi), c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, sa.hi), __builtin_bit_cast(v8bf, sb.lo), c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, sa.hi), __builtin_bit_cast(v8bf, sb.hi), c, 0, 0, 0);
+#else
 #pragma unroll
   for (int j = 0; j < 8; j++) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[j], b.v[j], c, 0, 0, 0);
   return c;
+#endif
 }
 
 // two ds_read_b64_tr_b16 at a lane address and OFF elements further: 8 consecutive voxels (k) of one column

@@ -38,9 +38,16 @@ __device__ __forceinline__ v16f mma32(const Frag8<f16_t>& a, const Frag8<f16_t>&
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, a.u), __builtin_bit_cast(v8h, b.u), c, 0, 0, 0);
 }
 __device__ __forceinline__ v16f mma32(const Frag8<float>& a, const Frag8<float>& b, v16f c) {
+#ifdef DP_F32_SPLIT
+  const Split8 sa = split_bf16(a), sb = split_bf16(b);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, sa.lo), __builtin_bit_cast(v8bf, sb.hi), c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, sa.hi), __builtin_bit_cast(v8bf, sb.lo), c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, sa.hi), __builtin_bit_cast(v8bf, sb.hi), c, 0, 0, 0);
+#else
 #pragma unroll
   for (int j = 0; j < 8; j++) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[j], b.v[j], c, 0, 0, 0);
   return c;
+#endif
 }
 
 struct TiledGeom {
