@@ -210,9 +210,13 @@ struct WgHkGeom {
   int N, D, H, W, Cin, Cout, ldx, ldgy;
   int tiles_h, tiles_w, MT, NTn, ydim;
   const void* x2; int ldx2, csplit;   // virtual concat of the input
+  int dbg;                            // experiments only (env DP_DBG): 1 = no staging, 2 = no sweep, 4 = no epilogue
+  float* dw; int64_t s_co, s_ci, s_tap; int rezero;     // destination of the finish pass (3^3: per-block slabs instead of atomics)
 };
 bool wgrad_hk_applicable(int Cout, int k, int H, int W, int dtype);
-int wgrad_hk_launch(const void* x, const void* gy, float* ws, const WgHkGeom& g, int k, int dtype, hipStream_t s);
+int64_t wgrad_hk_ws_elems(int Cin, int Cout, int k);     // fp32 scratch elements the K-along-H kernels may use (0: no extra need)
+// *finished = 1: dW has been written (no unpack of the tap-major scratch needed)
+int wgrad_hk_launch(const void* x, const void* gy, float* ws, const WgHkGeom& g, int k, int dtype, hipStream_t s, int* finished);
 
 // conv_cc16.hip: 16x16x32-MFMA convolution for the Cout <= 16 layers at W >= 96 (chosen by shape alone, so that the packed-weight
 // layout is known from (Cin, Cout, k, W))

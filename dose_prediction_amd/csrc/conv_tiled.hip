@@ -1224,7 +1224,9 @@ static inline bool wgt_applicable(int Cin, int Cout, int k, int stride, int pad,
 // fp32 scratch elements needed by dp_conv3d_wgrad_tiled (0: shape not supported, use dp_conv3d_wgrad)
 extern "C" int dp_conv3d_wgrad_tiled_ws_elems(int Cin, int Cout, int k, int stride, int pad, int dil, int shift, int W) {
   if (!wgt_applicable(Cin, Cout, k, stride, pad, dil, shift, W)) return 0;
-  return k * k * k * Cin * Cout;
+  const int64_t base = (int64_t)k * k * k * Cin * Cout, hk = wgrad_hk_ws_elems(Cin, Cout, k);
+  const int64_t n = base > hk ? base : hk;
+  return n > 2000000000LL ? 0 : (int)n;
 }
 
 template <typename T, int KS, int NPAIR, int MPAIR>
@@ -1295,11 +1297,20 @@ extern "C" int dp_conv3d_wgrad_tiled2(const void* x, int ldx, const void* x2, in
                        (!x2 || (csplit % 8 == 0 && ldx2 % 8 == 0 && ((uintptr_t)x2 & 15) == 0)) &&
                        (int64_t)H * W * (ldx > ldgy ? (ldx > ldx2 ? ldx : ldx2) : (ldgy > ldx2 ? ldgy : ldx2)) < (1ll << 30);
   const bool cc16 = k > 1 && dtype != DP_F32 && aligned && !getenv("DP_NO_CC16");
+  bool hk_done = false;
   const bool hk_wide = getenv("DP_HK_NARROW") == nullptr;         // (experiments: restrict the K-along-H kernel to Cout <= 16)
   if (k > 1 && dtype != DP_F32 && aligned && (np == 2 || hk_wide) && wgrad_hk_applicable(Cout, k, H, W, dtype)) {     // 7^3, planes >= 32 x 32: K along H (conv_wgrad_hk.hip)
     WgHkGeom hg; hg.N = N; hg.D = D; hg.H = H; hg.W = W; hg.Cin = Cin; hg.Cout = Cout; hg.ldx = ldx; hg.ldgy = ldgy;
-    hg.tiles_h = hg.tiles_w = hg.MT = hg.NTn = hg.ydim = 0; hg.x2 = x2; hg.ldx2 = ldx2; hg.csplit = csplit;
-    rc = wgrad_hk_launch(x, gy, ws, hg, k, dtype, s);
+    hg.tiles_h = hg.tiles_w = hg.MT = hg.NTn = hg.ydim = 0; hg.dbg = g.dbg; hg.x2 = x2; hg.ldx2 = ldx2; hg.csplit = csplit;
+    hg.dw = dw; hg.s_co = s_co; hg.s_ci = s_ci; hg.s_tap = s_tap; hg.rezero = g_scratch_zeroed;
+    int finished = 0;
+    rc = wgrad_hk_launch(x, gy, ws, hg, k, dtype, s, &finished);
+    if (rc > 0) return rc;
+    if (finished) { DP_CHECK_LAUNCH("wgrad_hk"); return 0; }
+    hk_done = rc == 0;                      // rc < 0: shape outside that kernel's limits, take the K-along-W kernels below
+    rc = 0;
+  }
+  if (hk_done) {
   } else if (cc16 && np == 2) {           // Cout <= 16: one tap per 16x16x32 MFMA, no tap-pairing padding
     if (dtype == DP_BF16) rc = k == 7 ? launch_wg16<bf16_t, 7, 1>(x, gy, ws, g, s) : launch_wg16<bf16_t, 3, 1>(x, gy, ws, g, s);
     else rc = k == 7 ? launch_wg16<f16_t, 7, 1>(x, gy, ws, g, s) : launch_wg16<f16_t, 3, 1>(x, gy, ws, g, s);

@@ -250,15 +250,247 @@ int launch_hk(const void* x, const void* gy, float* ws, WgHkGeom g, hipStream_t 
   return 0;
 }
 
+
+// ================================================================================================ 3 x 3 x 3: all 27 taps per block, marching along depth
+// The 3^3 weight gradients are fabric-bound (AI ~ 200 FLOP/B): what matters is that every x / gy plane is staged ONCE.  The kernels
+// of conv_tiled.hip give each kd its own block (3 x the staging) and re-read the +-1 halo rows of 8-row tiles (1.25 x).  Here a block
+// owns a 32 x 32 column of gy over a depth segment and marches through it: the three x planes a gy plane needs live in an LDS ring
+// (148 KB with the gy tile: one block per CU), plane d+2 and gy plane d+1 are in flight in registers while plane d is swept, and
+// the 27 tap accumulators (108 registers) stay in the wave for the whole segment.  Wave w walks gy columns 8w .. 8w+7 with K along H
+// as above: per column step 9 x fragments ((kd, kh) rows) + 1 gy fragment for 27 MFMAs.
+constexpr int HK3_MAX_BLOCKS = 512;          // slabs of 27 x 256 floats in the scratch (dp_conv3d_wgrad_tiled_ws_elems)
+
+template <typename T>
+struct Hk3Cfg {
+  static constexpr int KS = 3, PAD = 1, TH = 32, TW = 32, XC = 16, GC = 16;
+  static constexpr int LR = TH + 2, LC = TW + 2, LP = LC | 1, GP = TW + 1;
+  static constexpr int CW = TW / 4, STEPS = CW + KS - 1, NROW = KS * KS;
+  static constexpr int XPLANE = LR * LP * XC;                   // elements of one x plane tile
+  static constexpr size_t SMEM = ((size_t)3 * XPLANE + (size_t)TH * GP * GC) * sizeof(T);
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256, 1) k_wgrad_hk3(const T* __restrict__ x, const T* __restrict__ gy, float* __restrict__ dwt, WgHkGeom g) {
+  static_assert(sizeof(T) == 2, "16-bit storage types only");
+  using C = Hk3Cfg<T>;
+  constexpr int KS = 3;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* xs = (T*)smem_raw;
+  T* gs = xs + (size_t)3 * C::XPLANE;
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4, i16 = lane & 15;
+  // block -> (column (n, th, tw), depth segment, input-channel tile, output-channel tile); ydim = depth segments
+  int b = blockIdx.x;
+  const int seg = b % g.ydim; b /= g.ydim; const int mt = b % g.MT; b /= g.MT; const int nt = b % g.NTn; b /= g.NTn;
+  const int tw = b % g.tiles_w; b /= g.tiles_w; const int th = b % g.tiles_h; const int n = b / g.tiles_h;
+  const int DS = (g.D + g.ydim - 1) / g.ydim, z0 = seg * DS, z1 = min(g.D, z0 + DS);       // (the launcher leaves no segment empty)
+  const int h0 = th * C::TH, w0 = tw * C::TW, g0 = wv * C::CW;
+  const int rowoff = 16 * (q >> 1) + 4 * (q & 1) + (i16 >> 2), c4 = 4 * (i16 & 3);
+  const T* const xl = xs + rowoff * C::LP * C::XC + g0 * C::XC + c4;          // + slot * XPLANE + (kh * LP + column) * XC
+  const T* const gb = gs + rowoff * C::GP * C::GC + g0 * C::GC + c4;
+
+  v4f acc[27];
+#pragma unroll
+  for (int a = 0; a < 27; a++) acc[a] = (v4f){0.f, 0.f, 0.f, 0.f};
+
+  constexpr int PX = (C::LR * C::LC * 2 + 255) / 256, PG = C::TH * C::TW * 2 / 256;
+  v4u rx[PX], rg[PG];
+  const int piece = tid & 1, cpiece = mt * C::XC + piece * 8;
+  const bool xsecond = g.x2 && cpiece >= g.csplit;
+  const T* xsrc = (xsecond ? (const T*)g.x2 : x) + cpiece - (xsecond ? g.csplit : 0);
+  const int ldsrc = xsecond ? g.ldx2 : g.ldx;
+  const T* gsrc = gy + nt * C::GC + piece * 8;
+  const bool x_exists = cpiece + 8 <= (g.x2 ? g.csplit + g.ldx2 : g.ldx), g_exists = nt * C::GC + piece * 8 + 8 <= g.ldgy;
+  auto opaque = [](int v) { asm volatile("" : "+v"(v)); return v; };
+  auto xvox = [&](int t2, int j, int& lr, int& lc) { const int v = j * 128 + t2; lr = v / C::LC; lc = v - lr * C::LC; return v < C::LR * C::LC; };
+  const int g_r = tid >> 6, g_c = (tid >> 1) & 31;
+  auto issue_x = [&](int p) {                            // x plane p (zeros outside the volume) -> rx
+    const bool pin = p >= 0 && p < g.D;
+    const T* xplane = xsrc + (((int64_t)n * g.D + (pin ? p : 0)) * g.H) * (int64_t)g.W * ldsrc;
+    const int ihb = h0 - C::PAD, iwb = w0 - C::PAD, t2 = opaque(tid >> 1);
+#pragma unroll
+    for (int j = 0; j < PX; j++) {
+      int lr, lc; const bool in = xvox(t2, j, lr, lc);
+      const int ih = ihb + lr, iw = iwb + lc;
+      const bool ok = pin && x_exists && in && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
+      v4u v = *(const v4u*)(xplane + (ok ? (ih * g.W + iw) * ldsrc : 0));
+      rx[j] = ok ? v : (v4u){0, 0, 0, 0};
+    }
+  };
+  auto issue_g = [&](int d) {
+    const T* gplane = gsrc + (((int64_t)n * g.D + d) * g.H) * (int64_t)g.W * g.ldgy;
+#pragma unroll
+    for (int j = 0; j < PG; j++) {
+      const int oh = h0 + 4 * j + g_r, ow = w0 + g_c;
+      const bool ok = g_exists && oh < g.H && ow < g.W;
+      v4u v = *(const v4u*)(gplane + (ok ? (oh * g.W + ow) * g.ldgy : 0));
+      rg[j] = ok ? v : (v4u){0, 0, 0, 0};
+    }
+  };
+  auto commit_x = [&](int slot) {
+    const int t2 = opaque(tid >> 1);
+    T* dst = xs + slot * C::XPLANE;
+#pragma unroll
+    for (int j = 0; j < PX; j++) {
+      int lr, lc;
+      if (xvox(t2, j, lr, lc)) *(v4u*)(dst + (lr * C::LP + lc) * C::XC + piece * 8) = rx[j];
+    }
+  };
+  auto commit_g = [&]() {
+#pragma unroll
+    for (int j = 0; j < PG; j++) *(v4u*)(gs + ((4 * j + g_r) * C::GP + g_c) * C::GC + piece * 8) = rg[j];
+  };
+  auto slot_of = [](int p) { return (p + 3) % 3; };     // p >= -1
+
+  // gy plane d against x planes d-1, d, d+1 (kd = 0, 1, 2): rows r = 3 kd + kh; a row's next column is requested right after its own
+  // three MFMAs (24 MFMAs of other rows before its first use), the gy fragment of column cc+1 at the start of step cc (ring of KS + 1)
+  auto sweep = [&](int d) {
+    const T* xb[3];
+#pragma unroll
+    for (int kd = 0; kd < 3; kd++) xb[kd] = xl + slot_of(d + kd - 1) * C::XPLANE;
+    Frag8<T> X[9], G[KS + 1];
+    auto ldx = [&](auto r_, auto cc_) {
+      constexpr int r = decltype(r_)::value, cc = decltype(cc_)::value;
+      if constexpr (cc < C::STEPS) X[r] = tr_pair<8 * C::LP * C::XC, T>(xb[r / 3] + ((r % 3) * C::LP + cc) * C::XC);
+    };
+    auto ldg = [&](auto gc_) {
+      constexpr int gc = decltype(gc_)::value;
+      if constexpr (gc < C::CW) G[gc % (KS + 1)] = tr_pair<8 * C::GP * C::GC, T>(gb + gc * C::GC);
+    };
+    static_for<0, 9>([&](auto r_) { ldx(r_, std::integral_constant<int, 0>{}); });
+    ldg(std::integral_constant<int, 0>{});
+    static_for<0, C::STEPS>([&](auto cc_) {
+      constexpr int cc = decltype(cc_)::value;
+      constexpr std::integral_constant<int, cc + 1> nx{};
+      ldg(nx);
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<0, 9>([&](auto r_) {
+        constexpr int r = decltype(r_)::value;
+        static_for<0, KS>([&](auto kw_) {
+          constexpr int kw = decltype(kw_)::value, gc = cc - kw;
+          if constexpr (gc >= 0 && gc < C::CW) acc[r * 3 + kw] = mma16(X[r], G[gc % (KS + 1)], acc[r * 3 + kw]);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        ldx(r_, nx);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    });
+  };
+
+  const bool fast = (g.ldx % 8 == 0) && (g.ldgy % 8 == 0) && (((uintptr_t)x & 15) == 0) && (((uintptr_t)gy & 15) == 0) &&
+                    (!g.x2 || ((g.csplit % 8 == 0) && (g.ldx2 % 8 == 0) && (((uintptr_t)g.x2 & 15) == 0)));
+  // (the launcher only selects this kernel for aligned operands; an unaligned call leaves zero slabs)
+  // prologue: x planes z0-1 and z0 into the ring, then x plane z0+1 + gy plane z0 in flight
+  if (fast && z0 < z1) {
+    issue_x(z0 - 1); commit_x(slot_of(z0 - 1));
+    issue_x(z0); commit_x(slot_of(z0));
+    issue_x(z0 + 1); issue_g(z0);
+  }
+  for (int d = z0; fast && d < z1; d++) {
+    lds_barrier();                                                  // sweep d-1 is over: slot of plane d-2 and the gy tile are free
+    if (!(g.dbg & 1)) { commit_x(slot_of(d + 1)); commit_g(); }
+    if (d + 1 < z1 && !(g.dbg & 1)) { issue_x(d + 2); issue_g(d + 1); }
+    lds_barrier();
+    if (!(g.dbg & 2)) sweep(d);
+  }
+  // The four waves hold partial sums of the SAME 27 x 16 x 16 block (they walked different gy columns): add them up through LDS
+  // (the ring is free now), then one non-atomic 27 KB slab per block -- k_wgrad_hk3_finish adds the slabs of all blocks.  (Atomics
+  // into the 6 912-element tap-major scratch: 1 024 adds per address, measured 73 of the kernel's 110 us.)
+  lds_barrier();
+  float* red = (float*)smem_raw;                                   // [4 waves][27][16 ci][16 co]
+#pragma unroll
+  for (int t = 0; t < 27; t++)
+#pragma unroll
+    for (int e = 0; e < 4; e++) red[(wv * 27 + t) * 256 + (4 * q + e) * 16 + (lane & 15)] = acc[t][e];
+  lds_barrier();
+  float* slab = dwt + (int64_t)blockIdx.x * (27 * 256);
+#pragma unroll
+  for (int j = 0; j < 27; j++) {
+    const int i = j * 256 + tid;
+    slab[i] = (red[i] + red[27 * 256 + i]) + (red[2 * 27 * 256 + i] + red[3 * 27 * 256 + i]);
+  }
+}
+
+// dW[co][ci][tap] = sum over the blocks of (mt, nt) of slab[tap][ci % 16][co % 16]; the slabs are handed back zeroed (scratch contract).
+// Block = 64 consecutive slab elements x 4 groups of slabs (8 independent loads in flight per thread), LDS add of the four groups.
+__global__ void __launch_bounds__(256) k_wgrad_hk3_finish(float* __restrict__ slabs, float* __restrict__ dw, int Cin, int Cout, int MT, int NTn, int nseg,
+                                                          int nsp, int64_t s_co, int64_t s_ci, int64_t s_tap, int rezero) {
+  __shared__ float red[256];
+  int b = blockIdx.x;
+  const int chunk = b % 108; b /= 108; const int mt = b % MT; const int nt = b / MT;        // 108 x 64 = 27 x 256 elements
+  const int el = chunk * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+  const int nslab = nsp * nseg, per = (nslab + 3) / 4, j0 = part * per, j1 = min(nslab, j0 + per);
+  // slab j of this (mt, nt): j = sp * nseg + sg  ->  block index ((sp * NTn + nt) * MT + mt) * nseg + sg
+  auto addr = [&](int j) { const int sp = j / nseg, sg = j - sp * nseg; return slabs + ((((int64_t)sp * NTn + nt) * MT + mt) * nseg + sg) * (27 * 256) + el; };
+  float sacc = 0.f;
+  int j = j0;
+  for (; j + 8 <= j1; j += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) v[u] = *addr(j + u);
+#pragma unroll
+    for (int u = 0; u < 8; u++) { sacc += v[u]; if (rezero) *addr(j + u) = 0.f; }
+  }
+  for (; j < j1; j++) { sacc += *addr(j); if (rezero) *addr(j) = 0.f; }
+  red[threadIdx.x] = sacc;
+  __syncthreads();
+  if (part == 0) {
+    const float t = (red[threadIdx.x] + red[64 + threadIdx.x]) + (red[128 + threadIdx.x] + red[192 + threadIdx.x]);
+    const int tap = el >> 8, ci = mt * 16 + ((el >> 4) & 15), co = nt * 16 + (el & 15);
+    if (ci < Cin && co < Cout) dw[co * s_co + ci * s_ci + tap * s_tap] = t;
+  }
+}
+
+template <typename T>
+int launch_hk3(const void* x, const void* gy, float* ws, WgHkGeom g, hipStream_t s) {
+  using C = Hk3Cfg<T>;
+  auto kern = k_wgrad_hk3<T>;
+  static bool raised = false;
+  if (!raised) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::SMEM);
+    if (e != hipSuccess) { dp_set_error("wgrad_hk3: cannot raise dynamic LDS to %zu: %s", C::SMEM, hipGetErrorString(e)); return 1; }
+    raised = true;
+  }
+  g.tiles_h = cdiv(g.H, C::TH); g.tiles_w = cdiv(g.W, C::TW);
+  g.MT = cdiv(g.Cin, C::XC); g.NTn = cdiv(g.Cout, C::GC);
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0; hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount;
+    if (ncu < 1) ncu = 256;
+  }
+  // depth segments: one resident wave of blocks (one block per CU); a segment re-reads two x planes, so no more of them than needed
+  const int64_t cols = (int64_t)g.N * g.tiles_h * g.tiles_w * g.MT * g.NTn;
+  int nseg = (int)(ncu / cols); if (nseg < 1) nseg = 1; if (nseg > g.D) nseg = g.D;
+  const int DS = cdiv(g.D, nseg); nseg = cdiv(g.D, DS);
+  g.ydim = nseg;
+  if (cols * nseg > HK3_MAX_BLOCKS) return -1;                       // more slabs than the scratch holds: the caller takes the K-along-W kernel
+  hipLaunchKernelGGL(kern, dim3((unsigned)(cols * nseg)), dim3(256), C::SMEM, s, (const T*)x, (const T*)gy, ws, g);
+  hipLaunchKernelGGL(k_wgrad_hk3_finish, dim3(108 * g.MT * g.NTn), dim3(256), 0, s, ws, g.dw, g.Cin, g.Cout, g.MT, g.NTn, nseg,
+                     g.N * g.tiles_h * g.tiles_w, g.s_co, g.s_ci, g.s_tap, g.rezero);
+  return 0;
+}
+
 }  // namespace
 
 bool wgrad_hk_applicable(int Cout, int k, int H, int W, int dtype) {
   static const bool off = getenv("DP_NO_HK") != nullptr;
+  static const bool off3 = getenv("DP_NO_HK3") != nullptr;
   (void)Cout;
-  return !off && dtype != DP_F32 && k == 7 && H >= 32 && W >= 32;
+  return !off && dtype != DP_F32 && (k == 7 || (k == 3 && !off3)) && H >= 32 && W >= 32;
 }
 
-int wgrad_hk_launch(const void* x, const void* gy, float* ws, const WgHkGeom& g, int k, int dtype, hipStream_t s) {
+int64_t wgrad_hk_ws_elems(int Cin, int Cout, int k) {
+  (void)Cin; (void)Cout;
+  return k == 3 ? (int64_t)HK3_MAX_BLOCKS * 27 * 256 : 0;
+}
+
+int wgrad_hk_launch(const void* x, const void* gy, float* ws, const WgHkGeom& g, int k, int dtype, hipStream_t s, int* finished) {
+  *finished = 0;
+  if (k == 3) {
+    const int rc = dtype == DP_BF16 ? launch_hk3<bf16_t>(x, gy, ws, g, s) : launch_hk3<f16_t>(x, gy, ws, g, s);
+    if (rc == 0) *finished = 1;
+    return rc;
+  }
   if (k != 7) { dp_set_error("wgrad_hk: kernel size %d not built", k); return 1; }
   return dtype == DP_BF16 ? launch_hk<bf16_t, 7>(x, gy, ws, g, s) : launch_hk<f16_t, 7>(x, gy, ws, g, s);
 }

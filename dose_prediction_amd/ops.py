@@ -652,7 +652,7 @@ class Conv3dCat(torch.autograd.Function):
         if ctx.needs_input_grad[2]:
             gw = _wgrad_buffer(weight, False)      # overwritten by the tiled kernel
             taps = k * k * k
-            ws = _zero_scratch(xa.device, taps * cin * cout)
+            ws = _zero_scratch(xa.device, max(taps * cin * cout, _lib.lib().dp_conv3d_wgrad_tiled_ws_elems(cin, cout, k, 1, k // 2, 1, 1, W)))
             _lib.call("dp_conv3d_wgrad_tiled2", _p(xa), lda, _p(xb), ldb, ca, _p(gy), ldg, _p(gw), _p(ws), N, D, H, W, cin, cout, k,
                       cin * taps, taps, 1, dtc, _stream())
         if has_bias and ctx.needs_input_grad[3]:

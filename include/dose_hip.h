@@ -248,7 +248,8 @@ int dp_conv3d_wgrad(const void* x, int ldx, const void* gy, int ldgy, float* dw,
 /* LDS-tiled weight gradient for the hot layers (stride 1, dilation 1, "same" padding, k in {3,7}).
  * dp_conv3d_wgrad_tiled_ws_elems: fp32 scratch elements needed, or 0 when the shape must take dp_conv3d_wgrad (NOT an error
  * code).  dp_conv3d_wgrad_tiled OVERWRITES dw[co*s_co + ci*s_ci + tap*s_tap] (every element of the
- * [Cout][Cin][taps] index space is written); neither dw nor ws need be initialised. */
+ * [Cout][Cin][taps] index space is written); neither dw nor ws need be initialised.  (k = 3: the scratch also holds the per-block
+ * partial sums of the depth-marching kernel, 512 x 27 x 256 floats, so that no atomics are needed.) */
 int dp_conv3d_wgrad_tiled_ws_elems(int Cin, int Cout, int k, int stride, int pad, int dil, int shift, int W);
 int dp_conv3d_wgrad_tiled(const void* x, int ldx, const void* gy, int ldgy, float* dw, float* ws, int N, int D, int H, int W,
                           int Cin, int Cout, int k, int64_t s_co, int64_t s_ci, int64_t s_tap, int dtype, void* stream);

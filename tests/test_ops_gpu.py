@@ -100,6 +100,13 @@ DTYPES = [torch.float32, torch.bfloat16, torch.float16]
     (1, 24, 8, 5, 64, 32, 7, 1, 3, 1, True),
     (1, 32, 32, 2, 32, 40, 7, 1, 3, 1, True),     # ... wider layers: several 16-channel output tiles on the grid
     (1, 64, 40, 2, 33, 32, 7, 1, 3, 1, False),
+    # 3^3 weight gradient marching along depth (k_wgrad_hk3: all 27 taps per block, x planes in an LDS ring): one plane, a few
+    # planes, depth segments with ragged ends, ragged tiles, several channel tiles
+    (1, 16, 16, 1, 32, 32, 3, 1, 1, 1, True),
+    (1, 16, 16, 5, 32, 32, 3, 1, 1, 1, False),
+    (2, 32, 16, 7, 40, 36, 3, 1, 1, 1, True),
+    (1, 24, 40, 3, 33, 64, 3, 1, 1, 1, True),
+    (1, 16, 8, 19, 64, 64, 3, 1, 1, 1, False),
 ])
 def test_conv3d(cfg, dtype):
     from dose_prediction_amd import ops
@@ -501,7 +508,8 @@ def test_fused_adam_matches_torch(amsgrad):
     # (N, Ca, Cb_logical, Cb_physical, Cout, D, H, W, k)
     (2, 16, 16, 16, 16, 3, 9, 40, 7), (1, 16, 9, 16, 16, 4, 10, 32, 3), (1, 32, 32, 32, 32, 2, 9, 33, 7),
     (1, 64, 64, 64, 64, 2, 6, 16, 3), (1, 16, 16, 16, 8, 2, 5, 20, 3), (1, 8, 8, 8, 16, 3, 5, 6, 3),
-    (1, 16, 16, 16, 16, 2, 34, 40, 7)])      # (the last: K-along-H weight gradient, second input behind the channel split)
+    (1, 16, 16, 16, 16, 2, 34, 40, 7),       # (K-along-H weight gradient, second input behind the channel split)
+    (1, 16, 16, 16, 16, 4, 34, 40, 3)])      # (the depth-marching 3^3 weight gradient with a split input)
 def test_conv3d_virtual_concat(cfg, dtype):
     """conv3d((a, b)) == conv3d(cat(a, b)) of the oracle, forward and every gradient (dp_conv3d_tiled2 / dp_conv3d_wgrad_tiled2;
     the last config is too narrow for the tiled kernels and must take the materialised-cat fallback)."""
