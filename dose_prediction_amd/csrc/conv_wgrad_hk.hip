@@ -189,16 +189,18 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_hk(const T* __restrict__ x, co
   if (!fast) return;                                                // the launcher only selects this kernel for aligned operands
   int cu = u0;
   while (cu < u1 && !tile_ok(cu)) cu++;
-  if (cu < u1) issue(tile_of(cu));
+  const bool nostage = g.dbg & 1, nosweep = g.dbg & 2;               // experiments only (env DP_DBG)
+  if (cu < u1 && !nostage) issue(tile_of(cu));
   while (cu < u1) {
     lds_barrier();
-    commit();
+    if (!nostage) commit();
     const int nu = next_ok(cu);
-    if (nu < u1) issue(tile_of(nu));
+    if (nu < u1 && !nostage) issue(tile_of(nu));
     lds_barrier();
-    if (last_role) sweep(RoleLast{}); else sweep(RolePair{});
+    if (!nosweep) { if (last_role) sweep(RoleLast{}); else sweep(RolePair{}); }
     cu = nu;
   }
+  if (g.dbg & 4) return;
   // C/D of the 16x16 MFMA: col (co) = lane&15, row (ci) = 4*(lane>>4) + e
   const int co = nt * 16 + (lane & 15);
   if (co >= g.Cout) return;
