@@ -335,7 +335,17 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("DOSE_DDP_BACKEND", "nccl")      # nccl == RCCL on ROCm
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            # RCCL's kernels compete for CU slots with full-chip (partly persistent-grid) compute kernels: a high-priority stream lets
+            # the collective's workgroups in first whenever slots free up
+            opts = None
+            try:
+                opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+            except Exception:
+                pass
+            if opts is not None:
+                dist.init_process_group("nccl", device_id=dev, pg_options=opts)
+            else:
+                dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
     shape = tuple(args.size * 3) if len(args.size) == 1 else tuple(args.size)
