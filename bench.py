@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--roi", type=int, default=0, help="cascade: segmentation crop (sliding-window inference when smaller than the volume)")
     ap.add_argument("--loss-scale", type=float, default=1.0, help="static loss scale for 16-bit storage (fp16)")
     ap.add_argument("--grad-dtype", default="fp32", choices=["fp32", "bf16"], help="dtype of the all-reduce buckets (N > 1)")
+    ap.add_argument("--bucket-mb", type=float, default=32.0, help="size of the gradient all-reduce buckets (N > 1)")
     ap.add_argument("--no-side-stream", action="store_true", help="run the ViT branch on the main stream (no second HIP stream)")
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the extra fp32-mode timing (default workload only)")
     ap.add_argument("--own-stream", action="store_true", help="run the timed steps on a non-default (non-blocking) HIP stream")
@@ -339,7 +340,7 @@ def main():
             # the collective's workgroups in first whenever slots free up
             opts = None
             try:
-                opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+                opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=os.environ.get("DOSE_DDP_PRIO", "1") == "1")
             except Exception:
                 pass
             if opts is not None:
@@ -356,7 +357,7 @@ def main():
     dose_shape = shape[::-1] if args.model == "cascade" else shape
     net = build_model(args, dose_shape, dev)
     if ddp_on:
-        attach_gradient_allreduce(net, bucket_mb=32.0, grad_dtype=torch.bfloat16 if args.grad_dtype == "bf16" else torch.float32)
+        attach_gradient_allreduce(net, bucket_mb=args.bucket_mb, grad_dtype=torch.bfloat16 if args.grad_dtype == "bf16" else torch.float32)
     params = [p for p in net.parameters() if p.requires_grad]
     use_graph = (not ddp_on) and args.graph
     from dose_prediction_amd.optim import FusedAdam

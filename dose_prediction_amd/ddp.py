@@ -8,7 +8,9 @@ time ``loss.backward()`` returns.
 
 Design for 8 x MI355X: gradients are packed in REVERSE registration order (approximately the order autograd produces
 them) into flat buckets; a bucket is all-reduced asynchronously as soon as its last gradient arrives, on RCCL's own
-stream, while the remaining backward kernels keep the compute stream busy.  The patch-embedding weight (78.6 M of
+stream, while the remaining backward kernels keep the compute stream busy.  Every rank issues the collectives in the
+same sequence: bucket index order in the first pass, afterwards the order in which the buckets completed in that pass
+(rank 0's, broadcast once) -- a bucket whose gradients arrive late must not hold back the ones behind it.  The patch-embedding weight (78.6 M of
 162.6 M elements) is given a bucket of its own, split in chunks, and is reduced in place on its gradient.  The graph is
 static: parameters that received no gradient in the FIRST backward pass (MainSubsetModel.out, cls_token, UnetResBlock.conv3
 when Cin == Cout) are taken out of the buckets' arrival counts from the second pass on, so that they cannot hold back the
@@ -18,8 +20,13 @@ callback still reduces everything (correct, just without overlap for that bucket
 ``grad_dtype=torch.bfloat16`` exchanges bf16 copies of the gradients (half the xGMI bytes: 325 MB instead of 650 MB per step for
 DOSE-PYFER); the fp32 ``.grad`` tensors are overwritten with the averaged values afterwards.
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+_DRY = os.environ.get("DOSE_DDP_DRY", "0") == "1"
+_REORDER = os.environ.get("DOSE_DDP_REORDER", "1") == "1"
 
 
 class GradAllReducer:
@@ -82,6 +89,7 @@ class GradAllReducer:
         self.grad_ref = [None] * len(self.buckets)
         self.no_grad = None          # parameters without a gradient in the first backward pass (static graph), set by _finish
         self.stats = {"launched_in_backward": 0, "launched_at_end": 0}
+        self.launch_order = None     # set after the first backward pass: the order in which its buckets completed
         self._reset()
         for p in self.params:
             p.register_post_accumulate_grad_hook(self._hook)
@@ -117,6 +125,7 @@ class GradAllReducer:
         skip = self.no_grad or ()
         self.pending = [sum(1 for p, _, _ in b if p not in skip) for b in self.buckets]
         self.launched = [False] * len(self.buckets)
+        self._arrivals, self._last_arrival = 0, [0] * len(self.buckets)
         self.callback_queued = False
         self.work = []
         self._taken = set()
@@ -129,7 +138,9 @@ class GradAllReducer:
         cur = torch.cuda.current_stream() if flat.is_cuda else None
         if cur is not None:
             # gradients of this bucket may have been produced on another stream (the ViT branch runs on a side stream): the
-            # collective is ordered after the current stream only, so make that one wait for the others first
+            # collective is ordered after the current stream only, so make that one wait for the others first.  (Launching from a
+            # stream of its own that waits for all of them instead was measured: 1-rank RCCL step 27.5 -> 28.3 ms, 32 ms with a
+            # high-priority RCCL stream.)
             for s in self._streams:
                 if s != cur:
                     cur.wait_stream(s)
@@ -145,6 +156,8 @@ class GradAllReducer:
         self.launched[bi] = True
         self.stats["launched_at_end" if at_end else "launched_in_backward"] += 1
         n = flat.numel()
+        if _DRY:
+            return               # (diagnosis only, DOSE_DDP_DRY=1: everything but the collective itself)
         for c0 in range(0, n, self.chunk):
             piece = flat[c0:min(n, c0 + self.chunk)]
             if self.backend == "nccl":
@@ -168,15 +181,24 @@ class GradAllReducer:
         if self.no_grad is not None and p in self.no_grad:
             return               # unexpected gradient of a parameter that had none in the first pass: handled by _finish
         self.pending[bi] -= 1
-        # launch in bucket order so every rank issues the same collective sequence
-        while True:
-            nxt = next((i for i in range(len(self.buckets)) if not self.launched[i]), None)
-            if nxt is None or self.pending[nxt] > 0:
+        self._arrivals += 1
+        self._last_arrival[bi] = self._arrivals          # (the bucket is complete when its last gradient has arrived)
+        # every rank must issue the same collective sequence: bucket index order in the first pass, from then on the order in
+        # which the buckets completed in that pass (rank 0's, broadcast once).  Index order = reverse registration order is only an
+        # approximation of the backward order: the transformer's gradients arrive BEFORE those of skip1, which is registered after
+        # it, so in index order every transformer bucket and the 314 MB patch-embedding exchange waited for the very last
+        # gradients of the pass (kernel trace: 10 of 12 buckets launched after the backward pass had ended).
+        order = self.launch_order if self.launch_order is not None else range(len(self.buckets))
+        for i in order:
+            if self.launched[i]:
+                continue
+            if self.pending[i] > 0:
                 break
-            self._launch(nxt)
+            self._launch(i)
 
     def _finish(self):
-        if self.no_grad is None:
+        first_pass = self.no_grad is None
+        if first_pass:
             self.no_grad = {p for p in self.params if not getattr(p, "_dp_has_grad", False)}
         # parameters without a gradient this step contribute zeros (identical on every rank: same graph)
         for bi, b in enumerate(self.buckets):
@@ -190,7 +212,17 @@ class GradAllReducer:
                     if not getattr(p, "_dp_has_grad", False) and not getattr(p, "_dp_slice_zero", False):
                         self.flat[bi][off:off + n].zero_()
                         p._dp_slice_zero = True
+        for bi in (self.launch_order if self.launch_order is not None else range(len(self.buckets))):
+            if not self.launched[bi]:
                 self._launch(bi, at_end=True)
+        if first_pass:
+            # launch order of the following passes: completion order of this one (buckets that never completed last), agreed on
+            # by all ranks (the graph is static and identical, so the orders should agree anyway; rank 0's is authoritative)
+            nb = len(self.buckets)
+            seq = sorted(range(nb), key=lambda i: (self._last_arrival[i] if self._last_arrival[i] else 1 << 60, i))
+            t = torch.tensor(seq, dtype=torch.int64, device=self.flat[0].device if self.backend == "nccl" else "cpu")
+            dist.broadcast(t, 0, group=self.pg)
+            self.launch_order = [int(v) for v in t.tolist()] if _REORDER else None
         for w in self.work:
             if isinstance(w, tuple):
                 w[0].wait()

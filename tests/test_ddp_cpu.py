@@ -101,6 +101,77 @@ def test_bucketed_allreduce_gloo():
     assert r0["launched0"][1] >= 1
 
 
+class OutOfOrderNet(nn.Module):
+    """Registration order first, second; the forward pass runs `second` BEFORE `first` (like DOSE-PYFER, whose transformer is
+    registered before skip1 but enqueued after it), so the backward pass delivers first's gradients before second's -- the opposite
+    of reverse registration order."""
+
+    def __init__(self):
+        super().__init__()
+        self.first = nn.Linear(8, 600)
+        self.second = nn.Linear(8, 600)
+        self.head = nn.Linear(600, 4)
+
+    def forward(self, x):
+        s = torch.tanh(self.second(x))
+        f = torch.tanh(self.first(x))
+        return self.head(f * s).sum()
+
+
+def _worker_order(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dose_prediction_amd.ddp import attach_gradient_allreduce
+    torch.manual_seed(5)
+    net = OutOfOrderNet()
+    red = attach_gradient_allreduce(net, bucket_mb=0.01)
+    res = {}
+    for step in range(3):
+        net.zero_grad(set_to_none=True)
+        x = torch.randn(6, 8, generator=torch.Generator().manual_seed(20 + rank + 10 * step))
+        before = dict(red.stats)
+        net(x).backward()
+        res[f"g{step}"] = {k: p.grad.clone() for k, p in net.named_parameters()}
+        res[f"x{step}"] = x
+        res[f"launched{step}"] = (red.stats["launched_in_backward"] - before["launched_in_backward"],
+                                  red.stats["launched_at_end"] - before["launched_at_end"], len(red.buckets))
+    res["order"] = list(red.launch_order)
+    res["where"] = {k: red.where[p][0] for k, p in net.named_parameters()}
+    out[rank] = res
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_buckets_launch_in_the_order_the_backward_pass_completes_them():
+    """From the second pass on the buckets are exchanged in the order in which they completed in the first (rank 0's order,
+    broadcast): a bucket whose gradients arrive late no longer holds back the ones behind it in index order."""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_order, args=(world, _free_port(), out), nprocs=world, join=True)
+    r0, r1 = out[0], out[1]
+    assert r0["order"] == r1["order"] and sorted(r0["order"]) == list(range(r0["launched0"][2]))
+    # index order would exchange second's bucket(s) before first's; the recorded order has first's bucket(s) earlier
+    pos = {b: i for i, b in enumerate(r0["order"])}
+    assert pos[r0["where"]["first.weight"]] < pos[r0["where"]["second.weight"]]
+    assert r0["where"]["first.weight"] > r0["where"]["second.weight"]          # (reverse registration order = index order)
+    for step in (1, 2):
+        in_bwd, at_end, nb = r0[f"launched{step}"]
+        assert in_bwd == nb and at_end == 0, (step, r0[f"launched{step}"])
+    ref = OutOfOrderNet()
+    torch.manual_seed(5)
+    ref = OutOfOrderNet()
+    for step in range(3):
+        gs = []
+        for r in (r0, r1):
+            ref.zero_grad()
+            ref(r[f"x{step}"]).backward()
+            gs.append({k: p.grad.clone() for k, p in ref.named_parameters()})
+        for k in gs[0]:
+            assert torch.allclose(r0[f"g{step}"][k], 0.5 * (gs[0][k] + gs[1][k]), rtol=1e-5, atol=1e-6), (step, k)
+            assert torch.equal(r0[f"g{step}"][k], r1[f"g{step}"][k])
+
+
 def test_bf16_gradient_buckets_gloo():
     """grad_dtype=torch.bfloat16 halves the exchanged bytes; the averaged gradients equal the fp32 exchange up to one bf16
     rounding of each rank's contribution (2^-9 relative), are identical on both ranks, and .grad stays fp32."""
