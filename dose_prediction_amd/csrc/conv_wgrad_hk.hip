@@ -295,7 +295,7 @@ __global__ void __launch_bounds__(256, 1) k_wgrad_hk3(const T* __restrict__ x, c
   for (int a = 0; a < 27; a++) acc[a] = (v4f){0.f, 0.f, 0.f, 0.f};
 
   constexpr int PX = (C::LR * C::LC * 2 + 255) / 256, PG = C::TH * C::TW * 2 / 256;
-  v4u rx[PX], rg[PG];
+  v4u rxs[2][PX], rgs[2][PG];          // two register sets: the loads of plane d+3 / gy d+2 are issued while plane d is swept
   const int piece = tid & 1, cpiece = mt * C::XC + piece * 8;
   const bool xsecond = g.x2 && cpiece >= g.csplit;
   const T* xsrc = (xsecond ? (const T*)g.x2 : x) + cpiece - (xsecond ? g.csplit : 0);
@@ -305,7 +305,7 @@ __global__ void __launch_bounds__(256, 1) k_wgrad_hk3(const T* __restrict__ x, c
   auto opaque = [](int v) { asm volatile("" : "+v"(v)); return v; };
   auto xvox = [&](int t2, int j, int& lr, int& lc) { const int v = j * 128 + t2; lr = v / C::LC; lc = v - lr * C::LC; return v < C::LR * C::LC; };
   const int g_r = tid >> 6, g_c = (tid >> 1) & 31;
-  auto issue_x = [&](int p) {                            // x plane p (zeros outside the volume) -> rx
+  auto issue_x = [&](int p, v4u* rx) {                   // x plane p (zeros outside the volume) -> rx
     const bool pin = p >= 0 && p < g.D;
     const T* xplane = xsrc + (((int64_t)n * g.D + (pin ? p : 0)) * g.H) * (int64_t)g.W * ldsrc;
     const int ihb = h0 - C::PAD, iwb = w0 - C::PAD, t2 = opaque(tid >> 1);
@@ -318,7 +318,7 @@ __global__ void __launch_bounds__(256, 1) k_wgrad_hk3(const T* __restrict__ x, c
       rx[j] = ok ? v : (v4u){0, 0, 0, 0};
     }
   };
-  auto issue_g = [&](int d) {
+  auto issue_g = [&](int d, v4u* rg) {
     const T* gplane = gsrc + (((int64_t)n * g.D + d) * g.H) * (int64_t)g.W * g.ldgy;
 #pragma unroll
     for (int j = 0; j < PG; j++) {
@@ -328,7 +328,7 @@ __global__ void __launch_bounds__(256, 1) k_wgrad_hk3(const T* __restrict__ x, c
       rg[j] = ok ? v : (v4u){0, 0, 0, 0};
     }
   };
-  auto commit_x = [&](int slot) {
+  auto commit_x = [&](int slot, const v4u* rx) {
     const int t2 = opaque(tid >> 1);
     T* dst = xs + slot * C::XPLANE;
 #pragma unroll
@@ -337,7 +337,7 @@ __global__ void __launch_bounds__(256, 1) k_wgrad_hk3(const T* __restrict__ x, c
       if (xvox(t2, j, lr, lc)) *(v4u*)(dst + (lr * C::LP + lc) * C::XC + piece * 8) = rx[j];
     }
   };
-  auto commit_g = [&]() {
+  auto commit_g = [&](const v4u* rg) {
 #pragma unroll
     for (int j = 0; j < PG; j++) *(v4u*)(gs + ((4 * j + g_r) * C::GP + g_c) * C::GC + piece * 8) = rg[j];
   };
@@ -382,17 +382,26 @@ __global__ void __launch_bounds__(256, 1) k_wgrad_hk3(const T* __restrict__ x, c
                     (!g.x2 || ((g.csplit % 8 == 0) && (g.ldx2 % 8 == 0) && (((uintptr_t)g.x2 & 15) == 0)));
   // (the launcher only selects this kernel for aligned operands; an unaligned call leaves zero slabs)
   // prologue: x planes z0-1 and z0 into the ring, then x plane z0+1 + gy plane z0 in flight
+  // Two planes ahead (one block per CU = one wave per SIMD: nothing else hides the HBM latency, and one plane of loads in flight
+  // per CU left the fabric at 2.5 TB/s): iteration d commits set d & 1 (x plane d+1, gy plane d; issued at d-2) and refills it
+  // with x plane d+3 / gy plane d+2.  The depth loop is unrolled by two so that the set index is static.
+  const bool nostage = g.dbg & 1, nosweep = g.dbg & 2;               // experiments only (env DP_DBG)
   if (fast && z0 < z1) {
-    issue_x(z0 - 1); commit_x(slot_of(z0 - 1));
-    issue_x(z0); commit_x(slot_of(z0));
-    issue_x(z0 + 1); issue_g(z0);
+    issue_x(z0 - 1, rxs[0]); commit_x(slot_of(z0 - 1), rxs[0]);
+    issue_x(z0, rxs[0]); commit_x(slot_of(z0), rxs[0]);
+    issue_x(z0 + 1, rxs[0]); issue_g(z0, rgs[0]);
+    if (z0 + 1 < z1) { issue_x(z0 + 2, rxs[1]); issue_g(z0 + 1, rgs[1]); }
   }
-  for (int d = z0; fast && d < z1; d++) {
+  auto step = [&](int d, v4u* rx, v4u* rg) {
     lds_barrier();                                                  // sweep d-1 is over: slot of plane d-2 and the gy tile are free
-    if (!(g.dbg & 1)) { commit_x(slot_of(d + 1)); commit_g(); }
-    if (d + 1 < z1 && !(g.dbg & 1)) { issue_x(d + 2); issue_g(d + 1); }
+    if (!nostage) { commit_x(slot_of(d + 1), rx); commit_g(rg); }
+    if (d + 2 < z1 && !nostage) { issue_x(d + 3, rx); issue_g(d + 2, rg); }
     lds_barrier();
-    if (!(g.dbg & 2)) sweep(d);
+    if (!nosweep) sweep(d);
+  };
+  for (int d = z0; fast && d < z1; d += 2) {
+    step(d, rxs[0], rgs[0]);
+    if (d + 1 < z1) step(d + 1, rxs[1], rgs[1]);
   }
   // The four waves hold partial sums of the SAME 27 x 16 x 16 block (they walked different gy columns): add them up through LDS
   // (the ring is free now), then one non-atomic 27 KB slab per block -- k_wgrad_hk3_finish adds the slabs of all blocks.  (Atomics
