@@ -107,6 +107,12 @@ DTYPES = [torch.float32, torch.bfloat16, torch.float16]
     (2, 32, 16, 7, 40, 36, 3, 1, 1, 1, True),
     (1, 24, 40, 3, 33, 64, 3, 1, 1, 1, True),
     (1, 16, 8, 19, 64, 64, 3, 1, 1, 1, False),
+    # 3^3 forward / data gradient of the 16-channel layers on long rows (k_conv_cc16<3>: W >= 96): ragged H / W tiles, a partial
+    # input chunk, fewer than 16 output channels, many depth slices
+    (1, 16, 16, 5, 9, 130, 3, 1, 1, 1, True),
+    (2, 9, 16, 4, 20, 100, 3, 1, 1, 1, True),
+    (1, 16, 8, 37, 8, 128, 3, 1, 1, 1, False),
+    (1, 16, 16, 4, 40, 96, 3, 1, 1, 1, True),
 ])
 def test_conv3d(cfg, dtype):
     from dose_prediction_amd import ops
