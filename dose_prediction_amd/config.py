@@ -42,6 +42,13 @@ def loss_scale():
     return _loss_scale
 
 
+def effective_loss_scale():
+    """The scale actually applied to the backward pass: set_loss_scale()'s value while the storage type is 16-bit, 1.0 in fp32 storage
+    (there the boundary gradient is not scaled, so nothing may be divided out again).  The ONE place every consumer asks:
+    ops.FromNDHWC / ToNDHWC, FusedAdam, ops.unscale_grads."""
+    return _loss_scale if _compute_dtype in (torch.bfloat16, torch.float16) else 1.0
+
+
 def set_activation_checkpointing(on):
     """Recompute the four pyramid decoder blocks in the backward pass (torch.utils.checkpoint around each ModifiedUnetrUpBlock /
     UnetrUpBlock of PyMSCDecoder): their 128^3..16^3 intermediates are the bulk of the saved activations (BASELINE.json configs[4])."""

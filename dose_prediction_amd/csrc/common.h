@@ -35,6 +35,12 @@ __device__ __forceinline__ void st_f(float* p, float v) { *p = v; }
 __device__ __forceinline__ void st_f(bf16_t* p, float v) { *p = f2bf(v); }
 __device__ __forceinline__ float ld_f(const f16_t* p) { return (float)*p; }
 __device__ __forceinline__ void st_f(f16_t* p, float v) { *p = (f16_t)v; }
+// v as it reads back after being stored as T (the normalisation statistics a convolution epilogue accumulates are those of the
+// STORED tensor, so that mean / variance belong to the values the normalisation kernels read: ADVICE r2)
+template <typename T> __device__ __forceinline__ float as_stored(float v);
+template <> __device__ __forceinline__ float as_stored<float>(float v) { return v; }
+template <> __device__ __forceinline__ float as_stored<bf16_t>(float v) { return bf2f(f2bf(v)); }
+template <> __device__ __forceinline__ float as_stored<f16_t>(float v) { return (float)(f16_t)v; }
 
 // 8 consecutive elements of T as a register fragment.
 template <typename T> struct Frag8;

@@ -237,7 +237,7 @@ __global__ void __launch_bounds__(256, OCC) k_conv_cc16(const T* __restrict__ x,
           const int m = mt * 16 + 4 * q + e;
           const float v = acc[od][t][mt][e] + bv;
           st_f(pp + m * NC + r, v);
-          const float vs = (oh < g.H && wbase_o + m < g.W) ? v : 0.f;
+          const float vs = (oh < g.H && wbase_o + m < g.W) ? as_stored<T>(v) : 0.f;
           st1 += vs; st2 += vs * vs;
         }
       __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier();

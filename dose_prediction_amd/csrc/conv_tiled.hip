@@ -64,9 +64,9 @@ struct TiledGeom {
   // contiguous voxel rows of ONE tensor (a 32-channel row read 16 channels at a time touches every cache line twice and
   // held the L2 hit rate of the 32->16 7x7x7 layer at ~25 % against ~90 % for 16-channel inputs).
   const void* x2; void* y2; int ldx2, csplit, ldy2, osplit;
-  // Normalisation statistics of the OUTPUT, taken from the fp32 accumulators in the epilogue (the InstanceNorm / BatchNorm that
-  // follows every convolution of the path then needs no read pass over y, and its mean / variance are those of the unrounded
-  // values): block (n, d, tile_h, tile_w) writes its per-channel (sum, sum of squares) over the voxels it owns to
+  // Normalisation statistics of the OUTPUT, taken in the epilogue from the accumulators rounded to the storage type (the
+  // InstanceNorm / BatchNorm that follows every convolution of the path then needs no read pass over y, and its mean / variance
+  // are exactly those of the tensor it reads -- the same numbers the row pass dp_stats_partial(y) would produce): block (n, d, tile_h, tile_w) writes its per-channel (sum, sum of squares) over the voxels it owns to
   // stat_part[((n * stat_nblk + blk) * 2 + {0,1}) * Cout + c]; the partial rows are combined in fp64 by dp_stats_finalize.
   // Only with the wide (16-byte) epilogue and without split-kd (dp_conv3d_tiled_stat_blocks tells).
   float* stat_part; int stat_nblk; int wide;
@@ -389,7 +389,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, 
           const float v = (low ? acc[t][0][k] + __uint_as_float(sw[1]) : acc[t + 1][0][k + 8] + __uint_as_float(sw[0])) + bv;
           const int m = (k & 3) + 8 * (k >> 2) + 4 * hh + (low ? 0 : 16);
           st_f(pp + m * NC + co, v);
-          const float vs = (rowok && wbase_o + m < g.W) ? v : 0.f;      // branch-free: voxels outside the volume count as 0
+          const float vs = (rowok && wbase_o + m < g.W) ? as_stored<T>(v) : 0.f;      // branch-free: voxels outside the volume count as 0
           st1 += vs; st2 += vs * vs;
         }
         __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier();
@@ -441,7 +441,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, 
           const float v = acc[i][j][e] + bv;
           st_f(pp + m * NC + r, v);
           const int oh = W16 ? hw0 + 2 * i + (m >> 4) : hw0 + i, ow = W16 ? (m & 15) : wbase_o + m;
-          const float vs = (oh < g.H && ow < g.W) ? v : 0.f;
+          const float vs = (oh < g.H && ow < g.W) ? as_stored<T>(v) : 0.f;
           st1[j] += vs; st2[j] += vs * vs;
         }
         __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier();

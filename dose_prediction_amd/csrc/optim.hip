@@ -10,7 +10,8 @@ struct AdamTensor { float* p; const float* g; float* m; float* v; float* vmax; i
 
 __global__ void __launch_bounds__(256) k_adam_multi(const AdamTensor* __restrict__ tab, const int* __restrict__ chunk_t, const int* __restrict__ chunk_i,
                                                     float lr_c1, float beta1, float beta2, float omb1, float omb2, float eps, float wd, float rsqrt_c2, int amsgrad,
-                                                    const int* __restrict__ step_dev, double lr_d, double beta1_d, double beta2_d, float gscale) {
+                                                    const int* __restrict__ step_dev, double lr_d, double beta1_d, double beta2_d, float gscale,
+                                                    int* __restrict__ found_inf) {
   const AdamTensor T = tab[chunk_t[blockIdx.x]];
   if (step_dev) {   // capturable mode: the step count lives on the device (a HIP graph replays the launch with fresh bias corrections)
     const double st = (double)*step_dev;
@@ -20,7 +21,11 @@ __global__ void __launch_bounds__(256) k_adam_multi(const AdamTensor* __restrict
   const int64_t base = (int64_t)chunk_i[blockIdx.x] * ADAM_CHUNK;
   const int64_t end = min(T.n, base + ADAM_CHUNK);
   const bool vec = (((uintptr_t)T.p | (uintptr_t)T.g | (uintptr_t)T.m | (uintptr_t)T.v | (uintptr_t)T.vmax) & 15) == 0;
+  bool bad = false;
   auto upd = [&](float& p, float g, float& m, float& v, float& vm) {
+    // a non-finite gradient (fp16 overflow under a static loss scale) must not reach the parameter or the moments: one NaN in
+    // max_exp_avg_sq would stay there for ever.  The element is left untouched and *found_inf is raised.
+    if (!(fabsf(g) <= 3.402823466e38f)) { bad = true; return; }
     g = g * gscale + wd * p;             // gscale = 1 / loss scale (fp16 training), 1 otherwise
     m = beta1 * m + omb1 * g;            // (1 - beta) is formed in double on the host, as torch does
     v = beta2 * v + omb2 * g * g;
@@ -57,31 +62,32 @@ __global__ void __launch_bounds__(256) k_adam_multi(const AdamTensor* __restrict
   } else {
     for (int64_t j = base + threadIdx.x; j < end; j += 256) { float vx = amsgrad ? T.vmax[j] : 0.f; upd(T.p[j], T.g[j], T.m[j], T.v[j], vx); if (amsgrad) T.vmax[j] = vx; }
   }
+  if (bad && found_inf) *found_inf = 1;
 }
 
 // table: device array of {p, g, m, v, vmax, n} (6 x 8 bytes per tensor); chunk_t / chunk_i: device int arrays mapping each
 // block to (tensor, chunk index of ADAM_CHUNK elements).  step >= 1 is the step count AFTER this update.
 extern "C" int dp_adam_chunk(void) { return ADAM_CHUNK; }
 extern "C" int dp_adam_multi(const void* table, const int32_t* chunk_t, const int32_t* chunk_i, int nchunks, double lr, double beta1, double beta2,
-                             double eps, double weight_decay, double inv_grad_scale, int step, int amsgrad, void* stream) {
+                             double eps, double weight_decay, double inv_grad_scale, int step, int amsgrad, int32_t* found_inf, void* stream) {
   if (nchunks <= 0) return 0;
   if (step < 1) DP_FAIL("adam: step must be >= 1");
   double c1 = 1.0 - pow(beta1, (double)step), c2 = 1.0 - pow(beta2, (double)step);
   hipLaunchKernelGGL(k_adam_multi, dim3(nchunks), dim3(256), 0, STREAM, (const AdamTensor*)table, (const int*)chunk_t, (const int*)chunk_i,
                      (float)(lr / c1), (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)weight_decay, (float)(1.0 / sqrt(c2)), amsgrad,
-                     (const int*)nullptr, lr, beta1, beta2, (float)inv_grad_scale);
+                     (const int*)nullptr, lr, beta1, beta2, (float)inv_grad_scale, (int*)found_inf);
   DP_CHECK_LAUNCH("adam_multi"); return 0;
 }
 // Capturable variant: *step_dev (device int32) is incremented first and the bias corrections are formed from it on the device, so
 // the launch pair can be replayed from a captured HIP graph and still be Adam (a host-side step count would be frozen at capture).
 __global__ void k_adam_tick(int* step) { *step += 1; }
 extern "C" int dp_adam_multi_dev(const void* table, const int32_t* chunk_t, const int32_t* chunk_i, int nchunks, double lr, double beta1, double beta2,
-                                 double eps, double weight_decay, double inv_grad_scale, int32_t* step_dev, int amsgrad, void* stream) {
+                                 double eps, double weight_decay, double inv_grad_scale, int32_t* step_dev, int amsgrad, int32_t* found_inf, void* stream) {
   if (nchunks <= 0) return 0;
   if (!step_dev) DP_FAIL("adam_multi_dev: step_dev is NULL");
   hipLaunchKernelGGL(k_adam_tick, dim3(1), dim3(1), 0, STREAM, (int*)step_dev);
   hipLaunchKernelGGL(k_adam_multi, dim3(nchunks), dim3(256), 0, STREAM, (const AdamTensor*)table, (const int*)chunk_t, (const int*)chunk_i,
                      0.f, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)weight_decay, 0.f, amsgrad,
-                     (const int*)step_dev, lr, beta1, beta2, (float)inv_grad_scale);
+                     (const int*)step_dev, lr, beta1, beta2, (float)inv_grad_scale, (int*)found_inf);
   DP_CHECK_LAUNCH("adam_multi_dev"); return 0;
 }

@@ -133,7 +133,12 @@ class GradAllReducer:
 
     def _launch(self, bi, at_end=False):
         from . import ops
-        ops.flush_deferred()         # gradient tensors handed out unwritten (grouped Linear weight gradients) are filled first
+        # gradient tensors handed out unwritten (grouped Linear weight gradients) are filled first: flush_deferred() launches EVERY
+        # recorded entry (it holds aliases of the handed-out tensors, so it does not depend on which .grad autograd has accumulated
+        # so far -- ADVICE r2: the old flush re-pended entries whose partner gradient had not arrived and the bucket went out unwritten)
+        ops.flush_deferred()
+        if ops.deferred_pending():
+            raise RuntimeError("gradient all-reduce: deferred weight gradients still pending after the flush")
         flat = self.flat[bi]
         cur = torch.cuda.current_stream() if flat.is_cuda else None
         if cur is not None:

@@ -102,12 +102,12 @@ _REPACK_PLANS = {}
 
 
 def unscale_grads(params):
-    """Divide the gradients of ``params`` by config.loss_scale() in one multi-tensor pass (for optimizers other than FusedAdam,
+    """Divide the gradients of ``params`` by config.effective_loss_scale() in one multi-tensor pass (for optimizers other than FusedAdam,
     which unscales inside its kernel)."""
     from . import config
     gs = [p.grad for p in params if p.grad is not None]
-    if gs and config.loss_scale() != 1.0:
-        torch._foreach_mul_(gs, 1.0 / config.loss_scale())
+    if gs and config.effective_loss_scale() != 1.0:
+        torch._foreach_mul_(gs, 1.0 / config.effective_loss_scale())
 
 
 def invalidate_packs(params):
@@ -211,8 +211,8 @@ _ZERO_POOL = {}
 
 def _zero_bias_grad(bias):
     """An all-zero fp32 gradient for a bias whose gradient is identically zero (bias_grad_zero): a persistent per-parameter slice of
-    one zero buffer per device instead of a fill launch per layer and step.  Nothing ever writes a non-zero into it: optimizers only
-    read gradients, zero_grad / scaling / accumulating another such gradient leave zeros zero."""
+    one zero buffer per device instead of a fill launch per layer and step.  Optimizers only read gradients and zero_grad / scaling /
+    accumulating another such gradient leave zeros zero; the pool is wiped once per backward pass in case somebody did write."""
     dev = bias.device
     pool = _ZERO_POOL.get(dev)
     if pool is None:
@@ -225,6 +225,12 @@ def _zero_bias_grad(bias):
             return torch.zeros(bias.shape, dtype=torch.float32, device=dev)
         off = pool["slots"][key] = pool["used"]
         pool["used"] += (n + 63) // 64 * 64
+    if not pool.get("armed"):
+        # first hand-out of this backward pass: wipe the pool (one 256 KB fill), so that whatever was written into a previous step's
+        # .grad in place (a regulariser's grad.add_, a NaN from clip_grad_norm_) cannot survive into this step
+        pool["buf"].zero_()
+        pool["armed"] = True
+        torch.autograd.Variable._execution_engine.queue_callback(lambda: pool.__setitem__("armed", False))
     # a FRESH view object every time: autograd adopts it as .grad without a copy only if nobody else holds the tensor object
     return pool["buf"][off:off + n].view(bias.shape)
 
@@ -375,8 +381,8 @@ class ToNDHWC(torch.autograd.Function):
         gx = torch.empty((N, ctx.C) + sp, dtype=torch.float32, device=gy.device)
         _lib.call("dp_ndhwc_to_ncdhw", _p(gy), _p(gx), N, ctx.C, rows // N, ld, 0, _dt(gy), _stream())
         from . import config
-        if config.loss_scale() != 1.0 and gy.dtype != torch.float32:
-            gx = gx / config.loss_scale()
+        if config.effective_loss_scale() != 1.0 and gy.dtype != torch.float32:
+            gx = gx / config.effective_loss_scale()
         return gx, None, None
 
 
@@ -399,8 +405,8 @@ class FromNDHWC(torch.autograd.Function):
     def backward(ctx, gy):
         gy = gy.contiguous().float()
         from . import config
-        if config.loss_scale() != 1.0 and ctx.dtype != torch.float32:
-            gy = gy * config.loss_scale()         # loss scaling enters the 16-bit domain here (config.set_loss_scale)
+        if config.effective_loss_scale() != 1.0 and ctx.dtype != torch.float32:
+            gy = gy * config.effective_loss_scale()         # loss scaling enters the 16-bit domain here (config.set_loss_scale)
         N, C = gy.shape[:2]
         sp = tuple(gy.shape[2:])
         gx = torch.empty((N,) + sp + (C,), dtype=ctx.dtype, device=gy.device)
@@ -463,7 +469,7 @@ class Conv3d(torch.autograd.Function):
             wq = _pack_conv_tiled(weight, 0, x.dtype, te, Wi)
             nblk = _lib.lib().dp_conv3d_tiled_stat_blocks(N, Di, Hi, Wi, cin, cout, k, cout, _dt(x)) if want_stats else 0
             if nblk:
-                # the statistics of the normalisation that follows come out of the epilogue's fp32 accumulators
+                # the statistics of the normalisation that follows come out of the convolution's epilogue (values as stored)
                 part = torch.empty((N, nblk, 2, cout), dtype=torch.float32, device=x.device)
                 _lib.call("dp_conv3d_tiled_stats", _p(x), ldx, 0, 0, 0, _p(wq), _p(b32), _p(y), cout, _p(_tiled_ws(x, N, Di, Hi, Wi, cin, cout, k)),
                           _p(part), N, Di, Hi, Wi, cin, cout, k, _dt(x), _stream())
@@ -583,7 +589,8 @@ def _stats_partial(y):
 
 def conv3d(x, weight, bias=None, stride=1, pad=0, dil=1, stats=False, bias_grad_zero=False):
     """stats=True: returns (y, part) where part [N, nblk, 2, Cout] are the partial normalisation statistics of y (taken from the
-    convolution's fp32 accumulators when the tiled kernel runs, otherwise by a statistics pass): hand it to norm_act(..., stats=part).
+    convolution's epilogue when the tiled kernel runs -- accumulators rounded to the storage type, i.e. the statistics of y as stored --
+    otherwise by a statistics pass): hand it to norm_act(..., stats=part).
     bias_grad_zero=True: the caller normalises y over batch statistics next (InstanceNorm, or BatchNorm in training mode), which
     makes the bias gradient identically zero: it is returned as exact zeros instead of a column sum of round-off."""
     if isinstance(x, (tuple, list)):
@@ -756,24 +763,38 @@ def conv_transpose2x(x, weight):
 _DEFER = {"pending": [], "queued": False, "host": None, "rot": 0, "enabled": os.environ.get("DOSE_HIP_DEFER_WGRAD", "1") != "0"}
 
 
-def _defer_wgrad(gy, ldg, x, ldx, weight, bias, nout, nin, rows):
-    """(the PARAMETERS are recorded, not the gradient tensors handed to autograd: holding a second reference to those would make
-    AccumulateGrad clone them, and the grouped launch would then fill the orphaned originals; at flush time p.grad is the tensor
-    autograd kept)"""
+def _alias(t):
+    """A second tensor object on t's storage that is NOT a view of t: holding it keeps the memory alive without raising t's own
+    reference count, so AccumulateGrad still adopts t as .grad without a copy (it clones a gradient somebody else holds), and
+    torch.autograd.grad() callers get t itself.  Whatever tensor ends up owning the storage sees what is written through the alias."""
+    return torch.empty(0, dtype=t.dtype, device=t.device).set_(t.untyped_storage(), t.storage_offset(), t.shape, t.stride())
+
+
+def _defer_wgrad(gy, ldg, x, ldx, gw, gb, nout, nin, rows):
+    """Record one weight (+ bias) gradient for the grouped launch.  gw / gb are the still unwritten fp32 tensors the backward node is
+    about to hand to autograd; aliases of them are recorded (recording the PARAMETERS and looking up p.grad at flush time
+    left a window in which a parameter's hook had fired -- and the data-parallel reducer had exchanged its bucket -- while the entry
+    was waiting for the partner's .grad, and leaked entries for ever under torch.autograd.grad)."""
     ev = torch.cuda.Event()
     ev.record()                                            # on the stream that produced gy (the ViT branch runs on a side stream)
-    _DEFER["pending"].append((gy, ldg, x, ldx, weight, bias, nout, nin, rows, ev, torch.cuda.current_stream()))
+    _DEFER["pending"].append((gy, ldg, x, ldx, _alias(gw), None if gb is None else _alias(gb), nout, nin, rows, ev, torch.cuda.current_stream()))
     if not _DEFER["queued"]:
         # (safety net: whatever is still pending at the end of the backward pass is flushed then)
         torch.autograd.Variable._execution_engine.queue_callback(flush_deferred)
         _DEFER["queued"] = True
 
 
+def deferred_pending():
+    """Number of recorded weight gradients that have not been launched yet (0 after flush_deferred())."""
+    return len(_DEFER["pending"])
+
+
 def flush_deferred(*_unused):
     """Launch the grouped weight-gradient GEMM for everything recorded so far, on the stream that recorded it (the ViT branch's side
     stream: the launch then overlaps the 128^3 branch's backward on the main stream), and make the current stream wait for it.
-    No-op when nothing is pending.  Also usable as a post-accumulate-grad hook (PatchEmbeddingBlock registers it on its weight: the
-    first layer of the transformer is its last backward node)."""
+    EVERY recorded entry is launched (nothing is ever carried over to a later flush).  No-op when nothing is pending.  Also usable as
+    a post-accumulate-grad hook (PatchEmbeddingBlock registers it on its weight: the first layer of the transformer is its last
+    backward node)."""
     _DEFER["queued"] = False
     pend, _DEFER["pending"] = _DEFER["pending"], []
     cur = torch.cuda.current_stream() if (pend or _DEFER.get("last_stream") is not None) else None
@@ -782,13 +803,9 @@ def flush_deferred(*_unused):
         by.setdefault((e[0].dtype, e[0].device, e[10]), []).append(e)
     for (dtype, dev, st), lst in by.items():
         rows_tab, tile0 = [], 0
-        for gy, ldg, x, ldx, weight, bias, nout, nin, rows, ev, _st in lst:
-            gw, gb = weight.grad, (None if bias is None else bias.grad)
-            if gw is None or (bias is not None and gb is None):
-                _DEFER["pending"].append((gy, ldg, x, ldx, weight, bias, nout, nin, rows, ev, st))    # not accumulated yet: next flush
-                continue
+        for gy, ldg, x, ldx, gw, gb, nout, nin, rows, ev, _st in lst:
             if gw.dtype != torch.float32 or not gw.is_contiguous() or (gb is not None and not gb.is_contiguous()):
-                raise _lib.DoseHipError("deferred weight gradient: the parameter's .grad is not a contiguous fp32 tensor")
+                raise _lib.DoseHipError("deferred weight gradient: the gradient tensor is not a contiguous fp32 tensor")
             tm, tn = -(-nout // 64), -(-nin // 64)
             rows_tab.append((gy.data_ptr(), x.data_ptr(), gw.data_ptr(), 0 if gb is None else gb.data_ptr(), ldg, ldx, nin, nout, nin, rows, tile0, tm))
             tile0 += tm * tn
@@ -872,7 +889,7 @@ class Linear(torch.autograd.Function):
             # recorded for the grouped launch at the end of the backward pass; dW and db are returned unwritten
             gw = _wgrad_buffer(weight, False)
             gb = torch.empty((nout,), dtype=torch.float32, device=x.device) if want_b else None
-            _defer_wgrad(gy, ldg, x, ldx, weight, ctx.bias_ref if want_b else None, nout, K, rows)
+            _defer_wgrad(gy, ldg, x, ldx, gw, gb, nout, K, rows)
             return gx, gw, gb, None, None
         if ctx.needs_input_grad[1]:
             if rows <= 16384:
@@ -936,7 +953,7 @@ class MLP(torch.autograd.Function):
             if _DEFER["enabled"] and rows <= 16384 and w.grad is None and b.grad is None:
                 gw = _wgrad_buffer(w, False)
                 gb = torch.empty((no,), dtype=torch.float32, device=x.device)
-                _defer_wgrad(g2, ldg2, inp, ldi, w, b, no, ni, rows)
+                _defer_wgrad(g2, ldg2, inp, ldi, gw, gb, no, ni, rows)
             else:
                 gw = _wgrad_buffer(w, False)
                 _lib.call("dp_gemm_tn", _p(g2), ldg2, _p(inp), ldi, _p(gw), ni, no, ni, rows, 1, dtc, _stream())

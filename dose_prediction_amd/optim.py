@@ -18,6 +18,9 @@ class FusedAdam(torch.optim.Optimizer):
             raise ValueError("invalid Adam hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad, capturable=capturable))
         self._plans = {}
+        # 0-dim int32 device tensor raised by the kernel when a gradient element was not finite (that element's update is skipped);
+        # it is never cleared by step(): read it with found_inf() / clear it with reset_found_inf()
+        self._found_inf = None
         # gradients arrive multiplied by this factor (config.set_loss_scale: fp16 training); None = follow the global setting
         self.grad_scale = grad_scale
 
@@ -43,6 +46,15 @@ class FusedAdam(torch.optim.Optimizer):
                     [None])
             self._plans[key] = plan
         return plan
+
+    def found_inf(self):
+        """True when any step() since the last reset_found_inf() met a non-finite gradient element (fp16 overflow under a static
+        loss scale): those elements were skipped, parameter and Adam moments untouched.  Synchronises with the device."""
+        return self._found_inf is not None and bool(self._found_inf.item())
+
+    def reset_found_inf(self):
+        if self._found_inf is not None:
+            self._found_inf.zero_()
 
     @staticmethod
     def _step_value(s):
@@ -92,8 +104,10 @@ class FusedAdam(torch.optim.Optimizer):
             b1, b2 = group["betas"]
             stream = torch.cuda.current_stream().cuda_stream
             from . import config
-            gs = float(self.grad_scale if self.grad_scale is not None else config.loss_scale())
+            gs = float(self.grad_scale if self.grad_scale is not None else config.effective_loss_scale())
             inv_gs = 1.0 / gs
+            if self._found_inf is None or self._found_inf.device != plist[0].device:
+                self._found_inf = torch.zeros((), dtype=torch.int32, device=plist[0].device)
             if capt:
                 sdev = self.state[plist[0]]["step"]
                 if not (torch.is_tensor(sdev) and sdev.is_cuda and sdev.dtype == torch.int32):
@@ -105,7 +119,7 @@ class FusedAdam(torch.optim.Optimizer):
                 for p in plist:
                     self.state[p]["step"] = sdev
                 _lib.call("dp_adam_multi_dev", devtab.data_ptr(), ct.data_ptr(), ci.data_ptr(), nchunks, float(group["lr"]), float(b1),
-                          float(b2), float(group["eps"]), float(group["weight_decay"]), inv_gs, sdev.data_ptr(), 1 if group["amsgrad"] else 0, stream)
+                          float(b2), float(group["eps"]), float(group["weight_decay"]), inv_gs, sdev.data_ptr(), 1 if group["amsgrad"] else 0, self._found_inf.data_ptr(), stream)
             else:
                 steps = {self._step_value(self.state[p]["step"]) for p in plist}
                 if len(steps) != 1:
@@ -114,7 +128,8 @@ class FusedAdam(torch.optim.Optimizer):
                 for p in plist:
                     self.state[p]["step"] = step
                 _lib.call("dp_adam_multi", devtab.data_ptr(), ct.data_ptr(), ci.data_ptr(), nchunks, float(group["lr"]), float(b1), float(b2),
-                          float(group["eps"]), float(group["weight_decay"]), inv_gs, int(step), 1 if group["amsgrad"] else 0, stream)
+                          float(group["eps"]), float(group["weight_decay"]), inv_gs, int(step), 1 if group["amsgrad"] else 0,
+                          self._found_inf.data_ptr(), stream)
             # the kernel wrote the parameters through raw pointers (p._version did not move): rebuild their packed copies now
             ops.refresh_packs(plist)
         return loss

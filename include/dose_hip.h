@@ -258,15 +258,17 @@ int dp_conv3d_wgrad_tiled(const void* x, int ldx, const void* gy, int ldgy, floa
 /* replaces: optim.Adam(..., amsgrad=True).step() as built by NetworkTrainer.set_optimizer (network_trainer.py:120-125): one
  * launch over all parameter tensors.  table: device array of {float* p; const float* g; float* m; float* v; float* vmax;
  * int64_t n}; chunk_t/chunk_i map each block to (tensor, chunk of dp_adam_chunk() elements); step = count after this update.
- * inv_grad_scale multiplies every gradient first (1 / loss scale when the backward pass ran on a scaled loss: fp16 storage). */
+ * inv_grad_scale multiplies every gradient first (1 / loss scale when the backward pass ran on a scaled loss: fp16 storage).
+ * An element whose gradient is not finite is left untouched (parameter and moments) and *found_inf (device int32, may be NULL;
+ * the caller zeroes it) is set to 1: an fp16 overflow cannot poison the AMSGrad state. */
 int dp_adam_chunk(void);
 int dp_adam_multi(const void* table, const int32_t* chunk_t, const int32_t* chunk_i, int nchunks, double lr, double beta1, double beta2,
-                  double eps, double weight_decay, double inv_grad_scale, int step, int amsgrad, void* stream);
+                  double eps, double weight_decay, double inv_grad_scale, int step, int amsgrad, int32_t* found_inf, void* stream);
 
 /* Capturable variant: *step_dev (device int32, the number of updates done so far) is incremented by the call and the bias
  * corrections are computed from it on the device, so a captured HIP graph replays a correct Adam step. */
 int dp_adam_multi_dev(const void* table, const int32_t* chunk_t, const int32_t* chunk_i, int nchunks, double lr, double beta1, double beta2,
-                      double eps, double weight_decay, double inv_grad_scale, int32_t* step_dev, int amsgrad, void* stream);
+                      double eps, double weight_decay, double inv_grad_scale, int32_t* step_dev, int amsgrad, int32_t* found_inf, void* stream);
 
 /* ---- packed-weight refresh after optimizer.step() (network_trainer.py:213) ----------------------------------------------
  * The kernels read kernel-layout copies of the fp32 nn.Parameters; ONE launch rebuilds all copies of the parameters a step

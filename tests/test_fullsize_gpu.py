@@ -205,6 +205,9 @@ SAMPLED = [
     (2, 128, 128, 128, 16, 0, 16, 7, torch.float32),       # the same launch geometry in the fp32 parity mode
     (2, 16, 16, 16, 256, 0, 128, 7, torch.bfloat16),       # split-kd / W16 tiles (decoder4 at 16^3)
     (2, 32, 32, 32, 128, 64, 64, 3, torch.bfloat16),       # two N tiles, virtual concat, 32^3
+    # BASELINE.json configs[2] (OAR-TRANSEG 128^3 bf16 batch 2): the two launches no other configuration has
+    (2, 128, 128, 128, 1, 0, 16, 3, torch.bfloat16, 16),   # encoder1's first 3^3 conv: ONE input channel in a 16-channel padded row (oar_transeg.py:92-100)
+    (2, 128, 128, 128, 16, 0, 8, 1, torch.bfloat16),       # the 1x1x1 output head 16 -> 8 classes + bias (base_blocks.py:151-162)
 ]
 
 
@@ -213,7 +216,8 @@ def test_conv_sampled_oracle_full_size(cfg):
     """Forward, data gradient and weight gradient of the hot launches vs oracle.conv3d on >= 4096 sampled voxels / 256 taps."""
     from dose_prediction_amd import ops
     dev = _dev()
-    N, D, H, W, cin, ca, cout, k, dtype = cfg
+    N, D, H, W, cin, ca, cout, k, dtype = cfg[:9]
+    cpad = cfg[9] if len(cfg) > 9 else cin       # row pitch of the input: channels >= cin are another tensor's data (must be ignored)
     big = D >= 128
     nsample = 4096 if big else 1024
     tol = 2e-5 if dtype == torch.float32 else 6e-3
@@ -222,7 +226,10 @@ def test_conv_sampled_oracle_full_size(cfg):
     w = (torch.randn((cout, cin, k, k, k), generator=g) * (cin * k ** 3) ** -0.5)
     bias = 0.1 * torch.randn((cout,), generator=g)
     r = torch.randn((N, D, H, W, cout), generator=g).to(dtype)
-    xd = x.to(dev).requires_grad_(True)
+    if cpad > cin:
+        xd = torch.cat((x, torch.randn((N, D, H, W, cpad - cin), generator=g).to(dtype)), -1).to(dev).requires_grad_(True)
+    else:
+        xd = x.to(dev).requires_grad_(True)
     wd, bd = w.to(dev).requires_grad_(True), bias.to(dev).requires_grad_(True)
     if ca:
         xa, xb = xd[..., :ca].detach().contiguous().requires_grad_(True), xd[..., ca:].detach().contiguous().requires_grad_(True)
@@ -232,6 +239,9 @@ def test_conv_sampled_oracle_full_size(cfg):
     y.backward(r.to(dev))
     torch.cuda.synchronize()
     gx = torch.cat((xa.grad, xb.grad), -1) if ca else xd.grad
+    if cpad > cin:
+        assert float(gx[..., cin:].abs().max()) == 0.0       # the padding channels receive no gradient
+        gx = gx[..., :cin]
     wq = w if dtype == torch.float32 else w.to(dtype).float()           # the kernels multiply by the 16-bit packed weights
     p = k // 2
     pos = _positions(N, D, H, W, nsample, 5)
@@ -335,4 +345,156 @@ def test_c5_cascade_fp16_checkpointing_192x192x128():
     finally:
         dose_prediction_amd.set_activation_checkpointing(False)
         dose_prediction_amd.set_loss_scale(1.0)
+        dose_prediction_amd.set_compute_dtype(torch.float32)
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE.json configs[2] and [3]
+def _transeg(dev, shape, seed=8765):
+    from dose_prediction_amd.models import oar_transeg
+    torch.manual_seed(seed)
+    # hyper-parameters: OARSegmentation/train_light_transeg.py:110-124 (oar_transeg.py:20-35)
+    return oar_transeg.Model(in_channels=1, out_channels=8, img_size=shape, feature_size=16, hidden_size=768, mlp_dim=3072, num_heads=12,
+                             pos_embed="perceptron", norm_name="instance", res_block=True, conv_block=True).to(dev)
+
+
+def test_c3_transeg_training_steps_128_bf16():
+    """BASELINE.json configs[2]: OAR-TRANSEG at 128^3, bf16 storage, batch 2 on one GPU -- forward (logits [2, 8, 128^3]) + cross
+    entropy + backward + fused Adam, four steps: every gradient finite, every parameter that the graph reaches receives one, the loss
+    falls.  (The 1 -> 16 first convolution and the 16 -> 8 head are checked against the oracle at this size in
+    test_conv_sampled_oracle_full_size; 12-head d = 64 attention at B = 2, N = 512 in test_ops_gpu.test_fused_attention_full_size.)"""
+    import dose_prediction_amd
+    from dose_prediction_amd import synth
+    from dose_prediction_amd.optim import FusedAdam
+    dev = _dev()
+    dose_prediction_amd.set_compute_dtype(torch.bfloat16)
+    try:
+        net = _transeg(dev, S).train()
+        opt = FusedAdam(net.parameters(), lr=1e-4, weight_decay=1e-5)
+        x = synth.ct_input(2, S).to(dev)
+        lab = torch.randint(0, 8, (2,) + S, generator=torch.Generator().manual_seed(5678)).to(dev)
+        hist = []
+        for it in range(4):
+            opt.zero_grad(set_to_none=True)
+            logits = net(x)
+            assert logits.shape == (2, 8) + S and logits.dtype == torch.float32
+            loss = torch.nn.functional.cross_entropy(logits, lab)
+            loss.backward()
+            if it == 0:
+                missing = [k for k, p in net.named_parameters() if p.grad is None]
+                # parameters the reference graph never reaches: cls_token, and conv3 / norm3 of the Cin == Cout residual blocks
+                assert all(("cls_token" in k) or (".conv3." in k) for k in missing), missing
+            assert all(torch.isfinite(p.grad).all() for p in net.parameters() if p.grad is not None)
+            opt.step()
+            hist.append(loss.item())
+        print(f"[c3] cross-entropy {hist}")
+        assert all(h == h and h < 1e3 for h in hist) and hist[-1] < hist[0], hist
+        assert not opt.found_inf()
+    finally:
+        dose_prediction_amd.set_compute_dtype(torch.float32)
+
+
+def test_c4_cascade_training_step_128_bf16():
+    """BASELINE.json configs[3], the per-GPU share (batch 2 of the global 16): OAR-TRANSEG forward without gradients at 128^3 ->
+    arg-max / one-hot glue with axis reversal, staged in place (train_light_linked_model.py:143-167) -> DOSE-PYFER forward_staged ->
+    GenLoss -> backward -> fused Adam, bf16 storage.  One-hot validity, CT / PTV pass-through, finite gradients, falling loss; the
+    segmentation network receives no gradient and its weights do not move."""
+    import dose_prediction_amd
+    from dose_prediction_amd import cascade, losses, synth
+    from dose_prediction_amd.models import dose_pyfer
+    from dose_prediction_amd.optim import FusedAdam
+    dev = _dev()
+    dose_prediction_amd.set_compute_dtype(torch.bfloat16)
+    try:
+        seg = _transeg(dev, S).eval()
+        torch.manual_seed(4321)
+        net = dose_pyfer.Model(in_ch=9, out_ch=1, list_ch_A=[-1, 16, 32, 64, 128, 256], feature_size=16, img_size=S, num_layers=8,
+                               num_heads=6, act="mish").to(dev).train()
+        for n, p in net.named_parameters():
+            if "net_A" in n or "conv_out_A" in n:
+                p.requires_grad = False
+        opt = FusedAdam([p for p in net.parameters() if p.requires_grad], lr=1e-4, weight_decay=3e-5, amsgrad=True)
+        full = synth.dose_input(2, S).to(dev)
+        ct = full[:, 8:9].permute(0, 1, 4, 3, 2).contiguous()              # the segmentation loader's axis order
+        ptv = full[:, 0:1].contiguous()
+        gt = synth.dose_target(2, S).to(dev)
+        seg_before = [p.detach().clone() for p in list(seg.parameters())[:4]]
+        # the fp32 view of the staged input (what LinkedNet hands to the dose network, lines 165-167)
+        structures, labels = cascade.cascade_structures(seg, ct, ptv)
+        assert structures.shape == (2, 9) + S and labels.shape == (2,) + S and labels.dtype == torch.int32
+        assert int(labels.min()) >= 0 and int(labels.max()) <= 7
+        assert torch.equal(structures[:, 8], full[:, 8].bfloat16().float()) and torch.equal(structures[:, 0], full[:, 0].bfloat16().float())
+        onehot = structures[:, 1:8]
+        assert set(onehot.unique().tolist()) <= {0.0, 1.0} and float(onehot.sum(1).max()) <= 1.0
+        # one-hot channel c is exactly (label == c) in the dose loader's axis order
+        lab_dose = labels.permute(0, 3, 2, 1)
+        for c in range(1, 8):
+            assert torch.equal(onehot[:, c - 1] > 0, lab_dose == c), c
+        hist = []
+        for _ in range(3):
+            opt.zero_grad(set_to_none=True)
+            staged, _ = cascade.cascade_structures(seg, ct, ptv, staged=True)
+            assert staged.shape == (2,) + S + (16,) and staged.dtype == torch.bfloat16
+            out = net.forward_staged(staged)
+            loss = losses.gen_loss(out, gt, 10.0, 1.0, casecade=True, freez=True)
+            loss.backward()
+            assert all(torch.isfinite(p.grad).all() for p in net.parameters() if p.grad is not None)
+            opt.step()
+            hist.append(loss.item())
+        print(f"[c4] losses {hist}")
+        assert all(h == h and h < 1e4 for h in hist) and hist[-1] < hist[0], hist
+        assert all(p.grad is None for p in seg.parameters())
+        assert all(torch.equal(a, b.detach()) for a, b in zip(seg_before, list(seg.parameters())[:4]))
+        # the staged buffer the training step consumed holds the same nine channels as the fp32 view (CT / PTV exactly; the masks up to
+        # arg-max near-ties: the segmentation forward is not bitwise reproducible, its 16^3 layers accumulate with fp32 atomics)
+        st9 = staged[..., :9].permute(0, 4, 1, 2, 3).float()
+        assert torch.equal(st9[:, 0], structures[:, 0]) and torch.equal(st9[:, 8], structures[:, 8])
+        assert float((st9[:, 1:8] != structures[:, 1:8]).float().mean()) < 1e-3
+    finally:
+        dose_prediction_amd.set_compute_dtype(torch.float32)
+
+
+def test_pyfer_128_one_rank_rccl_every_bucket_is_exchanged_inside_backward():
+    """The production bucket layout (DOSE-PYFER's 162.6 M trainable parameters, 32 MiB buckets, the 78.6 M-element patch embedding
+    reduced in place) on one rank over RCCL: from the second backward pass on EVERY bucket is launched from the gradient hooks, i.e.
+    inside the backward pass (DESIGN section 7's overlap claim, so far asserted on gloo / CPU only), no deferred weight gradient is
+    left pending when a bucket goes out, and the step still trains."""
+    import os
+    import torch.distributed as dist
+    import dose_prediction_amd
+    from dose_prediction_amd import losses, ops, synth
+    from dose_prediction_amd.ddp import attach_gradient_allreduce
+    from dose_prediction_amd.models import dose_pyfer
+    from dose_prediction_amd.optim import FusedAdam
+    dev = _dev()
+    dose_prediction_amd.set_compute_dtype(torch.bfloat16)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29543")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        torch.manual_seed(4321)
+        net = dose_pyfer.Model(in_ch=9, out_ch=1, list_ch_A=[-1, 16, 32, 64, 128, 256], feature_size=16, img_size=S, num_layers=8,
+                               num_heads=6, act="mish").to(dev).train()
+        for n, p in net.named_parameters():
+            if "net_A" in n or "conv_out_A" in n:
+                p.requires_grad = False
+        red = attach_gradient_allreduce(net, bucket_mb=32.0)
+        nb = len(red.buckets)
+        assert nb >= 10 and any(red.inplace)
+        opt = FusedAdam([p for p in net.parameters() if p.requires_grad], lr=1e-4, weight_decay=3e-5, amsgrad=True)
+        x, gt = synth.dose_input(2, S).to(dev), synth.dose_target(2, S).to(dev)
+        hist = []
+        for it in range(3):
+            opt.zero_grad(set_to_none=True)
+            before = dict(red.stats)
+            loss = losses.gen_loss(net(x), gt, 10.0, 1.0, casecade=True, freez=True)
+            loss.backward()
+            assert ops.deferred_pending() == 0
+            if it >= 1:
+                assert red.stats["launched_in_backward"] - before["launched_in_backward"] == nb, (it, before, red.stats, nb)
+                assert red.stats["launched_at_end"] == before["launched_at_end"]
+            opt.step()
+            hist.append(loss.item())
+        assert all(h == h for h in hist) and hist[-1] < hist[0], hist
+        red.close()
+    finally:
+        dist.destroy_process_group()
         dose_prediction_amd.set_compute_dtype(torch.float32)

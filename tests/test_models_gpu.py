@@ -411,6 +411,23 @@ def test_gradient_allreduce_single_rank_rccl_is_identity():
                 assert e < 5e-3, (step, k, e)
 
 
+def test_gradient_allreduce_two_ranks_matches_the_mean_of_local_gradients():
+    """World size 2 on the GPU (gloo, both ranks on this box's one GPU; tests/ddp_gpu_worker.py): with bucket boundaries that fall
+    between deferred Linear weights and their biases (such a bucket used to be exchanged before the grouped weight-gradient
+    launch had written it), every gradient after the exchange equals the mean of the two ranks' local gradients, over three passes."""
+    import os
+    import subprocess
+    import sys
+    _dev()
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29547", os.path.join(here, "ddp_gpu_worker.py")], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "DDP_GPU_WORKER_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
 def test_bench_two_ranks_gloo_on_one_gpu():
     """`python bench.py --gpus 2` (no launcher: bench.py starts its own torch.distributed.run child) with the gloo backend, both ranks
     on the one GPU of the test box: the N > 1 path (rank env, bucketed exchange, barrier + max-over-ranks timing, one JSON line
