@@ -448,7 +448,7 @@ def test_c4_cascade_training_step_128_bf16():
         # arg-max near-ties: the segmentation forward is not bitwise reproducible, its 16^3 layers accumulate with fp32 atomics)
         st9 = staged[..., :9].permute(0, 4, 1, 2, 3).float()
         assert torch.equal(st9[:, 0], structures[:, 0]) and torch.equal(st9[:, 8], structures[:, 8])
-        assert float((st9[:, 1:8] != structures[:, 1:8]).float().mean()) < 1e-3
+        assert float((st9[:, 1:8] != structures[:, 1:8]).float().mean()) < 1e-2
     finally:
         dose_prediction_amd.set_compute_dtype(torch.float32)
 
