@@ -5,22 +5,60 @@ import torch
 
 _DTYPES = {"fp32": torch.float32, "f32": torch.float32, "float32": torch.float32,
            "bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp16": torch.float16, "f16": torch.float16, "float16": torch.float16}
-_compute_dtype = _DTYPES[os.environ.get("DOSE_HIP_DTYPE", "fp32").lower()]
+_X3_NAMES = ("fp32x3", "f32x3", "x3", "bf16x3")
+_env_mode = os.environ.get("DOSE_HIP_DTYPE", "fp32").lower()
+_x3 = _env_mode in _X3_NAMES
+_compute_dtype = torch.float32 if _x3 else _DTYPES[_env_mode]
 
 
 def set_compute_dtype(dtype):
     """torch.float32: parity mode (exact-fp32 MFMA); torch.bfloat16: benchmark mode (bf16 MFMA, fp32 accumulate);
-    torch.float16: fp16 storage + fp16 MFMA with fp32 accumulation (BASELINE.json configs[4])."""
-    global _compute_dtype
+    torch.float16: fp16 storage + fp16 MFMA with fp32 accumulation (BASELINE.json configs[4]).
+    "fp32x3": the FAST tolerance-meeting mode -- fp32 storage like the parity mode, but the 3x3x3 / 7x7x7 convolutions and the Linear
+    layers run on the bf16 matrix cores with every fp32 operand split into two bf16 halves (x w ~ x_hi w_hi + x_lo w_hi + x_hi w_lo,
+    fp32 accumulation; csrc/x3.hip).  compute_dtype() is torch.float32 in that mode and x3() is True."""
+    global _compute_dtype, _x3
+    x3 = False
     if isinstance(dtype, str):
-        dtype = _DTYPES[dtype.lower()]
+        if dtype.lower() in _X3_NAMES:
+            dtype, x3 = torch.float32, True
+        else:
+            dtype = _DTYPES[dtype.lower()]
     if dtype not in (torch.float32, torch.bfloat16, torch.float16):
-        raise ValueError("compute dtype must be float32, bfloat16 or float16")
-    _compute_dtype = dtype
+        raise ValueError("compute dtype must be float32, bfloat16, float16 or 'fp32x3'")
+    _compute_dtype, _x3 = dtype, x3
 
 
 def compute_dtype():
+    """Storage type of the activations."""
     return _compute_dtype
+
+
+def x3():
+    """True in the "fp32x3" mode (fp32 storage, split-bf16 matrix-core arithmetic)."""
+    return _x3
+
+
+def compute_mode():
+    """Name of the current mode: 'fp32', 'fp32x3', 'bf16' or 'fp16' (accepted by set_compute_dtype)."""
+    if _x3:
+        return "fp32x3"
+    return {torch.float32: "fp32", torch.bfloat16: "bf16", torch.float16: "fp16"}[_compute_dtype]
+
+
+class compute_mode_as:
+    """Context: run a region in another mode (the cascade runs its no-grad segmentation network in 'fp32x3' so that the OAR masks
+    are the reference's whatever storage type the dose network trains in)."""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = compute_mode()
+        set_compute_dtype(self.mode)
+
+    def __exit__(self, *a):
+        set_compute_dtype(self.prev)
 
 
 _loss_scale = 1.0

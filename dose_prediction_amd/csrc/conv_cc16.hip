@@ -63,9 +63,11 @@ int cc16_pack(const float* w, void* dst, int Cout, int Cin, int k, int tf, int d
   DP_CHECK_LAUNCH("pack_conv_weight_cc16"); return 0;
 }
 
-template <typename T, int KS, int DT, int OCC>
+// TO = type of the OUTPUT tensor: T, or float for DP_X3 launches (bf16 operands that are the hi / lo halves of fp32 values, see
+// dp_split_rows: the three partial products are separate 16-channel chunks of a 3x wider "virtual" input, the sum is kept in fp32)
+template <typename T, int KS, int DT, int OCC, typename TO>
 __global__ void __launch_bounds__(256, OCC) k_conv_cc16(const T* __restrict__ x, const T* __restrict__ wq, const float* __restrict__ bias,
-                                                   T* __restrict__ y, Cc16Geom g) {
+                                                   TO* __restrict__ y, Cc16Geom g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* slab = (T*)smem_raw;
   constexpr int PAD = KS / 2, KWP = (KS + 1) / 2, RWO = 8, ROWS = RWO + KS - 1, CK = 16, TW = 128;
@@ -195,13 +197,13 @@ __global__ void __launch_bounds__(256, OCC) k_conv_cc16(const T* __restrict__ x,
   // epilogue.  C/D layout of the 16x16 MFMA: column (output channel) = lane & 15, row (position) = 4 * (lane >> 4) + e.
   // Each wave transposes one output row (32 positions x 16 channels) through a private LDS patch and writes 16-byte chunks.
   constexpr int NC = 16;
-  constexpr int EPC = 16 / (int)sizeof(T), CPP = NC / EPC, PASSES = 32 * CPP / 64;
+  constexpr int EPC = 16 / (int)sizeof(TO), CPP = NC / EPC, PASSES = 32 * CPP / 64;
   if (g.dbg & 4) return;
   __syncthreads();                                                // every wave is done reading the slab
-  T* patch = slab + wv * (2 * 32 * NC);
+  TO* patch = (TO*)smem_raw + wv * (2 * 32 * NC);
   const float bv = (bias && r < g.Cout) ? bias[r] : 0.f;
   const int wbase_o = w0 + wv * 32;
-  T* y2 = (T*)g.y2;
+  TO* y2 = (TO*)g.y2;
   if (!g.wide) {                                                  // unaligned output rows: plain 2/4-byte stores (rare shapes)
 #pragma unroll
     for (int od = 0; od < DT; od++)
@@ -214,7 +216,7 @@ __global__ void __launch_bounds__(256, OCC) k_conv_cc16(const T* __restrict__ x,
             const int d = d0 + od, oh = h0 + t, ow = wbase_o + mt * 16 + 4 * q + e;
             if (d < g.D && oh < g.H && ow < g.W && r < g.Cout) {
               const int64_t vox = (((int64_t)n * g.D + d) * g.H + oh) * g.W + ow;
-              T* dst = (y2 && r >= g.osplit) ? y2 + vox * g.ldy2 + (r - g.osplit) : y + vox * g.ldy + r;
+              TO* dst = (y2 && r >= g.osplit) ? y2 + vox * g.ldy2 + (r - g.osplit) : y + vox * g.ldy + r;
               st_f(dst, acc[od][t][mt][e] + bv);
             }
           }
@@ -228,7 +230,7 @@ __global__ void __launch_bounds__(256, OCC) k_conv_cc16(const T* __restrict__ x,
     if (g.stat_part) { st1 = 0.f; st2 = 0.f; }
 #pragma unroll
     for (int t = 0; t < RWO; t++) {
-      T* pp = patch + (t & 1) * (32 * NC);
+      TO* pp = patch + (t & 1) * (32 * NC);
       const int oh = h0 + t;
 #pragma unroll
       for (int mt = 0; mt < 2; mt++)
@@ -237,7 +239,7 @@ __global__ void __launch_bounds__(256, OCC) k_conv_cc16(const T* __restrict__ x,
           const int m = mt * 16 + 4 * q + e;
           const float v = acc[od][t][mt][e] + bv;
           st_f(pp + m * NC + r, v);
-          const float vs = (oh < g.H && wbase_o + m < g.W) ? as_stored<T>(v) : 0.f;
+          const float vs = (oh < g.H && wbase_o + m < g.W) ? as_stored<TO>(v) : 0.f;
           st1 += vs; st2 += vs * vs;
         }
       __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier();
@@ -247,7 +249,7 @@ __global__ void __launch_bounds__(256, OCC) k_conv_cc16(const T* __restrict__ x,
         const int ow = wbase_o + m;
         if (oh < g.H && ow < g.W && cc < g.Cout) {
           const int64_t vox = (((int64_t)n * g.D + d) * g.H + oh) * g.W + ow;
-          T* dst = (y2 && cc >= g.osplit) ? y2 + vox * g.ldy2 + (cc - g.osplit) : y + vox * g.ldy + cc;
+          TO* dst = (y2 && cc >= g.osplit) ? y2 + vox * g.ldy2 + (cc - g.osplit) : y + vox * g.ldy + cc;
           if (cc + EPC <= g.Cout) *(v4u*)dst = *(const v4u*)(pp + m * NC + cc);
           else for (int k = 0; k < EPC; k++) if (cc + k < g.Cout) dst[k] = pp[m * NC + cc + k];
         }
@@ -258,7 +260,7 @@ __global__ void __launch_bounds__(256, OCC) k_conv_cc16(const T* __restrict__ x,
       float a1 = st1 + __shfl_xor(st1, 16, 64), a2 = st2 + __shfl_xor(st2, 16, 64);
       a1 += __shfl_xor(a1, 32, 64); a2 += __shfl_xor(a2, 32, 64);
       __syncthreads();
-      float* sred = (float*)(smem_raw + 4 * 2 * 32 * NC * sizeof(T));      // behind the four waves' patches
+      float* sred = (float*)(smem_raw + 4 * 2 * 32 * NC * sizeof(TO));      // behind the four waves' patches
       if (lane < 16) { sred[(wv * 2) * 16 + lane] = a1; sred[(wv * 2 + 1) * 16 + lane] = a2; }
       __syncthreads();
       if (tid < 32) {
@@ -276,23 +278,23 @@ __global__ void __launch_bounds__(256, OCC) k_conv_cc16(const T* __restrict__ x,
 
 int cc16_stat_blocks(int D, int H, int W) { return D * cdiv(H, 8) * cdiv(W, 128); }
 
-template <typename T, int KS, int DT, int OCC>
+template <typename T, int KS, int DT, int OCC, typename TO>
 static int cc16_go_impl(const void* x, const void* wq, const float* bias, void* y, Cc16Geom g, hipStream_t s);
-template <typename T, int KS>
+template <typename T, int KS, typename TO = T>
 static int cc16_go(const void* x, const void* wq, const float* bias, void* y, Cc16Geom g, hipStream_t s) {
   // (fp32 fragments are twice as wide: one depth slice per block keeps the parity mode's register spills down)
   // 3x3x3 with one input chunk: one depth slice per block = 64 accumulator registers -> three blocks per CU, whose staging / sweep /
   // epilogue phases overlap (16->16 at 2 x 128^3: 112 -> 100 us; with two chunks the two variants tie)
-  if constexpr (KS == 3 && sizeof(T) == 2) { if (g.NCH == 1) return cc16_go_impl<T, KS, 1, 3>(x, wq, bias, y, g, s); }
-  return cc16_go_impl<T, KS, (sizeof(T) == 4 ? 1 : 2), 2>(x, wq, bias, y, g, s);
+  if constexpr (KS == 3 && sizeof(T) == 2 && sizeof(TO) == 2) { if (g.NCH == 1) return cc16_go_impl<T, KS, 1, 3, TO>(x, wq, bias, y, g, s); }
+  return cc16_go_impl<T, KS, (sizeof(T) == 4 ? 1 : 2), 2, TO>(x, wq, bias, y, g, s);
 }
-template <typename T, int KS, int DT, int OCC>
+template <typename T, int KS, int DT, int OCC, typename TO>
 static int cc16_go_impl(const void* x, const void* wq, const float* bias, void* y, Cc16Geom g, hipStream_t s) {
   constexpr int ROWS = 8 + KS - 1, LP = (128 + KS - 1 + 7) & ~7;
   size_t smem = (size_t)ROWS * LP * 16 * sizeof(T);
-  const size_t need = 4 * 2 * 32 * 16 * sizeof(T) + 8 * 16 * sizeof(float);      // epilogue patches + statistics scratch
+  const size_t need = 4 * 2 * 32 * 16 * sizeof(TO) + 8 * 16 * sizeof(float);      // epilogue patches + statistics scratch
   if (smem < need) smem = need;
-  auto kern = k_conv_cc16<T, KS, DT, OCC>;
+  auto kern = k_conv_cc16<T, KS, DT, OCC, TO>;
   if (smem > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) { dp_set_error("conv_cc16: cannot raise dynamic LDS to %zu: %s", smem, hipGetErrorString(e)); return 1; }
@@ -300,12 +302,12 @@ static int cc16_go_impl(const void* x, const void* wq, const float* bias, void* 
   g.dtiles = cdiv(g.D, DT);
   const int64_t blocks = (int64_t)g.N * g.dtiles * g.tiles_h * g.tiles_w;
   if (blocks > 2000000000LL) { dp_set_error("conv_cc16: grid too large"); return 1; }
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), smem, s, (const T*)x, (const T*)wq, bias, (T*)y, g);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), smem, s, (const T*)x, (const T*)wq, bias, (TO*)y, g);
   return 0;
 }
 
 bool cc16_wide(const void* y, int ldy, const void* y2, int ldy2, int osplit, int dtype) {
-  const int es = dtype == DP_F32 ? 4 : 2, epc = 16 / es;
+  const int es = (dtype == DP_F32 || dtype == DP_X3) ? 4 : 2, epc = 16 / es;      // element size of the OUTPUT
   return (ldy * es) % 16 == 0 && (((uintptr_t)y & 15) == 0) && (!y2 || ((ldy2 * es) % 16 == 0 && (((uintptr_t)y2 & 15) == 0) && osplit % epc == 0));
 }
 int cc16_launch(const void* x, int ldx, const void* x2, int ldx2, int csplit, const void* wq, const float* bias, void* y, int ldy,
@@ -321,6 +323,7 @@ int cc16_launch(const void* x, int ldx, const void* x2, int ldx2, int csplit, co
   if (dtype == DP_BF16) rc = k == 7 ? cc16_go<bf16_t, 7>(x, wq, bias, y, g, s) : cc16_go<bf16_t, 3>(x, wq, bias, y, g, s);
   else if (dtype == DP_F16) rc = k == 7 ? cc16_go<f16_t, 7>(x, wq, bias, y, g, s) : cc16_go<f16_t, 3>(x, wq, bias, y, g, s);
   else if (dtype == DP_F32) rc = k == 7 ? cc16_go<float, 7>(x, wq, bias, y, g, s) : cc16_go<float, 3>(x, wq, bias, y, g, s);
+  else if (dtype == DP_X3) rc = k == 7 ? cc16_go<bf16_t, 7, float>(x, wq, bias, y, g, s) : cc16_go<bf16_t, 3, float>(x, wq, bias, y, g, s);
   else { dp_set_error("conv_cc16: bad dtype"); return 1; }
   if (rc) return rc;
   DP_CHECK_LAUNCH("conv_cc16"); return 0;

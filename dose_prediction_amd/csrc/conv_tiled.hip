@@ -138,9 +138,10 @@ extern "C" int dp_pack_conv_weight_tiled(const float* w, void* dst, int Cout, in
 // TWP: wave columns (1, 2 or 4 x 32 positions; the other waves stack as row groups), or 0 = "W16": volumes with W <= 16,
 // where one 32-row MFMA tile covers TWO image rows x 16 positions (NPAIR == 1 only).  A template parameter so that the slab
 // pitch is a compile-time constant: every LDS row address is then one base register + an immediate offset.
-template <typename T, int KS, int NPAIR, int RW, int NT, int TWP>
+// TO: type of the output tensor (T, or float for DP_X3 launches: bf16 hi / lo operand halves, fp32 result -- see conv_cc16.hip).
+template <typename T, int KS, int NPAIR, int RW, int NT, int TWP, typename TO>
 __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, const T* __restrict__ wq, const float* __restrict__ bias,
-                                                    T* __restrict__ y, float* __restrict__ ws, TiledGeom g) {
+                                                    TO* __restrict__ y, float* __restrict__ ws, TiledGeom g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* slab = (T*)smem_raw;
   constexpr int PAD = KS / 2, JH = NPAIR == 2 ? (KS + 1) / 2 : KS, RWO = RW - (NPAIR - 1), NTAP = JH * KS, CK = 16;
@@ -342,25 +343,25 @@ __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, 
   if (g.dbg == 4) return;                                         // experiment: loop skeleton only
   const int hw0 = h0 + rg * RWO * RPA, wbase_o = w0 + wc * 32;
   constexpr int NC = NPAIR == 2 ? 16 : 32;                       // channels per output tile
-  constexpr int EPC = 16 / (int)sizeof(T);                       // elements per 16-byte chunk
+  constexpr int EPC = 16 / (int)sizeof(TO);                       // elements per 16-byte chunk
   constexpr int CPP = NC / EPC;                                  // chunks per position
   constexpr int PASSES = 32 * CPP / 64;
   __syncthreads();                                               // every wave is done reading the slab
-  T* patch = slab + (wv & 3) * (2 * 32 * 32);                      // two alternating [32 positions][NC] patches per wave
-  T* y2 = (T*)g.y2;
+  TO* patch = (TO*)smem_raw + (wv & 3) * (2 * 32 * 32);                      // two alternating [32 positions][NC] patches per wave
+  TO* y2 = (TO*)g.y2;
   const bool wide = g.wide != 0;      // (host-computed: no split-kd, 16-byte aligned output rows)
   const int dd = d, nn = n;
   const int stat_blk = (dd * g.tiles_h + th) * g.tiles_w + tw;
   // destination of output channel c of voxel `vox` (virtual concat: channels >= osplit live in y2)
-  auto out_ptr = [&](int64_t vox, int c) -> T* { return (y2 && c >= g.osplit) ? y2 + vox * g.ldy2 + (c - g.osplit) : y + vox * g.ldy + c; };
-  auto store_tile = [&](const T* pt, int oh_lo, int nt_idx) {   // tile in `pt` as [32 positions][NC channels]; oh_lo: image row of position 0
+  auto out_ptr = [&](int64_t vox, int c) -> TO* { return (y2 && c >= g.osplit) ? y2 + vox * g.ldy2 + (c - g.osplit) : y + vox * g.ldy + c; };
+  auto store_tile = [&](const TO* pt, int oh_lo, int nt_idx) {   // tile in `pt` as [32 positions][NC channels]; oh_lo: image row of position 0
     const int cbase = NPAIR == 2 ? 0 : nt_idx * 32;
 #pragma unroll
     for (int ps = 0; ps < PASSES; ps++) {
       const int q = ps * 64 + lane, m = q / CPP, cc = (q % CPP) * EPC;
       const int oh = W16 ? oh_lo + (m >> 4) : oh_lo, ow = W16 ? (m & 15) : wbase_o + m;
       if (oh < g.H && ow < g.W && cbase + cc < g.Cout) {
-        T* dst = out_ptr((((int64_t)n * g.D + d) * g.H + oh) * g.W + ow, cbase + cc);
+        TO* dst = out_ptr((((int64_t)n * g.D + d) * g.H + oh) * g.W + ow, cbase + cc);
         if (cbase + cc + EPC <= g.Cout) *(v4u*)dst = *(const v4u*)(pt + m * NC + cc);
         else for (int k = 0; k < EPC; k++) if (cbase + cc + k < g.Cout) dst[k] = pt[m * NC + cc + k];
       }
@@ -378,7 +379,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, 
       float st1 = 0.f, st2 = 0.f;
 #pragma unroll
       for (int t = 0; t < RWO; t++) {
-        T* pp = patch + (t & 1) * (32 * NC);
+        TO* pp = patch + (t & 1) * (32 * NC);
         const bool rowok = hw0 + t < g.H;
 #pragma unroll
         for (int k = 0; k < 8; k++) {
@@ -389,7 +390,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, 
           const float v = (low ? acc[t][0][k] + __uint_as_float(sw[1]) : acc[t + 1][0][k + 8] + __uint_as_float(sw[0])) + bv;
           const int m = (k & 3) + 8 * (k >> 2) + 4 * hh + (low ? 0 : 16);
           st_f(pp + m * NC + co, v);
-          const float vs = (rowok && wbase_o + m < g.W) ? as_stored<T>(v) : 0.f;      // branch-free: voxels outside the volume count as 0
+          const float vs = (rowok && wbase_o + m < g.W) ? as_stored<TO>(v) : 0.f;      // branch-free: voxels outside the volume count as 0
           st1 += vs; st2 += vs * vs;
         }
         __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier();
@@ -434,14 +435,14 @@ __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, 
       st1[j] = 0.f; st2[j] = 0.f;
 #pragma unroll
       for (int i = 0; i < RW; i++) {
-        T* pp = patch + (i & 1) * (32 * NC);
+        TO* pp = patch + (i & 1) * (32 * NC);
 #pragma unroll
         for (int e = 0; e < 16; e++) {
           const int m = (e & 3) + 8 * (e >> 2) + 4 * hh;
           const float v = acc[i][j][e] + bv;
           st_f(pp + m * NC + r, v);
           const int oh = W16 ? hw0 + 2 * i + (m >> 4) : hw0 + i, ow = W16 ? (m & 15) : wbase_o + m;
-          const float vs = (oh < g.H && ow < g.W) ? as_stored<T>(v) : 0.f;
+          const float vs = (oh < g.H && ow < g.W) ? as_stored<TO>(v) : 0.f;
           st1[j] += vs; st2[j] += vs * vs;
         }
         __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier();
@@ -504,11 +505,11 @@ __global__ void k_conv_split_finish(float* __restrict__ ws, const float* __restr
   }
 }
 
-template <typename T, int KS, int NPAIR, int RW, int NT, int TWP>
+template <typename T, int KS, int NPAIR, int RW, int NT, int TWP, typename TO = T>
 static int launch_tiled(const void* x, const void* wq, const float* bias, void* y, float* ws, TiledGeom g, int ygrid, hipStream_t s) {
   size_t smem = (size_t)g.LR * g.LP * 16 * sizeof(T);
-  if (smem < 8 * 32 * 32 * sizeof(T)) smem = 8 * 32 * 32 * sizeof(T);     // the epilogue transposes through 2 patches per wave
-  auto kern = k_conv_tiled<T, KS, NPAIR, RW, NT, TWP>;
+  if (smem < 8 * 32 * 32 * sizeof(TO)) smem = 8 * 32 * 32 * sizeof(TO);     // the epilogue transposes through 2 patches per wave
+  auto kern = k_conv_tiled<T, KS, NPAIR, RW, NT, TWP, TO>;
   if (smem > 160 * 1024) { dp_set_error("conv3d_tiled: slab %zu B exceeds LDS", smem); return 1; }
   if (smem > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -524,11 +525,11 @@ static int launch_tiled(const void* x, const void* wq, const float* bias, void* 
     hipError_t me = hipMemsetAsync(ws, 0, (size_t)g.N * g.D * g.H * g.W * g.Cout * sizeof(float), s);
     if (me != hipSuccess) { dp_set_error("conv3d_tiled: memset failed"); return 1; }
   }
-  hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, (const T*)x, (const T*)wq, bias, (T*)y, ws, g);
+  hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, (const T*)x, (const T*)wq, bias, (TO*)y, ws, g);
   if (g.splitkd) {
     int64_t rows = (int64_t)g.N * g.D * g.H * g.W;
     int gb = (int)((rows * g.Cout + 255) / 256); if (gb > 4096) gb = 4096;
-    hipLaunchKernelGGL(k_conv_split_finish<T>, dim3(gb), dim3(256), 0, s, ws, bias, (T*)y, rows, g.Cout, g.ldy, (T*)g.y2, g.ldy2, g.osplit, g_scratch_zeroed);
+    hipLaunchKernelGGL(k_conv_split_finish<TO>, dim3(gb), dim3(256), 0, s, ws, bias, (TO*)y, rows, g.Cout, g.ldy, (TO*)g.y2, g.ldy2, g.osplit, g_scratch_zeroed);
   }
   return 0;
 }
@@ -560,7 +561,7 @@ extern "C" int dp_conv3d_tiled_ws_elems(int N, int D, int H, int W, int Cin, int
 }
 
 static bool tiled_wide(const TiledGeom& g, const void* y, int dtype) {
-  const int es = dtype == DP_F32 ? 4 : 2, epc = 16 / es;
+  const int es = (dtype == DP_F32 || dtype == DP_X3) ? 4 : 2, epc = 16 / es;      // element size of the OUTPUT
   return !g.splitkd && (g.ldy * es) % 16 == 0 && (((uintptr_t)y & 15) == 0) &&
          (!g.y2 || ((g.ldy2 * es) % 16 == 0 && (((uintptr_t)g.y2 & 15) == 0) && g.osplit % epc == 0));
 }
@@ -627,12 +628,14 @@ static int conv3d_tiled_impl(const void* x, int ldx, const void* x2, int ldx2, i
   if ((int64_t)N * D * g.tiles_h * g.tiles_w > 2000000000LL) DP_FAIL("conv3d_tiled: grid too large");
   int rc = 0;
   hipStream_t s = STREAM;
-#define GO(TT, KS_, NP, RW_, NT_, TWP_) rc = launch_tiled<TT, KS_, NP, RW_, NT_, TWP_>(x, wq, bias, y, ws, g, ygrid, s)
+#define GO(TT, KS_, NP, RW_, NT_, TWP_) rc = x3 ? launch_tiled<bf16_t, KS_, NP, RW_, NT_, TWP_, float>(x, wq, bias, y, ws, g, ygrid, s) \
+                                             : launch_tiled<TT, KS_, NP, RW_, NT_, TWP_>(x, wq, bias, y, ws, g, ygrid, s)
 #define BYTW(TT, KS_, NP, RW_, NT_) do { if (g.TWC == 4) GO(TT, KS_, NP, RW_, NT_, 4); else if (g.TWC == 2) GO(TT, KS_, NP, RW_, NT_, 2); \
                                          else GO(TT, KS_, NP, RW_, NT_, 1); } while (0)
 #define BYCFG(TT, KS_) do { if (np == 2) BYTW(TT, KS_, 2, 9, 1); else if (nt == 1) { if (w16) GO(TT, KS_, 1, 8, 1, 0); else BYTW(TT, KS_, 1, 8, 1); } \
                             else { if (w16) GO(TT, KS_, 1, 4, 2, 0); else BYTW(TT, KS_, 1, 4, 2); } } while (0)
-  if (dtype == DP_BF16) { if (k == 7) BYCFG(bf16_t, 7); else BYCFG(bf16_t, 3); }
+  const bool x3 = dtype == DP_X3;
+  if (dtype == DP_BF16 || x3) { if (k == 7) BYCFG(bf16_t, 7); else BYCFG(bf16_t, 3); }
   else if (dtype == DP_F16) { if (k == 7) BYCFG(f16_t, 7); else BYCFG(f16_t, 3); }
   else if (dtype == DP_F32) { if (k == 7) BYCFG(float, 7); else BYCFG(float, 3); }
   else DP_FAIL("conv3d_tiled: bad dtype");

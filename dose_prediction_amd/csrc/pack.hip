@@ -11,6 +11,11 @@
 enum { PK_CAST = 0, PK_MAT = 1, PK_MAT_T = 2, PK_CONV = 3, PK_CONV_TILED = 4, PK_TCONV = 5, PK_CONV_CC16 = 6 };
 
 struct PackDesc { const float* src; void* dst; int64_t kind, a, b, c, d, e; };
+// x3 packs (fp32x3 mode, x3.hip): kind = base kind | pattern << 8 | cp << 16 with cp > 0.  The contraction axis of the packed copy
+// (input channels of a convolution, columns of a Linear matrix) is then 3 blocks of cp "virtual" channels over the SAME cp (zero
+// padded) real channels; block p holds bf16(w) when pattern bit p is 0 and bf16(w - bf16(w)) when it is 1 ([w_hi | w_hi | w_lo] = 0b100
+// against activations split [x_hi | x_lo | x_hi] = 0b010).
+__device__ __forceinline__ float x3_part(float v, int lo) { const float h = bf2f(f2bf(v)); return lo ? v - h : h; }
 
 template <typename T>
 __global__ void __launch_bounds__(256) k_pack_multi(const PackDesc* __restrict__ tab, const int* __restrict__ chunk_t,
@@ -19,7 +24,7 @@ __global__ void __launch_bounds__(256) k_pack_multi(const PackDesc* __restrict__
   const unsigned ck = (unsigned)chunk_i[blockIdx.x];
   const float* __restrict__ w = P.src;
   T* __restrict__ dst = (T*)P.dst;
-  const int kind = (int)P.kind;
+  const int kind = (int)(P.kind & 0xff), x3pat = (int)((P.kind >> 8) & 0xff), x3cp = (int)(P.kind >> 16);
   if (kind == PK_MAT_T) {
     // dst[r][c] (rows a, valid columns b, pitch c) = src[c][r] (src is [b][a]); tile = 64 dst rows x 128 dst columns
     __shared__ float tile[128][65];
@@ -29,7 +34,10 @@ __global__ void __launch_bounds__(256) k_pack_multi(const PackDesc* __restrict__
     for (unsigned i = threadIdx.x; i < 128 * 64; i += 256) {
       const unsigned sr = i >> 6, sc = i & 63;          // src row = dst col, src col = dst row
       float v = 0.f;
-      if (c0 + sr < cols && r0 + sc < rows) v = w[(int64_t)(c0 + sr) * rows + r0 + sc];
+      unsigned cv = c0 + sr, part = 0;
+      if (x3cp) { part = cv / (unsigned)x3cp; cv -= part * (unsigned)x3cp; }
+      if (cv < cols && part < 3 && r0 + sc < rows) v = w[(int64_t)cv * rows + r0 + sc];
+      if (x3cp) v = x3_part(v, (x3pat >> part) & 1);
       tile[sr][sc] = v;
     }
     __syncthreads();
@@ -59,16 +67,18 @@ __global__ void __launch_bounds__(256) k_pack_multi(const PackDesc* __restrict__
   else if (kind == PK_CONV) total = (unsigned)((P.d == 0 ? P.a : P.b) * P.c * ((( P.d == 0 ? P.b : P.a) + 7) & ~7));
   else if (kind == PK_CONV_TILED) {
     const int KS = (int)P.c, NP = (int)P.d;
-    total = (unsigned)(KS * (NP == 2 ? (KS + 1) / 2 : KS) * KS * ((P.b + 15) / 16) * ((P.a * NP + 31) / 32) * 512);
+    total = (unsigned)(KS * (NP == 2 ? (KS + 1) / 2 : KS) * KS * ((x3cp ? 3 * x3cp : (P.b + 15)) / 16) * ((P.a * NP + 31) / 32) * 512);
   } else if (kind == PK_CONV_CC16) {
     const int KS = (int)P.c;
-    total = (unsigned)(KS * ((P.b + 15) / 16) * ((KS + 1) / 2) * KS * 512);
+    total = (unsigned)(KS * ((x3cp ? 3 * x3cp : (P.b + 15)) / 16) * ((KS + 1) / 2) * KS * 512);
   } else total = (unsigned)(P.d ? P.a * P.c : 8 * P.b * P.c);
   const unsigned end = min(total, base + PACK_CHUNK);
   for (unsigned i = base + threadIdx.x; i < end; i += 256) {
     float v = 0.f;
+    int part = 0;
     if (kind == PK_MAT) {
-      const unsigned cols = (unsigned)P.b, pitch = (unsigned)P.c, r = i / pitch, c = i - r * pitch;
+      const unsigned cols = (unsigned)P.b, pitch = (unsigned)P.c, r = i / pitch; unsigned c = i - r * pitch;
+      if (x3cp) { part = (int)(c / (unsigned)x3cp); c -= (unsigned)part * (unsigned)x3cp; }
       if (c < cols) v = w[(int64_t)r * cols + c];
     } else if (kind == PK_CONV) {
       // mode 0: dst[co][t][ciP] = w[co][ci][t]; mode 1: dst[ci][t][coP]; mode 2: dst[ci][T-1-t][coP]   (k_pack_w)
@@ -82,14 +92,15 @@ __global__ void __launch_bounds__(256) k_pack_multi(const PackDesc* __restrict__
     } else if (kind == PK_CONV_TILED) {
       // dst[kd][jh][kw][chunk][ntile][col 32][ci 16]   (k_pack_w_tiled)
       const int Cout = (int)P.a, Cin = (int)P.b, KS = (int)P.c, NPAIR = (int)P.d, tf = (int)P.e;
-      const int JH = NPAIR == 2 ? (KS + 1) / 2 : KS, NCH = (Cin + 15) / 16, NTT = (Cout * NPAIR + 31) / 32, taps = KS * KS * KS;
+      const int JH = NPAIR == 2 ? (KS + 1) / 2 : KS, NCH = x3cp ? 3 * x3cp / 16 : (Cin + 15) / 16, NTT = (Cout * NPAIR + 31) / 32, taps = KS * KS * KS;
       const int c = (int)(i & 15), col = (int)((i >> 4) & 31); unsigned t = i >> 9;
       const int nt = (int)(t % NTT); t /= NTT; const int ch = (int)(t % NCH); t /= NCH; const int kw = (int)(t % KS); t /= KS;
       const int jh = (int)(t % JH), kd = (int)(t / JH);
       int kh, co;
       if (NPAIR == 2) { const int s = col >> 4; kh = 2 * jh + s; co = nt * 16 + (col & 15); }
       else { kh = jh; co = nt * 32 + col; }
-      const int ci = ch * 16 + c;
+      int ci = ch * 16 + c;
+      if (x3cp) { part = ci / x3cp; ci -= part * x3cp; }
       if (kh < KS && co < Cout && ci < Cin) {
         const int tap = (kd * KS + kh) * KS + kw;
         v = tf ? w[((int64_t)ci * Cout + co) * taps + (taps - 1 - tap)] : w[((int64_t)co * Cin + ci) * taps + tap];
@@ -97,10 +108,11 @@ __global__ void __launch_bounds__(256) k_pack_multi(const PackDesc* __restrict__
     } else if (kind == PK_CONV_CC16) {
       // dst[kd][chunk][kwp][kh][co 16][k 32]   (k_pack_w_cc16)
       const int Cout = (int)P.a, Cin = (int)P.b, KS = (int)P.c, tf = (int)P.e;
-      const int KWP = (KS + 1) / 2, NCH = (Cin + 15) / 16, taps = KS * KS * KS;
+      const int KWP = (KS + 1) / 2, NCH = x3cp ? 3 * x3cp / 16 : (Cin + 15) / 16, taps = KS * KS * KS;
       const int k = (int)(i & 31), co = (int)((i >> 5) & 15); unsigned t = i >> 9;
       const int kh = (int)(t % KS); t /= KS; const int kwp = (int)(t % KWP); t /= KWP; const int ch = (int)(t % NCH); const int kd = (int)(t / NCH);
-      const int kw = 2 * kwp + (k >> 4), ci = ch * 16 + (k & 15);
+      const int kw = 2 * kwp + (k >> 4); int ci = ch * 16 + (k & 15);
+      if (x3cp) { part = ci / x3cp; ci -= part * x3cp; }
       if (kw < KS && co < Cout && ci < Cin) {
         const int tap = (kd * KS + kh) * KS + kw;
         v = tf ? w[((int64_t)ci * Cout + co) * taps + (taps - 1 - tap)] : w[((int64_t)co * Cin + ci) * taps + tap];
@@ -113,6 +125,7 @@ __global__ void __launch_bounds__(256) k_pack_multi(const PackDesc* __restrict__
       if (P.d == 0) { q = r; ci = c; ok = c < cin; } else { ci = r; q = c; ok = c < 8 * cout; }
       if (ok) { const unsigned abc = q / cout, co = q - abc * cout; v = w[((int64_t)ci * cout + co) * 8 + abc]; }
     }
+    if (x3cp) v = x3_part(v, (x3pat >> part) & 1);
     st_f(dst + i, v);
   }
 }

@@ -149,7 +149,7 @@ def refresh_packs(params):
             for t, (p, d, desc) in enumerate(lst):
                 kind, a, b, c = desc[0], desc[1], desc[2], desc[3]
                 rows.append((p.data_ptr(), d.data_ptr()) + tuple(desc))
-                n = (-(-a // 64)) * (-(-c // 128)) if kind == 2 else -(-d.numel() // chunk)
+                n = (-(-a // 64)) * (-(-c // 128)) if (kind & 0xff) == 2 else -(-d.numel() // chunk)
                 ct += [t] * n
                 ci += list(range(n))
             plan = (torch.tensor(rows, dtype=torch.int64, device=dev), torch.tensor(ct, dtype=torch.int32, device=dev),
@@ -595,6 +595,8 @@ def conv3d(x, weight, bias=None, stride=1, pad=0, dil=1, stats=False, bias_grad_
     makes the bias gradient identically zero: it is returned as exact zeros instead of a column sum of round-off."""
     if isinstance(x, (tuple, list)):
         return conv3d_cat(x[0], x[1], weight, bias, stride, pad, dil, stats, bias_grad_zero)
+    if _x3_conv_ok(x, None, weight, stride, pad, dil):
+        return Conv3dX3.apply(x, None, weight, bias, stats, bias_grad_zero)
     if stats or bias_grad_zero:
         return Conv3d.apply(x, weight, bias, stride, pad, dil, stats, bias_grad_zero)
     return Conv3d.apply(x, weight, bias, stride, pad, dil)
@@ -675,6 +677,8 @@ def conv3d_cat(xa, xb, weight, bias=None, stride=1, pad=0, dil=1, stats=False, b
     """conv3d(cat((xa, xb), channels)): virtual concat when the tiled kernels support the shape, else a real cat."""
     cout, cin, k = weight.shape[0], weight.shape[1], weight.shape[2]
     ca, W = xa.shape[-1], xa.shape[3]
+    if _x3_conv_ok(xa, xb, weight, stride, pad, dil):
+        return Conv3dX3.apply(xa, xb, weight, bias, stats, bias_grad_zero)
     ok = (USE_TILED and k > 1 and stride == 1 and dil == 1 and pad == k // 2 and ca % 8 == 0 and 0 < ca < cin
           and xb.shape[-1] >= cin - ca and xa.dtype == xb.dtype and tuple(xa.shape[:4]) == tuple(xb.shape[:4]))
     if ok:
@@ -752,6 +756,259 @@ class ConvTranspose2x(torch.autograd.Function):
 
 def conv_transpose2x(x, weight):
     return ConvTranspose2x.apply(x, weight)
+
+
+
+# ------------------------------------------------------------------------------------------------ fp32x3 mode (csrc/x3.hip)
+DP_X3 = 3
+_PAT_ACT, _PAT_W = 0b010, 0b100      # operand blocks [hi | lo | hi] against [hi | hi | lo]: hi*hi + lo*hi + hi*lo
+
+
+def _pack_one(w, dst, desc):
+    """Build ONE packed copy through dp_pack_multi (a one-row table): the x3 layouts only exist as dp_pack_multi kinds."""
+    L = _lib.lib()
+    n = (-(-desc[1] // 64)) * (-(-desc[3] // 128)) if (desc[0] & 0xff) == 2 else -(-dst.numel() // L.dp_pack_chunk())
+    dev = w.device
+    tab = torch.tensor([(w.data_ptr(), dst.data_ptr()) + tuple(desc)], dtype=torch.int64, device=dev)
+    ct = torch.zeros((n,), dtype=torch.int32, device=dev)
+    ci = torch.arange(n, dtype=torch.int32, device=dev)
+    _lib.call("dp_pack_multi", _p(tab), _p(ct), _p(ci), n, _DT[dst.dtype], _stream())
+
+
+def _x3_kind(base, pattern, cp):
+    return base | (pattern << 8) | (cp << 16)
+
+
+def _pack_conv_tiled_x3(w, tf, cp, W):
+    """bf16 weights of an x3 convolution: role input channels [w_hi | w_hi | w_lo] over 3 * cp virtual channels (tf = 1: transposed +
+    flipped, the data-gradient convolution, whose input channels are the layer's output channels)."""
+    k = w.shape[2]
+    co, ci = (w.shape[1], w.shape[0]) if tf else (w.shape[0], w.shape[1])
+    L = _lib.lib()
+    elems = L.dp_conv3d_tiled_weight_elems(3 * cp, co, k, 1, k // 2, 1, W)
+    layout = L.dp_conv3d_tiled_layout(3 * cp, co, k, 1, k // 2, 1, W)
+    if not elems:
+        raise _lib.DoseHipError("x3 convolution: shape outside the tiled kernels")
+    if layout == 2:
+        desc = (_x3_kind(6, _PAT_W, cp), co, ci, k, 0, 1 if tf else 0)
+    else:
+        desc = (_x3_kind(4, _PAT_W, cp), co, ci, k, L.dp_conv3d_tiled_npair(co), 1 if tf else 0)
+
+    def build():
+        dst = torch.empty((elems,), dtype=torch.bfloat16, device=w.device)
+        _pack_one(w.detach().contiguous(), dst, desc)
+        return dst
+    return _packs.get(w, ("conv_x3", tf, cp, elems, layout), build, lambda dst: desc)
+
+
+def _pack_mat_x3(w, transposed, cp, pattern):
+    """Linear weight [out][in] -> bf16 [out][3 cp] (cp >= in) or, transposed, [in][3 cp] (cp >= out), blocks per `pattern`."""
+    nout, nin = w.shape
+    rows = nin if transposed else nout
+    desc = (_x3_kind(2, pattern, cp), nin, nout, 3 * cp, 0, 0) if transposed else (_x3_kind(1, pattern, cp), nout, nin, 3 * cp, 0, 0)
+
+    def build():
+        dst = torch.empty((rows, 3 * cp), dtype=torch.bfloat16, device=w.device)
+        _pack_one(w.detach().contiguous(), dst, desc)
+        return dst
+    return _packs.get(w, ("mat_x3", transposed, cp, pattern), build, lambda dst: desc)
+
+
+def split_rows(a, ca, b, cb, cp, parts, pattern):
+    """fp32 rows cat(a[..., :ca], b[..., :cb]) -> bf16 [..., parts * cp] of hi / lo blocks (dp_split_rows)."""
+    rows, _, lda = rows_ld(a)
+    ldb = rows_ld(b)[2] if b is not None else 0
+    out = torch.empty(tuple(a.shape[:-1]) + (parts * cp,), dtype=torch.bfloat16, device=a.device)
+    _lib.call("dp_split_rows", _p(a), lda, ca, _p(b), ldb, cb, _p(out), cp, parts, pattern, rows, _stream())
+    return out
+
+
+def _x3_conv_ok(xa, xb, weight, stride, pad, dil):
+    from . import config
+    if not (config.x3() and USE_TILED and xa.dtype == torch.float32 and xa.is_cuda):
+        return False
+    cout, cin, k = weight.shape[0], weight.shape[1], weight.shape[2]
+    W = xa.shape[3]
+    if not (k in (3, 7) and stride == 1 and dil == 1 and pad == k // 2 and W >= 16 and cout >= 8):
+        return False
+    if xb is not None:
+        ca = xa.shape[-1]
+        if not (0 < ca < cin and xb.shape[-1] >= cin - ca and xb.dtype == xa.dtype and tuple(xa.shape[:4]) == tuple(xb.shape[:4])):
+            return False
+    elif xa.shape[-1] < cin:
+        return False
+    cp = (cin + 15) // 16 * 16
+    return bool(_lib.lib().dp_conv3d_tiled_weight_elems(3 * cp, cout, k, 1, pad, 1, W))
+
+
+class Conv3dX3(torch.autograd.Function):
+    """nn.Conv3d (k in {3, 7}, stride 1, "same" padding) in the fp32x3 mode, on a tensor or on the virtual concatenation of two:
+    fp32 tensors in HBM, the tuned bf16 MFMA kernels on split operands (csrc/x3.hip), fp32 results.  Forward and data gradient are
+    ONE launch each over 3 x the (16-padded) channels; the weight gradient is two launches (x_hi | x_lo against gy_hi, x_hi against
+    gy_lo) plus a small combine.  The split input is what is saved for the backward pass (same bytes as the fp32 tensor)."""
+
+    @staticmethod
+    def forward(ctx, xa, xb, weight, bias, want_stats=False, bias_grad_zero=False):
+        _chk_dev(xa, xb, weight)
+        xa = as_rows(xa)
+        xb = None if xb is None else as_rows(xb)
+        cout, cin, k = weight.shape[0], weight.shape[1], weight.shape[2]
+        N, D, H, W = xa.shape[:4]
+        ca = cin if xb is None else xa.shape[-1]
+        cb = cin - ca
+        cp = (cin + 15) // 16 * 16
+        xs = split_rows(xa, ca, xb, cb, cp, 2, 0b10)                   # [.., x_hi (cp) | x_lo (cp)]
+        wq = _pack_conv_tiled_x3(weight, 0, cp, W)
+        y = torch.empty((N, D, H, W, cout), dtype=torch.float32, device=xa.device)
+        b32 = None if bias is None else bias.detach()
+        L = _lib.lib()
+        nblk = L.dp_conv3d_tiled_stat_blocks(N, D, H, W, 3 * cp, cout, k, cout, DP_X3) if want_stats else 0
+        ws = _tiled_ws(xa, N, D, H, W, 3 * cp, cout, k)
+        part = None
+        # channels [0, 2cp) come from xs, the third block [2cp, 3cp) is xs's first cp channels again (x2 = xs: no third copy in memory)
+        if nblk:
+            part = torch.empty((N, nblk, 2, cout), dtype=torch.float32, device=xa.device)
+            _lib.call("dp_conv3d_tiled_stats", _p(xs), 2 * cp, _p(xs), 2 * cp, 2 * cp, _p(wq), _p(b32), _p(y), cout, _p(ws), _p(part),
+                      N, D, H, W, 3 * cp, cout, k, DP_X3, _stream())
+        else:
+            _lib.call("dp_conv3d_tiled2", _p(xs), 2 * cp, _p(xs), 2 * cp, 2 * cp, _p(wq), _p(b32), _p(y), cout, 0, 0, 0, _p(ws),
+                      N, D, H, W, 3 * cp, cout, k, DP_X3, _stream())
+        ctx.save_for_backward(xs, weight)
+        ctx.geom = (N, D, H, W, cin, cout, k, cp, ca, xa.shape[-1], None if xb is None else xb.shape[-1])
+        ctx.has_bias = bias is not None
+        ctx.bias_grad_zero = bias_grad_zero
+        ctx.bias_ref = bias if bias_grad_zero else None
+        if want_stats:
+            if part is None:
+                part = _stats_partial(y)
+            ctx.mark_non_differentiable(part)
+            return y, part
+        return y
+
+    @staticmethod
+    def backward(ctx, gy, *unused):
+        xs, weight = ctx.saved_tensors
+        N, D, H, W, cin, cout, k, cp, ca, cxa, cxb = ctx.geom
+        gy = as_rows(gy)
+        grows, _, ldg = rows_ld(gy)
+        dev = gy.device
+        L = _lib.lib()
+        pad, taps = k // 2, k * k * k
+        cpo = (cout + 15) // 16 * 16
+        need_x = ctx.needs_input_grad[0] or (cxb is not None and ctx.needs_input_grad[1])
+        need_w = ctx.needs_input_grad[2]
+        gys = split_rows(gy, cout, None, 0, cpo, 2, 0b10) if (need_x or need_w) else None
+        gxa = gxb = gw = gb = None
+        if need_x:
+            if L.dp_conv3d_tiled_weight_elems(3 * cpo, cin, k, 1, pad, 1, W):
+                wq = _pack_conv_tiled_x3(weight, 1, cpo, W)
+                ws = _tiled_ws(gy, N, D, H, W, 3 * cpo, cin, k)
+                if cxb is None or ca % 8:
+                    cx1 = cxa if cxb is None else cin            # (a concat split that is not a multiple of 8: one tensor, sliced below)
+                    gx = torch.empty((N, D, H, W, cx1), dtype=torch.float32, device=dev)
+                    if cx1 > cin:
+                        gx.zero_()
+                    _lib.call("dp_conv3d_tiled2", _p(gys), 2 * cpo, _p(gys), 2 * cpo, 2 * cpo, _p(wq), 0, _p(gx), cx1, 0, 0, 0, _p(ws),
+                              N, D, H, W, 3 * cpo, cin, k, DP_X3, _stream())
+                    if cxb is None:
+                        gxa = gx
+                    else:
+                        gxa = gx[..., :ca]
+                        gxb = gx[..., ca:] if cxb == cin - ca else torch.cat((gx[..., ca:], gx.new_zeros((N, D, H, W, cxb - (cin - ca)))), -1)
+                else:
+                    gxa = torch.empty((N, D, H, W, ca), dtype=torch.float32, device=dev)
+                    gxb = torch.empty((N, D, H, W, cxb), dtype=torch.float32, device=dev)
+                    if cxb > cin - ca:
+                        gxb.zero_()
+                    _lib.call("dp_conv3d_tiled2", _p(gys), 2 * cpo, _p(gys), 2 * cpo, 2 * cpo, _p(wq), 0, _p(gxa), ca, _p(gxb), cxb, ca, _p(ws),
+                              N, D, H, W, 3 * cpo, cin, k, DP_X3, _stream())
+            else:
+                # fewer than 8 input channels (no tiled kernel computes so narrow an output): the exact-fp32 gather kernel
+                wt = _pack_conv(weight, 2, torch.float32)
+                gx = torch.empty((N, D, H, W, cin), dtype=torch.float32, device=dev)
+                _lib.call("dp_conv3d", _p(gy), ldg, _p(wt), 0, _p(gx), cin, N, D, H, W, D, H, W, cout, cin, k, 1, k - 1 - pad, 1, 0, 0, _stream())
+                if cxb is None:
+                    gxa = gx if cxa == cin else torch.cat((gx, gx.new_zeros((N, D, H, W, cxa - cin))), -1)
+                else:
+                    gxa = gx[..., :ca]
+                    gxb = gx[..., ca:] if cxb == cin - ca else torch.cat((gx[..., ca:], gx.new_zeros((N, D, H, W, cxb - (cin - ca)))), -1)
+        if need_w:
+            # S[co][p cp + ci][tap]: blocks p = 0, 1 from (x_hi | x_lo) x gy_hi, block 2 from x_hi x gy_lo
+            S = torch.empty((cout, 3 * cp, taps), dtype=torch.float32, device=dev)
+            wse = max(L.dp_conv3d_wgrad_tiled_ws_elems(2 * cp, cout, k, 1, pad, 1, 1, W), L.dp_conv3d_wgrad_tiled_ws_elems(cp, cout, k, 1, pad, 1, 1, W))
+            if not wse:
+                raise _lib.DoseHipError("x3 convolution: weight gradient outside the tiled kernels")
+            ws = _zero_scratch(dev, wse)
+            _lib.call("dp_conv3d_wgrad_tiled", _p(xs), 2 * cp, _p(gys), 2 * cpo, _p(S), _p(ws), N, D, H, W, 2 * cp, cout, k,
+                      3 * cp * taps, taps, 1, 1, _stream())
+            _lib.call("dp_conv3d_wgrad_tiled", _p(xs), 2 * cp, gys.data_ptr() + 2 * cpo, 2 * cpo, S.data_ptr() + 4 * 2 * cp * taps, _p(ws),
+                      N, D, H, W, cp, cout, k, 3 * cp * taps, taps, 1, 1, _stream())
+            gw = _wgrad_buffer(weight, False)
+            _lib.call("dp_x3_wgrad_combine", _p(S), _p(gw), cout, cin, cp, taps, 3, _stream())
+        if ctx.has_bias and ctx.needs_input_grad[3]:
+            if ctx.bias_grad_zero:
+                gb = _zero_bias_grad(ctx.bias_ref)
+            else:
+                gb = torch.empty((cout,), dtype=torch.float32, device=dev)
+                colsum_into(_p(gy), ldg, grows, cout, gb, 0)
+        return gxa, gxb, gw, gb, None, None
+
+
+class LinearX3(torch.autograd.Function):
+    """nn.Linear on token rows in the fp32x3 mode: y = x' W'^T with x' = [x_hi | x_lo | x_hi] (one split pass) and the packed
+    W' = [w_hi | w_hi | w_lo]: the bf16 NT GEMM over 3 K, fp32 output.  Backward: gy' = [gy_hi | gy_hi | gy_lo] serves the data
+    gradient (against [w_hi | w_lo | w_hi] transposed) AND, read as 3 x rows of K-stacked operands next to the saved x', the weight
+    gradient (grouped TN launch): sum_k gy'[k] x'[k] = gy_hi x_hi + gy_hi x_lo + gy_lo x_hi."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, splitk, defer_wgrad=False):
+        _chk_dev(x, weight)
+        x = as_rows(x)
+        rows, K, ldx = rows_ld(x)
+        nout = weight.shape[0]
+        cp = (K + 7) // 8 * 8
+        xs = split_rows(x, K, None, 0, cp, 3, _PAT_ACT)
+        wp = _pack_mat_x3(weight, False, cp, _PAT_W)
+        b32 = None if bias is None else bias.detach()
+        y = (torch.zeros if splitk > 1 else torch.empty)(tuple(x.shape[:-1]) + (nout,), dtype=torch.float32, device=x.device)
+        gemm_nt(xs, wp, y, bias=b32, M=rows, N=nout, K=3 * cp, lda=3 * cp, ldb=3 * cp, ldc=nout, splitk=splitk)
+        ctx.save_for_backward(xs, weight)
+        ctx.geom = (tuple(x.shape), rows, K, cp)
+        ctx.has_bias = bias is not None
+        ctx.bias_ref = bias if defer_wgrad else None
+        ctx.defer = defer_wgrad
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        xs, weight = ctx.saved_tensors
+        xshape, rows, K, cp = ctx.geom
+        gy = as_rows(gy)
+        _, nout, ldg = rows_ld(gy)
+        cpo = (nout + 7) // 8 * 8
+        dev = gy.device
+        gx = gw = gb = None
+        gys = split_rows(gy, nout, None, 0, cpo, 3, _PAT_W)             # [gy_hi | gy_hi | gy_lo]
+        if ctx.needs_input_grad[0]:
+            wt = _pack_mat_x3(weight, True, cpo, _PAT_ACT)             # [in][w_hi | w_lo | w_hi]
+            gx = torch.empty(xshape, dtype=torch.float32, device=dev)
+            gemm_nt(gys, wt, gx, M=rows, N=K, K=3 * cpo, lda=3 * cpo, ldb=3 * cpo, ldc=K)
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1]:
+            gw = _wgrad_buffer(weight, False)
+            # K-stacked view: row (3 r + p) of the [3 rows][cp] matrix is block p of row r
+            if (ctx.defer and _DEFER["enabled"] and rows <= 16384 and weight.grad is None and (not want_b or ctx.bias_ref.grad is None)):
+                _defer_wgrad(gys, cpo, xs, cp, gw, None, nout, K, 3 * rows)
+            else:
+                tiles = -(-nout // 64) * -(-K // 64)
+                sk = max(1, min(3 * rows // 512, 512 // tiles)) if tiles < 256 else 1
+                if sk > 1:
+                    gw.zero_()
+                _lib.call("dp_gemm_tn", _p(gys), cpo, _p(xs), cp, _p(gw), K, nout, K, 3 * rows, sk, 1, _stream())
+        if want_b:
+            gb = torch.empty((nout,), dtype=torch.float32, device=dev)
+            colsum_into(_p(gy), ldg, rows, nout, gb, 0)
+        return gx, gw, gb, None, None
 
 
 # ------------------------------------------------------------------------------------------------ deferred weight gradients
@@ -975,6 +1232,9 @@ def mlp(x, w1, b1, w2, b2):
 def linear(x, weight, bias=None, splitk=1, defer_wgrad=False):
     """defer_wgrad=True (weights that are used once per forward pass and not shared): the weight / bias gradients are produced by
     one grouped launch at the end of the backward pass instead of two to three small launches here."""
+    from . import config
+    if config.x3() and x.dtype == torch.float32 and x.is_cuda and x.shape[-1] >= 16 and weight.shape[0] >= 16:
+        return LinearX3.apply(x, weight, bias, splitk, defer_wgrad)
     return Linear.apply(x, weight, bias, splitk, defer_wgrad)
 
 

@@ -17,6 +17,11 @@
  *     DP_F32 uses v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain) -- the parity mode;
  *     DP_BF16 uses v_mfma_f32_16x16x32_bf16 -- the benchmark mode;
  *     DP_F16 uses v_mfma_f32_16x16x32_f16 (BASELINE.json configs[4] trains in fp16).
+ *     DP_X3 (3), accepted by the tiled convolutions only: the "fp32x3" mode.  Activations live in HBM as fp32; dp_split_rows writes
+ *     each operand as bf16 halves hi = bf16(v), lo = bf16(v - hi) side by side ([hi | lo] channel blocks), the packed weights hold
+ *     [w_hi | w_hi | w_lo], and the convolution runs the bf16 MFMA kernels over the 3x wider "virtual" input [x_hi | x_lo | x_hi]:
+ *     x w ~ x_hi w_hi + x_lo w_hi + x_hi w_lo (relative error of a product ~1e-5 instead of 4e-3 for bf16 operands), fp32
+ *     accumulators written as fp32 OUTPUT.  x / wq are bf16, y / y2 are float.
  *   - every function returns 0 on success, non-zero on error; dp_last_error() gives the message.
  *   - no function allocates, frees or synchronises: workspaces are caller-provided.
  */
@@ -27,7 +32,7 @@
 extern "C" {
 #endif
 
-enum { DP_F32 = 0, DP_BF16 = 1, DP_F16 = 2 };
+enum { DP_F32 = 0, DP_BF16 = 1, DP_F16 = 2, DP_X3 = 3 };
 enum { DP_ACT_NONE = 0, DP_ACT_RELU = 1, DP_ACT_LRELU = 2, DP_ACT_MISH = 3, DP_ACT_GELU = 4 };
 
 const char* dp_last_error(void);
@@ -280,10 +285,24 @@ int dp_adam_multi_dev(const void* table, const int32_t* chunk_t, const int32_t* 
  *   kind 6 = dp_pack_conv_weight_cc16(Cout=a, Cin=b, k=c, transposed_flipped=e);
  *   kind 5 ConvTranspose3d(k2,s2) weight [Cin=a][Cout=b][8] -> d == 0: [(abc,co)][pitch c over ci], d != 0: [ci][pitch c over (abc,co)].
  * chunk_t/chunk_i map each block to (table row, chunk); a chunk is dp_pack_chunk() destination elements, for kind 2 one
- * 64-row x 128-column destination tile (row-major tile index).  All destinations share the storage type `dtype`. */
+ * 64-row x 128-column destination tile (row-major tile index).  All destinations share the storage type `dtype`.
+ * fp32x3 packs (dtype DP_BF16 destinations for DP_X3 launches): kind = base kind (1, 2, 4 or 6) | pattern << 8 | cp << 16 with cp > 0;
+ * the contraction axis of the copy (input channels of kinds 4 / 6 -- Cin = b stays the REAL channel count --, the columns of kinds
+ * 1 / 2, pitch c = 3 cp) is three blocks of cp virtual channels over the same zero-padded real ones; block p holds bf16(w) if
+ * pattern bit p is 0, bf16(w - bf16(w)) if it is 1. */
 int dp_pack_chunk(void);
 int dp_conv3d_tiled_npair(int Cout);
 int dp_pack_multi(const void* table, const int32_t* chunk_t, const int32_t* chunk_i, int nchunks, int dtype, void* stream);
+
+/* ---- fp32x3 mode: operand splitting (x3.hip) ---------------------------------------------------------------------------
+ * replaces: nothing in the reference (which computes in fp32 throughout); these two feed the bf16 matrix-core
+ * kernels with fp32-class operands.  dp_split_rows: dst bf16 [rows][parts * cp]; block p (p < parts <= 3) of a row holds, for the
+ * fp32 source row cat(a[row][0:ca], b[row][0:cb]) zero-padded to cp channels (cp % 8 == 0; b may be NULL with cb == 0), hi = bf16(v)
+ * when pattern bit p is 0 and lo = bf16(v - hi) when it is 1.  dp_x3_wgrad_combine: dw[co][ci][tap] = sum_{p < nblk}
+ * S[co][p*cp + ci][tap] (the partial weight gradients x_hi gy_hi, x_lo gy_hi, x_hi gy_lo of the bf16 weight-gradient kernels). */
+int dp_split_rows(const float* a, int lda, int ca, const float* b, int ldb, int cb, void* dst, int cp, int parts, int pattern,
+                  int64_t rows, void* stream);
+int dp_x3_wgrad_combine(const float* S, float* dw, int cout, int cin, int cp, int taps, int nblk, void* stream);
 
 /* ---- cascade glue ----------------------------------------------------------------------------- */
 /* replaces: AsDiscrete(argmax=True, to_onehot=True) + channel concat (train_light_linked_model.py:157-167):
