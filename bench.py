@@ -31,7 +31,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32", "fp32x3"],
+                    help="fp32x3: fp32 storage, split-bf16 matrix-core arithmetic (the fast mode that meets the 1e-3 / arg-max parity bar)")
     ap.add_argument("--size", type=int, nargs="+", default=[128])
     ap.add_argument("--batch", type=int, default=2, help="volumes per GPU")
     ap.add_argument("--model", default="pyfer", choices=["pyfer", "transeg", "cascade"],
@@ -48,7 +49,8 @@ def parse():
     ap.add_argument("--grad-dtype", default="fp32", choices=["fp32", "bf16"], help="dtype of the all-reduce buckets (N > 1)")
     ap.add_argument("--bucket-mb", type=float, default=32.0, help="size of the gradient all-reduce buckets (N > 1)")
     ap.add_argument("--no-side-stream", action="store_true", help="run the ViT branch on the main stream (no second HIP stream)")
-    ap.add_argument("--no-fp32-leg", action="store_true", help="skip the extra fp32-mode timing (default workload only)")
+    ap.add_argument("--no-fp32-leg", action="store_true", help="skip the extra tolerance-meeting-mode timings (default workload only)")
+    ap.add_argument("--exact-fp32-leg", action="store_true", help="also time the exact-fp32 MFMA mode (183 ms/step) next to fp32x3")
     ap.add_argument("--own-stream", action="store_true", help="run the timed steps on a non-default (non-blocking) HIP stream")
     ap.add_argument("--fp32-steps", type=int, default=3)
     return ap.parse_args()
@@ -192,13 +194,13 @@ def cpu_baseline_transeg(args):
         safe = (top2[:, 0] - top2[:, 1]) > 1e-3 * ref.abs().max()
         chk = {}
         budget = {}
-        if args.dtype != "fp32":
+        if args.dtype in ("bf16", "fp16"):
             with torch.no_grad(), oracle.storage(torch.bfloat16 if args.dtype == "bf16" else torch.float16):
                 em = oracle.oar_transeg({k: v.detach() for k, v in sd.items()}, x, num_heads=12, training=True)
             mm = em.argmax(1) != ref.argmax(1)
             budget[args.dtype] = {"rel_err_max": float((em - ref).abs().max() / ref.abs().max()), "argmax_mismatch": int(mm.sum()),
                                   "argmax_mismatch_off_near_ties": int((mm & safe).sum())}
-        for name in ("fp32", args.dtype) if args.dtype != "fp32" else ("fp32",):
+        for name in dict.fromkeys(("fp32", "fp32x3", args.dtype)):
             dose_prediction_amd.set_compute_dtype(name)
             hip = mk()
             hip.load_state_dict({k: v.detach() for k, v in sd.items()})
@@ -273,7 +275,7 @@ def cpu_baseline(args):
                 em = oracle.dose_pyfer({k: v.detach() for k, v in sd.items()}, x, num_layers=8, num_heads=6, act="mish", training=True)[1][0]
             budget[name] = {"rel_err_max": float((em - ref).abs().max() / ref.abs().max()),
                             "dose_mae_gy_vs_oracle": float(70.0 * (em - ref).abs()[mask].mean())}
-        for name, dt_ in (("fp32", torch.float32), ("bf16", torch.bfloat16)) + ((("fp16", torch.float16),) if args.dtype == "fp16" else ()):
+        for name, dt_ in (("fp32", torch.float32), ("fp32x3", "fp32x3"), ("bf16", torch.bfloat16)) + ((("fp16", torch.float16),) if args.dtype == "fp16" else ()):
             dose_prediction_amd.set_compute_dtype(dt_)
             hip = dose_pyfer.Model(in_ch=9, out_ch=1, list_ch_A=[-1, 16, 32, 64, 128, 256], feature_size=16, img_size=shape,
                                    num_layers=8, num_heads=6, act="mish")
@@ -466,34 +468,44 @@ def main():
     # the tolerance-meeting mode, timed by the same harness: the identical step in fp32 storage / exact-fp32 MFMA
     fp32_leg = None
     default_workload = args.model == "pyfer" and tuple(shape) == (128, 128, 128) and B == 2
-    if args.dtype != "fp32" and default_workload and not args.no_fp32_leg and not ddp_on:
-        try:
-            import dose_prediction_amd
+    if args.dtype in ("bf16", "fp16") and default_workload and not args.no_fp32_leg and not ddp_on:
+        import dose_prediction_amd
+
+        def time_mode(mode, nsteps):
+            nonlocal net, opt, params
             del net, opt, params
             torch.cuda.empty_cache()
-            a32 = argparse.Namespace(**vars(args))
-            a32.dtype = "fp32"
-            net = build_model(a32, dose_shape, dev)
+            am = argparse.Namespace(**vars(args))
+            am.dtype = mode
+            net = build_model(am, dose_shape, dev)
             params = [p for p in net.parameters() if p.requires_grad]
             opt = FusedAdam(params, lr=1e-4, weight_decay=3e-5, betas=(0.9, 0.999), eps=1e-8, amsgrad=True)
             step()
             sync()
-            t1 = time.perf_counter()
-            for _ in range(args.fp32_steps):
-                l32 = step()
-            sync()
-            d32 = time.perf_counter() - t1
-            fp32_leg = {"ms_per_step": 1e3 * d32 / args.fp32_steps, "value": B * args.fp32_steps / d32, "unit": "volumes/s", "steps": args.fp32_steps,
-                        "dtype": "fp32 storage, v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain)", "final_loss": float(l32.detach()),
-                        "note": "the mode that meets the north-star's 1e-3 / arg-max parity bar (check_vs_oracle.fp32)"}
+            ts = []
+            for _ in range(nsteps):
+                t1 = time.perf_counter()
+                lm = step()
+                sync()
+                ts.append(time.perf_counter() - t1)
+            ts.sort()
+            return {"ms_per_step": 1e3 * sum(ts) / nsteps, "ms_per_step_median": 1e3 * ts[len(ts) // 2], "value": B * nsteps / sum(ts),
+                    "unit": "volumes/s", "steps": nsteps, "final_loss": float(lm.detach())}
+        try:
+            fp32_leg = time_mode("fp32x3", max(args.fp32_steps, 5))
+            fp32_leg.update({"dtype": "fp32x3: fp32 storage, bf16 MFMA on split operands (x_hi w_hi + x_lo w_hi + x_hi w_lo), fp32 accumulation",
+                             "note": "the fast mode that meets the north-star's 1e-3 / arg-max parity bar (check_vs_oracle.fp32x3)"})
+            if args.exact_fp32_leg:
+                ex = time_mode("fp32", args.fp32_steps)
+                ex["dtype"] = "fp32 storage, v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain)"
+                fp32_leg["exact_fp32"] = ex
         except Exception as e:
             fp32_leg = {"error": repr(e)}
         finally:
-            import dose_prediction_amd
             dose_prediction_amd.set_compute_dtype(args.dtype)
     if rank == 0:
         prof = summarize_profile(records, prof_steps)
-        peak = PEAK_BF16_TFLOPS if args.dtype in ("bf16", "fp16") else PEAK_F32_TFLOPS
+        peak = PEAK_BF16_TFLOPS if args.dtype in ("bf16", "fp16", "fp32x3") else PEAK_F32_TFLOPS
         dom = prof.get("conv7x7x7_tiled", prof.get("conv7x7x7_generic", {"tflops": 0.0, "avg_launch_ms": 0.0, "launches_per_step": 0}))
         default_cfg = args.model == "pyfer" and args.dtype == "bf16" and tuple(shape) == (128, 128, 128) and B == 2
         traffic, traffic_src = pmc_traffic(("k_conv_tiled<unsigned short, 7,", "k_conv_cc16<unsigned short, 7,")) if default_cfg else (None, None)

@@ -325,6 +325,13 @@ class PatchEmbeddingBlock(nn.Module):
 
     def forward(self, x):
         lin = self.patch_embeddings[1]
+        if config.x3() and x.dtype == torch.float32 and not x.requires_grad:
+            # fp32x3: split the voxels once, patchify the bf16 halves straight into the GEMM's operand blocks (no fp32 token matrix)
+            n_tok_rows = x.shape[0] * (x.shape[1] // self.patch) * (x.shape[2] // self.patch) * (x.shape[3] // self.patch)
+            sk = max(1, min(32, 480 // max(1, -(-n_tok_rows // 128) * -(-lin.out_features // 128))))
+            t = ops.patch_embed_x3(x, self.in_channels, self.patch, lin.weight, lin.bias, sk if lin.in_features >= 4096 else 1)
+            if t is not None:
+                return ops.add_broadcast(t, self.position_embeddings)
         tok = ops.patchify(x, self.in_channels, self.patch)
         rows = tok.shape[0] * tok.shape[1]
         # K = p^3*C is huge while M x N is small: split K so the GEMM fills the 256 CUs

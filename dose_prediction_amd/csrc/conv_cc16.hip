@@ -29,6 +29,10 @@ struct Cc16Geom {
   void* y2; int ldy2, osplit;             // output channels >= osplit go to y2 (data gradient of a virtual concat)
   int wide;                               // 16-byte aligned output rows: transposing epilogue; else scalar stores
   int dbg;                                // experiments only (env DP_DBG): bit 0 skip staging, bit 1 skip the MFMA sweep, bit 2 skip the epilogue
+  // DP_X3 launches: the input tensor holds 2 * x3 chunks ([x_hi | x_lo], x3 = real 16-channel chunks) while the packed weights hold
+  // NCH = 3 * x3 chunks ([w_hi | w_hi | w_lo]).  Every x_hi slab is staged ONCE and swept with both of its weight blocks (chunk ch
+  // and chunk 2 * x3 + ch); 0 = ordinary launch (one sweep per staged chunk).
+  int x3;
 };
 
 bool cc16_applicable(int Cin, int Cout, int k, int W) {
@@ -90,7 +94,8 @@ __global__ void __launch_bounds__(256, OCC) k_conv_cc16(const T* __restrict__ x,
 
   constexpr int pieces = LR * LP * 2;              // 8-channel pieces of the slab
   constexpr int SU = 8;
-  const bool fast = SWZ && (g.NCH * 16 <= (g.x2 ? g.csplit + g.ldx2 : g.ldx)) && (g.ldx % 8 == 0) && (((uintptr_t)x & 15) == 0) &&
+  const int cin_in = g.x3 ? 32 * g.x3 : g.Cin;       // channels of the INPUT tensor (a DP_X3 launch reads [x_hi | x_lo])
+  const bool fast = SWZ && ((g.x3 ? 2 * g.x3 : g.NCH) * 16 <= (g.x2 ? g.csplit + g.ldx2 : g.ldx)) && (g.ldx % 8 == 0) && (((uintptr_t)x & 15) == 0) &&
                     (!g.x2 || ((g.csplit % 16 == 0) && (g.ldx2 % 8 == 0) && (((uintptr_t)g.x2 & 15) == 0))) &&
                     (int64_t)g.H * g.W * max(g.ldx, g.x2 ? g.ldx2 : 0) < (1ll << 30);
   const int st_half = tid & 1, st_lp0 = (tid >> 1) % LP, st_lr0 = (tid >> 1) / LP;
@@ -102,7 +107,8 @@ __global__ void __launch_bounds__(256, OCC) k_conv_cc16(const T* __restrict__ x,
 
   for (int z = d0 - PAD; z < d0 + DT + PAD; z++) {
     if (z < 0 || z >= g.D) continue;               // block-uniform: the whole depth slice is zero padding
-    for (int ch = 0; ch < g.NCH; ch++) {
+    const int nstage = g.x3 ? 2 * g.x3 : g.NCH;
+    for (int ch = 0; ch < nstage; ch++) {
       lds_barrier();                               // every wave is done with the previous slab
       if (g.dbg & 1) {
       } else if (fast) {
@@ -132,7 +138,7 @@ __global__ void __launch_bounds__(256, OCC) k_conv_cc16(const T* __restrict__ x,
         for (int p = tid; p < pieces; p += 256) {
           int half = p & 1, v = p >> 1, lp = v % LP, lr = v / LP;
           int ih = h0 - PAD + lr, iw = w0 - PAD + lp, c = ch * CK + half * 8;
-          int nv = g.Cin - c; nv = nv > 8 ? 8 : nv;
+          int nv = cin_in - c; nv = nv > 8 ? 8 : nv;
           bool ok = ih >= 0 && ih < g.H && iw >= 0 && iw < g.W && nv > 0;
           const bool second = g.x2 && c >= g.csplit;
           if (!second && g.x2 && c + nv > g.csplit) nv = g.csplit - c;
@@ -143,11 +149,15 @@ __global__ void __launch_bounds__(256, OCC) k_conv_cc16(const T* __restrict__ x,
         }
       }
       lds_barrier();
+      const int nrep = (g.x3 && ch < g.x3) ? 2 : 1;      // an x_hi slab meets w_hi (chunk ch) and w_lo (chunk 2 x3 + ch)
+#pragma unroll 1
+      for (int rep = 0; rep < nrep; rep++) {
+      const int wch = rep ? ch + 2 * g.x3 : ch;
 #pragma unroll
       for (int od = 0; od < DT; od++) {
         const int kd = z - (d0 + od) + PAD;
         if (kd < 0 || kd >= KS || d0 + od >= g.D || (g.dbg & 2)) continue;        // block-uniform
-        const T* wbase = wq + ((int64_t)(kd * g.NCH + ch) * KWP) * KS * WT + lane_off;
+        const T* wbase = wq + ((int64_t)(kd * g.NCH + wch) * KWP) * KS * WT + lane_off;
         Frag8<T> b0[KS], b1[KS];
         auto load_b = [&](int kwp, Frag8<T>* bb) {
 #pragma unroll
@@ -190,6 +200,7 @@ __global__ void __launch_bounds__(256, OCC) k_conv_cc16(const T* __restrict__ x,
           if (kwp + 2 < KWP) { load_b(kwp + 2, b0); __builtin_amdgcn_sched_barrier(0); }
           do_pair(kwp + 1, b1, kwp + 2 < KWP);
         }
+      }
       }
     }
   }
@@ -313,6 +324,11 @@ bool cc16_wide(const void* y, int ldy, const void* y2, int ldy2, int osplit, int
 int cc16_launch(const void* x, int ldx, const void* x2, int ldx2, int csplit, const void* wq, const float* bias, void* y, int ldy,
                 void* y2, int ldy2, int osplit, float* stat_part, int N, int D, int H, int W, int Cin, int Cout, int k, int dtype, hipStream_t s) {
   Cc16Geom g;
+  g.x3 = 0;
+  if (dtype == DP_X3) {
+    if (x2 || Cin % 48 || ldx < 2 * (Cin / 3)) { dp_set_error("conv_cc16: a DP_X3 launch takes ONE [x_hi | x_lo] tensor of 2/3 Cin channels (Cin = 3 x a multiple of 16)"); return 1; }
+    g.x3 = Cin / 48;
+  }
   { const char* e = getenv("DP_DBG"); g.dbg = e ? atoi(e) : 0; }
   g.y2 = y2; g.ldy2 = ldy2; g.osplit = osplit; g.wide = cc16_wide(y, ldy, y2, ldy2, osplit, dtype) ? 1 : 0;
   if (stat_part && !g.wide) { dp_set_error("conv_cc16: statistics need 16-byte aligned output rows"); return 1; }

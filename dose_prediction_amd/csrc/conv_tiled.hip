@@ -70,6 +70,9 @@ struct TiledGeom {
   // stat_part[((n * stat_nblk + blk) * 2 + {0,1}) * Cout + c]; the partial rows are combined in fp64 by dp_stats_finalize.
   // Only with the wide (16-byte) epilogue and without split-kd (dp_conv3d_tiled_stat_blocks tells).
   float* stat_part; int stat_nblk; int wide;
+  // DP_X3 launches (see Cc16Geom::x3 in conv_cc16.hip): the input holds 2 * x3 chunks [x_hi | x_lo], the packed weights NCH = 3 * x3
+  // chunks [w_hi | w_hi | w_lo]; an x_hi slab is staged once and swept with weight chunks ch and 2 * x3 + ch.  0 = ordinary launch.
+  int x3;
 };
 
 // ---------------------------------------------------------------------------------------------- weight packing
@@ -183,7 +186,8 @@ __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, 
   constexpr int SU = STAGE_UNROLL;
   // whole 16-channel chunks must EXIST in memory (row pitch), not be logical channels: channels >= Cin of a padded row meet
   // zero packed weights (25 = 16 + 9 -> 16 + 16 channel rows of the first skip block take the fast path)
-  const bool fast = SWZ && (g.NCH * 16 <= (g.x2 ? g.csplit + g.ldx2 : g.ldx)) && (g.ldx % 8 == 0) && (((uintptr_t)x & 15) == 0) &&
+  const int cin_in = g.x3 ? 32 * g.x3 : g.Cin, nstage = g.x3 ? 2 * g.x3 : g.NCH;     // channels / chunks of the INPUT tensor
+  const bool fast = SWZ && (nstage * 16 <= (g.x2 ? g.csplit + g.ldx2 : g.ldx)) && (g.ldx % 8 == 0) && (((uintptr_t)x & 15) == 0) &&
                     (!g.x2 || ((g.csplit % 16 == 0) && (g.ldx2 % 8 == 0) && (((uintptr_t)g.x2 & 15) == 0))) &&
                     (int64_t)g.H * g.W * max(g.ldx, g.x2 ? g.ldx2 : 0) < (1ll << 30);
   const int lp_par = SWZ ? ((LP >> 3) & 1) : 0;
@@ -202,10 +206,10 @@ __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, 
   for (int kd = kd_lo; kd < kd_hi; kd++) {
     const int id = d + kd - PAD;
     if (id < 0 || id >= g.D) continue;             // block-uniform: the whole depth slice is zero padding
-    for (int ch = 0; ch < g.NCH; ch++) {
+    for (int ch = 0; ch < nstage; ch++) {
       // packed weights of this (kd, chunk) pass; the first kw column is requested BEFORE the slab is staged so that its
       // L2 latency hides behind the staging loads.
-      const T* wbase = wq + ((int64_t)kd * NTAP * g.NCH + ch) * g.NTT * 512 + (int64_t)nt0 * 512;
+      const T* wbase = wq + ((int64_t)kd * NTAP * g.NCH + ch) * g.NTT * 512 + (int64_t)nt0 * 512;      // (not const: a DP_X3 x_hi slab is swept twice)
       Frag8<T> b0[JH], b1[JH];
       load_bk(wbase, 0, 0, b0);
       lds_barrier();                    // LDS-only: __syncthreads() would drain the weight loads just issued (vmcnt(0))
@@ -240,7 +244,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, 
         for (int p = tid; p < pieces; p += 256) {
           int half = p & 1, v = p >> 1, lp = v % LP, lr = v / LP;
           int ih = h0 - PAD + lr, iw = w0 - PAD + lp, c = ch * CK + half * 8;
-          int nv = g.Cin - c; nv = nv > 8 ? 8 : nv;
+          int nv = cin_in - c; nv = nv > 8 ? 8 : nv;
           bool ok = ih >= 0 && ih < g.H && iw >= 0 && iw < g.W && nv > 0;
           const bool second = g.x2 && c >= g.csplit;
           if (!second && g.x2 && c + nv > g.csplit) nv = g.csplit - c;        // a piece never straddles the two operands (csplit % 8 == 0 is required)
@@ -252,6 +256,10 @@ __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, 
       }
       lds_barrier();
       if (g.dbg >= 2) continue;
+      const int nrep = (g.x3 && ch < g.x3) ? 2 : 1;     // DP_X3: the x_hi slab also meets its w_lo block (weight chunk 2 x3 + ch)
+#pragma unroll 1
+      for (int rep = 0; rep < nrep; rep++) {
+      if (rep) { wbase += (int64_t)2 * g.x3 * g.NTT * 512; load_bk(wbase, 0, 0, b0); }
       // Sweep: for one kw column, EVERY slab row is read from LDS once and feeds all the kh taps (pairs) that use it
       // (output row i and tap jh share the input row RS*i + TS*jh).  A tap-outer loop read the A fragment again for every
       // (row, tap) pair -- 1 KiB of LDS per 32-cycle MFMA per SIMD, i.e. exactly the CU's whole LDS bandwidth -- and held
@@ -332,6 +340,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, 
           if (kw + 1 < KS) { load_bk(wbase, kw + 1, 0, b0); __builtin_amdgcn_sched_barrier(0); }
           do_kw(kw, J1, b1, kw + 1 < KS);
         }
+      }
       }
     }
   }
@@ -612,6 +621,11 @@ static int conv3d_tiled_impl(const void* x, int ldx, const void* x2, int ldx2, i
   g.N = N; g.D = D; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.ldx = ldx; g.ldy = ldy;
   g.x2 = x2; g.ldx2 = ldx2; g.csplit = csplit; g.y2 = y2; g.ldy2 = ldy2; g.osplit = osplit;
   int ygrid; bool w16; tiled_geometry(g, k, np, rw, nt, &ygrid, &w16);
+  g.x3 = 0;
+  if (dtype == DP_X3) {
+    if (x2 || Cin % 48 || ldx < 2 * (Cin / 3)) DP_FAIL("conv3d_tiled: a DP_X3 launch takes ONE [x_hi | x_lo] tensor of 2/3 Cin channels (Cin = 3 x a multiple of 16)");
+    g.x3 = Cin / 48;
+  }
   g.wide = tiled_wide(g, y, dtype) ? 1 : 0;
   g.stat_part = stat_part; g.stat_nblk = D * g.tiles_h * g.tiles_w;
   if (stat_part && !g.wide) DP_FAIL("conv3d_tiled_stats: this launch cannot produce statistics (dp_conv3d_tiled_stat_blocks == 0)");

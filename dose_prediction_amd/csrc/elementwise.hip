@@ -222,7 +222,7 @@ __global__ void k_patchify(const T* __restrict__ x, T* __restrict__ out, int B, 
 // per-voxel kernel above issued 2*C two-byte accesses per voxel and ran at 1.5 TB/s.
 template <typename T, bool INV>
 __global__ void __launch_bounds__(256) k_patchify_runs(const T* __restrict__ x, T* __restrict__ out, int nruns, int S0, int S1, int S2, int C, int ld,
-                                                       int p, unsigned cmul) {
+                                                       int p, unsigned cmul, int64_t ldo) {
   __shared__ __attribute__((aligned(16))) T strip[4][1024];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   T* ls = strip[wv];
@@ -231,7 +231,7 @@ __global__ void __launch_bounds__(256) k_patchify_runs(const T* __restrict__ x, 
     int t = run; const int p2 = t % p; t /= p; const int p1 = t % p; t /= p;
     const int tok = t % ntok, b = t / ntok, t2 = tok % f2, r1 = tok / f2, t1 = r1 % f1, t0 = r1 / f1;
     const int64_t vox = (((int64_t)b * S0 + t0 * p + p1) * S1 + t1 * p + p2) * S2 + t2 * p;
-    const T* xr = x + vox * ld; T* orow = out + (int64_t)run * p * C;
+    const T* xr = x + vox * ld; T* orow = out + (int64_t)t * ldo + (p1 * p + p2) * p * C;      // token row pitch ldo (p^3 C when the rows are dense)
     if (!INV) {
       for (int j = lane; j < nin; j += 64) *(v4u*)(ls + 8 * j) = *(const v4u*)(xr + 8 * j);
       for (int j = lane; j < nout; j += 64) {
@@ -261,18 +261,27 @@ __global__ void __launch_bounds__(256) k_patchify_runs(const T* __restrict__ x, 
     }
   }
 }
-static bool patchify_fast(const void* x, const void* out, int B, int S0, int S1, int S2, int C, int ld, int p, int dtype) {
+static bool patchify_fast(const void* x, const void* out, int B, int S0, int S1, int S2, int C, int ld, int p, int dtype, int64_t ldo = 0) {
   const int64_t nruns = (int64_t)B * (S0 / p) * (S1 / p) * (S2 / p) * p * p;
-  return dtype != DP_F32 && (ld & 7) == 0 && ((p * C) & 7) == 0 && p * ld <= 1024 && p * C <= 1024 && (int64_t)p * C * C < (1 << 20) && nruns < (1ll << 31) &&
+  return dtype != DP_F32 && (ld & 7) == 0 && ((p * C) & 7) == 0 && (ldo & 7) == 0 && p * ld <= 1024 && p * C <= 1024 && (int64_t)p * C * C < (1 << 20) && nruns < (1ll << 31) &&
          ((((uintptr_t)x) | ((uintptr_t)out)) & 15) == 0;
 }
 template <bool INV>
-static void patchify_runs_launch(const void* x, void* out, int B, int S0, int S1, int S2, int C, int ld, int p, int dtype, hipStream_t st) {
+static void patchify_runs_launch(const void* x, void* out, int B, int S0, int S1, int S2, int C, int ld, int p, int dtype, hipStream_t st, int64_t ldo = 0) {
   const int nruns = B * (S0 / p) * (S1 / p) * (S2 / p) * p * p;
   const unsigned cmul = ((1u << 20) + C - 1) / C;
   const int grid = grid_for(nruns, 4, 256 * 32);
-  if (dtype == DP_BF16) hipLaunchKernelGGL((k_patchify_runs<bf16_t, INV>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)out, nruns, S0, S1, S2, C, ld, p, cmul);
-  else hipLaunchKernelGGL((k_patchify_runs<f16_t, INV>), dim3(grid), dim3(256), 0, st, (const f16_t*)x, (f16_t*)out, nruns, S0, S1, S2, C, ld, p, cmul);
+  if (ldo <= 0) ldo = (int64_t)p * p * p * C;
+  if (dtype == DP_BF16) hipLaunchKernelGGL((k_patchify_runs<bf16_t, INV>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)out, nruns, S0, S1, S2, C, ld, p, cmul, ldo);
+  else hipLaunchKernelGGL((k_patchify_runs<f16_t, INV>), dim3(grid), dim3(256), 0, st, (const f16_t*)x, (f16_t*)out, nruns, S0, S1, S2, C, ld, p, cmul, ldo);
+}
+// dp_patchify into token rows of pitch ldo >= p^3 C (16-bit storage, fast path shapes only): the fp32x3 mode writes the hi / lo
+// halves of the patch-embedding input straight into the column blocks of its split operand matrix.
+extern "C" int dp_patchify_ld(const void* x, void* out, int64_t ldo, int B, int S0, int S1, int S2, int C, int ld, int p, int dtype, void* stream) {
+  if (S0 % p || S1 % p || S2 % p) DP_FAIL("patchify_ld: size not divisible by patch");
+  if (ldo < (int64_t)p * p * p * C || !patchify_fast(x, out, B, S0, S1, S2, C, ld, p, dtype, ldo)) DP_FAIL("patchify_ld: shape outside the 16-bit run kernel");
+  patchify_runs_launch<false>(x, out, B, S0, S1, S2, C, ld, p, dtype, STREAM, ldo);
+  DP_CHECK_LAUNCH("patchify_ld"); return 0;
 }
 extern "C" int dp_patchify(const void* x, void* out, int B, int S0, int S1, int S2, int C, int ld, int p, int dtype, void* stream) {
   if (S0 % p || S1 % p || S2 % p) DP_FAIL("patchify: size not divisible by patch");

@@ -242,7 +242,7 @@ __global__ void __launch_bounds__(NT) k_norm_act_fwd(NormArgs a) {
 #pragma unroll
       for (int u = 0; u < RU; u++) {
 #pragma unroll
-        for (int i = 0; i < 8; i++) { float z = t[u][i] * sc[i] + sh[i]; if (res) z += rr[u][i]; t[u][i] = (ACT == DP_ACT_MISH && sizeof(T) == 2) ? mish_fwd_fast(z) : act_fwd(z, ACT); }
+        for (int i = 0; i < 8; i++) { float z = t[u][i] * sc[i] + sh[i]; if (res) z += rr[u][i]; t[u][i] = ((ACT == DP_ACT_MISH && sizeof(T) == 2) || ACT == DP_ACT_MISH_FAST) ? mish_fwd_fast(z) : act_fwd(z, ACT); }
         st8(y + (nb + vs + u * g.rpi) * a.ldy + g.cg * 8, t[u]);
       }
     }
@@ -253,7 +253,7 @@ __global__ void __launch_bounds__(NT) k_norm_act_fwd(NormArgs a) {
     unpack8<T>(x + row * ldx + xoff, g.nv, t);
     if (res) unpack8<T>(res + row * a.ldr + g.cg * 8, g.nv, rr);
 #pragma unroll
-    for (int i = 0; i < 8; i++) { float z = t[i] * sc[i] + sh[i]; if (res) z += rr[i]; t[i] = (ACT == DP_ACT_MISH && sizeof(T) == 2) ? mish_fwd_fast(z) : act_fwd(z, ACT); }
+    for (int i = 0; i < 8; i++) { float z = t[i] * sc[i] + sh[i]; if (res) z += rr[i]; t[i] = ((ACT == DP_ACT_MISH && sizeof(T) == 2) || ACT == DP_ACT_MISH_FAST) ? mish_fwd_fast(z) : act_fwd(z, ACT); }
     pack8(y + row * a.ldy + g.cg * 8, g.nv, t);
   }
 }
@@ -277,7 +277,7 @@ __global__ void __launch_bounds__(NT) k_norm_act_bwd_partial(NormArgs a) {
     for (int i = 0; i < 8; i++) {
       float xh = (t[i] - k.m[i]) * k.r[i];
       float z = xh * k.ga[i] + k.be[i]; if (res) z += rr[i];
-      float gg = d[i] * ((ACT == DP_ACT_MISH && sizeof(T) == 2) ? mish_bwd_fast(z) : act_bwd(z, ACT));
+      float gg = d[i] * (((ACT == DP_ACT_MISH && sizeof(T) == 2) || ACT == DP_ACT_MISH_FAST) ? mish_bwd_fast(z) : act_bwd(z, ACT));
       s1[i] += gg; s2[i] += gg * xh;
     }
   };
@@ -332,7 +332,7 @@ __global__ void __launch_bounds__(NT) k_norm_act_bwd_apply(NormArgs a) {
     for (int i = 0; i < 8; i++) {
       float xh = (t[i] - k.m[i]) * k.r[i];
       float z = xh * k.ga[i] + k.be[i]; if (res) z += rr[i];
-      gg[i] = d[i] * ((ACT == DP_ACT_MISH && sizeof(T) == 2) ? mish_bwd_fast(z) : act_bwd(z, ACT));
+      gg[i] = d[i] * (((ACT == DP_ACT_MISH && sizeof(T) == 2) || ACT == DP_ACT_MISH_FAST) ? mish_bwd_fast(z) : act_bwd(z, ACT));
       t[i] = k.ga[i] * k.r[i] * (gg[i] - a1[i] - xh * a2[i]);
     }
   };
@@ -373,6 +373,8 @@ __global__ void __launch_bounds__(NT) k_norm_act_bwd_apply(NormArgs a) {
       case DP_ACT_LRELU: DP_DISPATCH(dtype, hipLaunchKernelGGL((KERN<T, DP_ACT_LRELU>), grid, dim3(NT), 0, STREAM, args)); break; \
       case DP_ACT_MISH: DP_DISPATCH(dtype, hipLaunchKernelGGL((KERN<T, DP_ACT_MISH>), grid, dim3(NT), 0, STREAM, args)); break; \
       case DP_ACT_GELU: DP_DISPATCH(dtype, hipLaunchKernelGGL((KERN<T, DP_ACT_GELU>), grid, dim3(NT), 0, STREAM, args)); break; \
+      case DP_ACT_MISH_FAST: if (dtype != DP_F32) DP_FAIL("DP_ACT_MISH_FAST is an fp32-storage activation code"); \
+        hipLaunchKernelGGL((KERN<float, DP_ACT_MISH_FAST>), grid, dim3(NT), 0, STREAM, args); break; \
       default: DP_FAIL("bad activation %d", act); } } while (0)
 
 static inline int norm_fast(int C, int ldx, const void* x, int ldg, const void* gy, int ldr, const void* res, int ldy, const void* y, int ldgr, const void* gr) {

@@ -19,6 +19,16 @@ ACT = {None: 0, "none": 0, "relu": 1, "lrelu": 2, "mish": 3, "gelu": 4}
 _DT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
 
 
+def _act_code(act, dtype=None):
+    """Activation code of the normalisation kernels; Mish on fp32 tensors in the fp32x3 mode uses the hardware exp2 / rcp forms
+    (DP_ACT_MISH_FAST: ~1e-7 relative, as the 16-bit modes always do)."""
+    if act == "mish" and dtype == torch.float32:
+        from . import config
+        if config.x3():
+            return 5
+    return ACT[act]
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -823,6 +833,24 @@ def split_rows(a, ca, b, cb, cp, parts, pattern):
     return out
 
 
+_SPLIT_LAST = [None]
+
+
+def _split_conv_input(xa, ca, xb, cb, cp):
+    """split_rows for a convolution input, remembering the LAST result: the 3^3 and the 7^3 branch of a multi-scale block read the
+    same (virtually concatenated) tensor one after the other (blocks_MDUNet.py:150-152) and share one split.  The entry is valid only
+    while the very same tensor objects are alive and unmodified (weak references + version counters)."""
+    import weakref
+    key = (ca, cb, cp, xa.data_ptr(), xa._version, tuple(xa.shape), xa.stride(),
+           None if xb is None else (xb.data_ptr(), xb._version, tuple(xb.shape), xb.stride()), torch.cuda.current_stream().cuda_stream)
+    ent = _SPLIT_LAST[0]
+    if ent is not None and ent[0] == key and ent[1]() is xa and (xb is None or ent[2]() is xb):
+        return ent[3]
+    xs = split_rows(xa, ca, xb, cb, cp, 2, 0b10)
+    _SPLIT_LAST[0] = (key, weakref.ref(xa), None if xb is None else weakref.ref(xb), xs)
+    return xs
+
+
 def _x3_conv_ok(xa, xb, weight, stride, pad, dil):
     from . import config
     if not (config.x3() and USE_TILED and xa.dtype == torch.float32 and xa.is_cuda):
@@ -857,7 +885,7 @@ class Conv3dX3(torch.autograd.Function):
         ca = cin if xb is None else xa.shape[-1]
         cb = cin - ca
         cp = (cin + 15) // 16 * 16
-        xs = split_rows(xa, ca, xb, cb, cp, 2, 0b10)                   # [.., x_hi (cp) | x_lo (cp)]
+        xs = _split_conv_input(xa, ca, xb, cb, cp)                     # [.., x_hi (cp) | x_lo (cp)]
         wq = _pack_conv_tiled_x3(weight, 0, cp, W)
         y = torch.empty((N, D, H, W, cout), dtype=torch.float32, device=xa.device)
         b32 = None if bias is None else bias.detach()
@@ -865,13 +893,14 @@ class Conv3dX3(torch.autograd.Function):
         nblk = L.dp_conv3d_tiled_stat_blocks(N, D, H, W, 3 * cp, cout, k, cout, DP_X3) if want_stats else 0
         ws = _tiled_ws(xa, N, D, H, W, 3 * cp, cout, k)
         part = None
-        # channels [0, 2cp) come from xs, the third block [2cp, 3cp) is xs's first cp channels again (x2 = xs: no third copy in memory)
+        # a DP_X3 launch: Cin = 3 cp names the packed weights' contraction axis; the input is the 2 cp channel tensor [x_hi | x_lo], whose
+        # x_hi chunks are staged once and swept against both their weight blocks
         if nblk:
             part = torch.empty((N, nblk, 2, cout), dtype=torch.float32, device=xa.device)
-            _lib.call("dp_conv3d_tiled_stats", _p(xs), 2 * cp, _p(xs), 2 * cp, 2 * cp, _p(wq), _p(b32), _p(y), cout, _p(ws), _p(part),
+            _lib.call("dp_conv3d_tiled_stats", _p(xs), 2 * cp, 0, 0, 0, _p(wq), _p(b32), _p(y), cout, _p(ws), _p(part),
                       N, D, H, W, 3 * cp, cout, k, DP_X3, _stream())
         else:
-            _lib.call("dp_conv3d_tiled2", _p(xs), 2 * cp, _p(xs), 2 * cp, 2 * cp, _p(wq), _p(b32), _p(y), cout, 0, 0, 0, _p(ws),
+            _lib.call("dp_conv3d_tiled2", _p(xs), 2 * cp, 0, 0, 0, _p(wq), _p(b32), _p(y), cout, 0, 0, 0, _p(ws),
                       N, D, H, W, 3 * cp, cout, k, DP_X3, _stream())
         ctx.save_for_backward(xs, weight)
         ctx.geom = (N, D, H, W, cin, cout, k, cp, ca, xa.shape[-1], None if xb is None else xb.shape[-1])
@@ -908,7 +937,7 @@ class Conv3dX3(torch.autograd.Function):
                     gx = torch.empty((N, D, H, W, cx1), dtype=torch.float32, device=dev)
                     if cx1 > cin:
                         gx.zero_()
-                    _lib.call("dp_conv3d_tiled2", _p(gys), 2 * cpo, _p(gys), 2 * cpo, 2 * cpo, _p(wq), 0, _p(gx), cx1, 0, 0, 0, _p(ws),
+                    _lib.call("dp_conv3d_tiled2", _p(gys), 2 * cpo, 0, 0, 0, _p(wq), 0, _p(gx), cx1, 0, 0, 0, _p(ws),
                               N, D, H, W, 3 * cpo, cin, k, DP_X3, _stream())
                     if cxb is None:
                         gxa = gx
@@ -920,7 +949,7 @@ class Conv3dX3(torch.autograd.Function):
                     gxb = torch.empty((N, D, H, W, cxb), dtype=torch.float32, device=dev)
                     if cxb > cin - ca:
                         gxb.zero_()
-                    _lib.call("dp_conv3d_tiled2", _p(gys), 2 * cpo, _p(gys), 2 * cpo, 2 * cpo, _p(wq), 0, _p(gxa), ca, _p(gxb), cxb, ca, _p(ws),
+                    _lib.call("dp_conv3d_tiled2", _p(gys), 2 * cpo, 0, 0, 0, _p(wq), 0, _p(gxa), ca, _p(gxb), cxb, ca, _p(ws),
                               N, D, H, W, 3 * cpo, cin, k, DP_X3, _stream())
             else:
                 # fewer than 8 input channels (no tiled kernel computes so narrow an output): the exact-fp32 gather kernel
@@ -961,19 +990,27 @@ class LinearX3(torch.autograd.Function):
     gradient (grouped TN launch): sum_k gy'[k] x'[k] = gy_hi x_hi + gy_hi x_lo + gy_lo x_hi."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, splitk, defer_wgrad=False):
-        _chk_dev(x, weight)
-        x = as_rows(x)
-        rows, K, ldx = rows_ld(x)
-        nout = weight.shape[0]
-        cp = (K + 7) // 8 * 8
-        xs = split_rows(x, K, None, 0, cp, 3, _PAT_ACT)
+    def forward(ctx, x, weight, bias, splitk, defer_wgrad=False, xs=None):
+        """xs: the operand already split ([..., rows, 3 cp] bf16, blocks hi | lo | hi; x is then None and receives no gradient)."""
+        nout, K = weight.shape
+        if xs is None:
+            _chk_dev(x, weight)
+            x = as_rows(x)
+            rows, _, ldx = rows_ld(x)
+            cp = (K + 7) // 8 * 8
+            xs = split_rows(x, K, None, 0, cp, 3, _PAT_ACT)
+            xshape = tuple(x.shape)
+        else:
+            cp = xs.shape[-1] // 3
+            rows = xs.numel() // (3 * cp)
+            xshape = tuple(xs.shape[:-1]) + (K,)
+            x = xs
         wp = _pack_mat_x3(weight, False, cp, _PAT_W)
         b32 = None if bias is None else bias.detach()
-        y = (torch.zeros if splitk > 1 else torch.empty)(tuple(x.shape[:-1]) + (nout,), dtype=torch.float32, device=x.device)
+        y = (torch.zeros if splitk > 1 else torch.empty)(xshape[:-1] + (nout,), dtype=torch.float32, device=xs.device)
         gemm_nt(xs, wp, y, bias=b32, M=rows, N=nout, K=3 * cp, lda=3 * cp, ldb=3 * cp, ldc=nout, splitk=splitk)
         ctx.save_for_backward(xs, weight)
-        ctx.geom = (tuple(x.shape), rows, K, cp)
+        ctx.geom = (xshape, rows, K, cp)
         ctx.has_bias = bias is not None
         ctx.bias_ref = bias if defer_wgrad else None
         ctx.defer = defer_wgrad
@@ -1008,7 +1045,31 @@ class LinearX3(torch.autograd.Function):
         if want_b:
             gb = torch.empty((nout,), dtype=torch.float32, device=dev)
             colsum_into(_p(gy), ldg, rows, nout, gb, 0)
-        return gx, gw, gb, None, None
+        return gx, gw, gb, None, None, None
+
+
+def patch_embed_x3(x, C, p, weight, bias, splitk):
+    """fp32x3 patch embedding (MONAI PatchEmbeddingBlock 'perceptron': Rearrange + Linear) without an fp32 token matrix: the voxel
+    tensor is split once ([x_hi | x_lo] per voxel) and each half is patchified straight into its column block(s) of the
+    [hi | lo | hi] operand of the x3 GEMM (dp_patchify_ld).  Returns None when the shape is outside that kernel's fast path."""
+    x = as_rows(x)
+    _, cx, ld = rows_ld(x)
+    B, S0, S1, S2 = x.shape[:4]
+    K = p * p * p * C
+    cpv = (C + 15) // 16 * 16
+    if (K % 8 or weight.shape[1] != K or p * 2 * cpv > 1024 or p * C > 1024 or (p * C) % 8 or p * C * C >= (1 << 20) or S0 % p or S1 % p
+            or S2 % p or x.dtype != torch.float32):
+        return None
+    # (the run kernel moves whole p-voxel runs of `ld` channels starting at the half it was pointed to: the x_lo pass reads cpv
+    # elements past the last voxel row, so the split tensor gets one spare row)
+    nvox = B * S0 * S1 * S2
+    xv = torch.empty(((nvox + 1) * 2 * cpv,), dtype=torch.bfloat16, device=x.device)
+    _lib.call("dp_split_rows", _p(x), ld, C, 0, 0, 0, _p(xv), cpv, 2, 0b10, nvox, _stream())
+    ntok = (S0 // p) * (S1 // p) * (S2 // p)
+    xs = torch.empty((B, ntok, 3 * K), dtype=torch.bfloat16, device=x.device)
+    for blk, part in ((0, 0), (1, 1), (2, 0)):
+        _lib.call("dp_patchify_ld", xv.data_ptr() + 2 * part * cpv, xs.data_ptr() + 2 * blk * K, 3 * K, B, S0, S1, S2, C, 2 * cpv, p, 1, _stream())
+    return LinearX3.apply(None, weight, bias, splitk, True, xs)
 
 
 # ------------------------------------------------------------------------------------------------ deferred weight gradients
@@ -1278,7 +1339,7 @@ def _norm_forward(x, kind, gamma, beta, running_mean, running_var, training, res
     g32 = None if gamma is None else gamma.detach()
     b32 = None if beta is None else beta.detach()
     ldr = rows_ld(res)[2] if res is not None else 0
-    _lib.call("dp_norm_act_fwd", _p(x), ldx, _p(mean), _p(rstd), ssn, _p(g32), _p(b32), _p(res), ldr, ACT[act],
+    _lib.call("dp_norm_act_fwd", _p(x), ldx, _p(mean), _p(rstd), ssn, _p(g32), _p(b32), _p(res), ldr, _act_code(act, x.dtype),
               y_ptr, ldy, N, V, C, dtc, _stream())
     return mean, rstd, use_batch_stats, ssn
 
@@ -1304,7 +1365,7 @@ def _norm_backward(x, mean, rstd, gamma, beta, res, kind, act, use_stats, ssn, g
     dbeta = mk((C,), dtype=torch.float32, device=dev) if need_gb else None
     if use_stats or need_gb:
         _lib.call("dp_norm_act_bwd_partial", _p(x), ldx, gy_ptr, ldg, _p(mean), _p(rstd), ssn, _p(g32), _p(b32), _p(res), ldr,
-                  ACT[act], N, V, C, _p(part), dtc, _stream())
+                  _act_code(act, x.dtype), N, V, C, _p(part), dtc, _stream())
         _lib.call("dp_norm_bwd_finalize", _p(part), N, nblk, C, 0 if kind == "instance" else 1, _p(s1), _p(s2),
                   _p(dgamma), _p(dbeta), _stream())
     gx = gres = None
@@ -1313,7 +1374,7 @@ def _norm_backward(x, mean, rstd, gamma, beta, res, kind, act, use_stats, ssn, g
         gres = torch.empty(x.shape, dtype=x.dtype, device=dev) if need_res else None
         cnt = V if kind == "instance" else N * V
         _lib.call("dp_norm_act_bwd_apply", _p(x), ldx, gy_ptr, ldg, _p(mean), _p(rstd), ssn, _p(g32), _p(b32), _p(res), ldr,
-                  ACT[act], _p(s1), _p(s2), 1.0 / cnt, 1 if use_stats else 0, _p(gx), C, _p(gres), C, N, V, C, dtc, _stream())
+                  _act_code(act, x.dtype), _p(s1), _p(s2), 1.0 / cnt, 1 if use_stats else 0, _p(gx), C, _p(gres), C, N, V, C, dtc, _stream())
     return gx, dgamma, dbeta, gres
 
 
@@ -1364,7 +1425,7 @@ class NormActCat(torch.autograd.Function):
         mb, rb, _, ssb = _norm_forward(xb, "instance", None, None, None, None, True, None, act, eps, 0.1, 0, 0, apply=False, part=stats_b)
         N = xa.shape[0]
         # one pass over both sources: every 2*(ca+cb)-byte output row is written whole (two launches wrote alternating halves)
-        _lib.call("dp_norm_act_cat_fwd", _p(xa), rows_ld(xa)[2], _p(ma), _p(ra), ca, _p(xb), rows_ld(xb)[2], _p(mb), _p(rb), cb, ACT[act],
+        _lib.call("dp_norm_act_cat_fwd", _p(xa), rows_ld(xa)[2], _p(ma), _p(ra), ca, _p(xb), rows_ld(xb)[2], _p(mb), _p(rb), cb, _act_code(act, xa.dtype),
                   _p(y), ca + cb, N, rows_ld(xa)[0] // N, _dt(xa), _stream())
         ctx.save_for_backward(xa, xb, ma, ra, mb, rb)
         ctx.cfg = (act, ssa, ssb)
@@ -1388,7 +1449,7 @@ class NormActCat(torch.autograd.Function):
             s12 = torch.empty((2, N, ca + cb), dtype=torch.float32, device=dev)
             ga = torch.empty(xa.shape, dtype=xa.dtype, device=dev)
             gb = torch.empty(xb.shape, dtype=xb.dtype, device=dev)
-            src = (_p(xa), rows_ld(xa)[2], _p(ma), _p(ra), ca, _p(xb), rows_ld(xb)[2], _p(mb), _p(rb), cb, _p(gy), ldg, ACT[act])
+            src = (_p(xa), rows_ld(xa)[2], _p(ma), _p(ra), ca, _p(xb), rows_ld(xb)[2], _p(mb), _p(rb), cb, _p(gy), ldg, _act_code(act, xa.dtype))
             _lib.call("dp_norm_act_cat_bwd_partial", *src, N, V, _p(part), dtc, _stream())
             _lib.call("dp_norm_bwd_finalize", _p(part), N, nblk, ca + cb, 0, _p(s12[0]), _p(s12[1]), 0, 0, _stream())
             _lib.call("dp_norm_act_cat_bwd_apply", *src, _p(s12[0]), _p(s12[1]), 1.0 / V, _p(ga), ca, _p(gb), cb, N, V, dtc, _stream())

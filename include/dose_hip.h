@@ -21,7 +21,9 @@
  *     each operand as bf16 halves hi = bf16(v), lo = bf16(v - hi) side by side ([hi | lo] channel blocks), the packed weights hold
  *     [w_hi | w_hi | w_lo], and the convolution runs the bf16 MFMA kernels over the 3x wider "virtual" input [x_hi | x_lo | x_hi]:
  *     x w ~ x_hi w_hi + x_lo w_hi + x_hi w_lo (relative error of a product ~1e-5 instead of 4e-3 for bf16 operands), fp32
- *     accumulators written as fp32 OUTPUT.  x / wq are bf16, y / y2 are float.
+ *     accumulators written as fp32 OUTPUT.  x / wq are bf16, y / y2 are float.  In a DP_X3 launch `Cin` = 3 cp (cp a multiple of
+ *     16) is the contraction axis of the packed weights, `x` is the [x_hi | x_lo] tensor of 2 cp channels (x2 must be NULL): the
+ *     kernels stage every x_hi chunk once and sweep it against both of its weight blocks.
  *   - every function returns 0 on success, non-zero on error; dp_last_error() gives the message.
  *   - no function allocates, frees or synchronises: workspaces are caller-provided.
  */
@@ -33,7 +35,9 @@ extern "C" {
 #endif
 
 enum { DP_F32 = 0, DP_BF16 = 1, DP_F16 = 2, DP_X3 = 3 };
-enum { DP_ACT_NONE = 0, DP_ACT_RELU = 1, DP_ACT_LRELU = 2, DP_ACT_MISH = 3, DP_ACT_GELU = 4 };
+/* DP_ACT_MISH_FAST (fp32 storage only, used by the fp32x3 mode): Mish through the hardware exp2 / rcp approximations (~1e-7
+ * relative, far below that mode's 4e-6 operator error) instead of the correctly rounded expf / divisions of DP_ACT_MISH. */
+enum { DP_ACT_NONE = 0, DP_ACT_RELU = 1, DP_ACT_LRELU = 2, DP_ACT_MISH = 3, DP_ACT_GELU = 4, DP_ACT_MISH_FAST = 5 };
 
 const char* dp_last_error(void);
 int dp_version(void);
@@ -55,6 +59,9 @@ int dp_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n,
 /* replaces: einops Rearrange "b c (h p1)(w p2)(d p3) -> b (h w d)(p1 p2 p3 c)" in MONAI
  * PatchEmbeddingBlock (call site dose_pyfer.py:55-67).  x NDHWC pitch ld -> out [B][ntok][p^3*C]. */
 int dp_patchify(const void* x, void* out, int B, int S0, int S1, int S2, int C, int ld, int p, int dtype, void* stream);
+/* the same into token rows of pitch ldo >= p^3 C elements (16-bit storage, 16-byte aligned, p*ld <= 1024): used by the fp32x3 mode to
+ * fill the [hi | lo | hi] column blocks of the patch-embedding operand directly from the split voxel tensor. */
+int dp_patchify_ld(const void* x, void* out, int64_t ldo, int B, int S0, int S1, int S2, int C, int ld, int p, int dtype, void* stream);
 int dp_unpatchify(const void* gout, void* gx, int B, int S0, int S1, int S2, int C, int ld, int p, int dtype, void* stream);
 /* replaces: the scatter half of nn.ConvTranspose3d(k2,s2) (base_blocks.py:118-127): src [N*D*H*W][8*C]
  * (column = ((a*2+b)*2+c)*C + co) -> dst NDHWC at (2d+a,2h+b,2w+c), pitch ldd.  unshuffle = inverse gather. */
