@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optimizer", action="store_true")
     ap.add_argument("--cpu-size", type=int, default=64)
+    ap.add_argument("--no-cpu-full-forward", dest="cpu_full_forward", action="store_false",
+                    help="skip the real 128^3 oracle forward of cpu_baseline (the 64^3 step stays: it is also the checker)")
     ap.add_argument("--cpu-steps", type=int, default=2, help="oracle steps timed for cpu_baseline (2 x ~6 s on the GPU box's host)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph (GPU-bound either way)")
     ap.add_argument("--torch-adam", action="store_true", help="use torch.optim.Adam instead of the fused HIP Adam")
@@ -259,6 +261,26 @@ def cpu_baseline(args):
            "sample": f"{nstep} step(s) (forward + GenLoss + backward, net_A frozen) of the fp32 CPU oracle on one {S}^3 volume: "
                      f"{dt:.2f} s per step with {threads} torch threads on {cores} host cores; scaled by voxel count ({scale:.4f})",
            "seconds": dt * nstep}
+    if args.cpu_full_forward and tuple(args.size * 3 if len(args.size) == 1 else args.size) == (128, 128, 128):
+        # ONE real forward of the same network at the benchmark's own size (no voxel-count scaling: the patch-embedding GEMM and the
+        # attention do not scale like the convolutions), fp32, no gradients
+        try:
+            torch.manual_seed(4321)
+            full = (128, 128, 128)
+            net128 = dose_pyfer.Model(in_ch=9, out_ch=1, list_ch_A=[-1, 16, 32, 64, 128, 256], feature_size=16, img_size=full,
+                                      num_layers=8, num_heads=6, act="mish")
+            sd128 = {k: v.detach() for k, v in net128.state_dict().items()}
+            x128 = synth.dose_input(1, full)
+            with torch.no_grad():
+                t1 = time.time()
+                o128 = oracle.dose_pyfer(sd128, x128, num_layers=8, num_heads=6, act="mish", training=True)
+                d128 = time.time() - t1
+            res["forward_128"] = {"value": 1.0 / d128, "unit": "128^3 volumes/s (forward only)", "seconds": d128,
+                                  "sample": f"one fp32 oracle forward of DOSE-PYFER on a real 128^3 volume, {threads} torch threads",
+                                  "finite": bool(torch.isfinite(o128[1][0]).all())}
+            del net128, sd128, o128
+        except Exception as e:
+            res["forward_128"] = {"error": repr(e)}
     # the oracle as the CHECKER of this very sample (rel-error on output [1][0] and dose-MAE in Gy): the HIP path runs
     # the same weights and input in both storage modes; nothing of this is timed or shipped
     try:
@@ -446,16 +468,22 @@ def main():
     own = torch.cuda.stream(side) if args.own_stream else contextlib.nullcontext()
     if args.own_stream:
         side.wait_stream(torch.cuda.current_stream())
+    # per-step times from HIP events recorded on the launch stream after every step (no host synchronisation inside the timed region)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
     with own:
-        for _ in range(args.steps):
+        marks[0].record()
+        for i in range(args.steps):
             if graph is not None:
                 graph.replay()
                 loss = static_loss
             else:
                 loss = step()
+            marks[i + 1].record()
     sync()
     dt = time.perf_counter() - t0
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
     if ddp_on:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -512,8 +540,11 @@ def main():
         res = {
             "metric": "128\u00b3 CT volumes/sec (fwd+bwd)", "value": world * B * args.steps / dt, "unit": "volumes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "ms_per_step_median": median_ms, "ms_per_step_min_max": [step_ms[0], step_ms[-1]],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": ("End-to-end cascade TRANSEG -> PYFER (BASELINE.json configs[3], per-GPU batch)" if args.model == "cascade" else
+            "config": {"workload": (("End-to-end cascade TRANSEG -> PYFER, 192 x 192 x 128 fp16 + activation checkpointing (BASELINE.json configs[4], per-GPU batch)"
+                                     if (args.checkpoint and args.dtype == "fp16" and tuple(shape) != (128, 128, 128)) else
+                                     "End-to-end cascade TRANSEG -> PYFER (BASELINE.json configs[3], per-GPU batch)") if args.model == "cascade" else
                                     "DOSE-PYFER dose-only path (BASELINE.json configs[1])" if args.model == "pyfer"
                                     else "OAR-TRANSEG segmentation path (BASELINE.json configs[2])"),
                        "volume": list(shape), "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
@@ -523,6 +554,7 @@ def main():
                        "activation_checkpointing": bool(args.checkpoint), "loss_scale": args.loss_scale,
                        "vit_side_stream": not args.no_side_stream, "peak_memory_gib": peak_mem,
                        "grad_exchange_dtype": args.grad_dtype if ddp_on else None,
+                       "cascade_segmentation_mode": (__import__("dose_prediction_amd").config.cascade_seg_mode() or args.dtype) if args.model == "cascade" else None,
                        "final_loss": final_loss},
             "roofline": {"bound": "mfma", "kernel": "conv3d 7x7x7 implicit GEMM (forward + data-gradient launches)",
                          "achieved": dom["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": dom["tflops"] / peak,

@@ -73,15 +73,16 @@ class _ConvNormActPair(nn.Module):
                 x, st = ops.conv3d(x, conv.weight, conv.bias, 1, conv.padding[0], conv.dilation[0]), None
             else:
                 x, st = ops.conv3d(x, conv.weight, conv.bias, 1, conv.padding[0], conv.dilation[0], stats=True, bias_grad_zero=True)
+            nxt = self.conv[3] if i == 0 else None      # (fp32x3: the first normalisation writes the second convolution's split operand)
             if self._norm == "batch":
                 upd = self.training and config.bn_updates_enabled()
                 x = ops.norm_act(x, "batch", norm.weight, norm.bias, norm.running_mean if (upd or not self.training) else None,
                                  norm.running_var if (upd or not self.training) else None,
-                                 training=self.training, act=self._act, eps=norm.eps, momentum=norm.momentum, stats=st)
+                                 training=self.training, act=self._act, eps=norm.eps, momentum=norm.momentum, stats=st, x3_split_for=nxt)
                 if upd:
                     norm.num_batches_tracked += 1
             else:
-                x = ops.norm_act(x, "instance", act=self._act, eps=norm.eps, stats=st)
+                x = ops.norm_act(x, "instance", act=self._act, eps=norm.eps, stats=st, x3_split_for=nxt)
         return x
 
 
@@ -221,7 +222,7 @@ class UnetResBlock(nn.Module):
     def forward(self, inp, inp_cat=None):
         """inp_cat: optional (a, b) pair with cat((a, b)) == inp, used by the 3x3x3 convolution (virtual concat)."""
         out, st = _run_conv(self.conv1, inp_cat if inp_cat is not None else inp, stats=True)
-        out = ops.norm_act(out, "instance", act="lrelu", stats=st)
+        out = ops.norm_act(out, "instance", act="lrelu", stats=st, x3_split_for=self.conv2.conv)
         out, st = _run_conv(self.conv2, out, stats=True)
         res = inp
         if self.downsample:
@@ -242,7 +243,7 @@ class UnetBasicBlock(nn.Module):
     def forward(self, inp):
         """inp: tensor or (a, b) pair = virtual torch.cat."""
         out, st = _run_conv(self.conv1, inp, stats=True)
-        out = ops.norm_act(out, "instance", act="lrelu", stats=st)
+        out = ops.norm_act(out, "instance", act="lrelu", stats=st, x3_split_for=self.conv2.conv)
         out, st = _run_conv(self.conv2, out, stats=True)
         return ops.norm_act(out, "instance", act="lrelu", stats=st)
 

@@ -11,12 +11,28 @@ The arg-max / one-hot / channel packing is one HIP kernel (dp_argmax_onehot) wri
 PYFER input; the axis reversal is a strided copy.  Volumes larger than the segmentation crop go through
 sliding_window_logits() (MONAI sliding_window_inference with constant blending, the call at 152-153: roi = IMAGE_SIZE^3,
 overlap 0.25, sw_batch_size 4), stitched on device by dp_window_accumulate / dp_window_normalize."""
+import contextlib
 import math
 
 import torch
 
 from . import _lib, config, ops
 from .models.c3d import to_ndhwc, from_ndhwc
+
+
+def _seg_mode():
+    """The segmentation network of the cascade is inference-only (train_light_linked_model.py:152-160 runs it under no_grad) and its
+    arg-max masks are INPUTS of the dose network: it runs in config.cascade_seg_mode() (default 'fp32x3') so that the masks are the
+    reference's, independently of the storage type the dose network trains in."""
+    m = config.cascade_seg_mode()
+    return config.compute_mode_as(m) if m is not None and m != config.compute_mode() else contextlib.nullcontext()
+
+
+def _seg_logits(seg_model, ct, roi_size, sw_batch_size, overlap):
+    with _seg_mode():
+        if roi_size is not None and tuple(roi_size) != tuple(ct.shape[2:]):
+            return sliding_window_logits(seg_model, ct, tuple(roi_size), sw_batch_size, overlap)
+        return seg_model.forward_ndhwc(to_ndhwc(ct))
 
 
 def window_starts(image_size, roi_size, overlap=0.25):
@@ -74,7 +90,7 @@ def sliding_window_logits(seg_model, ct, roi_size, sw_batch_size=4, overlap=0.25
 @torch.no_grad()
 def oar_masks(seg_model, ct):
     """ct [B,1,D,H,W] fp32 -> (labels int32 [B,D,H,W], logits NDHWC) through the HIP segmentation network."""
-    logits = seg_model.forward_ndhwc(to_ndhwc(ct))
+    logits = _seg_logits(seg_model, ct, None, 4, 0.25)
     labels = ops.argmax_onehot(logits, None, 0, labels=True)
     return labels, logits
 
@@ -97,10 +113,7 @@ def cascade_structures(seg_model, ct, ptv, reverse_axes=True, roi_size=None, sw_
     network TRAINS on the segmentation network's masks (BASELINE.json configs[3], [4]); returns (structures, labels).
     staged=True returns the NDHWC staging buffer itself (compute dtype, 16 channels) for dose_model.forward_staged()."""
     B = ct.shape[0]
-    if roi_size is not None and tuple(roi_size) != tuple(ct.shape[2:]):
-        logits = sliding_window_logits(seg_model, ct, tuple(roi_size), sw_batch_size, overlap)
-    else:
-        logits = seg_model.forward_ndhwc(to_ndhwc(ct))
+    logits = _seg_logits(seg_model, ct, roi_size, sw_batch_size, overlap)
     D, H, W = logits.shape[1:4]
     staged_out = staged
     staged = torch.zeros((B, D, H, W, 16), dtype=config.compute_dtype(), device=ct.device)
@@ -121,10 +134,7 @@ def cascade_forward(seg_model, dose_model, ct, ptv, possible_dose_mask=None, rev
     and the CT are flipped to the dose loader's axis order (W,H,D) exactly as lines 158/163 do; ptv is taken as given.
     roi_size: crop the segmentation network was built for (sliding-window inference when it is smaller than the volume)."""
     B = ct.shape[0]
-    if roi_size is not None and tuple(roi_size) != tuple(ct.shape[2:]):
-        logits = sliding_window_logits(seg_model, ct, tuple(roi_size), sw_batch_size, overlap)
-    else:
-        logits = seg_model.forward_ndhwc(to_ndhwc(ct))                   # [B,D,H,W,8]
+    logits = _seg_logits(seg_model, ct, roi_size, sw_batch_size, overlap)   # [B,D,H,W,8]
     dt = config.compute_dtype()
     D, H, W = logits.shape[1:4]
     staged = torch.zeros((B, D, H, W, 16), dtype=dt, device=ct.device)   # channels: 0 PTV | 1..7 OARs | 8 CT | pad

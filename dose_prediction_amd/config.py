@@ -151,3 +151,23 @@ def set_vit_cus(n):
 
 def vit_cus():
     return _vit_cus
+
+
+_cascade_seg_mode = os.environ.get("DOSE_HIP_CASCADE_SEG_MODE", "fp32x3")
+
+
+def set_cascade_seg_mode(mode):
+    """Mode in which the cascade (dose_prediction_amd.cascade) runs its no-grad OAR-TRANSEG forward, whatever mode the dose network
+    trains in: 'fp32x3' (default: the OAR masks fed to DOSE-PYFER are the reference's, arg-max exact off near-ties), 'fp32', or None =
+    the current mode (bf16 storage flips ~0.8 % of the arg-max voxels of a random-init network: profiles/r02_f_bench_line_transeg.json).
+    Env DOSE_HIP_CASCADE_SEG_MODE ('same' = None)."""
+    global _cascade_seg_mode
+    if mode is not None and mode != "same":
+        prev = compute_mode()
+        set_compute_dtype(mode)           # validates the name
+        set_compute_dtype(prev)
+    _cascade_seg_mode = None if mode in (None, "same") else mode
+
+
+def cascade_seg_mode():
+    return None if _cascade_seg_mode in (None, "same") else _cascade_seg_mode

@@ -507,8 +507,8 @@ extern "C" int dp_softmax_bwd(const void* p, const void* gp, void* gs, int64_t r
 }
 
 // ------------------------------------------------------------------------------------------------ cascade glue
-template <typename T>
-__global__ void k_argmax_onehot(const T* __restrict__ lg, int ld, T* __restrict__ out, int ldo, int choff, int32_t* labels, int64_t rows, int C) {
+template <typename T, typename TO = T>
+__global__ void k_argmax_onehot(const T* __restrict__ lg, int ld, TO* __restrict__ out, int ldo, int choff, int32_t* labels, int64_t rows, int C) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < rows; i += (int64_t)gridDim.x * blockDim.x) {
     const T* a = lg + i * ld; float best = ld_f(a); int bi = 0;
     for (int c = 1; c < C; c++) { float v = ld_f(a + c); if (v > best) { best = v; bi = c; } }
@@ -519,6 +519,20 @@ __global__ void k_argmax_onehot(const T* __restrict__ lg, int ld, T* __restrict_
 extern "C" int dp_argmax_onehot(const void* logits, int ld, void* out, int ldo, int choff, int32_t* labels, int64_t rows, int C, int dtype, void* stream) {
   DP_DISPATCH(dtype, hipLaunchKernelGGL(k_argmax_onehot<T>, dim3(grid_for(rows, 256)), dim3(256), 0, STREAM, (const T*)logits, ld, (T*)out, ldo, choff, labels, rows, C));
   DP_CHECK_LAUNCH("argmax_onehot"); return 0;
+}
+// logits and one-hot destination of different storage types: the cascade runs its segmentation network in fp32x3 (fp32 logits, the
+// reference's masks) while the dose network's staging buffer is in the training storage type.
+extern "C" int dp_argmax_onehot2(const void* logits, int ld, int logits_dtype, void* out, int ldo, int out_dtype, int choff, int32_t* labels,
+                                 int64_t rows, int C, void* stream) {
+  if (logits_dtype == out_dtype || !out) return dp_argmax_onehot(logits, ld, out, ldo, choff, labels, rows, C, logits_dtype, stream);
+#define GO2(TL, TOUT) hipLaunchKernelGGL((k_argmax_onehot<TL, TOUT>), dim3(grid_for(rows, 256)), dim3(256), 0, STREAM, (const TL*)logits, ld, (TOUT*)out, ldo, choff, labels, rows, C)
+  if (logits_dtype == DP_F32 && out_dtype == DP_BF16) GO2(float, bf16_t);
+  else if (logits_dtype == DP_F32 && out_dtype == DP_F16) GO2(float, f16_t);
+  else if (logits_dtype == DP_BF16 && out_dtype == DP_F32) GO2(bf16_t, float);
+  else if (logits_dtype == DP_F16 && out_dtype == DP_F32) GO2(f16_t, float);
+  else DP_FAIL("argmax_onehot2: unsupported type pair (%d, %d)", logits_dtype, out_dtype);
+#undef GO2
+  DP_CHECK_LAUNCH("argmax_onehot2"); return 0;
 }
 
 // ------------------------------------------------------------------------------------------------ skinny pointwise conv

@@ -203,6 +203,18 @@ __device__ __forceinline__ NormConst load_consts(const float* mean, const float*
   return k;
 }
 
+// fp32x3 mode: 8 fp32 values written as their bf16 halves, hi at p, lo at p + cp (the [x_hi | x_lo] operand layout of csrc/x3.hip)
+__device__ __forceinline__ void st8_split(bf16_t* p, int cp, const float* o) {
+  v4u hi, lo;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const bf16_t h0 = f2bf(o[2 * r]), h1 = f2bf(o[2 * r + 1]);
+    const bf16_t l0 = f2bf(o[2 * r] - bf2f(h0)), l1 = f2bf(o[2 * r + 1] - bf2f(h1));
+    hi[r] = (unsigned)h0 | ((unsigned)h1 << 16); lo[r] = (unsigned)l0 | ((unsigned)l1 << 16);
+  }
+  *(v4u*)p = hi; *(v4u*)(p + cp) = lo;
+}
+
 // The three row-stream kernels are templated on the activation (no per-element switch) and have a fast path (C % 8 == 0,
 // pitches % 8 == 0, aligned bases: unguarded 16-byte accesses, RU rows in flight per thread) next to the generic guarded loop.
 struct NormArgs {
@@ -212,6 +224,9 @@ struct NormArgs {
   // second row source for channels >= csplit (normalise-into-concat and its backward in ONE pass over whole y / gy rows);
   // backward: y2 / ldy2 = the second source's gx
   const void* x2; int ldx2; const float* mean2; const float* rstd2; int ssn2; int csplit; void* y2; int ldy2;
+  // fp32x3 (T = float, fast path only): split_cp > 0: y (forward) / gx (backward) is a bf16 [rows][2 * split_cp] tensor of hi | lo
+  // halves instead of fp32 rows (split_cp2: the same for the second source's gx); the consumer is an x3 convolution
+  int split_cp, split_cp2;
 };
 
 template <typename T, int ACT>
@@ -243,6 +258,9 @@ __global__ void __launch_bounds__(NT) k_norm_act_fwd(NormArgs a) {
       for (int u = 0; u < RU; u++) {
 #pragma unroll
         for (int i = 0; i < 8; i++) { float z = t[u][i] * sc[i] + sh[i]; if (res) z += rr[u][i]; t[u][i] = ((ACT == DP_ACT_MISH && sizeof(T) == 2) || ACT == DP_ACT_MISH_FAST) ? mish_fwd_fast(z) : act_fwd(z, ACT); }
+        if constexpr (sizeof(T) == 4) {
+          if (a.split_cp) { st8_split((bf16_t*)a.y + (nb + vs + u * g.rpi) * (2 * a.split_cp) + g.cg * 8, a.split_cp, t[u]); continue; }
+        }
         st8(y + (nb + vs + u * g.rpi) * a.ldy + g.cg * 8, t[u]);
       }
     }
@@ -254,6 +272,9 @@ __global__ void __launch_bounds__(NT) k_norm_act_fwd(NormArgs a) {
     if (res) unpack8<T>(res + row * a.ldr + g.cg * 8, g.nv, rr);
 #pragma unroll
     for (int i = 0; i < 8; i++) { float z = t[i] * sc[i] + sh[i]; if (res) z += rr[i]; t[i] = ((ACT == DP_ACT_MISH && sizeof(T) == 2) || ACT == DP_ACT_MISH_FAST) ? mish_fwd_fast(z) : act_fwd(z, ACT); }
+    if constexpr (sizeof(T) == 4) {
+      if (a.split_cp) { st8_split((bf16_t*)a.y + row * (2 * a.split_cp) + g.cg * 8, a.split_cp, t); continue; }      // (C % 8 == 0 is required)
+    }
     pack8(y + row * a.ldy + g.cg * 8, g.nv, t);
   }
 }
@@ -349,7 +370,12 @@ __global__ void __launch_bounds__(NT) k_norm_act_bwd_apply(NormArgs a) {
       for (int u = 0; u < RU; u++) {
         const int64_t row = nb + vs + u * g.rpi;
         body(t[u], d[u], rr[u], gg[u]);
-        if (gx) st8(gx + row * ldgx + xoff, t[u]);
+        bool done = false;
+        if constexpr (sizeof(T) == 4) {
+          const int scp = second ? a.split_cp2 : a.split_cp;
+          if (scp && gx) { st8_split((bf16_t*)gx + row * (2 * scp) + xoff, scp, t[u]); done = true; }
+        }
+        if (gx && !done) st8(gx + row * ldgx + xoff, t[u]);
         if (gres) st8(gres + row * a.ldgres + g.cg * 8, gg[u]);
       }
     }
@@ -361,7 +387,12 @@ __global__ void __launch_bounds__(NT) k_norm_act_bwd_apply(NormArgs a) {
     unpack8<T>(gy + row * a.ldgy + g.cg * 8, g.nv, d);
     if (res) unpack8<T>(res + row * a.ldr + g.cg * 8, g.nv, rr);
     body(t, d, rr, gg);
-    if (gx) pack8(gx + row * ldgx + xoff, g.nv, t);
+    bool done = false;
+    if constexpr (sizeof(T) == 4) {
+      const int scp = second ? a.split_cp2 : a.split_cp;
+      if (scp && gx) { st8_split((bf16_t*)gx + row * (2 * scp) + xoff, scp, t); done = true; }
+    }
+    if (gx && !done) pack8(gx + row * ldgx + xoff, g.nv, t);
     if (gres) pack8(gres + row * a.ldgres + g.cg * 8, g.nv, gg);
   }
 }
@@ -473,6 +504,31 @@ extern "C" int dp_norm_act_bwd_apply(const void* x, int ldx, const void* gy, int
   a.fast = norm_fast(C, ldx, x, ldgy, gy, ldr, res, ldgx, gx, ldgres, gres);
   NORM_LAUNCH(k_norm_act_bwd_apply, a, dim3(a.nblk, N));
   DP_CHECK_LAUNCH("norm_act_bwd_apply"); return 0;
+}
+
+// fp32x3 variants (fp32 tensors in, the result written as the bf16 [hi | lo] operand of the x3 convolution that consumes it; cp =
+// channels per half, C <= cp, C % 8 == 0; channels [C, cp) of both halves are left untouched: the caller zero-fills them once)
+extern "C" int dp_norm_act_fwd_x3(const void* x, int ldx, const float* mean, const float* rstd, int ssn, const float* gamma, const float* beta,
+                                  const void* res, int ldr, int act, void* ys, int cp, int N, int64_t V, int C, void* stream) {
+  if (C > 8 * NT || (C & 7) || cp < C || (cp & 7)) DP_FAIL("norm_act_fwd_x3: need C %% 8 == 0 and cp >= C (%d, %d)", C, cp);
+  const int dtype = DP_F32;
+  NormArgs a = {}; a.x = x; a.ldx = ldx; a.mean = mean; a.rstd = rstd; a.ssn = ssn; a.gamma = gamma; a.beta = beta; a.res = res; a.ldr = ldr;
+  a.y = ys; a.ldy = 2 * cp; a.split_cp = cp; a.V = V; a.C = C; a.rpb = rows_per_block(V); a.nblk = dp_stats_nblk(V);
+  a.fast = norm_fast(C, ldx, x, 0, nullptr, ldr, res, 8, ys, 0, nullptr);
+  NORM_LAUNCH(k_norm_act_fwd, a, dim3(a.nblk, N));
+  DP_CHECK_LAUNCH("norm_act_fwd_x3"); return 0;
+}
+extern "C" int dp_norm_act_bwd_apply_x3(const void* x, int ldx, const void* gy, int ldgy, const float* mean, const float* rstd, int ssn,
+                                        const float* gamma, const float* beta, const void* res, int ldr, int act, const float* s1, const float* s2,
+                                        float inv_count, int use_stats, void* gxs, int cp, void* gres, int ldgres, int N, int64_t V, int C, void* stream) {
+  if (C > 8 * NT || (C & 7) || cp < C || (cp & 7) || !gxs) DP_FAIL("norm_act_bwd_apply_x3: need C %% 8 == 0, cp >= C and a destination");
+  const int dtype = DP_F32;
+  NormArgs a = {}; a.x = x; a.ldx = ldx; a.gy = gy; a.ldgy = ldgy; a.mean = mean; a.rstd = rstd; a.ssn = ssn; a.gamma = gamma; a.beta = beta;
+  a.res = res; a.ldr = ldr; a.y = gxs; a.ldy = 2 * cp; a.split_cp = cp; a.gres = gres; a.ldgres = ldgres; a.s1 = s1; a.s2 = s2; a.inv_count = inv_count;
+  a.use_stats = use_stats; a.V = V; a.C = C; a.rpb = rows_per_block(V); a.nblk = dp_stats_nblk(V);
+  a.fast = norm_fast(C, ldx, x, ldgy, gy, ldr, res, 8, gxs, ldgres, gres);
+  NORM_LAUNCH(k_norm_act_bwd_apply, a, dim3(a.nblk, N));
+  DP_CHECK_LAUNCH("norm_act_bwd_apply_x3"); return 0;
 }
 
 // ---------------------------------------------------------------------------- LayerNorm: one wave per row

@@ -606,7 +606,7 @@ def conv3d(x, weight, bias=None, stride=1, pad=0, dil=1, stats=False, bias_grad_
     if isinstance(x, (tuple, list)):
         return conv3d_cat(x[0], x[1], weight, bias, stride, pad, dil, stats, bias_grad_zero)
     if _x3_conv_ok(x, None, weight, stride, pad, dil):
-        return Conv3dX3.apply(x, None, weight, bias, stats, bias_grad_zero)
+        return _x3_conv_call(x, None, weight, bias, stats, bias_grad_zero)
     if stats or bias_grad_zero:
         return Conv3d.apply(x, weight, bias, stride, pad, dil, stats, bias_grad_zero)
     return Conv3d.apply(x, weight, bias, stride, pad, dil)
@@ -688,7 +688,7 @@ def conv3d_cat(xa, xb, weight, bias=None, stride=1, pad=0, dil=1, stats=False, b
     cout, cin, k = weight.shape[0], weight.shape[1], weight.shape[2]
     ca, W = xa.shape[-1], xa.shape[3]
     if _x3_conv_ok(xa, xb, weight, stride, pad, dil):
-        return Conv3dX3.apply(xa, xb, weight, bias, stats, bias_grad_zero)
+        return _x3_conv_call(xa, xb, weight, bias, stats, bias_grad_zero)
     ok = (USE_TILED and k > 1 and stride == 1 and dil == 1 and pad == k // 2 and ca % 8 == 0 and 0 < ca < cin
           and xb.shape[-1] >= cin - ca and xa.dtype == xb.dtype and tuple(xa.shape[:4]) == tuple(xb.shape[:4]))
     if ok:
@@ -833,6 +833,14 @@ def split_rows(a, ca, b, cb, cp, parts, pattern):
     return out
 
 
+def _x3_conv_shape_ok(W, cin, cout, k, stride, pad, dil):
+    """Shape test of the x3 convolution path (ops.Conv3dX3) alone."""
+    if not (USE_TILED and k in (3, 7) and stride == 1 and dil == 1 and pad == k // 2 and W >= 16 and cout >= 8 and cin >= 1):
+        return False
+    cp = (cin + 15) // 16 * 16
+    return bool(_lib.lib().dp_conv3d_tiled_weight_elems(3 * cp, cout, k, 1, pad, 1, W))
+
+
 _SPLIT_LAST = [None]
 
 
@@ -853,10 +861,17 @@ def _split_conv_input(xa, ca, xb, cb, cp):
 
 def _x3_conv_ok(xa, xb, weight, stride, pad, dil):
     from . import config
-    if not (config.x3() and USE_TILED and xa.dtype == torch.float32 and xa.is_cuda):
+    if not (config.x3() and USE_TILED and xa.is_cuda):
         return False
     cout, cin, k = weight.shape[0], weight.shape[1], weight.shape[2]
     W = xa.shape[3]
+    if xa.dtype == torch.bfloat16:
+        # an operand that already is split (norm_act(..., x3_split_for=...) wrote [x_hi | x_lo]): the producer checked the shape
+        if xb is not None or xa.shape[-1] != 2 * cin or cin % 16 or not _x3_conv_shape_ok(W, cin, cout, k, stride, pad, dil):
+            raise _lib.DoseHipError("conv3d: a bf16 tensor in the fp32x3 mode must be the [x_hi | x_lo] operand of an x3 convolution")
+        return True
+    if xa.dtype != torch.float32:
+        return False
     if not (k in (3, 7) and stride == 1 and dil == 1 and pad == k // 2 and W >= 16 and cout >= 8):
         return False
     if xb is not None:
@@ -869,6 +884,11 @@ def _x3_conv_ok(xa, xb, weight, stride, pad, dil):
     return bool(_lib.lib().dp_conv3d_tiled_weight_elems(3 * cp, cout, k, 1, pad, 1, W))
 
 
+# gradient tensors handed over in split form (NormAct.backward -> Conv3dX3.backward), keyed by address: a cheap handshake that the
+# fp32-typed tensor arriving at the convolution really holds [gy_hi | gy_lo]
+_GY_SPLIT_SENT = {}
+
+
 class Conv3dX3(torch.autograd.Function):
     """nn.Conv3d (k in {3, 7}, stride 1, "same" padding) in the fp32x3 mode, on a tensor or on the virtual concatenation of two:
     fp32 tensors in HBM, the tuned bf16 MFMA kernels on split operands (csrc/x3.hip), fp32 results.  Forward and data gradient are
@@ -876,7 +896,7 @@ class Conv3dX3(torch.autograd.Function):
     gy_lo) plus a small combine.  The split input is what is saved for the backward pass (same bytes as the fp32 tensor)."""
 
     @staticmethod
-    def forward(ctx, xa, xb, weight, bias, want_stats=False, bias_grad_zero=False):
+    def forward(ctx, xa, xb, weight, bias, want_stats=False, bias_grad_zero=False, gy_split=False):
         _chk_dev(xa, xb, weight)
         xa = as_rows(xa)
         xb = None if xb is None else as_rows(xb)
@@ -885,7 +905,13 @@ class Conv3dX3(torch.autograd.Function):
         ca = cin if xb is None else xa.shape[-1]
         cb = cin - ca
         cp = (cin + 15) // 16 * 16
-        xs = _split_conv_input(xa, ca, xb, cb, cp)                     # [.., x_hi (cp) | x_lo (cp)]
+        presplit = xa.dtype == torch.bfloat16
+        if presplit:
+            xs = xa.contiguous()                                       # written as [x_hi | x_lo] by the normalisation in front (NormAct)
+        else:
+            xs = _split_conv_input(xa, ca, xb, cb, cp)                 # [.., x_hi (cp) | x_lo (cp)]
+        # gy_split: a normalisation over this output follows (_x3_conv_call): its backward pass hands the gradient over ALREADY split
+        # (dp_norm_act_bwd_apply_x3), disguised as an fp32 tensor of y's shape so that it can cross the autograd edge -- see NormAct
         wq = _pack_conv_tiled_x3(weight, 0, cp, W)
         y = torch.empty((N, D, H, W, cout), dtype=torch.float32, device=xa.device)
         b32 = None if bias is None else bias.detach()
@@ -903,10 +929,11 @@ class Conv3dX3(torch.autograd.Function):
             _lib.call("dp_conv3d_tiled2", _p(xs), 2 * cp, 0, 0, 0, _p(wq), _p(b32), _p(y), cout, 0, 0, 0, _p(ws),
                       N, D, H, W, 3 * cp, cout, k, DP_X3, _stream())
         ctx.save_for_backward(xs, weight)
-        ctx.geom = (N, D, H, W, cin, cout, k, cp, ca, xa.shape[-1], None if xb is None else xb.shape[-1])
+        ctx.geom = (N, D, H, W, cin, cout, k, cp, ca, cin if presplit else xa.shape[-1], None if xb is None else xb.shape[-1])
         ctx.has_bias = bias is not None
         ctx.bias_grad_zero = bias_grad_zero
         ctx.bias_ref = bias if bias_grad_zero else None
+        ctx.presplit, ctx.gy_split = presplit, gy_split
         if want_stats:
             if part is None:
                 part = _stats_partial(y)
@@ -918,6 +945,10 @@ class Conv3dX3(torch.autograd.Function):
     def backward(ctx, gy, *unused):
         xs, weight = ctx.saved_tensors
         N, D, H, W, cin, cout, k, cp, ca, cxa, cxb = ctx.geom
+        if ctx.gy_split:
+            if not _GY_SPLIT_SENT.pop(gy.data_ptr(), False):
+                raise _lib.DoseHipError("Conv3dX3: expected the split gradient of the normalisation that follows this convolution")
+            gy = gy.contiguous()
         gy = as_rows(gy)
         grows, _, ldg = rows_ld(gy)
         dev = gy.device
@@ -926,7 +957,10 @@ class Conv3dX3(torch.autograd.Function):
         cpo = (cout + 15) // 16 * 16
         need_x = ctx.needs_input_grad[0] or (cxb is not None and ctx.needs_input_grad[1])
         need_w = ctx.needs_input_grad[2]
-        gys = split_rows(gy, cout, None, 0, cpo, 2, 0b10) if (need_x or need_w) else None
+        if ctx.gy_split:
+            gys = gy.view(torch.bfloat16)                 # [.., gy_hi (cout) | gy_lo (cout)] already (cpo == cout)
+        else:
+            gys = split_rows(gy, cout, None, 0, cpo, 2, 0b10) if (need_x or need_w) else None
         gxa = gxb = gw = gb = None
         if need_x:
             if L.dp_conv3d_tiled_weight_elems(3 * cpo, cin, k, 1, pad, 1, W):
@@ -980,7 +1014,20 @@ class Conv3dX3(torch.autograd.Function):
             else:
                 gb = torch.empty((cout,), dtype=torch.float32, device=dev)
                 colsum_into(_p(gy), ldg, grows, cout, gb, 0)
-        return gxa, gxb, gw, gb, None, None
+        if ctx.presplit and gxa is not None:
+            gxa = gxa.contiguous().view(torch.bfloat16)    # the input was a bf16 [.., 2 cin] tensor: same bytes, the producer (NormAct) reads it as fp32
+        return gxa, gxb, gw, gb, None, None, None
+
+
+def _x3_conv_call(xa, xb, weight, bias, stats, bias_grad_zero):
+    """Conv3dX3 with the split-gradient handshake: when statistics are requested (a normalisation over y follows and is y's only
+    consumer), the channel count is a multiple of 16 and no bias gradient has to be summed from gy, the partial-statistics tensor is
+    tagged so that norm_act(y, ..., stats=part) returns its input gradient already split."""
+    gy_split = bool(stats and weight.shape[0] % 16 == 0 and (bias is None or bias_grad_zero))
+    out = Conv3dX3.apply(xa, xb, weight, bias, stats, bias_grad_zero, gy_split)
+    if stats:
+        out[1]._dp_gy_split = gy_split
+    return out
 
 
 class LinearX3(torch.autograd.Function):
@@ -1300,7 +1347,8 @@ def linear(x, weight, bias=None, splitk=1, defer_wgrad=False):
 
 
 # ------------------------------------------------------------------------------------------------ normalisation
-def _norm_forward(x, kind, gamma, beta, running_mean, running_var, training, res, act, eps, momentum, y_ptr, ldy, apply=True, part=None):
+def _norm_forward(x, kind, gamma, beta, running_mean, running_var, training, res, act, eps, momentum, y_ptr, ldy, apply=True, part=None,
+                  split_cp=0):
     """Statistics + fused normalise/affine/residual/activation of one NDHWC tensor into (y_ptr, row pitch ldy).
     part: partial statistics rows [N, nblk, 2, C] already produced by the convolution that wrote x (conv3d(..., stats=True))."""
     rows, C, ldx = rows_ld(x)
@@ -1339,12 +1387,16 @@ def _norm_forward(x, kind, gamma, beta, running_mean, running_var, training, res
     g32 = None if gamma is None else gamma.detach()
     b32 = None if beta is None else beta.detach()
     ldr = rows_ld(res)[2] if res is not None else 0
-    _lib.call("dp_norm_act_fwd", _p(x), ldx, _p(mean), _p(rstd), ssn, _p(g32), _p(b32), _p(res), ldr, _act_code(act, x.dtype),
-              y_ptr, ldy, N, V, C, dtc, _stream())
+    if split_cp:
+        _lib.call("dp_norm_act_fwd_x3", _p(x), ldx, _p(mean), _p(rstd), ssn, _p(g32), _p(b32), _p(res), ldr, _act_code(act, x.dtype),
+                  y_ptr, split_cp, N, V, C, _stream())
+    else:
+        _lib.call("dp_norm_act_fwd", _p(x), ldx, _p(mean), _p(rstd), ssn, _p(g32), _p(b32), _p(res), ldr, _act_code(act, x.dtype),
+                  y_ptr, ldy, N, V, C, dtc, _stream())
     return mean, rstd, use_batch_stats, ssn
 
 
-def _norm_backward(x, mean, rstd, gamma, beta, res, kind, act, use_stats, ssn, gy_ptr, ldg, need_x, need_gb, need_res):
+def _norm_backward(x, mean, rstd, gamma, beta, res, kind, act, use_stats, ssn, gy_ptr, ldg, need_x, need_gb, need_res, split_cp=0):
     """Backward of _norm_forward for an upstream gradient at (gy_ptr, row pitch ldg) -> (gx, dgamma, dbeta, gres)."""
     rows, C, ldx = rows_ld(x)
     N = x.shape[0]
@@ -1370,9 +1422,14 @@ def _norm_backward(x, mean, rstd, gamma, beta, res, kind, act, use_stats, ssn, g
                   _p(dgamma), _p(dbeta), _stream())
     gx = gres = None
     if need_x or need_res:
-        gx = torch.empty(x.shape, dtype=x.dtype, device=dev) if need_x else None
         gres = torch.empty(x.shape, dtype=x.dtype, device=dev) if need_res else None
         cnt = V if kind == "instance" else N * V
+        if split_cp and need_x:
+            gx = torch.empty(tuple(x.shape[:-1]) + (2 * split_cp,), dtype=torch.bfloat16, device=dev)      # [gx_hi | gx_lo]
+            _lib.call("dp_norm_act_bwd_apply_x3", _p(x), ldx, gy_ptr, ldg, _p(mean), _p(rstd), ssn, _p(g32), _p(b32), _p(res), ldr,
+                      _act_code(act, x.dtype), _p(s1), _p(s2), 1.0 / cnt, 1 if use_stats else 0, _p(gx), split_cp, _p(gres), C, N, V, C, _stream())
+            return gx, dgamma, dbeta, gres
+        gx = torch.empty(x.shape, dtype=x.dtype, device=dev) if need_x else None
         _lib.call("dp_norm_act_bwd_apply", _p(x), ldx, gy_ptr, ldg, _p(mean), _p(rstd), ssn, _p(g32), _p(b32), _p(res), ldr,
                   _act_code(act, x.dtype), _p(s1), _p(s2), 1.0 / cnt, 1 if use_stats else 0, _p(gx), C, _p(gres), C, N, V, C, dtc, _stream())
     return gx, dgamma, dbeta, gres
@@ -1383,28 +1440,44 @@ class NormAct(torch.autograd.Function):
     kind: 'instance' | 'batch'.  For 'batch', running buffers are updated in place when training."""
 
     @staticmethod
-    def forward(ctx, x, kind, gamma, beta, running_mean, running_var, training, res, act, eps, momentum, stats=None):
+    def forward(ctx, x, kind, gamma, beta, running_mean, running_var, training, res, act, eps, momentum, stats=None, split_out=False,
+                grad_split=False):
+        """fp32x3 only -- split_out: y is written as the bf16 [y_hi | y_lo] operand of the x3 convolution that is its only consumer
+        (shape [.., 2C]); grad_split: x is the output of an x3 convolution, whose backward pass takes the gradient in the same split
+        form.  Both cross the autograd edge as a same-bytes reinterpretation: a bf16 [.., 2C] tensor and an fp32 [.., C] tensor are
+        the same memory, so the gradient of a bf16 [.., 2C] output arrives as fp32 data viewed as bf16 (Conv3dX3 returns
+        gx.view(bfloat16)), and the split gradient of an fp32 [.., C] input leaves as bf16 data viewed as fp32."""
         _chk_dev(x)
         x = as_rows(x)
         C = x.shape[-1]
         if res is not None:
             res = as_rows(res)
-        y = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+        if split_out:
+            y = torch.empty(tuple(x.shape[:-1]) + (2 * C,), dtype=torch.bfloat16, device=x.device)
+        else:
+            y = torch.empty(x.shape, dtype=x.dtype, device=x.device)
         mean, rstd, use_batch_stats, ssn = _norm_forward(x, kind, gamma, beta, running_mean, running_var, training, res, act, eps,
-                                                         momentum, _p(y), C, part=stats)
+                                                         momentum, _p(y), C, part=stats, split_cp=C if split_out else 0)
         ctx.save_for_backward(x, mean, rstd, gamma, beta, res)
         ctx.cfg = (kind, act, use_batch_stats, ssn)
+        ctx.split_out, ctx.grad_split = split_out, grad_split
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x, mean, rstd, gamma, beta, res = ctx.saved_tensors
         kind, act, use_stats, ssn = ctx.cfg
+        if ctx.split_out:
+            gy = gy.contiguous().view(torch.float32)      # fp32 [.., C] gradient that travelled as bf16 [.., 2C]
         gy = as_rows(gy)
         need_gb = gamma is not None and (ctx.needs_input_grad[2] or ctx.needs_input_grad[3])
         gx, dgamma, dbeta, gres = _norm_backward(x, mean, rstd, gamma, beta, res, kind, act, use_stats, ssn, _p(gy), rows_ld(gy)[2],
-                                                 ctx.needs_input_grad[0], need_gb, res is not None and ctx.needs_input_grad[7])
-        return gx, None, dgamma, dbeta, None, None, None, gres, None, None, None, None
+                                                 ctx.needs_input_grad[0], need_gb, res is not None and ctx.needs_input_grad[7],
+                                                 split_cp=x.shape[-1] if ctx.grad_split else 0)
+        if ctx.grad_split and gx is not None:
+            gx = gx.view(torch.float32)                   # [gx_hi | gx_lo] bf16 data in an fp32 tensor of x's shape
+            _GY_SPLIT_SENT[gx.data_ptr()] = True
+        return gx, None, dgamma, dbeta, None, None, None, gres, None, None, None, None, None, None
 
 
 class NormActCat(torch.autograd.Function):
@@ -1467,10 +1540,23 @@ def norm_act_cat(xa, xb, act=None, eps=1e-5, stats_a=None, stats_b=None):
 
 
 def norm_act(x, kind, gamma=None, beta=None, running_mean=None, running_var=None, training=True, res=None, act=None,
-             eps=1e-5, momentum=0.1, stats=None):
-    """stats: the partial-statistics tensor conv3d(..., stats=True) returned together with x (skips the statistics pass)."""
+             eps=1e-5, momentum=0.1, stats=None, x3_split_for=None):
+    """stats: the partial-statistics tensor conv3d(..., stats=True) returned together with x (skips the statistics pass).
+    x3_split_for: the nn.Conv3d that is the ONLY consumer of the result.  In the fp32x3 mode, when that convolution takes the x3
+    path, the result is written directly as its bf16 [hi | lo] operand (shape [.., 2C]; hand it to conv3d as is) instead of an
+    fp32 tensor that the convolution would split in a pass of its own."""
+    grad_split = bool(getattr(stats, "_dp_gy_split", False)) and x.dtype == torch.float32
     if kind == "batch" and not training:
         stats = None
+    split_out = False
+    if x3_split_for is not None and x.dtype == torch.float32 and x.is_cuda:
+        from . import config
+        c = x3_split_for
+        C = x.shape[-1]
+        split_out = (config.x3() and C % 16 == 0 and c.weight.shape[1] == C and
+                     _x3_conv_shape_ok(x.shape[3], C, c.weight.shape[0], c.kernel_size[0], c.stride[0], c.padding[0], c.dilation[0]))
+    if split_out or grad_split:
+        return NormAct.apply(x, kind, gamma, beta, running_mean, running_var, training, res, act, eps, momentum, stats, split_out, grad_split)
     return NormAct.apply(x, kind, gamma, beta, running_mean, running_var, training, res, act, eps, momentum, stats)
 
 
@@ -1822,7 +1908,10 @@ def argmax_onehot(logits, out=None, choff=0, labels=False):
     ldo = 0
     if out is not None:
         ldo = rows_ld(out)[2]
-    _lib.call("dp_argmax_onehot", _p(logits), ld, _p(out), ldo, choff, _p(lab), rows, C, _dt(logits), _stream())
+    if out is not None and out.dtype != logits.dtype:
+        _lib.call("dp_argmax_onehot2", _p(logits), ld, _dt(logits), _p(out), ldo, _dt(out), choff, _p(lab), rows, C, _stream())
+    else:
+        _lib.call("dp_argmax_onehot", _p(logits), ld, _p(out), ldo, choff, _p(lab), rows, C, _dt(logits), _stream())
     return lab
 
 

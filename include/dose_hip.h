@@ -310,6 +310,13 @@ int dp_pack_multi(const void* table, const int32_t* chunk_t, const int32_t* chun
 int dp_split_rows(const float* a, int lda, int ca, const float* b, int ldb, int cb, void* dst, int cp, int parts, int pattern,
                   int64_t rows, void* stream);
 int dp_x3_wgrad_combine(const float* S, float* dw, int cout, int cin, int cp, int taps, int nblk, void* stream);
+/* dp_norm_act_fwd / dp_norm_act_bwd_apply on fp32 tensors with the RESULT (y, resp. gx) written directly as the bf16 [hi | lo]
+ * operand (row pitch 2 cp, C <= cp, C % 8 == 0) of the x3 convolution that consumes it: no fp32 copy, no dp_split_rows pass. */
+int dp_norm_act_fwd_x3(const void* x, int ldx, const float* mean, const float* rstd, int ssn, const float* gamma, const float* beta,
+                       const void* res, int ldr, int act, void* ys, int cp, int N, int64_t V, int C, void* stream);
+int dp_norm_act_bwd_apply_x3(const void* x, int ldx, const void* gy, int ldgy, const float* mean, const float* rstd, int ssn,
+                             const float* gamma, const float* beta, const void* res, int ldr, int act, const float* s1, const float* s2,
+                             float inv_count, int use_stats, void* gxs, int cp, void* gres, int ldgres, int N, int64_t V, int C, void* stream);
 
 /* ---- cascade glue ----------------------------------------------------------------------------- */
 /* replaces: AsDiscrete(argmax=True, to_onehot=True) + channel concat (train_light_linked_model.py:157-167):
@@ -317,6 +324,10 @@ int dp_x3_wgrad_combine(const float* S, float* dw, int cout, int cin, int cp, in
  * 1..C-1 written to out[rows][ldo] channels [choff, choff+C-1); also writes the label (int32) if labels!=NULL. */
 int dp_argmax_onehot(const void* logits, int ld, void* out, int ldo, int choff, int32_t* labels, int64_t rows, int C,
                      int dtype, void* stream);
+/* the same with the one-hot destination in another storage type than the logits (fp32 logits of an fp32x3 segmentation pass into
+ * the bf16 / fp16 staging buffer of the dose network). */
+int dp_argmax_onehot2(const void* logits, int ld, int logits_dtype, void* out, int ldo, int out_dtype, int choff, int32_t* labels,
+                      int64_t rows, int C, void* stream);
 
 /* Gather for small-volume convolutions (c3d.py:16 at the 8^3 / 16^3 stages): col[row][tap*CinP + c] with CinP = Cin rounded
  * up to 8, row = output voxel (n, od, oh, ow), zero padding.  conv = dp_gemm_nt(col, weights packed [Cout][tap][CinP]). */

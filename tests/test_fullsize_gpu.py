@@ -445,10 +445,13 @@ def test_c4_cascade_training_step_128_bf16():
         assert all(p.grad is None for p in seg.parameters())
         assert all(torch.equal(a, b.detach()) for a, b in zip(seg_before, list(seg.parameters())[:4]))
         # the staged buffer the training step consumed holds the same nine channels as the fp32 view (CT / PTV exactly; the masks up to
-        # arg-max near-ties: the segmentation forward is not bitwise reproducible, its 16^3 layers accumulate with fp32 atomics)
+        # arg-max near-ties: the segmentation forward -- fp32x3 inside the cascade, config.cascade_seg_mode() -- is not bitwise
+        # reproducible, its 16^3 layers accumulate with fp32 atomics; in bf16 storage 0.27 % of the one-hot entries moved between two runs)
         st9 = staged[..., :9].permute(0, 4, 1, 2, 3).float()
         assert torch.equal(st9[:, 0], structures[:, 0]) and torch.equal(st9[:, 8], structures[:, 8])
-        assert float((st9[:, 1:8] != structures[:, 1:8]).float().mean()) < 1e-2
+        flips = float((st9[:, 1:8] != structures[:, 1:8]).float().mean())
+        print(f"[c4] one-hot entries that differ between two segmentation passes: {flips:.2e}")
+        assert flips < 2e-4
     finally:
         dose_prediction_amd.set_compute_dtype(torch.float32)
 

@@ -10,6 +10,8 @@ f = glob.glob(d + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows)
 marks = [e[0] for e in ev if "k_patchify" in e[2] and ("false" in e[2] or "chunks" in e[2])]
+# (the fp32x3 mode patchifies three operand blocks back to back: keep the first mark of each burst)
+marks = [m for i, m in enumerate(marks) if i == 0 or m - marks[i - 1] > 5_000_000]
 s0, s1 = marks[-2], marks[-1]
 sel = [e for e in ev if s0 <= e[0] < s1]
 busy = 0
