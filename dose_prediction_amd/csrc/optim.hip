@@ -6,7 +6,46 @@
 #define STREAM ((hipStream_t)stream)
 #define ADAM_CHUNK 8192          // elements per block
 
-struct AdamTensor { float* p; const float* g; float* m; float* v; float* vmax; int64_t n; };
+// cdst / ckind: a packed copy of the parameter that the update writes on the way (the parameter is in registers anyway; a separate
+// dp_pack_multi pass re-read 4 bytes per element for it): 0 none; 1 / 2 plain cast to bf16 / fp16 (the kernel layout of a Linear
+// weight whose row length is a multiple of 8); 3 the fp32x3 Linear operand bf16 [rows][3 cp] over rows of K elements, block b holding
+// hi or lo per the pattern bits (cpp = cp | pattern << 32).
+struct AdamTensor { float* p; const float* g; float* m; float* v; float* vmax; int64_t n; void* cdst; int64_t ckind, K, cpp; };
+
+__device__ __forceinline__ void adam_write_copy(const AdamTensor& T, int64_t i, const float* v4) {      // 4 consecutive new parameter values at index i
+  if (T.ckind == 1) {
+    const unsigned a = (unsigned)f2bf(v4[0]) | ((unsigned)f2bf(v4[1]) << 16), b = (unsigned)f2bf(v4[2]) | ((unsigned)f2bf(v4[3]) << 16);
+    *(uint2*)((bf16_t*)T.cdst + i) = make_uint2(a, b);
+  } else if (T.ckind == 2) {
+    f16_t* d = (f16_t*)T.cdst + i;
+    d[0] = (f16_t)v4[0]; d[1] = (f16_t)v4[1]; d[2] = (f16_t)v4[2]; d[3] = (f16_t)v4[3];
+  } else if (T.ckind == 3) {
+    const unsigned K = (unsigned)T.K, cp = (unsigned)(T.cpp & 0xffffffff), pat = (unsigned)(T.cpp >> 32);
+    const unsigned r = (unsigned)i / K, c = (unsigned)i - r * K;        // (n < 2^32; K % 4 == 0: the four elements share a row)
+    unsigned hi[2], lo[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const bf16_t h0 = f2bf(v4[2 * q]), h1 = f2bf(v4[2 * q + 1]);
+      const bf16_t l0 = f2bf(v4[2 * q] - bf2f(h0)), l1 = f2bf(v4[2 * q + 1] - bf2f(h1));
+      hi[q] = (unsigned)h0 | ((unsigned)h1 << 16); lo[q] = (unsigned)l0 | ((unsigned)l1 << 16);
+    }
+    bf16_t* d = (bf16_t*)T.cdst + (int64_t)r * (3 * cp) + c;
+#pragma unroll
+    for (int b = 0; b < 3; b++) *(uint2*)(d + b * cp) = ((pat >> b) & 1) ? make_uint2(lo[0], lo[1]) : make_uint2(hi[0], hi[1]);
+  }
+}
+
+__device__ __forceinline__ void adam_write_copy1(const AdamTensor& T, int64_t i, float v) {             // (unaligned tensors: element by element)
+  if (T.ckind == 1) ((bf16_t*)T.cdst)[i] = f2bf(v);
+  else if (T.ckind == 2) ((f16_t*)T.cdst)[i] = (f16_t)v;
+  else if (T.ckind == 3) {
+    const unsigned K = (unsigned)T.K, cp = (unsigned)(T.cpp & 0xffffffff), pat = (unsigned)(T.cpp >> 32);
+    const unsigned r = (unsigned)i / K, c = (unsigned)i - r * K;
+    const bf16_t h = f2bf(v), l = f2bf(v - bf2f(h));
+    bf16_t* d = (bf16_t*)T.cdst + (int64_t)r * (3 * cp) + c;
+    for (int b = 0; b < 3; b++) d[b * cp] = ((pat >> b) & 1) ? l : h;
+  }
+}
 
 __global__ void __launch_bounds__(256) k_adam_multi(const AdamTensor* __restrict__ tab, const int* __restrict__ chunk_t, const int* __restrict__ chunk_i,
                                                     float lr_c1, float beta1, float beta2, float omb1, float omb2, float eps, float wd, float rsqrt_c2, int amsgrad,
@@ -47,25 +86,27 @@ __global__ void __launch_bounds__(256) k_adam_multi(const AdamTensor* __restrict
         for (int k = 0; k < 4; k++) { float pp = p0[k], mm = m0[k], vv = v0[k], vx = x0[k]; upd(pp, g0[k], mm, vv, vx); p0[k] = pp; m0[k] = mm; v0[k] = vv; x0[k] = vx; }
         *(v4f*)(T.p + i0) = p0; *(v4f*)(T.m + i0) = m0; *(v4f*)(T.v + i0) = v0;
         if (amsgrad) *(v4f*)(T.vmax + i0) = x0;
+        if (T.ckind) { const float t4[4] = {p0[0], p0[1], p0[2], p0[3]}; adam_write_copy(T, i0, t4); }
       } else {
-        for (int64_t j = i0; j < end; j++) { float vx = amsgrad ? T.vmax[j] : 0.f; upd(T.p[j], T.g[j], T.m[j], T.v[j], vx); if (amsgrad) T.vmax[j] = vx; }
+        for (int64_t j = i0; j < end; j++) { float vx = amsgrad ? T.vmax[j] : 0.f; upd(T.p[j], T.g[j], T.m[j], T.v[j], vx); if (amsgrad) T.vmax[j] = vx; if (T.ckind) adam_write_copy1(T, j, T.p[j]); }
       }
       if (f1) {
 #pragma unroll
         for (int k = 0; k < 4; k++) { float pp = p1[k], mm = m1[k], vv = v1[k], vx = x1[k]; upd(pp, g1[k], mm, vv, vx); p1[k] = pp; m1[k] = mm; v1[k] = vv; x1[k] = vx; }
         *(v4f*)(T.p + i1) = p1; *(v4f*)(T.m + i1) = m1; *(v4f*)(T.v + i1) = v1;
         if (amsgrad) *(v4f*)(T.vmax + i1) = x1;
+        if (T.ckind) { const float t4[4] = {p1[0], p1[1], p1[2], p1[3]}; adam_write_copy(T, i1, t4); }
       } else {
-        for (int64_t j = i1; j < end; j++) { float vx = amsgrad ? T.vmax[j] : 0.f; upd(T.p[j], T.g[j], T.m[j], T.v[j], vx); if (amsgrad) T.vmax[j] = vx; }
+        for (int64_t j = i1; j < end; j++) { float vx = amsgrad ? T.vmax[j] : 0.f; upd(T.p[j], T.g[j], T.m[j], T.v[j], vx); if (amsgrad) T.vmax[j] = vx; if (T.ckind) adam_write_copy1(T, j, T.p[j]); }
       }
     }
   } else {
-    for (int64_t j = base + threadIdx.x; j < end; j += 256) { float vx = amsgrad ? T.vmax[j] : 0.f; upd(T.p[j], T.g[j], T.m[j], T.v[j], vx); if (amsgrad) T.vmax[j] = vx; }
+    for (int64_t j = base + threadIdx.x; j < end; j += 256) { float vx = amsgrad ? T.vmax[j] : 0.f; upd(T.p[j], T.g[j], T.m[j], T.v[j], vx); if (amsgrad) T.vmax[j] = vx; if (T.ckind) adam_write_copy1(T, j, T.p[j]); }
   }
   if (bad && found_inf) *found_inf = 1;
 }
 
-// table: device array of {p, g, m, v, vmax, n} (6 x 8 bytes per tensor); chunk_t / chunk_i: device int arrays mapping each
+// table: device array of {p, g, m, v, vmax, n, cdst, ckind, K, cpp} (10 x 8 bytes per tensor; cdst .. cpp: see AdamTensor); chunk_t / chunk_i: device int arrays mapping each
 // block to (tensor, chunk index of ADAM_CHUNK elements).  step >= 1 is the step count AFTER this update.
 extern "C" int dp_adam_chunk(void) { return ADAM_CHUNK; }
 extern "C" int dp_adam_multi(const void* table, const int32_t* chunk_t, const int32_t* chunk_i, int nchunks, double lr, double beta1, double beta2,

@@ -127,10 +127,28 @@ def invalidate_packs(params):
         p.__dict__["_dp_gen"] = p.__dict__.get("_dp_gen", 0) + 1
 
 
-def refresh_packs(params):
+def adam_fusable_pack(p):
+    """(key, dst pointer, ckind, K, cpp) of ONE packed copy of ``p`` that dp_adam_multi can write itself while it updates p (the
+    layouts that follow the parameter's own element order: plain 16-bit casts and fp32x3 Linear operands), or (None, 0, 0, 0, 0)."""
+    store = p.__dict__.get("_dp_packs")
+    if store and p.is_contiguous() and p.numel() < (1 << 32):
+        for key, ent in store.items():
+            dst, d = ent[1], ent[2]
+            if d is None or not ent[3] or dst.data_ptr() == p.data_ptr() or ent[0][1:3] != (p.data_ptr(), p.device):
+                continue
+            base, pat, cp = d[0] & 0xff, (d[0] >> 8) & 0xff, d[0] >> 16
+            if base == 0 and cp == 0 and dst.dtype in (torch.bfloat16, torch.float16) and dst.numel() == p.numel():
+                return key, dst.data_ptr(), 1 if dst.dtype == torch.bfloat16 else 2, 0, 0
+            if base == 1 and cp > 0 and d[3] == 3 * cp and d[2] % 4 == 0 and d[1] * d[2] == p.numel() and dst.dtype == torch.bfloat16:
+                return key, dst.data_ptr(), 3, d[2], cp | (pat << 32)
+    return None, 0, 0, 0, 0
+
+
+def refresh_packs(params, fused=None):
     """Rebuild, in ONE launch per storage type (dp_pack_multi), every packed copy of ``params`` that was used since the last
     refresh; called by FusedAdam.step() right after the update kernel, which changes the parameters through raw pointers
-    (p._version does not move).  Copies that were not used since the last refresh are dropped."""
+    (p._version does not move).  Copies that were not used since the last refresh are dropped.  fused: {id(p): key} of the copies
+    the update kernel has already rewritten itself (adam_fusable_pack)."""
     L = _lib.lib()
     chunk = L.dp_pack_chunk()
     jobs = {}
@@ -145,6 +163,9 @@ def refresh_packs(params):
             dst = ent[1]
             if dst.data_ptr() == p.data_ptr():          # the "copy" is the parameter itself (fp32 row-major matrix)
                 ent[0] = tag
+                continue
+            if fused and fused.get(id(p)) == key:       # written by dp_adam_multi together with the parameter
+                ent[0], ent[3] = tag, False
                 continue
             if ent[2] is None or not ent[3] or ent[0][1:3] != tag[1:3]:
                 del store[key]

@@ -18,6 +18,7 @@ class FusedAdam(torch.optim.Optimizer):
             raise ValueError("invalid Adam hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad, capturable=capturable))
         self._plans = {}
+        self.fuse_packs = True           # (A/B switch: False sends every packed copy through ops.refresh_packs)
         # 0-dim int32 device tensor raised by the kernel when a gradient element was not finite (that element's update is skipped);
         # it is never cleared by step(): read it with found_inf() / clear it with reset_found_inf()
         self._found_inf = None
@@ -42,7 +43,7 @@ class FusedAdam(torch.optim.Optimizer):
                 ci += list(range(n))
             dev = plist[0].device
             plan = (torch.tensor(ct, dtype=torch.int32, device=dev), torch.tensor(ci, dtype=torch.int32, device=dev), len(ct),
-                    torch.empty((len(plist), 6), dtype=torch.int64).pin_memory(), torch.empty((len(plist), 6), dtype=torch.int64, device=dev),
+                    torch.empty((len(plist), 10), dtype=torch.int64).pin_memory(), torch.empty((len(plist), 10), dtype=torch.int64, device=dev),
                     [None])
             self._plans[key] = plan
         return plan
@@ -92,11 +93,17 @@ class FusedAdam(torch.optim.Optimizer):
                 # thread may be several steps ahead of the GPU)
                 copied[0].synchronize()
             h = host.numpy()
+            fused = {}
             for t, p in enumerate(plist):
                 st = self.state[p]
                 vm = st.get("max_exp_avg_sq") if group["amsgrad"] else None
+                # one packed copy per parameter is written by the update kernel itself (plain 16-bit casts and fp32x3 Linear operands:
+                # the layouts that follow the parameter's own element order); ops.refresh_packs rebuilds the others
+                key, cdst, ckind, K, cpp = ops.adam_fusable_pack(p) if self.fuse_packs else (None, 0, 0, 0, 0)
+                if key is not None:
+                    fused[id(p)] = key
                 h[t] = (p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
-                        vm.data_ptr() if vm is not None else 0, p.numel())
+                        vm.data_ptr() if vm is not None else 0, p.numel(), cdst, ckind, K, cpp)
             devtab.copy_(host, non_blocking=True)
             if not torch.cuda.is_current_stream_capturing():
                 copied[0] = torch.cuda.Event()
@@ -131,5 +138,5 @@ class FusedAdam(torch.optim.Optimizer):
                           float(group["eps"]), float(group["weight_decay"]), inv_gs, int(step), 1 if group["amsgrad"] else 0,
                           self._found_inf.data_ptr(), stream)
             # the kernel wrote the parameters through raw pointers (p._version did not move): rebuild their packed copies now
-            ops.refresh_packs(plist)
+            ops.refresh_packs(plist, fused)
         return loss

@@ -269,7 +269,9 @@ int dp_conv3d_wgrad_tiled(const void* x, int ldx, const void* gy, int ldgy, floa
 /* ---- optimizer ------------------------------------------------------------ */
 /* replaces: optim.Adam(..., amsgrad=True).step() as built by NetworkTrainer.set_optimizer (network_trainer.py:120-125): one
  * launch over all parameter tensors.  table: device array of {float* p; const float* g; float* m; float* v; float* vmax;
- * int64_t n}; chunk_t/chunk_i map each block to (tensor, chunk of dp_adam_chunk() elements); step = count after this update.
+ * int64_t n; void* cdst; int64_t ckind, K, cpp} -- cdst: a kernel-layout copy of the parameter written by the same pass (ckind 0
+ * none, 1 / 2 plain bf16 / fp16 cast, 3 the fp32x3 Linear operand bf16 [n / K][3 cp] with cpp = cp | pattern << 32; the vector
+ * path needs K % 4 == 0) --; chunk_t/chunk_i map each block to (tensor, chunk of dp_adam_chunk() elements); step = count after this update.
  * inv_grad_scale multiplies every gradient first (1 / loss scale when the backward pass ran on a scaled loss: fp16 storage).
  * An element whose gradient is not finite is left untouched (parameter and moments) and *found_inf (device int32, may be NULL;
  * the caller zeroes it) is set to 1: an fp16 overflow cannot poison the AMSGrad state. */
