@@ -58,7 +58,8 @@ struct TiledGeom {
   int NTT;             // total 32-column N tiles in the packed weights
   int tiles_h, tiles_w;
   int dbg;             // experiments only (env DP_DBG): 1 = skip staging, 2 = skip the MFMA sweep, 3 = both, 4 = also skip the epilogue
-  int splitkd;         // 1: blockIdx.z selects ONE kd; results are atomically accumulated into the fp32 scratch `ws`
+  int splitkd;         // 1: blockIdx.z selects ONE kd (and one of `chsplit` shares of the input chunks); results are atomically accumulated into the fp32 scratch `ws`
+  int chsplit;
   // "virtual concat": input channels >= csplit come from x2 (pitch ldx2), output channels >= osplit go to y2 (pitch ldy2).
   // torch.cat((a, b), dim=1) feeding a convolution is never materialised -- and each 16-channel chunk pass then reads whole,
   // contiguous voxel rows of ONE tensor (a 32-channel row read 16 channels at a time touches every cache line twice and
@@ -142,14 +143,17 @@ extern "C" int dp_pack_conv_weight_tiled(const float* w, void* dst, int Cout, in
 // where one 32-row MFMA tile covers TWO image rows x 16 positions (NPAIR == 1 only).  A template parameter so that the slab
 // pitch is a compile-time constant: every LDS row address is then one base register + an immediate offset.
 // TO: type of the output tensor (T, or float for DP_X3 launches: bf16 hi / lo operand halves, fp32 result -- see conv_cc16.hip).
-template <typename T, int KS, int NPAIR, int RW, int NT, int TWP, typename TO>
+// WN: waves along N.  1: the four waves are TWC columns x TRG row groups over the SAME NT channel tiles.  2 (W16 tiles on planes of
+// <= 16 rows, Cout >= 128: the 16^3 level of the decoder): two row groups x two channel-tile groups -- with four row groups of
+// 4 x 2 image rows half of every block's MFMAs fell on rows >= H (7^3 at 16^3: 0.67 PFLOP/s against 1.1-1.4 at the other levels).
+template <typename T, int KS, int NPAIR, int RW, int NT, int TWP, typename TO, int WN = 1>
 __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, const T* __restrict__ wq, const float* __restrict__ bias,
                                                     TO* __restrict__ y, float* __restrict__ ws, TiledGeom g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* slab = (T*)smem_raw;
   constexpr int PAD = KS / 2, JH = NPAIR == 2 ? (KS + 1) / 2 : KS, RWO = RW - (NPAIR - 1), NTAP = JH * KS, CK = 16;
   constexpr bool W16 = TWP == 0;
-  constexpr int TWC = W16 ? 1 : TWP, TRG = 4 / TWC;
+  constexpr int TWC = W16 ? 1 : TWP, TRG = 4 / (TWC * WN);
   constexpr int LP = ((W16 ? 16 : TWC * 32) + KS - 1 + 7) & ~7;   // multiple of 8: the swizzle bit of a row differs from row 0 by (row * LP/8) & 1
   constexpr int LR = TRG * RWO * (W16 ? 2 : 1) + (NPAIR - 1) + (NPAIR == 2 ? 2 * (JH - 1) : KS - 1);
   // bf16: a voxel is 32 B (two 16-B halves); a ds_read_b128 lane group only ever asks for ONE half of 16 voxels, i.e. 8 of
@@ -158,7 +162,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, 
   // group over all 16 slots.
   constexpr bool SWZ = sizeof(T) == 2;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 31, hh = lane >> 5;
-  const int wc = wv % TWC, rg = wv / TWC;
+  const int wc = wv % TWC, rg = (wv / TWC) % TRG, wn = wv / (TWC * TRG);
   // XCD-aware block order: workgroups are dealt round-robin over the 8 XCDs (private 4 MiB L2 each), while the decode below
   // puts consecutive ids on neighbouring tiles / depth slices.  Give every XCD one CONTIGUOUS id range (= a range of depth
   // slices): the kd-neighbour slabs a block re-reads then come from its own L2 (the 3x3x3 layers fetched 2.7x and the
@@ -168,7 +172,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, 
   const int tw = b % g.tiles_w; b /= g.tiles_w; const int th = b % g.tiles_h; b /= g.tiles_h; const int d = b % g.D; const int n = b / g.D;
   constexpr int RPA = W16 ? 2 : 1;                 // image rows per accumulator row
   const int h0 = th * (TRG * RWO * RPA), w0 = W16 ? 0 : tw * (TWC * 32);
-  const int nt0 = blockIdx.y * NT;                 // first N tile of this block
+  const int nt0 = (blockIdx.y * WN + wn) * NT;     // first N tile of this wave
 
   v16f acc[RW][NT];
 #pragma unroll
@@ -202,11 +206,14 @@ __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, 
 #pragma unroll
     for (int jh = 0; jh < JH; jh++) bb[jh] = frag_ld_lds(wb + ((jh * KS + kw) * wts + j * 512) + lane_off);   // 32-bit uniform + lane offsets: saddr loads
   };
-  const int kd_lo = g.splitkd ? (int)blockIdx.z : 0, kd_hi = g.splitkd ? kd_lo + 1 : KS;
+  // split-kd launches: blockIdx.z = kd * chsplit + (which share of the staged chunks); partial sums meet through fp32 atomics
+  const int zsub = g.splitkd ? (int)blockIdx.z % g.chsplit : 0;
+  const int kd_lo = g.splitkd ? (int)blockIdx.z / g.chsplit : 0, kd_hi = g.splitkd ? kd_lo + 1 : KS;
+  const int ch_lo = g.splitkd ? (nstage * zsub) / g.chsplit : 0, ch_hi = g.splitkd ? (nstage * (zsub + 1)) / g.chsplit : nstage;
   for (int kd = kd_lo; kd < kd_hi; kd++) {
     const int id = d + kd - PAD;
     if (id < 0 || id >= g.D) continue;             // block-uniform: the whole depth slice is zero padding
-    for (int ch = 0; ch < nstage; ch++) {
+    for (int ch = ch_lo; ch < ch_hi; ch++) {
       // packed weights of this (kd, chunk) pass; the first kw column is requested BEFORE the slab is staged so that its
       // L2 latency hides behind the staging loads.
       const T* wbase = wq + ((int64_t)kd * NTAP * g.NCH + ch) * g.NTT * 512 + (int64_t)nt0 * 512;      // (not const: a DP_X3 x_hi slab is swept twice)
@@ -468,12 +475,12 @@ __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, 
         if (lane < 32) { sred[((wv * NT + j) * 2) * 32 + lane] = a1; sred[((wv * NT + j) * 2 + 1) * 32 + lane] = a2; }
       }
       __syncthreads();
-      for (int o = tid; o < NT * 2 * 32; o += 256) {
-        const int c32 = o & 31, which = (o >> 5) & 1, j = o >> 6, c = (nt0 + j) * 32 + c32;
+      for (int o = tid; o < WN * NT * 2 * 32; o += 256) {
+        const int c32 = o & 31, which = (o >> 5) & 1, jj = o >> 6, wn2 = jj / NT, j = jj % NT, c = ((blockIdx.y * WN + wn2) * NT + j) * 32 + c32;
         if (c < g.Cout) {
           float sum = 0.f;
 #pragma unroll
-          for (int w4 = 0; w4 < 4; w4++) sum += sred[((w4 * NT + j) * 2 + which) * 32 + c32];
+          for (int w4 = 0; w4 < 4 / WN; w4++) sum += sred[(((wn2 * (4 / WN) + w4) * NT + j) * 2 + which) * 32 + c32];
           g.stat_part[(((int64_t)nn * g.stat_nblk + stat_blk) * 2 + which) * g.Cout + c] = sum;
         }
       }
@@ -514,17 +521,17 @@ __global__ void k_conv_split_finish(float* __restrict__ ws, const float* __restr
   }
 }
 
-template <typename T, int KS, int NPAIR, int RW, int NT, int TWP, typename TO = T>
+template <typename T, int KS, int NPAIR, int RW, int NT, int TWP, typename TO = T, int WN = 1>
 static int launch_tiled(const void* x, const void* wq, const float* bias, void* y, float* ws, TiledGeom g, int ygrid, hipStream_t s) {
   size_t smem = (size_t)g.LR * g.LP * 16 * sizeof(T);
   if (smem < 8 * 32 * 32 * sizeof(TO)) smem = 8 * 32 * 32 * sizeof(TO);     // the epilogue transposes through 2 patches per wave
-  auto kern = k_conv_tiled<T, KS, NPAIR, RW, NT, TWP, TO>;
+  auto kern = k_conv_tiled<T, KS, NPAIR, RW, NT, TWP, TO, WN>;
   if (smem > 160 * 1024) { dp_set_error("conv3d_tiled: slab %zu B exceeds LDS", smem); return 1; }
   if (smem > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) { dp_set_error("conv3d_tiled: cannot raise dynamic LDS to %zu: %s", smem, hipGetErrorString(e)); return 1; }
   }
-  dim3 grid(g.N * g.D * g.tiles_h * g.tiles_w, ygrid, g.splitkd ? KS : 1);
+  dim3 grid(g.N * g.D * g.tiles_h * g.tiles_w, ygrid, g.splitkd ? KS * g.chsplit : 1);
   if (getenv("DP_DEBUG_OCC")) {
     int nb = -1; hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, 256, smem);
     fprintf(stderr, "[dp] conv_tiled KS=%d NPAIR=%d RW=%d NT=%d TWP=%d smem=%zu grid=%u x %u x %u occupancy(blocks/CU)=%d (%s)\n", KS, NPAIR, RW, NT, TWP, smem,
@@ -543,18 +550,26 @@ static int launch_tiled(const void* x, const void* wq, const float* bias, void* 
   return 0;
 }
 
-static void tiled_geometry(TiledGeom& g, int k, int np, int rw, int nt, int* ygrid, bool* w16) {
+static void tiled_geometry(TiledGeom& g, int k, int np, int rw, int nt, int* ygrid, bool* w16, int* wn_out = nullptr) {
   int rwo = rw - (np - 1), JH = np == 2 ? (k + 1) / 2 : k;
   *w16 = (g.W <= 16 && np == 1);
-  if (*w16) { g.TWC = 1; g.TRG = 4; } else if (g.W > 64) { g.TWC = 4; g.TRG = 1; } else if (g.W > 32) { g.TWC = 2; g.TRG = 2; } else { g.TWC = 1; g.TRG = 4; }
+  const int ntt = (g.Cout * np + 31) / 32;
+  // W16 tiles on planes of <= 16 rows with >= 4 channel tiles: two of the four waves take other channel tiles instead of rows >= H
+  static const bool no_wn = getenv("DP_NO_WN") != nullptr;
+  const int wn = (*w16 && nt == 2 && g.H <= 16 && ntt % 4 == 0 && !no_wn) ? 2 : 1;
+  if (wn_out) *wn_out = wn;
+  if (*w16) { g.TWC = 1; g.TRG = 4 / wn; } else if (g.W > 64) { g.TWC = 4; g.TRG = 1; } else if (g.W > 32) { g.TWC = 2; g.TRG = 2; } else { g.TWC = 1; g.TRG = 4; }
   int rpa = *w16 ? 2 : 1;
   g.LR = g.TRG * rwo * rpa + (np - 1) + (np == 2 ? 2 * (JH - 1) : k - 1);
   g.LP = ((*w16 ? 16 : g.TWC * 32) + k - 1 + 7) & ~7;   // multiple of 8: the LDS swizzle bit of a row differs from row 0 by (row * LP/8) & 1
   g.NCH = (g.Cin + 15) / 16; g.NTT = (g.Cout * np + 31) / 32;
   g.tiles_h = cdiv(g.H, g.TRG * rwo * rpa); g.tiles_w = *w16 ? 1 : cdiv(g.W, g.TWC * 32);
-  *ygrid = cdiv(g.NTT, nt);
+  *ygrid = cdiv(g.NTT, nt * wn);
   int64_t blocks = (int64_t)g.N * g.D * g.tiles_h * g.tiles_w * *ygrid;
   g.splitkd = (np == 1 && blocks < 400) ? 1 : 0;         // small volumes: one block per kd, fp32 atomic accumulation
+  // ... and, when even k blocks per tile leave the chip half empty, per share of the input chunks (>= 4 chunks per share)
+  g.chsplit = 1;
+  if (g.splitkd) { while (blocks * k * g.chsplit < 400 && g.NCH / (g.chsplit * 2) >= 4) g.chsplit *= 2; }
 }
 
 // fp32 scratch elements dp_conv3d_tiled needs for this shape (0 = none)
@@ -620,7 +635,7 @@ static int conv3d_tiled_impl(const void* x, int ldx, const void* x2, int ldx2, i
   TiledGeom g;
   g.N = N; g.D = D; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.ldx = ldx; g.ldy = ldy;
   g.x2 = x2; g.ldx2 = ldx2; g.csplit = csplit; g.y2 = y2; g.ldy2 = ldy2; g.osplit = osplit;
-  int ygrid; bool w16; tiled_geometry(g, k, np, rw, nt, &ygrid, &w16);
+  int ygrid; bool w16; int wn; tiled_geometry(g, k, np, rw, nt, &ygrid, &w16, &wn);
   g.x3 = 0;
   if (dtype == DP_X3) {
     if (x2 || Cin % 48 || ldx < 2 * (Cin / 3)) DP_FAIL("conv3d_tiled: a DP_X3 launch takes ONE [x_hi | x_lo] tensor of 2/3 Cin channels (Cin = 3 x a multiple of 16)");
@@ -644,10 +659,12 @@ static int conv3d_tiled_impl(const void* x, int ldx, const void* x2, int ldx2, i
   hipStream_t s = STREAM;
 #define GO(TT, KS_, NP, RW_, NT_, TWP_) rc = x3 ? launch_tiled<bf16_t, KS_, NP, RW_, NT_, TWP_, float>(x, wq, bias, y, ws, g, ygrid, s) \
                                              : launch_tiled<TT, KS_, NP, RW_, NT_, TWP_>(x, wq, bias, y, ws, g, ygrid, s)
+#define GOW2(TT, KS_) rc = x3 ? launch_tiled<bf16_t, KS_, 1, 4, 2, 0, float, 2>(x, wq, bias, y, ws, g, ygrid, s) \
+                              : launch_tiled<TT, KS_, 1, 4, 2, 0, TT, 2>(x, wq, bias, y, ws, g, ygrid, s)
 #define BYTW(TT, KS_, NP, RW_, NT_) do { if (g.TWC == 4) GO(TT, KS_, NP, RW_, NT_, 4); else if (g.TWC == 2) GO(TT, KS_, NP, RW_, NT_, 2); \
                                          else GO(TT, KS_, NP, RW_, NT_, 1); } while (0)
 #define BYCFG(TT, KS_) do { if (np == 2) BYTW(TT, KS_, 2, 9, 1); else if (nt == 1) { if (w16) GO(TT, KS_, 1, 8, 1, 0); else BYTW(TT, KS_, 1, 8, 1); } \
-                            else { if (w16) GO(TT, KS_, 1, 4, 2, 0); else BYTW(TT, KS_, 1, 4, 2); } } while (0)
+                            else { if (w16 && wn == 2) GOW2(TT, KS_); else if (w16) GO(TT, KS_, 1, 4, 2, 0); else BYTW(TT, KS_, 1, 4, 2); } } while (0)
   const bool x3 = dtype == DP_X3;
   if (dtype == DP_BF16 || x3) { if (k == 7) BYCFG(bf16_t, 7); else BYCFG(bf16_t, 3); }
   else if (dtype == DP_F16) { if (k == 7) BYCFG(f16_t, 7); else BYCFG(f16_t, 3); }
@@ -655,6 +672,7 @@ static int conv3d_tiled_impl(const void* x, int ldx, const void* x2, int ldx2, i
   else DP_FAIL("conv3d_tiled: bad dtype");
 #undef BYCFG
 #undef BYTW
+#undef GOW2
 #undef GO
   if (rc) return rc;
   DP_CHECK_LAUNCH("conv3d_tiled"); return 0;
