@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--exact-fp32-leg", action="store_true", help="also time the exact-fp32 MFMA mode (183 ms/step) next to fp32x3")
     ap.add_argument("--own-stream", action="store_true", help="run the timed steps on a non-default (non-blocking) HIP stream")
     ap.add_argument("--fp32-steps", type=int, default=3)
+    ap.add_argument("--seg-mode", default=None, choices=["fp32x3", "fp32", "same"],
+                    help="cascade: mode of the no-grad OAR-TRANSEG forward (default fp32x3: the reference's masks; 'same' = the dose network's storage type)")
     return ap.parse_args()
 
 
@@ -80,6 +82,8 @@ def build_model(args, shape, dev):
     dose_prediction_amd.set_loss_scale(args.loss_scale)
     dose_prediction_amd.set_activation_checkpointing(args.checkpoint)
     dose_prediction_amd.config.set_vit_side_stream(not args.no_side_stream)
+    if getattr(args, "seg_mode", None):
+        dose_prediction_amd.config.set_cascade_seg_mode(args.seg_mode)
     if args.model in ("pyfer", "cascade"):
         # hyper-parameters: DosePrediction/Train/train_light_pyfer.py:73-83
         net = dose_pyfer.Model(in_ch=9, out_ch=1, list_ch_A=[-1, 16, 32, 64, 128, 256], feature_size=16, img_size=shape,
@@ -523,6 +527,15 @@ def main():
             fp32_leg = time_mode("fp32x3", max(args.fp32_steps, 5))
             fp32_leg.update({"dtype": "fp32x3: fp32 storage, bf16 MFMA on split operands (x_hi w_hi + x_lo w_hi + x_hi w_lo), fp32 accumulation",
                              "note": "the fast mode that meets the north-star's 1e-3 / arg-max parity bar (check_vs_oracle.fp32x3)"})
+            # the same mode with single-product weight gradients (config.set_x3_wgrad_terms(1): forward and data gradients unchanged,
+            # weight gradients from bf16-rounded operands) -- a SEPARATE figure, never the fp32x3 number
+            dose_prediction_amd.config.set_x3_wgrad_terms(1)
+            try:
+                w1 = time_mode("fp32x3", max(args.fp32_steps, 5))
+                w1["dtype"] = "fp32x3 forward / data gradients, weight gradients x_hi gy_hi only (bf16-rounded operands, fp32 accumulation)"
+                fp32_leg["wgrad_single_product"] = w1
+            finally:
+                dose_prediction_amd.config.set_x3_wgrad_terms(3)
             if args.exact_fp32_leg:
                 ex = time_mode("fp32", args.fp32_steps)
                 ex["dtype"] = "fp32 storage, v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain)"

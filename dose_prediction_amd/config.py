@@ -171,3 +171,23 @@ def set_cascade_seg_mode(mode):
 
 def cascade_seg_mode():
     return None if _cascade_seg_mode in (None, "same") else _cascade_seg_mode
+
+
+_x3_wgrad_terms = int(os.environ.get("DOSE_HIP_X3_WGRAD_TERMS", "3"))
+
+
+def set_x3_wgrad_terms(n):
+    """fp32x3 mode: number of split products in the WEIGHT gradients.  3 (default): x_hi gy_hi + x_lo gy_hi + x_hi gy_lo, like every
+    other contraction of the mode.  1: x_hi gy_hi only, i.e. the weight gradients (and only they) are formed from bf16-rounded
+    operands with fp32 accumulation -- the forward pass and the data gradients are untouched, so outputs keep their 1e-4 parity; each
+    weight-gradient element picks up an unbiased ~1.6e-3 relative rounding error, below the 4e-3 that separates the exact-fp32 mode
+    from float64 on the same gradients (tools/x3_grad_probe.py).  Saves two thirds of the weight-gradient time (57 instead of
+    68 ms per step); reported separately by bench.py, never as the fp32x3 number."""
+    global _x3_wgrad_terms
+    if n not in (1, 3):
+        raise ValueError("x3 weight-gradient terms must be 1 or 3")
+    _x3_wgrad_terms = n
+
+
+def x3_wgrad_terms():
+    return _x3_wgrad_terms

@@ -1017,18 +1017,24 @@ class Conv3dX3(torch.autograd.Function):
                     gxa = gx[..., :ca]
                     gxb = gx[..., ca:] if cxb == cin - ca else torch.cat((gx[..., ca:], gx.new_zeros((N, D, H, W, cxb - (cin - ca)))), -1)
         if need_w:
-            # S[co][p cp + ci][tap]: blocks p = 0, 1 from (x_hi | x_lo) x gy_hi, block 2 from x_hi x gy_lo
-            S = torch.empty((cout, 3 * cp, taps), dtype=torch.float32, device=dev)
+            from . import config
             wse = max(L.dp_conv3d_wgrad_tiled_ws_elems(2 * cp, cout, k, 1, pad, 1, 1, W), L.dp_conv3d_wgrad_tiled_ws_elems(cp, cout, k, 1, pad, 1, 1, W))
             if not wse:
                 raise _lib.DoseHipError("x3 convolution: weight gradient outside the tiled kernels")
             ws = _zero_scratch(dev, wse)
-            _lib.call("dp_conv3d_wgrad_tiled", _p(xs), 2 * cp, _p(gys), 2 * cpo, _p(S), _p(ws), N, D, H, W, 2 * cp, cout, k,
-                      3 * cp * taps, taps, 1, 1, _stream())
-            _lib.call("dp_conv3d_wgrad_tiled", _p(xs), 2 * cp, gys.data_ptr() + 2 * cpo, 2 * cpo, S.data_ptr() + 4 * 2 * cp * taps, _p(ws),
-                      N, D, H, W, cp, cout, k, 3 * cp * taps, taps, 1, 1, _stream())
             gw = _wgrad_buffer(weight, False)
-            _lib.call("dp_x3_wgrad_combine", _p(S), _p(gw), cout, cin, cp, taps, 3, _stream())
+            if config.x3_wgrad_terms() == 1:
+                # (config.set_x3_wgrad_terms(1)) x_hi x gy_hi only: one bf16 launch straight into dW
+                _lib.call("dp_conv3d_wgrad_tiled", _p(xs), 2 * cp, _p(gys), 2 * cpo, _p(gw), _p(ws), N, D, H, W, cin, cout, k,
+                          cin * taps, taps, 1, 1, _stream())
+            else:
+                # S[co][p cp + ci][tap]: blocks p = 0, 1 from (x_hi | x_lo) x gy_hi, block 2 from x_hi x gy_lo
+                S = torch.empty((cout, 3 * cp, taps), dtype=torch.float32, device=dev)
+                _lib.call("dp_conv3d_wgrad_tiled", _p(xs), 2 * cp, _p(gys), 2 * cpo, _p(S), _p(ws), N, D, H, W, 2 * cp, cout, k,
+                          3 * cp * taps, taps, 1, 1, _stream())
+                _lib.call("dp_conv3d_wgrad_tiled", _p(xs), 2 * cp, gys.data_ptr() + 2 * cpo, 2 * cpo, S.data_ptr() + 4 * 2 * cp * taps, _p(ws),
+                          N, D, H, W, cp, cout, k, 3 * cp * taps, taps, 1, 1, _stream())
+                _lib.call("dp_x3_wgrad_combine", _p(S), _p(gw), cout, cin, cp, taps, 3, _stream())
         if ctx.has_bias and ctx.needs_input_grad[3]:
             if ctx.bias_grad_zero:
                 gb = _zero_bias_grad(ctx.bias_ref)
@@ -1049,6 +1055,21 @@ def _x3_conv_call(xa, xb, weight, bias, stats, bias_grad_zero):
     if stats:
         out[1]._dp_gy_split = gy_split
     return out
+
+
+_X3_SEL = {}
+
+
+def _x3_selector(n, dev):
+    """bf16 vector (1, 0, 1, 1, 0, 1, ...) of length n (n % 3 == 0): block weights that turn the K-stacked [hi | hi | lo] rows of a
+    gradient back into hi + lo."""
+    key = (dev.type, dev.index, n)
+    t = _X3_SEL.get(key)
+    if t is None:
+        if len(_X3_SEL) > 8:
+            _X3_SEL.clear()
+        t = _X3_SEL[key] = torch.tensor([1.0, 0.0, 1.0], dtype=torch.bfloat16, device=dev).repeat(n // 3)
+    return t
 
 
 class LinearX3(torch.autograd.Function):
@@ -1102,8 +1123,22 @@ class LinearX3(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             gw = _wgrad_buffer(weight, False)
             # K-stacked view: row (3 r + p) of the [3 rows][cp] matrix is block p of row r
-            if (ctx.defer and _DEFER["enabled"] and rows <= 16384 and weight.grad is None and (not want_b or ctx.bias_ref.grad is None)):
+            from . import config
+            if config.x3_wgrad_terms() == 1:
+                # gy_hi x_hi only: block 0 of every row of both operands (row pitch 3 cp)
+                if ctx.defer and _DEFER["enabled"] and rows <= 16384 and weight.grad is None and (not want_b or ctx.bias_ref.grad is None):
+                    _defer_wgrad(gys, 3 * cpo, xs, 3 * cp, gw, None, nout, K, rows)
+                else:
+                    _lib.call("dp_gemm_tn", _p(gys), 3 * cpo, _p(xs), 3 * cp, _p(gw), K, nout, K, rows, 1, 1, _stream())
+            elif (ctx.defer and _DEFER["enabled"] and rows <= 16384 and weight.grad is None and (not want_b or ctx.bias_ref.grad is None)):
                 _defer_wgrad(gys, cpo, xs, cp, gw, None, nout, K, 3 * rows)
+                if want_b:
+                    # the bias gradient joins the grouped launch as one more (N = 1) problem: column sums of gy = gy''^T s with the
+                    # K-stacked selector s = (1, 0, 1) per row: hi + lo of every row (the kernel's own column sum of the stacked
+                    # operand would be 2 hi + lo)
+                    gb = torch.empty((nout,), dtype=torch.float32, device=dev)
+                    _defer_wgrad(gys, cpo, _x3_selector(3 * rows, dev), 1, gb, None, nout, 1, 3 * rows)
+                    want_b = False
             else:
                 tiles = -(-nout // 64) * -(-K // 64)
                 sk = max(1, min(3 * rows // 512, 512 // tiles)) if tiles < 256 else 1

@@ -5,8 +5,11 @@ o=gpurun_out/${tag}_bench_line
 python bench.py > ${o}.json 2> ${o}.err
 python bench.py --model transeg > ${o}_transeg.json 2>> ${o}.err
 python bench.py --model cascade --no-cpu-baseline > ${o}_cascade.json 2>> ${o}.err
+python bench.py --model cascade --no-cpu-baseline --seg-mode same > ${o}_cascade_segsame.json 2>> ${o}.err
 python bench.py --dtype fp16 > ${o}_fp16.json 2>> ${o}.err
 python bench.py --graph --no-cpu-baseline --no-fp32-leg > ${o}_graph.json 2>> ${o}.err
 python bench.py --model cascade --dtype fp16 --size 192 192 128 --batch 1 --roi 96 --checkpoint --loss-scale 1024 --no-cpu-baseline > ${o}_c5.json 2>> ${o}.err
+python bench.py --model cascade --dtype fp16 --size 192 192 128 --batch 1 --roi 96 --checkpoint --loss-scale 1024 --no-cpu-baseline --seg-mode same > ${o}_c5_segsame.json 2>> ${o}.err
+python bench.py --dtype fp32x3 --no-cpu-baseline > ${o}_fp32x3.json 2>> ${o}.err
 for f in ${o}*.json; do echo "$f: $(python tools/show_bench.py $f 2>/dev/null | head -1)"; done
 tail -5 ${o}.err
