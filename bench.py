@@ -513,6 +513,7 @@ def main():
             params = [p for p in net.parameters() if p.requires_grad]
             opt = FusedAdam(params, lr=1e-4, weight_decay=3e-5, betas=(0.9, 0.999), eps=1e-8, amsgrad=True)
             step()
+            step()
             sync()
             ts = []
             for _ in range(nsteps):
