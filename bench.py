@@ -55,6 +55,7 @@ def parse():
     ap.add_argument("--exact-fp32-leg", action="store_true", help="also time the exact-fp32 MFMA mode (183 ms/step) next to fp32x3")
     ap.add_argument("--own-stream", action="store_true", help="run the timed steps on a non-default (non-blocking) HIP stream")
     ap.add_argument("--fp32-steps", type=int, default=3)
+    ap.add_argument("--no-branch-stream", action="store_true", help="3x3x3 branches / small skip blocks on the main stream (A/B)")
     ap.add_argument("--seg-mode", default=None, choices=["fp32x3", "fp32", "same"],
                     help="cascade: mode of the no-grad OAR-TRANSEG forward (default fp32x3: the reference's masks; 'same' = the dose network's storage type)")
     return ap.parse_args()
@@ -82,6 +83,8 @@ def build_model(args, shape, dev):
     dose_prediction_amd.set_loss_scale(args.loss_scale)
     dose_prediction_amd.set_activation_checkpointing(args.checkpoint)
     dose_prediction_amd.config.set_vit_side_stream(not args.no_side_stream)
+    if getattr(args, "no_branch_stream", False) or args.no_side_stream:
+        dose_prediction_amd.config.set_branch_stream(False)
     if getattr(args, "seg_mode", None):
         dose_prediction_amd.config.set_cascade_seg_mode(args.seg_mode)
     if args.model in ("pyfer", "cascade"):
@@ -566,7 +569,8 @@ def main():
                        "optimizer": (type(opt).__name__ + "(amsgrad)") if opt is not None else None,
                        "launch": "hipGraph replay" if graph is not None else "eager",
                        "activation_checkpointing": bool(args.checkpoint), "loss_scale": args.loss_scale,
-                       "vit_side_stream": not args.no_side_stream, "peak_memory_gib": peak_mem,
+                       "vit_side_stream": not args.no_side_stream, "branch_stream": __import__("dose_prediction_amd").config.branch_stream(),
+                       "peak_memory_gib": peak_mem,
                        "grad_exchange_dtype": args.grad_dtype if ddp_on else None,
                        "cascade_segmentation_mode": (__import__("dose_prediction_amd").config.cascade_seg_mode() or args.dtype) if args.model == "cascade" else None,
                        "final_loss": final_loss},

@@ -11,6 +11,17 @@ import torch.nn as nn
 from . import config, ops
 
 
+_BRANCH_STREAMS = {}
+
+
+def _branch_side_stream(device, main):
+    key = (device.index, main.cuda_stream)
+    st = _BRANCH_STREAMS.get(key)
+    if st is None:
+        st = _BRANCH_STREAMS[key] = torch.cuda.Stream(device=device)
+    return st
+
+
 def _act_name(act):
     return "relu" if act == "relu" else "mish"
 
@@ -129,7 +140,21 @@ class conv_3_1(nn.Module):
 
     def forward(self, x):
         """x: tensor or (a, b) pair = virtual torch.cat (the two first convolutions then read the operands directly)."""
-        r3, r7 = self.conv_3[0](x), self.conv_7[0](x)
+        first = x[0] if isinstance(x, (tuple, list)) else x
+        if config.branch_stream() and first.is_cuda and not torch.cuda.is_current_stream_capturing():
+            # the latency- / fabric-bound 3x3x3 branch on a second stream beside the MFMA-bound 7x7x7 branch
+            main = torch.cuda.current_stream(first.device)
+            side = _branch_side_stream(first.device, main)
+            side.wait_stream(main)
+            for t in (x if isinstance(x, (tuple, list)) else (x,)):
+                t.record_stream(side)
+            with torch.cuda.stream(side):
+                r3 = self.conv_3[0](x)
+            r7 = self.conv_7[0](x)
+            main.wait_stream(side)
+            r3.record_stream(main)
+        else:
+            r3, r7 = self.conv_3[0](x), self.conv_7[0](x)
         if r3.shape[-1] % 8 == 0:       # both branches normalised straight into the halves of the mixer's input (no cat copy)
             x37 = ops.norm_act_cat(r3, r7, act=self._act)
         else:

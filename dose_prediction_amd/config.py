@@ -191,3 +191,19 @@ def set_x3_wgrad_terms(n):
 
 def x3_wgrad_terms():
     return _x3_wgrad_terms
+
+
+_branch_stream = os.environ.get("DOSE_HIP_BRANCH_STREAM", "1") != "0"
+
+
+def set_branch_stream(on):
+    """Run the 3x3x3 branch of every multi-scale block (blocks_MDUNet.conv_3_1: conv_3 || conv_7 on the same input) on a second HIP
+    stream beside its 7x7x7 branch, and the 64^3 .. 16^3 up-sampling blocks of the encoder (skip2..4 / encoder2..4) beside the 128^3
+    block, forward and (through autograd's stream bookkeeping) backward.  On by default (DOSE-PYFER step 26.4 -> 25.5 ms, OAR-TRANSEG
+    24.0 -> 23.4); env DOSE_HIP_BRANCH_STREAM=0 / set_branch_stream(False) keeps those kernels on the caller's stream."""
+    global _branch_stream
+    _branch_stream = bool(on)
+
+
+def branch_stream():
+    return _branch_stream

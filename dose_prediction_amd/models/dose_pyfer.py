@@ -124,6 +124,44 @@ def run_vit_beside(vit, x_in, first=None, first_inputs=()):
     return _SideRun(z, hidden, events, side, main, part if first is not None else None), out
 
 
+class small_blocks_beside:
+    """Context for the 64^3 .. 16^3 up-sampling blocks that hang off the transformer's hidden states (UnetrPrUpBlock skip2..4 /
+    encoder2..4): with config.branch_stream() they run on a third HIP stream beside the 128^3 block of the main stream (their small
+    grids leave most of the chip idle); `join(*outs)` inside the context hands their results back to the caller's stream.  Without the
+    switch (or under a CU partition) it is run.beside()."""
+
+    def __init__(self, x_in, run):
+        from .. import config
+        self.run = run
+        self.on = bool(config.branch_stream() and x_in.is_cuda and run.side is not None and run.part is None
+                       and not torch.cuda.is_current_stream_capturing())
+        self.dev = x_in.device
+
+    def __enter__(self):
+        if not self.on:
+            self.ctx = self.run.beside()
+            self.ctx.__enter__()
+            return lambda *outs: None
+        from ..blocks import _branch_side_stream
+        self.main = torch.cuda.current_stream(self.dev)
+        self.side = _branch_side_stream(self.dev, self.main)
+        self.side.wait_stream(self.main)
+        self.ctx = torch.cuda.stream(self.side)
+        self.ctx.__enter__()
+
+        def join(*outs):
+            self.outs = outs
+        return join
+
+    def __exit__(self, *a):
+        r = self.ctx.__exit__(*a)
+        if self.on and a[0] is None:
+            self.main.wait_stream(self.side)
+            for o in getattr(self, "outs", ()):
+                o.record_stream(self.main)
+        return r
+
+
 class ViTEncoder(nn.Module):
     """dose_pyfer.ViTEncoder (22-144)."""
 
@@ -164,10 +202,11 @@ class ViTEncoder(nn.Module):
         """x_cat: optional (a, b) pair with cat((a, b)) == x_in (virtual concat for skip1's 3x3x3 convolution)."""
         i = self.num_layers // 4
         run, out_encoder_1 = run_vit_beside(self.vit, x_in, lambda: self.skip1(x_in, x_cat), x_cat or ())
-        with run.beside():
+        with small_blocks_beside(x_in, run) as join:
             out_encoder_2 = self.skip2(self.proj_feat(run.hidden(i)))
             out_encoder_3 = self.skip3(self.proj_feat(run.hidden(i * 2)))
             out_encoder_4 = self.skip4(self.proj_feat(run.hidden(i * 3)))
+            join(out_encoder_2, out_encoder_3, out_encoder_4)
         out_encoder_5 = self.proj_feat(run.final(out_encoder_1, out_encoder_2, out_encoder_3, out_encoder_4))
         return [out_encoder_1, out_encoder_2, out_encoder_3, out_encoder_4, out_encoder_5]
 

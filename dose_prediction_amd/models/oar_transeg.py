@@ -7,7 +7,7 @@ import torch.nn as nn
 from ..blocks import ViT, UnetrBasicBlock, UnetrPrUpBlock
 from .base_blocks import ModifiedUnetrUpBlock, ModifiedUnetOutBlock
 from .c3d import to_ndhwc, from_ndhwc
-from .dose_pyfer import ensure_tuple_rep, run_vit_beside
+from .dose_pyfer import ensure_tuple_rep, run_vit_beside, small_blocks_beside
 
 
 class Model(nn.Module):
@@ -53,10 +53,11 @@ class Model(nn.Module):
 
     def forward_ndhwc(self, x_in):
         run, enc1 = run_vit_beside(self.vit, x_in, lambda: self.encoder1(x_in))   # the transformer on a second HIP stream
-        with run.beside():
+        with small_blocks_beside(x_in, run) as join:
             enc2 = self.encoder2(self.proj_feat(run.hidden(3)))
             enc3 = self.encoder3(self.proj_feat(run.hidden(6)))
             enc4 = self.encoder4(self.proj_feat(run.hidden(9)))
+            join(enc2, enc3, enc4)
         dec3 = self.decoder5(self.proj_feat(run.final(enc1, enc2, enc3, enc4)), enc4)
         dec2 = self.decoder4(dec3, enc3)
         dec1 = self.decoder3(dec2, enc2)

@@ -874,6 +874,7 @@ def _split_conv_input(xa, ca, xb, cb, cp):
            None if xb is None else (xb.data_ptr(), xb._version, tuple(xb.shape), xb.stride()), torch.cuda.current_stream().cuda_stream)
     ent = _SPLIT_LAST[0]
     if ent is not None and ent[0] == key and ent[1]() is xa and (xb is None or ent[2]() is xb):
+        _SPLIT_LAST[0] = None             # (the pattern is exactly two consumers: do not keep half a gigabyte alive beyond the second)
         return ent[3]
     xs = split_rows(xa, ca, xb, cb, cp, 2, 0b10)
     _SPLIT_LAST[0] = (key, weakref.ref(xa), None if xb is None else weakref.ref(xb), xs)
@@ -908,6 +909,12 @@ def _x3_conv_ok(xa, xb, weight, stride, pad, dil):
 # gradient tensors handed over in split form (NormAct.backward -> Conv3dX3.backward), keyed by address: a cheap handshake that the
 # fp32-typed tensor arriving at the convolution really holds [gy_hi | gy_lo]
 _GY_SPLIT_SENT = {}
+_GY_SPLIT_CB = [False]
+
+
+def _gy_split_reset():
+    _GY_SPLIT_SENT.clear()
+    _GY_SPLIT_CB[0] = False
 
 
 class Conv3dX3(torch.autograd.Function):
@@ -1532,6 +1539,11 @@ class NormAct(torch.autograd.Function):
                                                  split_cp=x.shape[-1] if ctx.grad_split else 0)
         if ctx.grad_split and gx is not None:
             gx = gx.view(torch.float32)                   # [gx_hi | gx_lo] bf16 data in an fp32 tensor of x's shape
+            if not _GY_SPLIT_CB[0]:
+                # (entries are consumed by the convolution's backward node a moment later; whatever an interrupted pass leaves
+                # behind is dropped when the engine finishes)
+                _GY_SPLIT_CB[0] = True
+                torch.autograd.Variable._execution_engine.queue_callback(_gy_split_reset)
             _GY_SPLIT_SENT[gx.data_ptr()] = True
         return gx, None, dgamma, dbeta, None, None, None, gres, None, None, None, None, None, None
 

@@ -523,6 +523,48 @@ def test_cu_partitioned_branches_match_the_single_stream_result():
             assert cmp_prefix(outs[tag][1][n].cpu(), outs["ref"][1][n].cpu()) < 1e-4, (tag, n)
 
 
+def test_branch_streams_match_the_single_stream_result():
+    """config.set_branch_stream (on by default since round 3): the 3x3x3 branch of every multi-scale block and the small up-sampling
+    blocks of the encoder run on a further HIP stream beside the 7x7x7 branch / the 128^3 block.  Same outputs and gradients as with
+    everything on one stream -- on the default stream and on a user stream, bf16 included, repeated so that a missing event or an
+    allocator reuse across streams would show as a difference between the repetitions."""
+    import contextlib
+    import dose_prediction_amd
+    from dose_prediction_amd.models.dose_pyfer import MainSubsetModel
+    dev = _dev()
+    g = load_golden("g7_subset_multi")
+    user = torch.cuda.Stream()
+    for dtype, otol, gtol in ((torch.float32, 1e-5, 1e-4), (torch.bfloat16, 2e-2, 5e-2)):
+        _set(dtype)
+        outs = {}
+        try:
+            for tag, branch, side, stream in (("ref", False, False, None), ("on", True, True, None), ("on2", True, True, None), ("user", True, True, user)):
+                dose_prediction_amd.config.set_branch_stream(branch)
+                dose_prediction_amd.config.set_vit_side_stream(side)
+                net = MainSubsetModel(in_ch=5, out_ch=1, img_size=(32, 16, 16), feature_size=4, hidden_size=48, mlp_dim=96, num_heads=6,
+                                      num_layers=8, act="mish", mode_multi_dec=True, multiS_conv=True)
+                _load(net, pcg_state_dict(g["keys"], g["shapes"], g["seed"])).to(dev).train()
+                x, rs = g["x"].to(dev), [g[f"r{i}"].to(dev) for i in range(4)]
+                torch.cuda.synchronize()
+                with (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()):
+                    for _ in range(2):           # second pass: every buffer of the first one has been through the caching allocator
+                        net.zero_grad(set_to_none=True)
+                        o = net(x)
+                        torch.autograd.backward(o, rs)
+                torch.cuda.synchronize()
+                outs[tag] = ([t.detach().clone() for t in o], {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None})
+        finally:
+            dose_prediction_amd.config.set_branch_stream(True)
+            dose_prediction_amd.config.set_vit_side_stream(True)
+            _set(torch.float32)
+        for tag in ("on", "on2", "user"):
+            for a, b in zip(outs[tag][0], outs["ref"][0]):
+                assert rel_err(a.cpu(), b.cpu()) < otol, (dtype, tag)
+            assert outs[tag][1].keys() == outs["ref"][1].keys()
+            for n in outs["ref"][1]:
+                assert cmp_prefix(outs[tag][1][n].cpu(), outs["ref"][1][n].cpu()) < gtol, (dtype, tag, n)
+
+
 def test_host_running_ahead_of_the_gpu_does_not_corrupt_pointer_tables():
     """The fused Adam step and the grouped transformer weight-gradient launch read pointer tables that the host writes into PINNED
     buffers and copies asynchronously.  bench.py never synchronises between steps, so the host runs several steps ahead of the GPU;
