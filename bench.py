@@ -459,6 +459,28 @@ def main():
     sync()
     records, _lib.PROFILE = _lib.PROFILE, None
     prof_steps = 1
+    # the same per-kernel timing with every kernel alone on the chip (no second / third stream): under the default configuration
+    # the 7x7x7 launches share the CUs with the 3x3x3 branch and the transformer, so their in-step durations are longer than the
+    # kernel's own -- the step is shorter, the per-launch figure is not comparable with a roofline.  Both are reported.
+    records_serial = None
+    import dose_prediction_amd as _dpa
+    if _dpa.config.branch_stream() or _dpa.config.vit_side_stream():
+        bs, vs = _dpa.config.branch_stream(), _dpa.config.vit_side_stream()
+        _dpa.config.set_branch_stream(False)
+        _dpa.config.set_vit_side_stream(False)
+        try:
+            step()
+            sync()
+            _lib.PROFILE = []
+            step()
+            sync()
+            records_serial, _lib.PROFILE = _lib.PROFILE, None
+        finally:
+            _lib.PROFILE = None
+            _dpa.config.set_branch_stream(bs)
+            _dpa.config.set_vit_side_stream(vs)
+        step()
+        sync()
     if use_graph:
         try:
             if opt is not None:
@@ -552,6 +574,8 @@ def main():
         prof = summarize_profile(records, prof_steps)
         peak = PEAK_BF16_TFLOPS if args.dtype in ("bf16", "fp16", "fp32x3") else PEAK_F32_TFLOPS
         dom = prof.get("conv7x7x7_tiled", prof.get("conv7x7x7_generic", {"tflops": 0.0, "avg_launch_ms": 0.0, "launches_per_step": 0}))
+        prof_serial = summarize_profile(records_serial, 1) if records_serial else None
+        dom_serial = (prof_serial or {}).get("conv7x7x7_tiled")
         default_cfg = args.model == "pyfer" and args.dtype == "bf16" and tuple(shape) == (128, 128, 128) and B == 2
         traffic, traffic_src = pmc_traffic(("k_conv_tiled<unsigned short, 7,", "k_conv_cc16<unsigned short, 7,")) if default_cfg else (None, None)
         res = {
@@ -578,8 +602,15 @@ def main():
                          "achieved": dom["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": dom["tflops"] / peak,
                          "traffic": traffic, "traffic_unit": "bytes/launch (fabric reads x2-corrected + writes, PMC)",
                          "traffic_source": traffic_src, "avg_launch_ms": dom["avg_launch_ms"],
-                         "launches_per_step": dom["launches_per_step"]},
+                         "launches_per_step": dom["launches_per_step"],
+                         "note": "achieved / frac: HIP events around the launches of a step in the shipped configuration, where these kernels share "
+                                 "the chip with the 3x3x3 branch and the transformer on other streams; *_serial: the same launches with every "
+                                 "kernel alone on the chip (one stream)",
+                         "achieved_serial": dom_serial["tflops"] if dom_serial else None,
+                         "frac_serial": (dom_serial["tflops"] / peak) if dom_serial else None,
+                         "avg_launch_ms_serial": dom_serial["avg_launch_ms"] if dom_serial else None},
             "kernels": prof,
+            "kernels_serial": prof_serial,
         }
         if fp32_leg is not None:
             res["fp32_mode"] = fp32_leg
