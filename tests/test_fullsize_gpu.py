@@ -501,3 +501,46 @@ def test_pyfer_128_one_rank_rccl_every_bucket_is_exchanged_inside_backward():
     finally:
         dist.destroy_process_group()
         dose_prediction_amd.set_compute_dtype(torch.float32)
+
+
+def test_pyfer_training_steps_128_fp32x3():
+    """BASELINE.json configs[1] geometry in the fp32x3 mode (fp32 storage, split-bf16 matrix-core arithmetic): three full training
+    steps at 2 x 128^3 -- the production branches of the x3 path (DP_X3 launches of k_conv_cc16 / k_conv_tiled with x_hi slabs swept
+    twice, K-along-H weight gradients on 2 Cin x Cout problems, split operands written by the normalisation kernels, grouped
+    Linear gradients with the K-stacked bias selector, packed copies written by Adam) run, stay finite and reduce the loss; the first
+    step's loss equals the bf16 run's to storage precision (same weights, same data)."""
+    import dose_prediction_amd
+    from dose_prediction_amd import losses, synth
+    from dose_prediction_amd.models import dose_pyfer
+    from dose_prediction_amd.optim import FusedAdam
+    dev = _dev()
+    first = {}
+    try:
+        for mode in ("fp32x3", torch.bfloat16):
+            dose_prediction_amd.set_compute_dtype(mode)
+            torch.manual_seed(4321)
+            net = dose_pyfer.Model(in_ch=9, out_ch=1, list_ch_A=[-1, 16, 32, 64, 128, 256], feature_size=16, img_size=S, num_layers=8,
+                                   num_heads=6, act="mish").to(dev).train()
+            for prm in list(net.net_A.parameters()) + list(net.conv_out_A.parameters()):
+                prm.requires_grad_(False)
+            opt = FusedAdam([q for q in net.parameters() if q.requires_grad], lr=1e-4, weight_decay=3e-5, amsgrad=True)
+            x, gt = synth.dose_input(2, S).to(dev), synth.dose_target(2, S).to(dev)
+            hist = []
+            for _ in range(3 if mode == "fp32x3" else 1):
+                opt.zero_grad(set_to_none=True)
+                out = net(x)
+                loss = losses.gen_loss(out, gt, 10.0, 1.0, casecade=True, freez=True)
+                loss.backward()
+                assert all(torch.isfinite(q.grad).all() for q in net.parameters() if q.grad is not None)
+                opt.step()
+                hist.append(loss.item())
+            first[str(mode)] = hist[0]
+            if mode == "fp32x3":
+                assert all(h == h and h < 1e4 for h in hist) and hist[-1] < hist[0], hist
+                assert not opt.found_inf()
+            del net, opt
+            torch.cuda.empty_cache()
+        a, b = first["fp32x3"], first[str(torch.bfloat16)]
+        assert abs(a - b) < 5e-2 * abs(a), first
+    finally:
+        dose_prediction_amd.set_compute_dtype(torch.float32)
