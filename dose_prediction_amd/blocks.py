@@ -323,33 +323,55 @@ class UnetrUpBlock(nn.Module):
 
 # ------------------------------------------------------------------------------------------------ ViT (MONAI 0.7.0 semantics)
 class PatchEmbeddingBlock(nn.Module):
-    """MONAI PatchEmbeddingBlock(pos_embed='perceptron'): keys patch_embeddings.1.{weight,bias},
-    position_embeddings, cls_token."""
+    """MONAI PatchEmbeddingBlock: pos_embed='perceptron' (keys patch_embeddings.1.{weight,bias}; every reference call site) or
+    'conv' (keys patch_embeddings.{weight,bias}; the constructor default of oar_transeg.Model); position_embeddings, cls_token."""
 
     def __init__(self, in_channels, img_size, patch_size, hidden_size, num_heads, pos_embed, dropout_rate=0.0, spatial_dims=3):
         super().__init__()
-        if pos_embed != "perceptron":
-            raise ValueError("HIP path implements pos_embed='perceptron' (the reference's setting, dose_pyfer.py:273)")
+        if pos_embed not in ("perceptron", "conv"):
+            raise ValueError(f"pos_embed should be 'conv' or 'perceptron', got {pos_embed!r}")
         n_patches = 1
         for i, p in zip(img_size, patch_size):
             if i % p:
                 raise ValueError("img_size must be divisible by patch_size")
             n_patches *= i // p
-        self.in_channels, self.patch = in_channels, patch_size[0]
+        self.in_channels, self.patch, self.pos_embed = in_channels, patch_size[0], pos_embed
         patch_dim = in_channels * patch_size[0] * patch_size[1] * patch_size[2]
-        self.patch_embeddings = nn.Sequential(nn.Identity(), nn.Linear(patch_dim, hidden_size))
+        if pos_embed == "conv":
+            # MONAI: Conv3d(kernel = stride = patch) then flatten(2).transpose(-1, -2); keys patch_embeddings.{weight,bias}; default
+            # Conv3d initialisation (MONAI's _init_weights only touches Linear / LayerNorm).  It is the SAME contraction as the
+            # perceptron variant with the weight's input axes in (c, p1, p2, p3) instead of (p1, p2, p3, c) order.
+            self.patch_embeddings = nn.Conv3d(in_channels, hidden_size, kernel_size=patch_size[0], stride=patch_size[0])
+            lin = self.patch_embeddings
+        else:
+            self.patch_embeddings = nn.Sequential(nn.Identity(), nn.Linear(patch_dim, hidden_size))
+            lin = self.patch_embeddings[1]
         self.position_embeddings = nn.Parameter(torch.zeros(1, n_patches, hidden_size))
         self.cls_token = nn.Parameter(torch.zeros(1, 1, hidden_size))
         nn.init.trunc_normal_(self.position_embeddings, mean=0.0, std=0.02, a=-2.0, b=2.0)
-        lin = self.patch_embeddings[1]
-        nn.init.trunc_normal_(lin.weight, mean=0.0, std=0.02, a=-2.0, b=2.0)
-        nn.init.zeros_(lin.bias)
+        if pos_embed == "perceptron":
+            nn.init.trunc_normal_(lin.weight, mean=0.0, std=0.02, a=-2.0, b=2.0)
+            nn.init.zeros_(lin.bias)
         # the patch embedding is the transformer's first layer = its LAST backward node: once its gradient is in place, the grouped
         # launch fills every transformer weight gradient recorded during the backward pass (ops.flush_deferred), still on the ViT stream
         lin.bias.register_post_accumulate_grad_hook(ops.flush_deferred)
         lin.weight.register_post_accumulate_grad_hook(ops.flush_deferred)
 
+    def _forward_conv(self, x):
+        """pos_embed='conv': the Linear of the perceptron variant with the convolution weight viewed in the patchify order
+        (p1, p2, p3, c); the permuted copy is a torch op (autograd returns the gradient in the parameter's own layout).  The
+        transformer of OAR-TRANSEG has one input channel (3.1 M weight elements), so the copy is negligible there."""
+        conv = self.patch_embeddings
+        w2 = conv.weight.permute(0, 2, 3, 4, 1).reshape(conv.out_channels, -1)
+        tok = ops.patchify(x, self.in_channels, self.patch)
+        rows = tok.shape[0] * tok.shape[1]
+        splitk = max(1, min(32, 480 // max(1, -(-rows // 128) * -(-conv.out_channels // 128))))
+        t = ops.linear(tok, w2, conv.bias, splitk=splitk if tok.shape[-1] >= 4096 else 1)
+        return ops.add_broadcast(t, self.position_embeddings)
+
     def forward(self, x):
+        if self.pos_embed == "conv":
+            return self._forward_conv(x)
         lin = self.patch_embeddings[1]
         if config.x3() and x.dtype == torch.float32 and not x.requires_grad:
             # fp32x3: split the voxels once, patchify the bf16 halves straight into the GEMM's operand blocks (no fp32 token matrix)

@@ -162,8 +162,15 @@ def vit(sd, p, x, num_layers, num_heads):
     """MONAI 0.7.0 ViT(pos_embed='perceptron', classification=False): patchify -> Linear ->
     + position_embeddings -> num_layers pre-norm TransformerBlocks -> LayerNorm.
     Returns (normed last state, [output of every block])."""
-    t = R.linear(R.patchify(x), sd[p + "patch_embedding.patch_embeddings.1.weight"],
-                 sd[p + "patch_embedding.patch_embeddings.1.bias"])
+    if p + "patch_embedding.patch_embeddings.weight" in sd:
+        # pos_embed='conv' (the constructor default of oar_transeg.Model, oar_transeg.py:28): Conv3d(kernel = stride = patch), then
+        # flatten(2).transpose(-1, -2)  [MONAI 0.7.0 PatchEmbeddingBlock; parity unpinned like every MONAI leaf]
+        w = sd[p + "patch_embedding.patch_embeddings.weight"]
+        t = R.conv3d(x, w, sd[p + "patch_embedding.patch_embeddings.bias"], w.shape[2], 0, 1)
+        t = t.flatten(2).transpose(-1, -2)
+    else:
+        t = R.linear(R.patchify(x), sd[p + "patch_embedding.patch_embeddings.1.weight"],
+                     sd[p + "patch_embedding.patch_embeddings.1.bias"])
     t = R.store(t + R.store_weight(sd[p + "patch_embedding.position_embeddings"]))
     hidden = []
     for i in range(num_layers):

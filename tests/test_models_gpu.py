@@ -195,6 +195,44 @@ def test_g7_transeg(tag):
     _check_grads(net, sub(g, "grad"), tol=GRAD_TOL if tag == "new" else 1e-2)
 
 
+def test_transeg_default_conv_patch_embedding():
+    """oar_transeg.Model's own constructor default pos_embed="conv" (oar_transeg.py:28; MONAI PatchEmbeddingBlock: Conv3d with
+    kernel = stride = patch, flatten, transpose): state_dict keys patch_embeddings.{weight,bias} in MONAI's layout, forward and
+    backward against the oracle's restatement (torch conv3d), fp32 and fp32x3."""
+    import dose_prediction_amd
+    from dose_prediction_amd.models import oar_transeg
+    dev = _dev()
+    torch.manual_seed(3)
+    net = oar_transeg.Model(in_channels=1, out_channels=8, img_size=(32, 16, 16), feature_size=8, hidden_size=48, mlp_dim=96, num_heads=12)
+    keys = list(net.state_dict().keys())
+    assert "vit.patch_embedding.patch_embeddings.weight" in keys and "vit.patch_embedding.patch_embeddings.1.weight" not in keys
+    assert tuple(net.state_dict()["vit.patch_embedding.patch_embeddings.weight"].shape) == (48, 1, 16, 16, 16)
+    sd64 = {k: (v.detach().double().requires_grad_(v.dtype.is_floating_point and "running" not in k) if v.dtype.is_floating_point else v)
+            for k, v in net.state_dict().items()}
+    x = torch.randn((2, 1, 32, 16, 16), generator=torch.Generator().manual_seed(5))
+    r = torch.randn((2, 8, 32, 16, 16), generator=torch.Generator().manual_seed(6))
+    ref = oracle.oar_transeg(sd64, x.double(), num_heads=12, training=True)
+    ref.backward(r.double())
+    gw = sd64["vit.patch_embedding.patch_embeddings.weight"].grad
+    net.to(dev).train()
+    for mode in (torch.float32, "fp32x3"):
+        _set(mode)
+        try:
+            net.zero_grad(set_to_none=True)
+            y = net(x.to(dev))
+            assert rel_err(y.cpu(), ref.detach()) < OUT_TOL, mode
+            y.backward(r.to(dev))
+            got = net.vit.patch_embedding.patch_embeddings.weight.grad
+            # (2e-2: this gradient runs back through twelve transformer layers and the whole decoder of a tiny random network, where a
+            # handful of ReLU gates within round-off of zero move it by 0.1-0.6 % from run to run (split-kd atomics); a wrong axis
+            # order in the permuted weight view would be an O(1) error)
+            assert got.shape == gw.shape and rel_l2(got.cpu(), gw) < 2e-2, mode
+        finally:
+            _set(torch.float32)
+    with pytest.raises(ValueError):
+        oar_transeg.Model(in_channels=1, out_channels=8, img_size=(32, 16, 16), pos_embed="sincos")
+
+
 def test_cascade_glue():
     """TRANSEG -> arg-max -> one-hot -> axis reversal -> cat(ptv, oars, ct) -> PYFER -> mask/clip x70
     (train_light_linked_model.py:143-173) against the oracle.  The dose comparison feeds the ORACLE dose network with the
