@@ -210,6 +210,24 @@ __device__ __forceinline__ float act_bwd(float z, int act) {
   }
 }
 
+// Normalise + activate in the CONSUMER's staging (round 3; forward-only networks: the frozen C3D U-Net of DOSE-PYFER, c3d.py:11-38):
+// an input operand may be the PRE-normalisation output x_pre of the convolution in front; the staging path then stores
+// act(x_pre * scale[n][c] + shift[n][c]) into LDS (scale = rstd * gamma, shift = beta - mean * scale from dp_stats_finalize_ss), so
+// the normalised tensor is never written to or read from HBM.  Positions outside the volume stay zero (the padding pads the
+// normalised tensor).  16-bit storage, 3x3x3, fast (aligned, whole-chunk) staging only; ReLU / LeakyReLU / none.
+struct ConvPro { const float* sc; const float* sh; int ns; int act; };       // ns: elements between samples (0: one set for all)
+template <typename T>
+__device__ __forceinline__ v4u pro_apply(v4u t, const float* sc, const float* sh, int act) {
+  union { v4u raw; T e[8]; } w; w.raw = t;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    float z = ld_f(&w.e[i]) * sc[i] + sh[i];
+    z = act == DP_ACT_RELU ? fmaxf(z, 0.f) : (act == DP_ACT_LRELU ? (z >= 0.f ? z : 0.01f * z) : z);
+    st_f(&w.e[i], z);
+  }
+  return w.raw;
+}
+
 // conv_wgrad_hk.hip: weight gradient of the <= 16-output-channel 7x7x7 layers with K along H (shares the tap-major scratch and the
 // unpack kernel of dp_conv3d_wgrad_tiled2, which dispatches to it)
 struct WgHkGeom {
@@ -232,7 +250,8 @@ int cc16_pack(const float* w, void* dst, int Cout, int Cin, int k, int tf, int d
 int cc16_stat_blocks(int D, int H, int W);
 bool cc16_wide(const void* y, int ldy, const void* y2, int ldy2, int osplit, int dtype);
 int cc16_launch(const void* x, int ldx, const void* x2, int ldx2, int csplit, const void* wq, const float* bias, void* y, int ldy,
-                void* y2, int ldy2, int osplit, float* stat_part, int N, int D, int H, int W, int Cin, int Cout, int k, int dtype, hipStream_t s);
+                void* y2, int ldy2, int osplit, float* stat_part, int N, int D, int H, int W, int Cin, int Cout, int k, int dtype, hipStream_t s,
+                const ConvPro* pro1 = nullptr, const ConvPro* pro2 = nullptr);
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline int roundup8(int c) { return (c + 7) & ~7; }

@@ -164,7 +164,9 @@ __device__ __forceinline__ void combine_partials(const float* __restrict__ part,
 }
 
 __global__ void __launch_bounds__(256) k_stats_finalize(const float* __restrict__ part, int N, int nblk, int C, int64_t V, int batch_mode, float eps,
-                                                        float* mean, float* rstd, float* rmean, float* rvar, float momentum, int cpb) {
+                                                        float* mean, float* rstd, float* rmean, float* rvar, float momentum, int cpb,
+                                                        const float* __restrict__ gamma = nullptr, const float* __restrict__ beta = nullptr,
+                                                        float* sc = nullptr, float* sh = nullptr, int cpad = 0) {
   __shared__ double red[512];
   const int gidx = blockIdx.y, c0 = blockIdx.x * cpb;
   const int n0 = batch_mode ? 0 : gidx, n1 = batch_mode ? N : gidx + 1;
@@ -176,6 +178,10 @@ __global__ void __launch_bounds__(256) k_stats_finalize(const float* __restrict_
   double m = s1 / cnt, var = s2 / cnt - m * m;
   if (var < 0) var = 0;
   mean[gidx * C + c] = (float)m; rstd[gidx * C + c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (sc) {   // z = x * sc + sh, the form the fused normalise kernels and the convolution prologue evaluate (float arithmetic as in k_norm_act_fwd)
+    const float r_ = rstd[gidx * C + c], g_ = gamma ? gamma[c] : 1.f, b_ = beta ? beta[c] : 0.f, s_ = r_ * g_;
+    sc[gidx * cpad + c] = s_; sh[gidx * cpad + c] = b_ - mean[gidx * C + c] * s_;
+  }
   if (rmean && batch_mode) {
     double unb = cnt > 1 ? var * cnt / (cnt - 1) : var;
     rmean[c] = (float)((1.0 - momentum) * rmean[c] + momentum * m);
@@ -183,6 +189,16 @@ __global__ void __launch_bounds__(256) k_stats_finalize(const float* __restrict_
   }
 }
 static inline int pick_cpb(int C) { return C >= 32 ? 32 : (C >= 16 ? 16 : 8); }
+// dp_stats_finalize that ALSO leaves scale = rstd * gamma and shift = beta - mean * scale as [groups][cpad] rows (cpad >= C; the caller
+// zero-fills the padding once): the operands of the normalising prologue of dp_conv3d_tiled_pro
+extern "C" int dp_stats_finalize_ss(const float* part, int N, int nblk, int C, int64_t V, int batch_mode, float eps, float* mean, float* rstd,
+                                    const float* gamma, const float* beta, float* scale, float* shift, int cpad, void* stream) {
+  if (!scale || !shift || cpad < C) DP_FAIL("stats_finalize_ss: scale / shift rows of at least C elements are required");
+  int cpb = pick_cpb(C);
+  hipLaunchKernelGGL(k_stats_finalize, dim3(cdiv(C, cpb), batch_mode ? 1 : N), dim3(256), 0, STREAM, part, N, nblk, C, V, batch_mode, eps, mean, rstd,
+                     (float*)nullptr, (float*)nullptr, 0.f, cpb, gamma, beta, scale, shift, cpad);
+  DP_CHECK_LAUNCH("stats_finalize_ss"); return 0;
+}
 extern "C" int dp_stats_finalize(const float* part, int N, int nblk, int C, int64_t V, int batch_mode, float eps, float* mean, float* rstd,
                                  float* running_mean, float* running_var, float momentum, void* stream) {
   int cpb = pick_cpb(C);

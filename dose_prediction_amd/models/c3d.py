@@ -33,7 +33,10 @@ class Encoder(nn.Module):
     def forward(self, x):
         outs = []
         for lvl in range(1, 6):
-            x = getattr(self, f"encoder_{lvl}")(x)
+            blk = getattr(self, f"encoder_{lvl}")
+            # the first convolution's output feeds only the second one: its InstanceNorm + ReLU may be applied in that convolution's
+            # staging (ops.LazyNorm, forward-only networks); the level's output has several consumers and is written
+            x = blk[1](blk[0](x, lazy=True))
             outs.append(x)
         return outs
 
@@ -53,9 +56,12 @@ class Decoder(nn.Module):
     def forward(self, out_encoder):
         d = out_encoder[4]
         for lvl in (4, 3, 2, 1):
-            up = getattr(self, f"upconv_{lvl}")(d)
-            d = getattr(self, f"decoder_conv_{lvl}")((up, out_encoder[lvl - 1]))      # virtual torch.cat (c3d.py:103-113)
-        return d
+            up = getattr(self, f"upconv_{lvl}")(d, lazy=True)                         # (only consumer: the concat convolution below)
+            convs = getattr(self, f"decoder_conv_{lvl}")
+            d = convs[0]((up, out_encoder[lvl - 1]), lazy=len(convs) > 1)             # virtual torch.cat (c3d.py:103-113)
+            if len(convs) > 1:
+                d = convs[1](d)
+        return ops.dense(d)
 
 
 class BaseUNet(nn.Module):
