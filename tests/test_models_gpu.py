@@ -246,6 +246,7 @@ def test_frozen_c3d_normalises_in_the_consumer_staging(dtype, monkeypatch):
     from dose_prediction_amd.models.c3d import BaseUNet
     dev = _dev()
     _set(dtype)
+    lazy_default = ops._LAZY_NORM["enabled"]
     try:
         torch.manual_seed(11)
         net = BaseUNet(9, [-1, 16, 32, 32, 64, 64]).to(dev).eval()
@@ -284,7 +285,7 @@ def test_frozen_c3d_normalises_in_the_consumer_staging(dtype, monkeypatch):
         net(x).float().sum().backward()
         assert counts.get("dp_conv3d_tiled_pro", 0) == 0 and counts.get("dp_norm_act_fwd", 0) == 21
     finally:
-        ops._LAZY_NORM["enabled"] = True
+        ops._LAZY_NORM["enabled"] = lazy_default
         _set(torch.float32)
 
 
