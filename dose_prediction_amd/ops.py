@@ -1031,6 +1031,7 @@ def _x3_conv_ok(xa, xb, weight, stride, pad, dil):
 # fp32-typed tensor arriving at the convolution really holds [gy_hi | gy_lo]
 _GY_SPLIT_SENT = {}
 _GY_SPLIT_CB = [False]
+_PRESPLIT_OUT = {}            # split operands written by NormAct (by address) that no convolution has consumed yet
 
 
 def _gy_split_reset():
@@ -1056,7 +1057,11 @@ class Conv3dX3(torch.autograd.Function):
         cp = (cin + 15) // 16 * 16
         presplit = xa.dtype == torch.bfloat16
         if presplit:
-            xs = xa.contiguous()                                       # written as [x_hi | x_lo] by the normalisation in front (NormAct)
+            # written as [x_hi | x_lo] by the normalisation in front (NormAct).  Exactly ONE convolution may consume such a tensor: its
+            # gradient travels back as fp32 data in a bf16-typed tensor, which autograd could not add to a second consumer's
+            if not _PRESPLIT_OUT.pop(xa.data_ptr(), False):
+                raise _lib.DoseHipError("conv3d (fp32x3): a split operand written by norm_act(..., x3_split_for=conv) has a second consumer")
+            xs = xa.contiguous()
         else:
             xs = _split_conv_input(xa, ca, xb, cb, cp)                 # [.., x_hi (cp) | x_lo (cp)]
         # gy_split: a normalisation over this output follows (_x3_conv_call): its backward pass hands the gradient over ALREADY split
@@ -1645,6 +1650,10 @@ class NormAct(torch.autograd.Function):
         ctx.save_for_backward(x, mean, rstd, gamma, beta, res)
         ctx.cfg = (kind, act, use_batch_stats, ssn)
         ctx.split_out, ctx.grad_split = split_out, grad_split
+        if split_out:
+            if len(_PRESPLIT_OUT) > 256:
+                _PRESPLIT_OUT.clear()
+            _PRESPLIT_OUT[y.data_ptr()] = True
         return y
 
     @staticmethod
