@@ -316,6 +316,12 @@ static int cc16_go(const void* x, const void* wq, const float* bias, void* y, Cc
   // 3x3x3 with one input chunk: one depth slice per block = 64 accumulator registers -> three blocks per CU, whose staging / sweep /
   // epilogue phases overlap (16->16 at 2 x 128^3: 112 -> 100 us; with two chunks the two variants tie)
   if constexpr (KS == 3 && sizeof(T) == 2 && sizeof(TO) == 2) { if (g.NCH == 1) return cc16_go_impl<T, KS, 1, 3, TO>(x, wq, bias, y, g, s); }
+  if constexpr (KS == 3 && sizeof(T) == 2 && sizeof(TO) == 4) {
+    // DP_X3 with ONE real input chunk (16 -> 16 at the 128^3 level: two stagings, three sweeps per slab): one depth slice per block,
+    // three blocks per CU, like the bf16 single-chunk launch
+    static const int x3dt1 = [] { const char* e = getenv("DP_X3_DT1"); return e ? atoi(e) : 1; }();
+    if (x3dt1 && g.x3 == 1) return cc16_go_impl<T, KS, 1, 3, TO>(x, wq, bias, y, g, s);
+  }
   return cc16_go_impl<T, KS, (sizeof(T) == 4 ? 1 : 2), 2, TO>(x, wq, bias, y, g, s);
 }
 template <typename T, int KS, int DT, int OCC, typename TO, bool PRO>

@@ -41,6 +41,9 @@ def main():
     ap.add_argument("--filter", default="")
     a = ap.parse_args()
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    if a.dtype == "fp32x3":
+        import dose_prediction_amd
+        dose_prediction_amd.set_compute_dtype("fp32x3")
     dev = torch.device("cuda:0")
     for name, N, ci, co, S, k in SHAPES:
         if a.filter and a.filter not in name:
