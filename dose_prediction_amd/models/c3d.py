@@ -36,7 +36,7 @@ class Encoder(nn.Module):
             blk = getattr(self, f"encoder_{lvl}")
             # the first convolution's output feeds only the second one: its InstanceNorm + ReLU may be applied in that convolution's
             # staging (ops.LazyNorm, forward-only networks); the level's output has several consumers and is written
-            x = blk[1](blk[0](x, lazy=True))
+            x = blk[1](blk[0](x, lazy=True, next_conv=blk[1].single_conv[0]))
             outs.append(x)
         return outs
 
@@ -58,7 +58,8 @@ class Decoder(nn.Module):
         for lvl in (4, 3, 2, 1):
             up = getattr(self, f"upconv_{lvl}")(d, lazy=True)                         # (only consumer: the concat convolution below)
             convs = getattr(self, f"decoder_conv_{lvl}")
-            d = convs[0]((up, out_encoder[lvl - 1]), lazy=len(convs) > 1)             # virtual torch.cat (c3d.py:103-113)
+            d = convs[0]((up, out_encoder[lvl - 1]), lazy=len(convs) > 1,               # virtual torch.cat (c3d.py:103-113)
+                         next_conv=convs[1].single_conv[0] if len(convs) > 1 else None)
             if len(convs) > 1:
                 d = convs[1](d)
         return ops.dense(d)
