@@ -551,17 +551,18 @@ def main():
                     "unit": "volumes/s", "steps": nsteps, "final_loss": float(lm.detach())}
         try:
             fp32_leg = time_mode("fp32x3", max(args.fp32_steps, 5))
-            fp32_leg.update({"dtype": "fp32x3: fp32 storage, bf16 MFMA on split operands (x_hi w_hi + x_lo w_hi + x_hi w_lo), fp32 accumulation",
-                             "note": "the fast mode that meets the north-star's 1e-3 / arg-max parity bar (check_vs_oracle.fp32x3)"})
-            # the same mode with single-product weight gradients (config.set_x3_wgrad_terms(1): forward and data gradients unchanged,
-            # weight gradients from bf16-rounded operands) -- a SEPARATE figure, never the fp32x3 number
-            dose_prediction_amd.config.set_x3_wgrad_terms(1)
+            fp32_leg.update({"dtype": "fp32x3: fp32 storage, bf16 MFMA on split operands (x_hi w_hi + x_lo w_hi + x_hi w_lo) in the forward pass and "
+                                      "the data gradients, fp32 accumulation; weight gradients from x_hi gy_hi (config.set_x3_wgrad_terms, default 1)",
+                             "note": "the fast mode that meets the north-star's 1e-3 / arg-max parity bar (check_vs_oracle.fp32x3); "
+                                     "wgrad_three_products: the same with three-product weight gradients (measured indistinguishable in gradient "
+                                     "error and training trajectory, DESIGN section 3)"})
+            dose_prediction_amd.config.set_x3_wgrad_terms(3)
             try:
-                w1 = time_mode("fp32x3", max(args.fp32_steps, 5))
-                w1["dtype"] = "fp32x3 forward / data gradients, weight gradients x_hi gy_hi only (bf16-rounded operands, fp32 accumulation)"
-                fp32_leg["wgrad_single_product"] = w1
+                w3 = time_mode("fp32x3", max(args.fp32_steps, 5))
+                w3["dtype"] = "fp32x3 with three split products in the weight gradients as well"
+                fp32_leg["wgrad_three_products"] = w3
             finally:
-                dose_prediction_amd.config.set_x3_wgrad_terms(3)
+                dose_prediction_amd.config.set_x3_wgrad_terms(1)
             if args.exact_fp32_leg:
                 ex = time_mode("fp32", args.fp32_steps)
                 ex["dtype"] = "fp32 storage, v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain)"

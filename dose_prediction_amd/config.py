@@ -173,16 +173,19 @@ def cascade_seg_mode():
     return None if _cascade_seg_mode in (None, "same") else _cascade_seg_mode
 
 
-_x3_wgrad_terms = int(os.environ.get("DOSE_HIP_X3_WGRAD_TERMS", "3"))
+_x3_wgrad_terms = int(os.environ.get("DOSE_HIP_X3_WGRAD_TERMS", "1"))
 
 
 def set_x3_wgrad_terms(n):
-    """fp32x3 mode: number of split products in the WEIGHT gradients.  3 (default): x_hi gy_hi + x_lo gy_hi + x_hi gy_lo, like every
-    other contraction of the mode.  1: x_hi gy_hi only, i.e. the weight gradients (and only they) are formed from bf16-rounded
-    operands with fp32 accumulation -- the forward pass and the data gradients are untouched, so outputs keep their 1e-4 parity; each
-    weight-gradient element picks up an unbiased ~1.6e-3 relative rounding error, below the 4e-3 that separates the exact-fp32 mode
-    from float64 on the same gradients (tools/x3_grad_probe.py).  Saves two thirds of the weight-gradient time (57 instead of
-    68 ms per step); reported separately by bench.py, never as the fp32x3 number."""
+    """fp32x3 mode: number of split products in the WEIGHT gradients.  1 (default): x_hi gy_hi -- the weight gradients (and only they)
+    are formed from bf16-rounded operands with fp32 accumulation; the forward pass and the data gradients always use the three
+    products, so outputs keep their 1e-4 parity.  3: x_hi gy_hi + x_lo gy_hi + x_hi gy_lo like every other contraction of the mode
+    (10.5 ms per DOSE-PYFER step more).  Why 1 is the default: a weight-gradient element is a sum over millions of voxels, the
+    operand rounding is unbiased, and what it adds (~1.6e-3 relative per element) is below what separates the EXACT fp32 mode from
+    float64 on the same gradients (4.2e-3, ReLU gates of pre-activations within round-off of zero).  Measured at production width
+    (tools/x3_grad_probe.py, tools/x3_trajectory_probe.py): gradient vector vs float64 1.05e-2 (1 product) / 1.03e-2 (3 products);
+    parameters after six Adam steps 7.6 % of the update away from an exact-fp32 run in BOTH cases (two exact-fp32 runs: 4.6 %,
+    bf16: 44 %); the reference trainer's G6 sequence passes in both (tests/test_trainer_sequence.py)."""
     global _x3_wgrad_terms
     if n not in (1, 3):
         raise ValueError("x3 weight-gradient terms must be 1 or 3")

@@ -144,19 +144,30 @@ def test_g6_oracle_through_the_trainer_sequence(tmp_path):
     _check_against_g6(tr, g, str(tmp_path / "b"), 1e-6)
 
 
+@pytest.fixture
+def _restore_mode():
+    yield
+    import dose_prediction_amd
+    dose_prediction_amd.config.set_x3_wgrad_terms(1)
+    dose_prediction_amd.set_compute_dtype(torch.float32)
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("opt", ["torch_adam", "fused_adam"])
-def test_g6_hip_network_through_the_trainer_sequence(tmp_path, opt):
-    """The HIP-backed c3d.Model in fp32 parity mode, driven exactly like NetworkTrainer drives the reference module: .to(device),
-    train(), Adam(amsgrad) steps (each one must reach the packed weights), eval() forward, state_dict() -> torch.save ->
-    load_state_dict into a fresh module -> identical eval forward."""
+@pytest.mark.parametrize("opt,mode", [("torch_adam", "fp32"), ("fused_adam", "fp32"), ("fused_adam", "fp32x3"), ("fused_adam", "fp32x3w3")])
+def test_g6_hip_network_through_the_trainer_sequence(tmp_path, opt, mode, _restore_mode):
+    """The HIP-backed c3d.Model in the fp32 parity mode -- and in the fast fp32x3 mode, with its default single-product weight gradients and
+    with three-product ones (w3) -- driven exactly like NetworkTrainer drives the reference module: .to(device), train(), Adam(amsgrad) steps (each
+    one must reach the packed weights), eval() forward, state_dict() -> torch.save -> load_state_dict into a fresh module -> identical
+    eval forward.  Every mode has to land inside the SAME bands around the reference trainer's own numbers (2.5 x the distance between
+    the reference's fp32 and float64 runs)."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     import dose_prediction_amd
     from dose_prediction_amd import losses
     from dose_prediction_amd.models.c3d import Model
     from dose_prediction_amd.optim import FusedAdam
-    dose_prediction_amd.set_compute_dtype(torch.float32)
+    dose_prediction_amd.config.set_x3_wgrad_terms(3 if mode == "fp32x3w3" else 1)
+    dose_prediction_amd.set_compute_dtype("fp32x3" if mode.startswith("fp32x3") else torch.float32)
     dev = torch.device("cuda")
     g = load_golden("g6_trainer")
     sd0 = sub(g, "sd0")

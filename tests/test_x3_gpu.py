@@ -23,9 +23,14 @@ def _dev():
 
 @pytest.fixture(autouse=True)
 def _x3_mode():
+    """fp32x3 with THREE-product weight gradients: the operator tests below check every contraction of the mode at its 3e-5 accuracy;
+    the single-product weight gradients that are the mode's default have their own test."""
     import dose_prediction_amd
+    default_terms = dose_prediction_amd.config.x3_wgrad_terms()
+    dose_prediction_amd.config.set_x3_wgrad_terms(3)
     dose_prediction_amd.set_compute_dtype("fp32x3")
     yield
+    dose_prediction_amd.config.set_x3_wgrad_terms(default_terms)
     dose_prediction_amd.set_compute_dtype(torch.float32)
 
 
@@ -100,6 +105,49 @@ def test_x3_conv3d(cfg):
     check("gw", wh.grad, wr.grad)
     if has_b:
         check("gb", bh.grad, br.grad)
+
+
+@pytest.mark.parametrize("cfg", [(2, 32, 16, 16, 3, 33, 70, 7), (1, 16, 0, 16, 5, 32, 32, 3), (1, 64, 0, 40, 2, 33, 32, 7)])
+def test_x3_single_product_weight_gradients(cfg):
+    """config.set_x3_wgrad_terms(1), the mode's default: forward and data gradient are the three-product ones (3e-5); the weight
+    gradient is x_hi gy_hi, i.e. bf16-rounded operands with fp32 accumulation: within the bf16 operator tolerance (6e-3 relative L2,
+    unbiased).  Linear layers: the same through the grouped launch."""
+    import dose_prediction_amd
+    from dose_prediction_amd import ops
+    dev = _dev()
+    dose_prediction_amd.config.set_x3_wgrad_terms(1)
+    N, Cin, ca, Cout, D, H, W, k = cfg
+    x = rnd((N, Cin, D, H, W), 1) * 1.3 + 0.2
+    w = rnd((Cout, Cin, k, k, k), 2, (Cin * k ** 3) ** -0.5)
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    yr = oracle.conv3d(xr, wr, None, 1, k // 2, 1)
+    r = rnd(yr.shape, 4)
+    (yr * r.double()).sum().backward()
+    wh = w.to(dev).requires_grad_(True)
+    if ca:
+        xa, xb = ndhwc(x[:, :ca]).to(dev).requires_grad_(True), ndhwc(x[:, ca:]).to(dev).requires_grad_(True)
+        yh = ops.conv3d((xa, xb), wh, None, 1, k // 2, 1)
+    else:
+        xa = ndhwc(x).to(dev).requires_grad_(True)
+        yh = ops.conv3d(xa, wh, None, 1, k // 2, 1)
+    yh.backward(ndhwc(r).to(dev))
+    gx = torch.cat((xa.grad, xb.grad), -1) if ca else xa.grad
+    check("y", ncdhw(yh), yr)
+    check("gx", ncdhw(gx), xr.grad)
+    e = rel_l2(wh.grad.cpu(), wr.grad)
+    assert 1e-4 < e < 6e-3, e          # (bf16-operand error: two roundings of 2^-9 / sqrt(3) each; 3e-5 would mean three products ran)
+    xl, wl, bl = rnd((2, 512, 768), 5), rnd((96, 768), 6, 768 ** -0.5), 0.1 * rnd((96,), 7)
+    xlr, wlr, blr = xl.double().requires_grad_(True), wl.double().requires_grad_(True), bl.double().requires_grad_(True)
+    rl = rnd((2, 512, 96), 8)
+    (torch.nn.functional.linear(xlr, wlr, blr) * rl.double()).sum().backward()
+    xh, wh2, bh = xl.to(dev).requires_grad_(True), wl.to(dev).requires_grad_(True), bl.to(dev).requires_grad_(True)
+    yl = ops.linear(xh, wh2, bh, defer_wgrad=True)
+    yl.backward(rl.to(dev))
+    ops.flush_deferred()
+    torch.cuda.synchronize()
+    check("linear gx", xh.grad, xlr.grad)
+    assert rel_l2(wh2.grad.cpu(), wlr.grad) < 6e-3
+    check("linear gb", bh.grad, blr.grad, scale=20.0)
 
 
 def test_x3_conv3d_with_statistics_and_padded_rows():

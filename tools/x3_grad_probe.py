@@ -26,8 +26,8 @@ ref = oracle.dose_pyfer(sd64, x.double(), num_layers=8, num_heads=6, act="mish",
 torch.autograd.backward(ref, [r.double() for r in rs])
 net.to(dev).train()
 for mode in sys.argv[1:] or ("fp32", "fp32x3"):
-    dose_prediction_amd.config.set_x3_wgrad_terms(1 if mode == "fp32x3w1" else 3)
-    dose_prediction_amd.set_compute_dtype("fp32x3" if mode == "fp32x3w1" else mode)
+    dose_prediction_amd.config.set_x3_wgrad_terms(3 if mode == "fp32x3w3" else 1)
+    dose_prediction_amd.set_compute_dtype("fp32x3" if mode == "fp32x3w3" else mode)
     net.load_state_dict(sd)
     net.zero_grad(set_to_none=True)
     outs = net(x.to(dev))[1]

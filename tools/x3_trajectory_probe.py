@@ -1,0 +1,52 @@
+"""Training-trajectory distance between the modes: DOSE-PYFER at production width on a 64^3 sample, the same initial weights and data,
+K fused-Adam(amsgrad) steps per mode.  Reported per mode: the loss sequence, and the distance of the trained parameters from the
+exact-fp32 run's as a fraction of the update that run made -- next to the distance between TWO exact-fp32 runs (fp32 atomics make the
+mode itself non-reproducible: Adam turns round-off-level gradient differences into lr-sized steps)."""
+import os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import dose_prediction_amd
+from dose_prediction_amd import losses, synth
+from dose_prediction_amd.models.dose_pyfer import Model
+from dose_prediction_amd.optim import FusedAdam
+dev = torch.device("cuda:0")
+S, K = (64, 64, 64), int(os.environ.get("STEPS", "6"))
+torch.manual_seed(4321)
+net0 = Model(in_ch=9, out_ch=1, list_ch_A=[-1, 16, 32, 64, 128, 256], feature_size=16, img_size=S, num_layers=8, num_heads=6, act="mish")
+sd0 = {k: v.detach().clone() for k, v in net0.state_dict().items()}
+x, gt = synth.dose_input(2, S).to(dev), synth.dose_target(2, S).to(dev)
+
+
+def run(mode):
+    dose_prediction_amd.config.set_x3_wgrad_terms(3 if mode == "fp32x3w3" else 1)
+    dose_prediction_amd.set_compute_dtype("fp32x3" if mode.startswith("fp32x3") else mode)
+    net = Model(in_ch=9, out_ch=1, list_ch_A=[-1, 16, 32, 64, 128, 256], feature_size=16, img_size=S, num_layers=8, num_heads=6, act="mish")
+    net.load_state_dict(sd0)
+    net.to(dev).train()
+    for n, p in net.named_parameters():
+        if "net_A" in n or "conv_out_A" in n:
+            p.requires_grad = False
+    params = [p for p in net.parameters() if p.requires_grad]
+    opt = FusedAdam(params, lr=1e-4, weight_decay=3e-5, amsgrad=True)
+    ls = []
+    for _ in range(K):
+        opt.zero_grad(set_to_none=True)
+        loss = losses.gen_loss(net(x), gt, 10.0, 1.0, casecade=True, freez=True)
+        loss.backward()
+        opt.step()
+        ls.append(loss.item())
+    keys = [n for n, p in net.named_parameters() if p.requires_grad and not n.endswith(".bias")]
+    named = dict(net.named_parameters())
+    return ls, torch.cat([named[k].detach().double().reshape(-1).cpu() for k in keys]), keys
+
+
+w0 = None
+ref_l, ref_w, keys = run("fp32")
+w0 = torch.cat([sd0[k].double().reshape(-1) for k in keys])
+upd = (ref_w - w0).norm()
+print(f"exact fp32 losses {['%.5f' % l for l in ref_l]}  |update| {upd:.4e}")
+for mode in ("fp32", "fp32x3w3", "fp32x3", "bf16"):
+    l, w, _ = run(mode)
+    print(f"{mode:9s} losses {['%.5f' % v for v in l]}  max |loss - fp32| {max(abs(a - b) for a, b in zip(l, ref_l)):.2e}  "
+          f"weights: distance from the fp32 run / its update {float((w - ref_w).norm() / upd):.3f}")
