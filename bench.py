@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--own-stream", action="store_true", help="run the timed steps on a non-default (non-blocking) HIP stream")
     ap.add_argument("--fp32-steps", type=int, default=3)
     ap.add_argument("--no-branch-stream", action="store_true", help="3x3x3 branches / small skip blocks on the main stream (A/B)")
+    ap.add_argument("--no-wgrad-stream", action="store_true", help="convolution weight gradients on the caller's stream (A/B)")
     ap.add_argument("--seg-mode", default=None, choices=["fp32x3", "fp32", "same"],
                     help="cascade: mode of the no-grad OAR-TRANSEG forward (default fp32x3: the reference's masks; 'same' = the dose network's storage type)")
     return ap.parse_args()
@@ -85,6 +86,8 @@ def build_model(args, shape, dev):
     dose_prediction_amd.config.set_vit_side_stream(not args.no_side_stream)
     if getattr(args, "no_branch_stream", False) or args.no_side_stream:
         dose_prediction_amd.config.set_branch_stream(False)
+    if args.no_wgrad_stream or args.no_side_stream:
+        dose_prediction_amd.config.set_wgrad_stream(False)
     if getattr(args, "seg_mode", None):
         dose_prediction_amd.config.set_cascade_seg_mode(args.seg_mode)
     if args.model in ("pyfer", "cascade"):
@@ -464,10 +467,11 @@ def main():
     # kernel's own -- the step is shorter, the per-launch figure is not comparable with a roofline.  Both are reported.
     records_serial = None
     import dose_prediction_amd as _dpa
-    if _dpa.config.branch_stream() or _dpa.config.vit_side_stream():
-        bs, vs = _dpa.config.branch_stream(), _dpa.config.vit_side_stream()
+    if _dpa.config.branch_stream() or _dpa.config.vit_side_stream() or _dpa.config.wgrad_stream():
+        bs, vs, ws_ = _dpa.config.branch_stream(), _dpa.config.vit_side_stream(), _dpa.config.wgrad_stream()
         _dpa.config.set_branch_stream(False)
         _dpa.config.set_vit_side_stream(False)
+        _dpa.config.set_wgrad_stream(False)
         try:
             step()
             sync()
@@ -479,6 +483,7 @@ def main():
             _lib.PROFILE = None
             _dpa.config.set_branch_stream(bs)
             _dpa.config.set_vit_side_stream(vs)
+            _dpa.config.set_wgrad_stream(ws_)
         step()
         sync()
     if use_graph:
@@ -502,6 +507,7 @@ def main():
     t0 = time.perf_counter()
     with own:
         marks[0].record()
+        host_t = [time.perf_counter()]
         for i in range(args.steps):
             if graph is not None:
                 graph.replay()
@@ -509,7 +515,11 @@ def main():
             else:
                 loss = step()
             marks[i + 1].record()
+            host_t.append(time.perf_counter())
     sync()
+    # host time between two step() returns: equal to the GPU step time when the launch queue is what limits (the host waits for queue
+    # space or is itself the bottleneck), smaller when the host runs ahead
+    host_ms = sorted(1e3 * (b - a) for a, b in zip(host_t, host_t[1:]))
     dt = time.perf_counter() - t0
     step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
@@ -583,6 +593,7 @@ def main():
             "metric": "128\u00b3 CT volumes/sec (fwd+bwd)", "value": world * B * args.steps / dt, "unit": "volumes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "ms_per_step_median": median_ms, "ms_per_step_min_max": [step_ms[0], step_ms[-1]],
+            "host_enqueue_ms_per_step": [host_ms[0], host_ms[len(host_ms) // 2], host_ms[-1]],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": (("End-to-end cascade TRANSEG -> PYFER, 192 x 192 x 128 fp16 + activation checkpointing (BASELINE.json configs[4], per-GPU batch)"
                                      if (args.checkpoint and args.dtype == "fp16" and tuple(shape) != (128, 128, 128)) else

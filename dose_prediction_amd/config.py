@@ -210,3 +210,22 @@ def set_branch_stream(on):
 
 def branch_stream():
     return _branch_stream
+
+
+_wgrad_stream = os.environ.get("DOSE_HIP_WGRAD_STREAM", "1") != "0"
+
+
+def set_wgrad_stream(on):
+    """Launch the convolutions' weight-gradient kernels on a HIP stream of their own (one per device).  Nothing inside the backward pass
+    reads a weight gradient, so they leave the critical path dgrad -> normalisation backward -> dgrad ...: the MFMA-bound 7x7x7 /
+    3x3x3 weight gradients then run beside the HBM-bound normalisation passes of the layers in front.  The stream is joined before
+    anybody reads a gradient: at the end of the backward pass (autograd engine callback), in FusedAdam.step() and before the
+    data-parallel reducer launches a bucket.  Not used for a parameter that already holds a .grad (accumulation over micro-batches
+    adds on the caller's stream).  On by default; env DOSE_HIP_WGRAD_STREAM=0 / set_wgrad_stream(False) keeps them on the caller's
+    stream."""
+    global _wgrad_stream
+    _wgrad_stream = bool(on)
+
+
+def wgrad_stream():
+    return _wgrad_stream

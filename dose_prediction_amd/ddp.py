@@ -137,6 +137,7 @@ class GradAllReducer:
         # recorded entry (it holds aliases of the handed-out tensors, so it does not depend on which .grad autograd has accumulated
         # so far -- ADVICE r2: the old flush re-pended entries whose partner gradient had not arrived and the bucket went out unwritten)
         ops.flush_deferred()
+        ops.join_wgrad_stream()      # (convolution weight gradients run on a stream of their own, config.set_wgrad_stream)
         if ops.deferred_pending():
             raise RuntimeError("gradient all-reduce: deferred weight gradients still pending after the flush")
         flat = self.flat[bi]

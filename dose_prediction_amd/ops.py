@@ -478,6 +478,77 @@ def cat(xs):
     return Cat.apply(*xs)
 
 
+# ------------------------------------------------------------------------------------------------ weight-gradient stream
+_WG = {"streams": {}, "dirty": {}, "queued": False}
+
+
+def _wg_fork(weight, wanted=True):
+    """Called at the top of a convolution's backward node: returns the token for _wg_section (an event recorded on the current stream
+    BEFORE the data gradient is enqueued, so the weight gradient may start beside it), or None when the weight gradient stays on the
+    caller's stream (switch off, CPU, stream capture, or the parameter already holds a .grad: AccumulateGrad would then add on the
+    caller's stream what the other stream is still writing)."""
+    from . import config
+    if not (wanted and config.wgrad_stream() and weight.is_cuda and weight.grad is None) or torch.cuda.is_current_stream_capturing():
+        return None
+    dev = weight.device
+    cur = torch.cuda.current_stream(dev)
+    wg = _WG["streams"].get(dev.index)
+    if wg is None:
+        wg = _WG["streams"][dev.index] = torch.cuda.Stream(device=dev)      # (a high-priority stream here: 25.4 -> 38 ms per step)
+    if wg == cur:
+        return None
+    ev = torch.cuda.Event()
+    ev.record(cur)
+    return ev, cur, wg
+
+
+class _wg_section:
+    """with _wg_section(token, inputs) as sec: <weight-gradient launches>; sec.publish(gw, gb).  `inputs`: the tensors those launches
+    read (they were allocated on other streams and may be freed by autograd as soon as the node returns).  publish(): the results were
+    allocated on the weight-gradient stream and will be read on the caller's."""
+
+    def __init__(self, token, inputs):
+        self.token, self.inputs, self.ctx = token, inputs, None
+
+    def __enter__(self):
+        if self.token is not None:
+            ev, cur, wg = self.token
+            wg.wait_event(ev)
+            self.ctx = torch.cuda.stream(wg)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.token is not None:
+            ev, cur, wg = self.token
+            self.ctx.__exit__(*exc)
+            for t in self.inputs:
+                if t is not None:
+                    t.record_stream(wg)
+            _WG["dirty"][wg.device.index] = wg
+            if not _WG["queued"]:
+                _WG["queued"] = True
+                torch.autograd.Variable._execution_engine.queue_callback(join_wgrad_stream)
+        return False
+
+    def publish(self, *outs):
+        if self.token is not None:
+            for t in outs:
+                if t is not None:
+                    t.record_stream(self.token[1])
+
+
+def join_wgrad_stream():
+    """Make the current stream wait for the weight gradients launched on the weight-gradient stream so far (config.set_wgrad_stream).
+    Runs as an autograd-engine callback at the end of every backward pass that used the stream, in FusedAdam.step() and before the
+    data-parallel reducer packs / exchanges a bucket; call it yourself before reading a .grad from inside a hook."""
+    _WG["queued"] = False
+    if _WG["dirty"]:
+        for idx, wg in list(_WG["dirty"].items()):
+            torch.cuda.current_stream(wg.device).wait_stream(wg)
+        _WG["dirty"].clear()
+
+
 # ------------------------------------------------------------------------------------------------ convolution
 class Conv3d(torch.autograd.Function):
     """nn.Conv3d forward / data-gradient / weight-gradient (c3d.py:16, blocks_MDUNet.py:68,102,146)."""
@@ -544,6 +615,7 @@ class Conv3d(torch.autograd.Function):
         cin, k = weight.shape[1], weight.shape[2]
         dtc = _dt(x)
         gx = gw = gb = None
+        tok = _wg_fork(weight, ctx.needs_input_grad[1])
         if ctx.needs_input_grad[0]:
             gx = torch.empty((N, Di, Hi, Wi, cx), dtype=x.dtype, device=x.device)
             if cx > cin:
@@ -564,6 +636,17 @@ class Conv3d(torch.autograd.Function):
                 wt = _pack_conv(weight, 1, x.dtype)
                 _lib.call("dp_conv3d", _p(gy), ldg, _p(wt), 0, _p(gx), cx, N, Do, Ho, Wo, Di, Hi, Wi, cout, cin,
                           k, stride, pad, dil, 1, dtc, _stream())
+        with _wg_section(tok, (x, gy)) as sec:
+            gw, gb = Conv3d._weight_gradients(ctx, x, weight, gy, (N, Di, Hi, Wi, Do, Ho, Wo), (grows, cout, ldg, rows, cx, ldx, cin, k, dtc))
+            sec.publish(gw, gb)
+        return gx, gw, gb, None, None, None, None, None
+
+    @staticmethod
+    def _weight_gradients(ctx, x, weight, gy, dims, g):
+        N, Di, Hi, Wi, Do, Ho, Wo = dims
+        grows, cout, ldg, rows, cx, ldx, cin, k, dtc = g
+        stride, pad, dil, has_bias = ctx.cfg
+        gw = gb = None
         wse = _lib.lib().dp_pointwise_wgrad_ws_elems(grows, cin, cout) if (
             k == 1 and stride == 1 and pad == 0 and ctx.needs_input_grad[1] and grows >= 32768 and cout * cin <= 256) else 0
         if wse:
@@ -575,7 +658,7 @@ class Conv3d(torch.autograd.Function):
             _lib.call("dp_pointwise_wgrad_rows", _p(x), ldx, _p(gy), ldg, _p(gw), cin, _p(gb), _p(ws), grows, cin, cout, dtc, _stream())
             if has_bias and ctx.needs_input_grad[2] and ctx.bias_grad_zero:
                 gb = _zero_bias_grad(ctx.bias_ref)
-            return gx, gw, gb, None, None, None, None, None
+            return gw, gb
         if ctx.needs_input_grad[1] and k == 1 and stride == 1 and pad == 0 and grows < 32768:
             # pointwise conv over few voxels: dW[co][ci] = gy^T x, both k-major in memory (split over K to fill the chip)
             tiles = -(-cout // 64) * -(-cin // 64)
@@ -604,7 +687,7 @@ class Conv3d(torch.autograd.Function):
             else:
                 gb = torch.empty((cout,), dtype=torch.float32, device=x.device)
                 colsum_into(_p(gy), ldg, grows, cout, gb, dtc)
-        return gx, gw, gb, None, None, None, None, None
+        return gw, gb
 
 
 def _stats_partial(y):
@@ -693,6 +776,7 @@ class Conv3dCat(torch.autograd.Function):
         cin, k = weight.shape[1], weight.shape[2]
         dtc = _dt(xa)
         gxa = gxb = gw = gb = None
+        tok = _wg_fork(weight, ctx.needs_input_grad[2])
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             gxa = torch.empty((N, D, H, W, ca), dtype=xa.dtype, device=xa.device)
             gxb = torch.empty((N, D, H, W, cbp), dtype=xa.dtype, device=xa.device)
@@ -701,18 +785,20 @@ class Conv3dCat(torch.autograd.Function):
             wq = _pack_conv_tiled(weight, 1, xa.dtype, _tiled_elems(cout, cin, k, 1, k - 1 - pad, 1, W), W)
             _lib.call("dp_conv3d_tiled2", _p(gy), ldg, 0, 0, 0, _p(wq), 0, _p(gxa), ca, _p(gxb), cbp, ca,
                       _p(_tiled_ws(xa, N, D, H, W, cout, cin, k)), N, D, H, W, cout, cin, k, dtc, _stream())
-        if ctx.needs_input_grad[2]:
-            gw = _wgrad_buffer(weight, False)      # overwritten by the tiled kernel
-            taps = k * k * k
-            ws = _zero_scratch(xa.device, max(taps * cin * cout, _lib.lib().dp_conv3d_wgrad_tiled_ws_elems(cin, cout, k, 1, k // 2, 1, 1, W)))
-            _lib.call("dp_conv3d_wgrad_tiled2", _p(xa), lda, _p(xb), ldb, ca, _p(gy), ldg, _p(gw), _p(ws), N, D, H, W, cin, cout, k,
-                      cin * taps, taps, 1, dtc, _stream())
-        if has_bias and ctx.needs_input_grad[3]:
-            if ctx.bias_grad_zero:
-                gb = _zero_bias_grad(ctx.bias_ref)
-            else:
-                gb = torch.empty((cout,), dtype=torch.float32, device=xa.device)
-                colsum_into(_p(gy), ldg, grows, cout, gb, dtc)
+        with _wg_section(tok, (xa, xb, gy)) as sec:
+            if ctx.needs_input_grad[2]:
+                gw = _wgrad_buffer(weight, False)      # overwritten by the tiled kernel
+                taps = k * k * k
+                ws = _zero_scratch(xa.device, max(taps * cin * cout, _lib.lib().dp_conv3d_wgrad_tiled_ws_elems(cin, cout, k, 1, k // 2, 1, 1, W)))
+                _lib.call("dp_conv3d_wgrad_tiled2", _p(xa), lda, _p(xb), ldb, ca, _p(gy), ldg, _p(gw), _p(ws), N, D, H, W, cin, cout, k,
+                          cin * taps, taps, 1, dtc, _stream())
+            if has_bias and ctx.needs_input_grad[3]:
+                if ctx.bias_grad_zero:
+                    gb = _zero_bias_grad(ctx.bias_ref)
+                else:
+                    gb = torch.empty((cout,), dtype=torch.float32, device=xa.device)
+                    colsum_into(_p(gy), ldg, grows, cout, gb, dtc)
+            sec.publish(gw, gb)
         return gxa, gxb, gw, gb, None, None, None
 
 
@@ -1116,6 +1202,7 @@ class Conv3dX3(torch.autograd.Function):
         else:
             gys = split_rows(gy, cout, None, 0, cpo, 2, 0b10) if (need_x or need_w) else None
         gxa = gxb = gw = gb = None
+        tok = _wg_fork(weight, need_w)
         if need_x:
             if L.dp_conv3d_tiled_weight_elems(3 * cpo, cin, k, 1, pad, 1, W):
                 wq = _pack_conv_tiled_x3(weight, 1, cpo, W)
@@ -1149,31 +1236,33 @@ class Conv3dX3(torch.autograd.Function):
                 else:
                     gxa = gx[..., :ca]
                     gxb = gx[..., ca:] if cxb == cin - ca else torch.cat((gx[..., ca:], gx.new_zeros((N, D, H, W, cxb - (cin - ca)))), -1)
-        if need_w:
-            from . import config
-            wse = max(L.dp_conv3d_wgrad_tiled_ws_elems(2 * cp, cout, k, 1, pad, 1, 1, W), L.dp_conv3d_wgrad_tiled_ws_elems(cp, cout, k, 1, pad, 1, 1, W))
-            if not wse:
-                raise _lib.DoseHipError("x3 convolution: weight gradient outside the tiled kernels")
-            ws = _zero_scratch(dev, wse)
-            gw = _wgrad_buffer(weight, False)
-            if config.x3_wgrad_terms() == 1:
-                # (config.set_x3_wgrad_terms(1)) x_hi x gy_hi only: one bf16 launch straight into dW
-                _lib.call("dp_conv3d_wgrad_tiled", _p(xs), 2 * cp, _p(gys), 2 * cpo, _p(gw), _p(ws), N, D, H, W, cin, cout, k,
-                          cin * taps, taps, 1, 1, _stream())
-            else:
-                # S[co][p cp + ci][tap]: blocks p = 0, 1 from (x_hi | x_lo) x gy_hi, block 2 from x_hi x gy_lo
-                S = torch.empty((cout, 3 * cp, taps), dtype=torch.float32, device=dev)
-                _lib.call("dp_conv3d_wgrad_tiled", _p(xs), 2 * cp, _p(gys), 2 * cpo, _p(S), _p(ws), N, D, H, W, 2 * cp, cout, k,
-                          3 * cp * taps, taps, 1, 1, _stream())
-                _lib.call("dp_conv3d_wgrad_tiled", _p(xs), 2 * cp, gys.data_ptr() + 2 * cpo, 2 * cpo, S.data_ptr() + 4 * 2 * cp * taps, _p(ws),
-                          N, D, H, W, cp, cout, k, 3 * cp * taps, taps, 1, 1, _stream())
-                _lib.call("dp_x3_wgrad_combine", _p(S), _p(gw), cout, cin, cp, taps, 3, _stream())
-        if ctx.has_bias and ctx.needs_input_grad[3]:
-            if ctx.bias_grad_zero:
-                gb = _zero_bias_grad(ctx.bias_ref)
-            else:
-                gb = torch.empty((cout,), dtype=torch.float32, device=dev)
-                colsum_into(_p(gy), ldg, grows, cout, gb, 0)
+        with _wg_section(tok, (xs, gys, gy)) as sec:
+            if need_w:
+                from . import config
+                wse = max(L.dp_conv3d_wgrad_tiled_ws_elems(2 * cp, cout, k, 1, pad, 1, 1, W), L.dp_conv3d_wgrad_tiled_ws_elems(cp, cout, k, 1, pad, 1, 1, W))
+                if not wse:
+                    raise _lib.DoseHipError("x3 convolution: weight gradient outside the tiled kernels")
+                ws = _zero_scratch(dev, wse)
+                gw = _wgrad_buffer(weight, False)
+                if config.x3_wgrad_terms() == 1:
+                    # (config.set_x3_wgrad_terms(1)) x_hi x gy_hi only: one bf16 launch straight into dW
+                    _lib.call("dp_conv3d_wgrad_tiled", _p(xs), 2 * cp, _p(gys), 2 * cpo, _p(gw), _p(ws), N, D, H, W, cin, cout, k,
+                              cin * taps, taps, 1, 1, _stream())
+                else:
+                    # S[co][p cp + ci][tap]: blocks p = 0, 1 from (x_hi | x_lo) x gy_hi, block 2 from x_hi x gy_lo
+                    S = torch.empty((cout, 3 * cp, taps), dtype=torch.float32, device=dev)
+                    _lib.call("dp_conv3d_wgrad_tiled", _p(xs), 2 * cp, _p(gys), 2 * cpo, _p(S), _p(ws), N, D, H, W, 2 * cp, cout, k,
+                              3 * cp * taps, taps, 1, 1, _stream())
+                    _lib.call("dp_conv3d_wgrad_tiled", _p(xs), 2 * cp, gys.data_ptr() + 2 * cpo, 2 * cpo, S.data_ptr() + 4 * 2 * cp * taps, _p(ws),
+                              N, D, H, W, cp, cout, k, 3 * cp * taps, taps, 1, 1, _stream())
+                    _lib.call("dp_x3_wgrad_combine", _p(S), _p(gw), cout, cin, cp, taps, 3, _stream())
+            if ctx.has_bias and ctx.needs_input_grad[3]:
+                if ctx.bias_grad_zero:
+                    gb = _zero_bias_grad(ctx.bias_ref)
+                else:
+                    gb = torch.empty((cout,), dtype=torch.float32, device=dev)
+                    colsum_into(_p(gy), ldg, grows, cout, gb, 0)
+            sec.publish(gw, gb)
         if ctx.presplit and gxa is not None:
             gxa = gxa.contiguous().view(torch.bfloat16)    # the input was a bf16 [.., 2 cin] tensor: same bytes, the producer (NormAct) reads it as fp32
         return gxa, gxb, gw, gb, None, None, None

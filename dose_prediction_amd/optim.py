@@ -70,6 +70,7 @@ class FusedAdam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         ops.flush_deferred()          # (weight gradients recorded for the grouped launch: normally flushed at the end of backward)
+        ops.join_wgrad_stream()       # (convolution weight gradients launched on their own stream: normally joined there too)
         for gi, group in enumerate(self.param_groups):
             plist = [p for p in group["params"] if p.grad is not None]
             if not plist:

@@ -632,9 +632,12 @@ def test_branch_streams_match_the_single_stream_result():
         _set(dtype)
         outs = {}
         try:
-            for tag, branch, side, stream in (("ref", False, False, None), ("on", True, True, None), ("on2", True, True, None), ("user", True, True, user)):
+            for tag, branch, side, stream in (("ref", False, False, None), ("wg", False, False, None), ("on", True, True, None), ("on2", True, True, None),
+                                              ("user", True, True, user)):
                 dose_prediction_amd.config.set_branch_stream(branch)
                 dose_prediction_amd.config.set_vit_side_stream(side)
+                # (the convolutions' weight gradients on their own stream, config.set_wgrad_stream: everywhere but in the reference run)
+                dose_prediction_amd.config.set_wgrad_stream(tag != "ref")
                 net = MainSubsetModel(in_ch=5, out_ch=1, img_size=(32, 16, 16), feature_size=4, hidden_size=48, mlp_dim=96, num_heads=6,
                                       num_layers=8, act="mish", mode_multi_dec=True, multiS_conv=True)
                 _load(net, pcg_state_dict(g["keys"], g["shapes"], g["seed"])).to(dev).train()
@@ -650,8 +653,9 @@ def test_branch_streams_match_the_single_stream_result():
         finally:
             dose_prediction_amd.config.set_branch_stream(True)
             dose_prediction_amd.config.set_vit_side_stream(True)
+            dose_prediction_amd.config.set_wgrad_stream(True)
             _set(torch.float32)
-        for tag in ("on", "on2", "user"):
+        for tag in ("wg", "on", "on2", "user"):
             for a, b in zip(outs[tag][0], outs["ref"][0]):
                 assert rel_err(a.cpu(), b.cpu()) < otol, (dtype, tag)
             assert outs[tag][1].keys() == outs["ref"][1].keys()
