@@ -11,15 +11,13 @@ import torch.nn as nn
 from . import config, ops
 
 
-_BRANCH_STREAMS = {}
 
 
 def _branch_side_stream(device, main):
-    key = (device.index, main.cuda_stream)
-    st = _BRANCH_STREAMS.get(key)
-    if st is None:
-        st = _BRANCH_STREAMS[key] = torch.cuda.Stream(device=device)
-    return st
+    """The stream of the 3x3x3 branches / small up-sampling blocks for the caller's stream `main` (streams.side_stream: chosen so that it
+    does not share a hardware queue with the caller's stream)."""
+    from . import streams
+    return streams.side_stream(device, main, streams.ROLE_BRANCH)
 
 
 def _act_name(act):
@@ -152,6 +150,9 @@ class conv_3_1(nn.Module):
             # the latency- / fabric-bound 3x3x3 branch on a second stream beside the MFMA-bound 7x7x7 branch
             main = torch.cuda.current_stream(first.device)
             side = _branch_side_stream(first.device, main)
+        else:
+            main = side = None
+        if side is not None and side != main:
             side.wait_stream(main)
             for t in (x if isinstance(x, (tuple, list)) else (x,)):
                 t.record_stream(side)

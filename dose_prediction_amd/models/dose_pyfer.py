@@ -99,7 +99,8 @@ def run_vit_beside(vit, x_in, first=None, first_inputs=()):
         if vcu > 0:
             pair = (_cu_stream(x_in.device, 0, vcu), _cu_stream(x_in.device, vcu, 256))
         else:
-            pair = (torch.cuda.Stream(device=x_in.device), None)
+            from .. import streams
+            pair = (streams.side_stream(x_in.device, main, streams.ROLE_VIT), None)
         _SIDE_STREAMS[key] = pair
     side, part = pair
     fork = torch.cuda.Event()

@@ -702,3 +702,27 @@ def test_host_running_ahead_of_the_gpu_does_not_corrupt_pointer_tables():
     assert torch.allclose(l_run, l_ref, rtol=1e-4, atol=1e-6), (l_run, l_ref)
     for a, b in zip(p_run, p_ref):
         assert rel_l2(a, b) < 1e-3
+
+
+def test_side_streams_do_not_share_a_queue_with_the_callers_stream():
+    """dose_prediction_amd.streams: the transformer / branch / weight-gradient streams are drawn from torch's pool and kept only if a
+    launch on them can overtake a spin kernel enqueued earlier on the caller's stream (and on each other) -- HIP multiplexes streams
+    onto four hardware queues, and two streams on one queue run in host order.  Here: three distinct streams per caller's stream, all
+    accepted by the probe on a fresh process (more streams than queues would show as rejected candidates, which is legal), cached,
+    the same set whichever of them asks (root()), and a second caller's stream gets its own set."""
+    from dose_prediction_amd import streams
+    dev = _dev()
+    main = torch.cuda.current_stream(dev)
+    got = streams.side_streams(dev, main)
+    assert len(got) == 3 and len({s.cuda_stream for s in got} | {main.cuda_stream}) == 4
+    assert streams.side_streams(dev, main) is got
+    for role in (streams.ROLE_VIT, streams.ROLE_BRANCH, streams.ROLE_WGRAD):
+        assert streams.side_stream(dev, main, role) == got[role]
+        with torch.cuda.stream(got[role]):       # asked from ON a side stream: the set of the caller behind it
+            assert streams.side_stream(dev, torch.cuda.current_stream(dev), streams.ROLE_WGRAD) == got[streams.ROLE_WGRAD]
+    for s in got:
+        assert streams._overlap(main, s) and streams._overlap(s, main)
+    user = torch.cuda.Stream()
+    other = streams.side_streams(dev, user)
+    assert len(other) == 3 and user.cuda_stream not in {s.cuda_stream for s in other}
+    torch.cuda.synchronize()
