@@ -370,11 +370,13 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("DOSE_DDP_BACKEND", "nccl")      # nccl == RCCL on ROCm
         if backend == "nccl":
-            # RCCL's kernels compete for CU slots with full-chip (partly persistent-grid) compute kernels: a high-priority stream lets
-            # the collective's workgroups in first whenever slots free up
+            # RCCL's stream at NORMAL priority (DOSE_DDP_PRIO=1: high).  Round 3, 1-rank RCCL on one MI355X: 27.1 ms per step at normal
+            # priority against 32.2 at high priority once the weight gradients run on a stream of their own (a high-priority stream
+            # next to four busy ones costs the compute streams more than the collective gains; the same was seen with a
+            # high-priority weight-gradient stream: 25 -> 38 ms)
             opts = None
             try:
-                opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=os.environ.get("DOSE_DDP_PRIO", "1") == "1")
+                opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=os.environ.get("DOSE_DDP_PRIO", "0") == "1")
             except Exception:
                 pass
             if opts is not None:
@@ -449,12 +451,19 @@ def main():
     # (forward, loss, backward, capturable fused Adam with its packed-weight refresh) is captured ONCE into a HIP graph and the
     # timed region replays it; every kernel still runs every step.
     graph = None
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
+    side = torch.cuda.Stream() if (args.graph or args.own_stream) else None
+    if use_graph:
+        # (torch.cuda.graph wants the warm-up on a side stream)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(1, args.warmup)):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+    else:
+        # eager: warm up on the stream the timed steps run on -- the package chooses its side streams per caller's stream, and every
+        # further stream in use is one more tenant of the four hardware queues
         for _ in range(max(1, args.warmup)):
             step()
-    torch.cuda.current_stream().wait_stream(side)
     sync()
     # per-kernel HIP-event timing: one eager step on the launch stream (events cannot be recorded inside a capture)
     _lib.PROFILE = []

@@ -27,6 +27,25 @@ import torch.distributed as dist
 
 _DRY = os.environ.get("DOSE_DDP_DRY", "0") == "1"
 _REORDER = os.environ.get("DOSE_DDP_REORDER", "1") == "1"
+_TIMING = os.environ.get("DOSE_DDP_TIMING", "0") == "1"       # host seconds spent in the reducer's hooks (self.host_s), diagnosis
+
+
+def _timed(name):
+    def deco(fn):
+        if not _TIMING:
+            return fn
+        import functools
+        import time
+
+        @functools.wraps(fn)
+        def wrapper(self, *a, **k):
+            t0 = time.perf_counter()
+            try:
+                return fn(self, *a, **k)
+            finally:
+                self.host_s[name] = self.host_s.get(name, 0.0) + time.perf_counter() - t0
+        return wrapper
+    return deco
 
 
 class GradAllReducer:
@@ -87,6 +106,7 @@ class GradAllReducer:
                     if p.is_cuda and p.dtype == torch.float32 and p.is_contiguous():
                         ops.GRAD_DEST[p.data_ptr()] = self._dest(p, bi, off, n)
         self.grad_ref = [None] * len(self.buckets)
+        self.host_s = {}
         self.no_grad = None          # parameters without a gradient in the first backward pass (static graph), set by _finish
         self.stats = {"launched_in_backward": 0, "launched_at_end": 0}
         self.launch_order = None     # set after the first backward pass: the order in which its buckets completed
@@ -131,25 +151,42 @@ class GradAllReducer:
         self._taken = set()
         self._streams = []
 
+    @_timed("launch")
     def _launch(self, bi, at_end=False):
-        from . import ops
-        # gradient tensors handed out unwritten (grouped Linear weight gradients) are filled first: flush_deferred() launches EVERY
-        # recorded entry (it holds aliases of the handed-out tensors, so it does not depend on which .grad autograd has accumulated
-        # so far -- ADVICE r2: the old flush re-pended entries whose partner gradient had not arrived and the bucket went out unwritten)
-        ops.flush_deferred()
-        ops.join_wgrad_stream()      # (convolution weight gradients run on a stream of their own, config.set_wgrad_stream)
-        if ops.deferred_pending():
-            raise RuntimeError("gradient all-reduce: deferred weight gradients still pending after the flush")
+        from . import config, ops, streams
         flat = self.flat[bi]
-        cur = torch.cuda.current_stream() if flat.is_cuda else None
-        if cur is not None:
-            # gradients of this bucket may have been produced on another stream (the ViT branch runs on a side stream): the
-            # collective is ordered after the current stream only, so make that one wait for the others first.  (Launching from a
-            # stream of its own that waits for all of them instead was measured: 1-rank RCCL step 27.5 -> 28.3 ms, 32 ms with a
-            # high-priority RCCL stream.)
-            for s in self._streams:
-                if s != cur:
-                    cur.wait_stream(s)
+        if not flat.is_cuda:
+            self._flush(ops)
+            if ops.deferred_pending():
+                raise RuntimeError("gradient all-reduce: deferred weight gradients still pending after the flush")
+            return self._launch_on_current(bi, at_end)
+        cur = torch.cuda.current_stream()
+        home = streams.side_stream(flat.device, cur, streams.ROLE_WGRAD) if config.wgrad_stream() else cur
+        # The bucket is packed and handed to RCCL from the WEIGHT-GRADIENT stream (config.set_wgrad_stream): that stream already
+        # carries most of the bucket's producers, it is off the critical path of the backward pass, and RCCL orders the collective
+        # behind the stream it is called from -- so the stream that walks the backward chain never waits for a bucket (it used to
+        # wait for the transformer's and the weight-gradient stream at each of the 14 launches: 1-rank RCCL 28 -> 32 ms per step
+        # once the weight gradients had moved off it).  Gradients of this bucket produced on other streams: `home` waits for them.
+        for s_ in [cur] + self._streams:
+            if s_ != home:
+                home.wait_stream(s_)
+        self._home = home
+        if home != cur:
+            torch.cuda.set_stream(home)
+        try:
+            # gradient tensors handed out unwritten (grouped Linear weight gradients) are filled first: flush_deferred() launches
+            # EVERY recorded entry (it holds aliases of the handed-out tensors, so it does not depend on which .grad autograd has
+            # accumulated so far -- ADVICE r2) and makes the current stream (`home`) wait for that launch
+            self._flush(ops)
+            if ops.deferred_pending():
+                raise RuntimeError("gradient all-reduce: deferred weight gradients still pending after the flush")
+            self._launch_on_current(bi, at_end)
+        finally:
+            if home != cur:
+                torch.cuda.set_stream(cur)
+
+    def _launch_on_current(self, bi, at_end):
+        flat = self.flat[bi]
         if self.inplace[bi] and self.grad_ref[bi] is not None:
             flat = self.grad_ref[bi]
         else:
@@ -164,6 +201,10 @@ class GradAllReducer:
         n = flat.numel()
         if _DRY:
             return               # (diagnosis only, DOSE_DDP_DRY=1: everything but the collective itself)
+        self._collectives(flat, n)
+
+    @_timed("collectives")
+    def _collectives(self, flat, n):
         for c0 in range(0, n, self.chunk):
             piece = flat[c0:min(n, c0 + self.chunk)]
             if self.backend == "nccl":
@@ -171,6 +212,11 @@ class GradAllReducer:
             else:
                 self.work.append((dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.pg, async_op=True), piece))
 
+    @_timed("flush")
+    def _flush(self, ops):
+        ops.flush_deferred()
+
+    @_timed("hook")
     def _hook(self, p):
         if not self.callback_queued:
             self.callback_queued = True
@@ -202,6 +248,7 @@ class GradAllReducer:
                 break
             self._launch(i)
 
+    @_timed("finish")
     def _finish(self):
         first_pass = self.no_grad is None
         if first_pass:
@@ -229,6 +276,10 @@ class GradAllReducer:
             t = torch.tensor(seq, dtype=torch.int64, device=self.flat[0].device if self.backend == "nccl" else "cpu")
             dist.broadcast(t, 0, group=self.pg)
             self.launch_order = [int(v) for v in t.tolist()] if _REORDER else None
+        home = getattr(self, "_home", None)
+        if home is not None:
+            # (the collectives were issued from the weight-gradient stream: everything it carries is complete for the caller too)
+            torch.cuda.current_stream().wait_stream(home)
         for w in self.work:
             if isinstance(w, tuple):
                 w[0].wait()

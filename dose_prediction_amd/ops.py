@@ -29,7 +29,15 @@ def _act_code(act, dtype=None):
     return ACT[act]
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream():
+    """The current HIP stream as an integer handle (the launch thread has to stay ahead of the GPU: torch.cuda.current_stream() builds
+    a Stream object through three Python layers, 8 us x 750 launches per step)."""
+    if _raw_stream is not None:
+        return _raw_stream(_raw_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -52,19 +60,21 @@ def _chk_dev(*ts):
 
 def rows_ld(t):
     """(rows, C, ld) of an activation / matrix whose rows are uniformly pitched."""
-    C = t.shape[-1]
-    if t.stride(-1) != 1 and C > 1:
+    shape, st = t.shape, t.stride()          # (one call each: this runs ~900 times per training step)
+    C, nd = shape[-1], len(shape)
+    if st[-1] != 1 and C > 1:
         raise ValueError("last dim must be contiguous")
-    if t.dim() == 1:
+    if nd == 1:
         return 1, C, C
-    ld = t.stride(-2) if t.shape[-2] > 1 else max(C, t.stride(-2))
+    ld = st[-2] if shape[-2] > 1 else max(C, st[-2])
     rows = 1
     exp = ld
-    for d in range(t.dim() - 2, -1, -1):
-        if t.shape[d] > 1 and t.stride(d) != exp:
-            raise ValueError(f"tensor is not a uniformly pitched row matrix: shape {tuple(t.shape)} strides {t.stride()}")
-        exp *= t.shape[d]
-        rows *= t.shape[d]
+    for d in range(nd - 2, -1, -1):
+        n = shape[d]
+        if n > 1 and st[d] != exp:
+            raise ValueError(f"tensor is not a uniformly pitched row matrix: shape {tuple(shape)} strides {st}")
+        exp *= n
+        rows *= n
     return rows, C, ld
 
 
@@ -222,7 +232,7 @@ def _zero_scratch(device, n):
     hand it back zeroed, so no memset launch per call).  One buffer per (device, stream), grown on demand: two streams issuing
     atomically-accumulating kernels concurrently never share a scratch."""
     L = _lib.lib()
-    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+    key = (device.type, device.index, _stream())
     buf = _ZERO_SCRATCH.get(key)
     if buf is None or buf.numel() < n:
         buf = torch.zeros((max(n, 1 << 22),), dtype=torch.float32, device=device)
@@ -482,6 +492,18 @@ def cat(xs):
 _WG = {"dirty": {}, "queued": False}
 
 
+_STREAM_OBJ = {}
+
+
+def _current_stream_object(dev):
+    """torch.cuda.current_stream(dev), cached by raw handle (the Stream constructor costs 8 us, this runs ~100 times per step)."""
+    ptr = _stream()
+    s = _STREAM_OBJ.get(ptr)
+    if s is None:
+        s = _STREAM_OBJ[ptr] = torch.cuda.current_stream(dev)
+    return s
+
+
 def _wg_fork(weight, wanted=True):
     """Called at the top of a convolution's backward node: returns the token for _wg_section (an event recorded on the current stream
     BEFORE the data gradient is enqueued, so the weight gradient may start beside it), or None when the weight gradient stays on the
@@ -492,7 +514,7 @@ def _wg_fork(weight, wanted=True):
         return None
     from . import streams
     dev = weight.device
-    cur = torch.cuda.current_stream(dev)
+    cur = _current_stream_object(dev)
     wg = streams.side_stream(dev, cur, streams.ROLE_WGRAD)      # (a high-priority stream here: 25.4 -> 38 ms per step)
     if wg == cur:
         return None
@@ -513,14 +535,13 @@ class _wg_section:
         if self.token is not None:
             ev, cur, wg = self.token
             wg.wait_event(ev)
-            self.ctx = torch.cuda.stream(wg)
-            self.ctx.__enter__()
+            torch.cuda.set_stream(wg)          # (the context manager costs 20 us per use)
         return self
 
     def __exit__(self, *exc):
         if self.token is not None:
             ev, cur, wg = self.token
-            self.ctx.__exit__(*exc)
+            torch.cuda.set_stream(cur)
             for t in self.inputs:
                 if t is not None:
                     t.record_stream(wg)
@@ -1077,7 +1098,7 @@ def _split_conv_input(xa, ca, xb, cb, cp):
     while the very same tensor objects are alive and unmodified (weak references + version counters)."""
     import weakref
     key = (ca, cb, cp, xa.data_ptr(), xa._version, tuple(xa.shape), xa.stride(),
-           None if xb is None else (xb.data_ptr(), xb._version, tuple(xb.shape), xb.stride()), torch.cuda.current_stream().cuda_stream)
+           None if xb is None else (xb.data_ptr(), xb._version, tuple(xb.shape), xb.stride()), _stream())
     ent = _SPLIT_LAST[0]
     if ent is not None and ent[0] == key and ent[1]() is xa and (xb is None or ent[2]() is xb):
         _SPLIT_LAST[0] = None             # (the pattern is exactly two consumers: do not keep half a gigabyte alive beyond the second)
@@ -1463,8 +1484,11 @@ def flush_deferred(*_unused):
             for _h, e in (_DEFER["host"] or ()):
                 if e is not None:
                     e.synchronize()
-            _DEFER["host"] = [[torch.empty((max(n, 64), 12), dtype=torch.int64).pin_memory(), None] for _ in range(4)]
-        slot = _DEFER["host"][_DEFER["rot"] % 4]
+            # (64 slots: the data-parallel reducer flushes once per bucket, i.e. a dozen times per backward pass, and the host runs up to
+            # a whole step ahead of the GPU -- with 4 slots the wait below blocked the launch thread on the GPU in the middle of
+            # every backward pass: 4.9 ms of host time per step)
+            _DEFER["host"] = [[torch.empty((max(n, 64), 12), dtype=torch.int64).pin_memory(), None] for _ in range(64)]
+        slot = _DEFER["host"][_DEFER["rot"] % 64]
         _DEFER["rot"] += 1
         if slot[1] is not None and not torch.cuda.is_current_stream_capturing():     # (torch.cuda.graph synchronises on entry)
             slot[1].synchronize()

@@ -18,6 +18,14 @@ for n, p in net.named_parameters():
     if "net_A" in n or "conv_out_A" in n:
         p.requires_grad = False
 net.to(dev).train()
+if len(sys.argv) > 1 and sys.argv[1] == "ddp":
+    import os
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29656")
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    from dose_prediction_amd.ddp import attach_gradient_allreduce
+    red = attach_gradient_allreduce(net)
 x = torch.randn(2, 9, 128, 128, 128, device=dev)
 gt = torch.cat((torch.rand(2, 1, 128, 128, 128, device=dev), (torch.rand(2, 1, 128, 128, 128, device=dev) > 0.3).float()), 1)
 opt = FusedAdam([p for p in net.parameters() if p.requires_grad], lr=1e-4, weight_decay=3e-5, amsgrad=True)
