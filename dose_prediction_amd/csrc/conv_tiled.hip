@@ -562,15 +562,26 @@ static int launch_tiled(const void* x, const void* wq, const float* bias, void* 
   return 0;
 }
 
-static void tiled_geometry(TiledGeom& g, int k, int np, int rw, int nt, int* ygrid, bool* w16, int* wn_out = nullptr, bool allow_wn = true) {
+static void tiled_geometry(TiledGeom& g, int k, int np, int rw, int& nt, int* ygrid, bool* w16, int* wn_out = nullptr, bool allow_wn = true) {
   int rwo = rw - (np - 1), JH = np == 2 ? (k + 1) / 2 : k;
   *w16 = (g.W <= 16 && np == 1);
   const int ntt = (g.Cout * np + 31) / 32;
   // W16 tiles on planes of <= 16 rows with >= 4 channel tiles: two of the four waves take other channel tiles instead of rows >= H
   static const bool no_wn = getenv("DP_NO_WN") != nullptr;
-  const int wn = (*w16 && nt == 2 && g.H <= 16 && ntt % 4 == 0 && !no_wn && allow_wn) ? 2 : 1;
+  int wn = (*w16 && nt == 2 && g.H <= 16 && ntt % 4 == 0 && !no_wn && allow_wn) ? 2 : 1;
+  // One-column tiles (16 < W <= 32, the 32^3 level) with two channel tiles per wave: 4 row groups x 4 rows x 32 positions is a
+  // 16-row block, i.e. 128 blocks for 2 x 32^3 -- half of the compute units, or (what round 1-2 did) one block per kd with fp32
+  // atomics, whose epilogue + finish pass were 36 % of a 64 -> 64 launch (knock-outs, round 3: 0.231 ms of which 0.085 ms; without
+  // the split, on HALF of the chip, the same launch took 0.290 ms).  Two row groups x two channel-tile groups instead: 8-row
+  // blocks, every wave ONE channel tile of 4 rows (64 accumulator registers), 256 blocks, no split, no scratch, statistics from
+  // the epilogue.  Measured at 2 x 32^3 (tools/bench_conv.py): 7^3 64->64 0.223 -> 0.201 ms, 64->128 0.361 -> 0.292; 3^3 64->64
+  // 0.074 -> 0.032, 128->64 0.185 -> 0.054, 64->128 0.129 -> 0.043 (their split epilogues cost more than their sweeps); 7^3
+  // 128->64 0.380 -> 0.403: with 8 input chunks and one output-tile pair the split amortises, that shape keeps it.
+  static const bool no_wn32 = getenv("DP_NO_WN32") != nullptr;
+  if (!*w16 && np == 1 && nt == 2 && g.W <= 32 && ntt % 2 == 0 && allow_wn && !no_wn && !no_wn32 &&
+      !(k == 7 && ntt == 2 && g.Cin > 64) && (int64_t)g.N * g.D * cdiv(g.H, 16) * (ntt / 2) < 400) { wn = 2; nt = 1; }
   if (wn_out) *wn_out = wn;
-  if (*w16) { g.TWC = 1; g.TRG = 4 / wn; } else if (g.W > 64) { g.TWC = 4; g.TRG = 1; } else if (g.W > 32) { g.TWC = 2; g.TRG = 2; } else { g.TWC = 1; g.TRG = 4; }
+  if (*w16) { g.TWC = 1; g.TRG = 4 / wn; } else if (g.W > 64) { g.TWC = 4; g.TRG = 1; } else if (g.W > 32) { g.TWC = 2; g.TRG = 2; } else { g.TWC = 1; g.TRG = 4 / wn; }
   int rpa = *w16 ? 2 : 1;
   g.LR = g.TRG * rwo * rpa + (np - 1) + (np == 2 ? 2 * (JH - 1) : k - 1);
   g.LP = ((*w16 ? 16 : g.TWC * 32) + k - 1 + 7) & ~7;   // multiple of 8: the LDS swizzle bit of a row differs from row 0 by (row * LP/8) & 1
@@ -578,7 +589,8 @@ static void tiled_geometry(TiledGeom& g, int k, int np, int rw, int nt, int* ygr
   g.tiles_h = cdiv(g.H, g.TRG * rwo * rpa); g.tiles_w = *w16 ? 1 : cdiv(g.W, g.TWC * 32);
   *ygrid = cdiv(g.NTT, nt * wn);
   int64_t blocks = (int64_t)g.N * g.D * g.tiles_h * g.tiles_w * *ygrid;
-  g.splitkd = (np == 1 && blocks < 400) ? 1 : 0;         // small volumes: one block per kd, fp32 atomic accumulation
+  const int split_below = (!*w16 && wn == 2) ? 200 : 400;   // (the 8-row arrangement is there to AVOID the split: 256 blocks are enough)
+  g.splitkd = (np == 1 && blocks < split_below) ? 1 : 0;    // small volumes: one block per kd, fp32 atomic accumulation
   // ... and, when even k blocks per tile leave the chip half empty, per share of the input chunks (>= 4 chunks per share)
   g.chsplit = 1;
   if (g.splitkd) { while (blocks * k * g.chsplit < 400 && g.NCH / (g.chsplit * 2) >= 4) g.chsplit *= 2; }
@@ -642,6 +654,12 @@ static bool tiled_fast_inputs(const void* x, int ldx, const void* x2, int ldx2, 
          (!x2 || (csplit % 16 == 0 && ldx2 % 8 == 0 && ((uintptr_t)x2 & 15) == 0)) && (int64_t)H * W * (ldx > ldx2 ? ldx : ldx2) < (1ll << 30);
 }
 extern "C" int dp_conv3d_tiled_pro_ok(const void* x, int ldx, const void* x2, int ldx2, int csplit, int H, int W, int Cin, int Cout, int k, int dtype) {
+  // (no prologue instantiation of the two-channel-group arrangements: shapes that take one keep the materialised normalisation, so
+  // that dp_conv3d_tiled_stat_blocks / _ws_elems describe every launch of a shape)
+  if (!cc16_applicable(Cin, Cout, k, W) && tiled_applicable(Cin, Cout, k, 1, k / 2, 1, W)) {
+    int rw, nt; int np = tiled_config(Cout, &rw, &nt);
+    if (np == 1 && nt == 2 && W > 16 && W <= 32) return 0;      // (the 8-row two-channel-group arrangement of one-column tiles, tiled_geometry)
+  }
   return (k == 3 && (dtype == DP_BF16 || dtype == DP_F16) && tiled_applicable(Cin, Cout, k, 1, 1, 1, W) &&
           tiled_fast_inputs(x, ldx, x2, ldx2, csplit, Cin, H, W)) ? 1 : 0;
 }
@@ -702,7 +720,10 @@ static int conv3d_tiled_impl(const void* x, int ldx, const void* x2, int ldx2, i
                               : launch_tiled<TT, KS_, 1, 4, 2, 0, TT, 2>(x, wq, bias, y, ws, g, ygrid, s)
 #define BYTW(TT, KS_, NP, RW_, NT_) do { if (g.TWC == 4) GO(TT, KS_, NP, RW_, NT_, 4); else if (g.TWC == 2) GO(TT, KS_, NP, RW_, NT_, 2); \
                                          else GO(TT, KS_, NP, RW_, NT_, 1); } while (0)
-#define BYCFG(TT, KS_) do { if (np == 2) BYTW(TT, KS_, 2, 9, 1); else if (nt == 1) { if (w16) GO(TT, KS_, 1, 8, 1, 0); else BYTW(TT, KS_, 1, 8, 1); } \
+#define GOW32(TT, KS_) rc = x3 ? launch_tiled<bf16_t, KS_, 1, 4, 1, 1, float, 2>(x, wq, bias, y, ws, g, ygrid, s) \
+                               : launch_tiled<TT, KS_, 1, 4, 1, 1, TT, 2>(x, wq, bias, y, ws, g, ygrid, s)
+#define BYCFG(TT, KS_) do { if (np == 2) BYTW(TT, KS_, 2, 9, 1); else if (!w16 && wn == 2) GOW32(TT, KS_); \
+                            else if (nt == 1) { if (w16) GO(TT, KS_, 1, 8, 1, 0); else BYTW(TT, KS_, 1, 8, 1); } \
                             else { if (w16 && wn == 2) GOW2(TT, KS_); else if (w16) GO(TT, KS_, 1, 4, 2, 0); else BYTW(TT, KS_, 1, 4, 2); } } while (0)
   const bool x3 = dtype == DP_X3;
   if (pro) {
@@ -715,6 +736,7 @@ static int conv3d_tiled_impl(const void* x, int ldx, const void* x2, int ldx2, i
 #undef BYCFG
 #undef BYTW
 #undef GOW2
+#undef GOW32
 #undef BYCFGP
 #undef BYTWP
 #undef GOP
