@@ -18,6 +18,7 @@ SHAPES = [
     ("dec3.c7a 128->64 @32", 2, 128, 64, 32, 7), ("dec3.c7b 64->64 @32", 2, 64, 64, 32, 7), ("dec3.dgrad 64->128 @32", 2, 64, 128, 32, 7),
     ("c3 128->64 @32", 2, 128, 64, 32, 3), ("c3 64->128 @32", 2, 64, 128, 32, 3),
     ("dec4.c7a 256->128 @16", 2, 256, 128, 16, 7), ("dec4.c7b 128->128 @16", 2, 128, 128, 16, 7),
+    ("c3 128->128 @16", 2, 128, 128, 16, 3), ("c3 256->128 @16", 2, 256, 128, 16, 3), ("dec4.dgrad 128->256 @16", 2, 128, 256, 16, 7),
     ("c3 32->16 @128", 2, 32, 16, 128, 3), ("c3 16->16 @128", 2, 16, 16, 128, 3), ("c3 25->16 @128", 2, 32, 16, 128, 3),
     ("c3 64->32 @64", 2, 64, 32, 64, 3), ("c3 32->32 @64", 2, 32, 32, 64, 3), ("c3 64->64 @32", 2, 64, 64, 32, 3),
 ]
