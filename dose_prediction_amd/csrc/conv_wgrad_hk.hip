@@ -90,10 +90,14 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_hk(const T* __restrict__ x, co
   for (int a = 0; a < RolePair::NACC; a++) acc[a] = (v4f){0.f, 0.f, 0.f, 0.f};
 
   struct Tile { int n, d, id, h0, w0; };
-  auto tile_ok = [&](int u) { const int id = (u / per_plane) % g.D, d = id - kd + C::PAD; return d >= 0 && d < g.D; };
+  // Units are walked DEPTH-FASTEST inside a tile column (n, th, tw): the KS kd-blocks of a share (same XCD, same unit range) read
+  // the same x tile in the same step and the gy tile (column, d) in KS CONSECUTIVE steps (d = id - kd + PAD), so their XCD's L2
+  // serves six of the seven reads.  With plane-major units (round 2) a gy tile came back 16 tiles x kd later -- longer than a
+  // share's whole walk: FETCH_SIZE 1.6 GB per launch for 270-400 MB of operands (profiles/r03_r_pmc_traffic.md).
+  auto tile_ok = [&](int u) { const int id = u % g.D, d = id - kd + C::PAD; return d >= 0 && d < g.D; };
   auto tile_of = [&](int u) {
-    Tile t; const int tw = u % g.tiles_w, th = (u / g.tiles_w) % g.tiles_h, nd = u / per_plane;
-    t.id = nd % g.D; t.n = nd / g.D; t.d = t.id - kd + C::PAD; t.h0 = th * C::TH; t.w0 = tw * C::TW;
+    Tile t; const int col = u / g.D, tw = col % g.tiles_w, th = (col / g.tiles_w) % g.tiles_h;
+    t.id = u - col * g.D; t.n = col / per_plane; t.d = t.id - kd + C::PAD; t.h0 = th * C::TH; t.w0 = tw * C::TW;
     return t;
   };
   auto next_ok = [&](int u) { u++; while (u < u1 && !tile_ok(u)) u++; return u; };
@@ -246,7 +250,14 @@ int launch_hk(const void* x, const void* gy, float* ws, WgHkGeom g, hipStream_t 
   }
   int want = (ncu * occ) / (KS * g.MT * g.NTn); if (want < 1) want = 1;
   int ydim = units < want ? units : want;
-  if (ydim >= 8 && (ydim & 7) * 20 <= ydim) ydim &= ~7;
+  // Shares in multiples of 8 whenever there are at least 8: only then does the block decode give every XCD whole shares (all kd /
+  // channel-tile blocks of a unit range behind ONE L2).  Round 2 rounded down only when that cost < 5 % of the blocks; the layers
+  // with several channel tiles (want = 36 or 9) then ran with their blocks dealt round-robin over the XCDs: FETCH_SIZE 5.1 GB per
+  // launch for the 403 MB of a 32 -> 16 layer at 2 x 128^3, 2.9 GB for the 100 MB of 64 -> 32 at 64^3.  With whole shares (and the
+  // depth-fastest walk above): 0.66 GB and 0.18 GB; the launches take the same time (they are matrix-bound either way) and leave
+  // 12 GB per step of fabric traffic to the kernels on the other streams.  DP_HK_ROUND8=0: the old rule.
+  static const int round8 = [] { const char* e = getenv("DP_HK_ROUND8"); return e ? atoi(e) : 1; }();
+  if (ydim >= 8 && ((ydim & 7) * 20 <= ydim || round8)) ydim &= ~7;
   g.ydim = ydim;
   hipLaunchKernelGGL(kern, dim3(KS * ydim * g.MT * g.NTn), dim3(256), C::SMEM, s, (const T*)x, (const T*)gy, ws, g);
   return 0;
