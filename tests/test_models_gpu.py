@@ -726,3 +726,53 @@ def test_side_streams_do_not_share_a_queue_with_the_callers_stream():
     other = streams.side_streams(dev, user)
     assert len(other) == 3 and user.cuda_stream not in {s.cuda_stream for s in other}
     torch.cuda.synchronize()
+
+
+def test_weight_gradient_stream_accumulation_and_autograd_grad():
+    """config.set_wgrad_stream (on by default): the convolutions' weight gradients are launched on a stream of their own and joined at
+    the end of the backward pass.  (1) torch.autograd.grad() hands out tensors that are complete for the caller's stream; (2) a second
+    backward pass WITHOUT zero_grad (gradient accumulation over micro-batches: the parameters already hold a .grad, AccumulateGrad adds
+    on the caller's stream) gives exactly twice / the sum of the single-pass gradients -- that pass keeps the weight gradients on the
+    caller's stream; (3) plain torch.optim.SGD reads the gradients right after backward().  All against the one-stream run, repeated
+    so that an allocator reuse across streams would show."""
+    import dose_prediction_amd
+    from dose_prediction_amd.models.c3d import BaseUNet
+    dev = _dev()
+    _set(torch.float32)
+    torch.manual_seed(21)
+    net = BaseUNet(3, [-1, 8, 16, 16, 32, 32]).to(dev).train()
+    xs = [torch.randn((2, 3, 16, 16, 32), generator=torch.Generator().manual_seed(30 + i)).to(dev) for i in range(2)]
+    params = [p for p in net.parameters()]
+    ref = {}
+    try:
+        for on in (False, True, True):
+            dose_prediction_amd.config.set_wgrad_stream(on)
+            # (1) autograd.grad
+            gs = torch.autograd.grad(net(xs[0]).square().mean(), params)
+            torch.cuda.synchronize()
+            # (2) accumulation over two micro-batches
+            net.zero_grad(set_to_none=True)
+            for x in xs:
+                net(x).square().mean().backward()
+            torch.cuda.synchronize()
+            acc = [p.grad.clone() for p in params]
+            # (3) an optimizer that knows nothing about the stream
+            w0 = [p.detach().clone() for p in params]
+            opt = torch.optim.SGD(params, lr=0.5)
+            net.zero_grad(set_to_none=True)
+            net(xs[1]).square().mean().backward()
+            opt.step()
+            torch.cuda.synchronize()
+            delta = [p.detach() - w for p, w in zip(params, w0)]
+            with torch.no_grad():
+                for p, w in zip(params, w0):
+                    p.copy_(w)
+            dose_prediction_amd.ops.invalidate_packs(params)          # (restored through copy_: the packed copies follow the version counters anyway)
+            if not on:
+                ref = {"gs": gs, "acc": acc, "delta": delta}
+            else:
+                for name, got in (("gs", gs), ("acc", acc), ("delta", delta)):
+                    for a, b, p in zip(got, ref[name], params):
+                        assert cmp_prefix(a.cpu(), b.cpu()) < 1e-4, (name, tuple(p.shape))
+    finally:
+        dose_prediction_amd.config.set_wgrad_stream(True)
