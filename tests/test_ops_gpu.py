@@ -113,6 +113,11 @@ DTYPES = [torch.float32, torch.bfloat16, torch.float16]
     (2, 9, 16, 4, 20, 100, 3, 1, 1, 1, True),
     (1, 16, 8, 37, 8, 128, 3, 1, 1, 1, False),
     (1, 16, 16, 4, 40, 96, 3, 1, 1, 1, True),
+    # one-column tiles (16 < W <= 32) with two or four 32-channel output tiles and enough planes to skip the kd split: 8-row blocks,
+    # two row groups x two channel-tile groups per block (tiled_geometry, round 3); ragged H / W, a second block row of channel tiles
+    (2, 64, 64, 32, 30, 24, 3, 1, 1, 1, True),
+    (2, 64, 128, 26, 32, 20, 3, 1, 1, 1, False),
+    (4, 32, 64, 26, 12, 32, 7, 1, 3, 1, True),
 ])
 def test_conv3d(cfg, dtype):
     from dose_prediction_amd import ops
@@ -515,7 +520,8 @@ def test_fused_adam_matches_torch(amsgrad):
     (2, 16, 16, 16, 16, 3, 9, 40, 7), (1, 16, 9, 16, 16, 4, 10, 32, 3), (1, 32, 32, 32, 32, 2, 9, 33, 7),
     (1, 64, 64, 64, 64, 2, 6, 16, 3), (1, 16, 16, 16, 8, 2, 5, 20, 3), (1, 8, 8, 8, 16, 3, 5, 6, 3),
     (1, 16, 16, 16, 16, 2, 34, 40, 7),       # (K-along-H weight gradient, second input behind the channel split)
-    (1, 16, 16, 16, 16, 4, 34, 40, 3)])      # (the depth-marching 3^3 weight gradient with a split input)
+    (1, 16, 16, 16, 16, 4, 34, 40, 3),       # (the depth-marching 3^3 weight gradient with a split input)
+    (2, 32, 32, 32, 64, 30, 29, 24, 3)])     # (one-column tiles, two channel-tile groups per block, no kd split)
 def test_conv3d_virtual_concat(cfg, dtype):
     """conv3d((a, b)) == conv3d(cat(a, b)) of the oracle, forward and every gradient (dp_conv3d_tiled2 / dp_conv3d_wgrad_tiled2;
     the last config is too narrow for the tiled kernels and must take the materialised-cat fallback)."""
@@ -721,6 +727,8 @@ def test_fused_adam_capturable_replays_correct_steps():
     (2, 16, 0, 32, 50, 61, 40, 3),      # NPAIR == 1, one N tile (>= 400 blocks: no split-kd), ragged H
     (1, 24, 0, 72, 20, 78, 33, 3),      # two N tiles per block + a second channel block (grid.y), ragged Cout / H
     (4, 32, 0, 64, 100, 16, 16, 3),     # W16 tiles (two image rows per MFMA tile)
+    (2, 64, 0, 64, 32, 27, 24, 3),      # one-column tiles, 8-row blocks with two channel-tile groups (no kd split): ragged H and W
+    (2, 32, 16, 128, 26, 32, 32, 3),    # ... four channel tiles (two block rows), virtual concat
     (1, 128, 0, 64, 4, 8, 16, 7),       # split-kd volume: statistics fall back to the row pass
     (1, 12, 0, 8, 6, 6, 6, 3)])         # too small for the tiled kernel: generic convolution + row pass
 def test_conv_epilogue_statistics(cfg, dtype):
