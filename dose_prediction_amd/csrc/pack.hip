@@ -76,6 +76,7 @@ __global__ void __launch_bounds__(256) k_pack_multi(const PackDesc* __restrict__
   for (unsigned i = base + threadIdx.x; i < end; i += 256) {
     float v = 0.f;
     int part = 0;
+    unsigned di = i;                 // destination element (the tiled convolution layouts permute the thread order)
     if (kind == PK_MAT) {
       const unsigned cols = (unsigned)P.b, pitch = (unsigned)P.c, r = i / pitch; unsigned c = i - r * pitch;
       if (x3cp) { part = (int)(c / (unsigned)x3cp); c -= (unsigned)part * (unsigned)x3cp; }
@@ -93,9 +94,14 @@ __global__ void __launch_bounds__(256) k_pack_multi(const PackDesc* __restrict__
       // dst[kd][jh][kw][chunk][ntile][col 32][ci 16]   (k_pack_w_tiled)
       const int Cout = (int)P.a, Cin = (int)P.b, KS = (int)P.c, NPAIR = (int)P.d, tf = (int)P.e;
       const int JH = NPAIR == 2 ? (KS + 1) / 2 : KS, NCH = x3cp ? 3 * x3cp / 16 : (Cin + 15) / 16, NTT = (Cout * NPAIR + 31) / 32, taps = KS * KS * KS;
-      const int c = (int)(i & 15), col = (int)((i >> 4) & 31); unsigned t = i >> 9;
-      const int nt = (int)(t % NTT); t /= NTT; const int ch = (int)(t % NCH); t /= NCH; const int kw = (int)(t % KS); t /= KS;
+      // thread order (kd, jh, chunk, ntile | col, ci | kw): consecutive lanes walk the KS kw taps of one (co, ci) pair, which are
+      // consecutive floats of the source (7 lanes per 28-byte run instead of 64 lanes on 64 different sectors: the 4-byte gathers
+      // 1372 bytes apart made this the slowest HBM kernel of the step, 0.75 TB/s); a bijection of the destination indices
+      unsigned t = i;
+      const int kw = (int)(t % KS); t /= KS; const int c = (int)(t & 15), col = (int)((t >> 4) & 31); t >>= 9;
+      const int nt = (int)(t % NTT); t /= NTT; const int ch = (int)(t % NCH); t /= NCH;
       const int jh = (int)(t % JH), kd = (int)(t / JH);
+      di = ((((unsigned)((kd * JH + jh) * KS + kw) * NCH + ch) * NTT + nt) << 9) + (col << 4) + c;
       int kh, co;
       if (NPAIR == 2) { const int s = col >> 4; kh = 2 * jh + s; co = nt * 16 + (col & 15); }
       else { kh = jh; co = nt * 32 + col; }
@@ -109,9 +115,13 @@ __global__ void __launch_bounds__(256) k_pack_multi(const PackDesc* __restrict__
       // dst[kd][chunk][kwp][kh][co 16][k 32]   (k_pack_w_cc16)
       const int Cout = (int)P.a, Cin = (int)P.b, KS = (int)P.c, tf = (int)P.e;
       const int KWP = (KS + 1) / 2, NCH = x3cp ? 3 * x3cp / 16 : (Cin + 15) / 16, taps = KS * KS * KS;
-      const int k = (int)(i & 31), co = (int)((i >> 5) & 15); unsigned t = i >> 9;
-      const int kh = (int)(t % KS); t /= KS; const int kwp = (int)(t % KWP); t /= KWP; const int ch = (int)(t % NCH); const int kd = (int)(t / NCH);
-      const int kw = 2 * kwp + (k >> 4); int ci = ch * 16 + (k & 15);
+      // thread order (kd, chunk, kh | co, ci | kw): see PK_CONV_TILED
+      unsigned t = i;
+      const int kw = (int)(t % (2 * KWP)); t /= 2 * KWP; const int c16 = (int)(t & 15), co = (int)((t >> 4) & 15); t >>= 8;
+      const int kh = (int)(t % KS); t /= KS; const int ch = (int)(t % NCH); const int kd = (int)(t / NCH);
+      const int kwp = kw >> 1, k = ((kw & 1) << 4) + c16;
+      di = ((((unsigned)(kd * NCH + ch) * KWP + kwp) * KS + kh) << 9) + (co << 5) + k;
+      int ci = ch * 16 + c16;
       if (x3cp) { part = ci / x3cp; ci -= part * x3cp; }
       if (kw < KS && co < Cout && ci < Cin) {
         const int tap = (kd * KS + kh) * KS + kw;
@@ -126,7 +136,7 @@ __global__ void __launch_bounds__(256) k_pack_multi(const PackDesc* __restrict__
       if (ok) { const unsigned abc = q / cout, co = q - abc * cout; v = w[((int64_t)ci * cout + co) * 8 + abc]; }
     }
     if (x3cp) v = x3_part(v, (x3pat >> part) & 1);
-    st_f(dst + i, v);
+    st_f(dst + di, v);
   }
 }
 
