@@ -167,6 +167,81 @@ def summarize_profile(records, steps):
     return out
 
 
+def check_pyfer_128(sd, x, ref_maps, gt, args, modes=None):
+    """HIP DOSE-PYFER (same weights, batch 1, train-mode statistics like the oracle call) on the 128^3 volume `x` against the
+    oracle's four dose maps `ref_maps`: rel_err_max = max|d| / max|ref| on output [1][0], the worst of the four maps,
+    and the masked dose-MAE in Gy.  The oracle is the checker here, never the thing timed."""
+    import dose_prediction_amd
+    from dose_prediction_amd.models import dose_pyfer
+    dev = torch.device("cuda", torch.cuda.current_device())
+    mask = gt[:, 1:2] > 0
+    chk = {}
+    modes = modes or tuple(dict.fromkeys(("fp32x3", "fp32", "bf16") + ((args.dtype,) if args.dtype in ("fp16",) else ())))
+    try:
+        for name in modes:
+            dose_prediction_amd.set_compute_dtype(name)
+            hip = dose_pyfer.Model(in_ch=9, out_ch=1, list_ch_A=[-1, 16, 32, 64, 128, 256], feature_size=16, img_size=tuple(x.shape[2:]),
+                                   num_layers=8, num_heads=6, act="mish")
+            hip.load_state_dict(sd)
+            hip = hip.to(dev).train()
+            with torch.no_grad():
+                got = [o.float().cpu() for o in hip(x.to(dev))[1]]
+            errs = [float((g - r).abs().max() / r.abs().max()) for g, r in zip(got, ref_maps)]
+            chk[name] = {"rel_err_max": errs[0], "rel_err_max_all_four_maps": max(errs),
+                         "dose_mae_gy_vs_oracle": float(70.0 * (got[0] - ref_maps[0]).abs()[mask].mean()),
+                         "within_1e-3": bool(max(errs) < 1e-3)}
+            del hip, got
+            torch.cuda.empty_cache()
+    finally:
+        dose_prediction_amd.set_compute_dtype(args.dtype)
+    return chk
+
+
+def check_transeg_128(args, threads):
+    """OAR-TRANSEG at the benchmark size: ONE fp32 oracle forward on a real 128^3 CT (timed, forward only) and the HIP network with
+    the same weights in every mode: logit rel-err, arg-max mismatch COUNT and the count off near-ties (voxels whose top-2 oracle
+    margin exceeds 1e-3 of the logit range) -- north_star: "bit-exact on OAR argmax masks" (oar_transeg.py:171-185)."""
+    import oracle
+    import dose_prediction_amd
+    from dose_prediction_amd import synth
+    from dose_prediction_amd.models import oar_transeg
+    full = (128, 128, 128)
+    torch.manual_seed(4321)
+    mk = lambda: oar_transeg.Model(in_channels=1, out_channels=8, img_size=full, feature_size=16, hidden_size=768, mlp_dim=3072,  # noqa: E731
+                                   num_heads=12, pos_embed="perceptron", norm_name="instance", res_block=True, conv_block=True)
+    sd = {k: v.detach().clone() for k, v in mk().state_dict().items()}
+    x = synth.ct_input(1, full)
+    with torch.no_grad():
+        t1 = time.time()
+        ref = oracle.oar_transeg(sd, x, num_heads=12, training=True)
+        d128 = time.time() - t1
+    out = {"forward_128": {"value": 1.0 / d128, "unit": "128^3 volumes/s (forward only)", "seconds": d128,
+                           "sample": f"one fp32 oracle forward of OAR-TRANSEG on a real 128^3 CT, {threads} torch threads"}}
+    dev = torch.device("cuda", torch.cuda.current_device())
+    top2 = ref.topk(2, dim=1).values
+    safe = (top2[:, 0] - top2[:, 1]) > 1e-3 * ref.abs().max()
+    ra = ref.argmax(1)
+    chk = {}
+    try:
+        for name in dict.fromkeys(("fp32x3", "fp32", args.dtype)):
+            dose_prediction_amd.set_compute_dtype(name)
+            hip = mk()
+            hip.load_state_dict(sd)
+            hip = hip.to(dev).train()
+            with torch.no_grad():
+                got = hip(x.to(dev)).float().cpu()
+            mism = got.argmax(1) != ra
+            chk[name] = {"rel_err_max": float((got - ref).abs().max() / ref.abs().max()), "argmax_mismatch": int(mism.sum()),
+                         "argmax_mismatch_off_near_ties": int((mism & safe).sum()), "voxels": int(mism.numel()),
+                         "near_tie_voxels": int((~safe).sum())}
+            del hip, got
+            torch.cuda.empty_cache()
+    finally:
+        dose_prediction_amd.set_compute_dtype(args.dtype)
+    out["check_vs_oracle_128"] = chk
+    return out
+
+
 def cpu_baseline_transeg(args):
     """OAR-TRANSEG counterpart of cpu_baseline(): the oracle's forward + cross-entropy + backward at cpu_size^3, and the HIP path
     checked on the same sample (logit rel-err, arg-max mismatch count -- SURVEY 8d)."""
@@ -230,6 +305,11 @@ def cpu_baseline_transeg(args):
         res["check_vs_oracle"] = f"failed: {e!r}"
     finally:
         dose_prediction_amd.set_compute_dtype(args.dtype)
+    if args.cpu_full_forward and tuple(args.size * 3 if len(args.size) == 1 else args.size) == (128, 128, 128):
+        try:
+            res.update(check_transeg_128(args, threads))
+        except Exception as e:
+            res["forward_128"] = {"error": repr(e)}
     return res
 
 
@@ -288,6 +368,12 @@ def cpu_baseline(args):
             res["forward_128"] = {"value": 1.0 / d128, "unit": "128^3 volumes/s (forward only)", "seconds": d128,
                                   "sample": f"one fp32 oracle forward of DOSE-PYFER on a real 128^3 volume, {threads} torch threads",
                                   "finite": bool(torch.isfinite(o128[1][0]).all())}
+            # the north-star parity statement AT the benchmark size: the HIP network with the same weights on the
+            # same 128^3 volume in every mode, against this oracle forward (dose_pyfer.py:355-360)
+            try:
+                res["check_vs_oracle_128"] = check_pyfer_128(sd128, x128, [o.detach() for o in o128[1]], synth.dose_target(1, full), args)
+            except Exception as e:
+                res["check_vs_oracle_128"] = f"failed: {e!r}"
             del net128, sd128, o128
         except Exception as e:
             res["forward_128"] = {"error": repr(e)}

@@ -1293,6 +1293,11 @@ def _x3_conv_call(xa, xb, weight, bias, stats, bias_grad_zero):
     consumer), the channel count is a multiple of 16 and no bias gradient has to be summed from gy, the partial-statistics tensor is
     tagged so that norm_act(y, ..., stats=part) returns its input gradient already split."""
     gy_split = bool(stats and weight.shape[0] % 16 == 0 and (bias is None or bias_grad_zero))
+    if gy_split:
+        # (ADVICE r3) fewer than 8 input channels: the data gradient falls back to the exact-fp32 gather kernel, which needs the real
+        # fp32 gy -- the normalisation behind then hands its gradient over unsplit
+        cout, cin, k = weight.shape[0], weight.shape[1], weight.shape[2]
+        gy_split = bool(_lib.lib().dp_conv3d_tiled_weight_elems(3 * cout, cin, k, 1, k // 2, 1, xa.shape[3]))
     out = Conv3dX3.apply(xa, xb, weight, bias, stats, bias_grad_zero, gy_split)
     if stats:
         out[1]._dp_gy_split = gy_split

@@ -166,6 +166,32 @@ def test_x3_conv3d_with_statistics_and_padded_rows():
     assert rel_l2(s1, yd.sum((1, 2, 3)).cpu()) < 1e-5 and rel_l2(s2, (yd * yd).sum((1, 2, 3)).cpu()) < 1e-5
 
 
+@pytest.mark.parametrize("cin", [1, 3, 7, 9])
+def test_x3_conv_norm_input_gradient_with_few_input_channels(cin):
+    """ conv3d(..., stats=True, bias_grad_zero=True) -> instance norm -> ReLU on an input that REQUIRES a gradient and has
+    fewer than 8 channels: the data gradient falls back to the exact-fp32 gather kernel, which must see the real fp32 gy (the
+    split-gradient handshake has to stay off for this shape)."""
+    from dose_prediction_amd import ops
+    dev = _dev()
+    w, b = rnd((16, cin, 3, 3, 3), 2, 0.2), rnd((16,), 3, 0.1)
+    gam, bet = 1 + 0.2 * rnd((16,), 4), rnd((16,), 5, 0.1)
+    x = rnd((1, cin, 6, 24, 40), 1)
+    gz = rnd((1, 16, 6, 24, 40), 6)
+    xr, wr, br = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    gr, ber = gam.double().requires_grad_(True), bet.double().requires_grad_(True)
+    zr = torch.relu(torch.nn.functional.instance_norm(oracle.conv3d(xr, wr, br, 1, 1, 1), weight=gr, bias=ber, eps=1e-5))
+    zr.backward(gz.double())
+    xh = ndhwc(x).to(dev).requires_grad_(True)
+    wh, bh, gh, beh = (t.to(dev).requires_grad_(True) for t in (w, b, gam, bet))
+    y, st = ops.conv3d(xh, wh, bh, 1, 1, 1, stats=True, bias_grad_zero=True)
+    z = ops.norm_act(y, "instance", gh, beh, act="relu", eps=1e-5, stats=st)
+    z.backward(ndhwc(gz).to(dev))
+    check("z", ncdhw(z.detach()), zr.detach())
+    check("gx", ncdhw(xh.grad), xr.grad, scale=30.0)
+    check("gw", wh.grad, wr.grad, scale=30.0)
+    check("ggamma", gh.grad, gr.grad, scale=30.0)
+
+
 @pytest.mark.parametrize("cfg", [(300, 768, 96, True), (64, 48, 144, False), (1024, 1000, 64, True), (1024, 768, 3072, True)])
 def test_x3_linear(cfg):
     from dose_prediction_amd import ops
