@@ -10,7 +10,8 @@ import re
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 HEADER = os.path.join(_ROOT, "include", "dose_hip.h")
-LIB_PATH = os.path.join(_HERE, "libdose_hip.so")
+# (DOSE_HIP_LIB: another build of the same C ABI, for A/B measurements on one box -- tools/build_ab.sh)
+LIB_PATH = os.path.abspath(os.environ["DOSE_HIP_LIB"]) if os.environ.get("DOSE_HIP_LIB") else os.path.join(_HERE, "libdose_hip.so")
 
 _CTYPES = {
     "int": ctypes.c_int, "int64_t": ctypes.c_int64, "float": ctypes.c_float, "int32_t": ctypes.c_int32,

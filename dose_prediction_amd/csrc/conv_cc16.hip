@@ -41,18 +41,28 @@ bool cc16_applicable(int Cin, int Cout, int k, int W) {
   if (off < 0) { const char* e = getenv("DP_NO_CC16"); off = (e && atoi(e)) ? 1 : 0; }
   return !off && (k == 3 || k == 7) && Cout >= 8 && Cout <= 16 && Cin >= 1 && W >= 96;
 }
-int cc16_weight_elems(int Cin, int Cout, int k) { return k * ((Cin + 15) / 16) * ((k + 1) / 2) * k * 512; }
+// tap pairs (K = 32 MFMA slots) per (kd, input chunk).  3x3x3: [kwp 2][kh 3] (kw = 2 kwp, 2 kwp + 1; the odd tap of kwp 1 is padding).
+// 7x7x7 (round 4): the 49 (kh, kw) taps in LINEAR order t = 7 kh + kw, slot j = taps 2j, 2j + 1: 25 slots, one padding half, instead
+// of the 28 slots of [kwp 4][kh 7] (an eighth of every 7x7x7 sweep was multiplication by zero weights).  Slots with kw = 6 on the
+// left straddle two kernel rows: (kh, 6) | (kh + 1, 0) -- both taps feed output row rho - kh when the right half of the A fragment
+// comes from slab row rho + 1.
+__host__ __device__ inline int cc16_slots(int k) { return k == 7 ? 25 : ((k + 1) / 2) * k; }
+int cc16_weight_elems(int Cin, int Cout, int k) { return k * ((Cin + 15) / 16) * cc16_slots(k) * 512; }
 
-// dst[kd][chunk][kwp][kh][co 16][k 32], k < 16: tap kw = 2 kwp, ci = chunk*16 + k; k >= 16: kw = 2 kwp + 1, ci = chunk*16 + k - 16.
+// KS = 3: dst[kd][chunk][kwp][kh][co 16][k 32], k < 16: tap kw = 2 kwp, ci = chunk*16 + k; k >= 16: kw = 2 kwp + 1, ci = chunk*16 + k - 16.
+// KS = 7: dst[kd][chunk][slot j][co 16][k 32], k < 16: tap t = 2j, k >= 16: tap t = 2j + 1 (t = 7 kh + kw; t = 49: zero).
 // transposed_flipped: w'[co][ci][tap] = w[ci][co][taps-1-tap] (data gradient as a forward convolution).
 template <typename T>
 __global__ void k_pack_w_cc16(const float* __restrict__ w, T* __restrict__ dst, int Cout, int Cin, int KS, int tf) {
-  const int KWP = (KS + 1) / 2, NCH = (Cin + 15) / 16, taps = KS * KS * KS;
-  const int total = KS * NCH * KWP * KS * 512;
+  const int KWP = (KS + 1) / 2, NCH = (Cin + 15) / 16, taps = KS * KS * KS, NS = cc16_slots(KS);
+  const int total = KS * NCH * NS * 512;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     const int k = i & 31, co = (i >> 5) & 15; int t = i >> 9;
-    const int kh = t % KS; t /= KS; const int kwp = t % KWP; t /= KWP; const int ch = t % NCH; const int kd = t / NCH;
-    const int kw = 2 * kwp + (k >> 4), ci = ch * 16 + (k & 15);
+    int kh, kw;
+    if (KS == 7) { const int j = t % NS; t /= NS; const int tt = 2 * j + (k >> 4); kh = tt / 7; kw = tt % 7; if (tt >= 49) kw = KS; }
+    else { kh = t % KS; t /= KS; const int kwp = t % KWP; t /= KWP; kw = 2 * kwp + (k >> 4); }
+    const int ch = t % NCH; const int kd = t / NCH;
+    const int ci = ch * 16 + (k & 15);
     float v = 0.f;
     if (kw < KS && co < Cout && ci < Cin) {
       const int tap = (kd * KS + kh) * KS + kw;
@@ -169,6 +179,82 @@ __global__ void __launch_bounds__(256, OCC) k_conv_cc16(const T* __restrict__ x,
       for (int od = 0; od < DT; od++) {
         const int kd = z - (d0 + od) + PAD;
         if (kd < 0 || kd >= KS || d0 + od >= g.D || (g.dbg & 2)) continue;        // block-uniform
+        if constexpr (KS == 7) {
+          // 25 tap-pair slots in linear tap order (see cc16_slots).  Seven A-fragment TYPES per slab row rho and M tile:
+          //   E_p (p = 0..2): taps (kh, 2p) | (kh, 2p + 1) for the even kh -> positions v + 2p | v + 2p + 1 of row rho,
+          //   O_p (p = 0..2): taps (kh, 2p + 1) | (kh, 2p + 2) for the odd kh -> positions v + 2p + 1 | v + 2p + 2 of row rho,
+          //   S = "E_3":      taps (kh, 6) | (kh + 1, 0) for kh = 0, 2, 4 and the lone (6, 6) | zero -> position v + 6 of row rho | v of row rho + 1.
+          // Every fragment feeds the MFMAs of all its kh whose output row rho - kh lies in the tile (up to 4 for E / S, 3 for O).
+          const T* wbase = wq + ((int64_t)(kd * g.NCH + wch) * 25) * WT + lane_off;
+          Frag8<T> bE[4], bO[3];
+          auto load_bE = [&](int p) {          // slots of taps (kh, 2p) for kh = 0, 2, 4, 6: j = (7 kh + 2p) / 2 = 7 i + p  (p = 3: the straddling slots)
+#pragma unroll
+            for (int i = 0; i < 4; i++) bE[i] = frag_ld_lds(wbase + (7 * i + p) * WT);
+          };
+          auto load_bO = [&](int p) {          // slots of taps (kh, 2p + 1) for kh = 1, 3, 5: j = (7 kh + 2p + 1) / 2 = 7 i + 4 + p
+#pragma unroll
+            for (int i = 0; i < 3; i++) bO[i] = frag_ld_lds(wbase + (7 * i + 4 + p) * WT);
+          };
+          const int v_base = wv * 32 + r;
+          // Steps k = (slab row, M tile) in row order; the rows that feed no MFMA of a type (rows 0 and 13 for the odd kh) are not read.
+          // The fragments run through a ring of four register sets, three reads in flight.
+          constexpr int NE = 28, NO = 24;
+          constexpr int ordE[NE] = {0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+          constexpr int mtE[NE] = {0, 1, 0, 1, 0, 1, 0, 1, 0, 1, 0, 1, 0, 1, 0, 1, 0, 1, 0, 1, 0, 1, 0, 1, 0, 1, 0, 1};
+          constexpr int ordO[NO] = {1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12};
+          constexpr int mtO[NO] = {0, 1, 0, 1, 0, 1, 0, 1, 0, 1, 0, 1, 0, 1, 0, 1, 0, 1, 0, 1, 0, 1, 0, 1};
+          Frag8<T> fa[4];
+          // the lane's fragment of type (odd, p) at slab row rho, M tile mt
+          auto a_ptr = [&](int odd, int p, int rho, int mt) -> const T* {
+            int pos = v_base + 2 * p + odd + (q >> 1), row = rho;
+            // straddling type: the right-hand tap lives at the start of the next slab row (the last slab row only serves the lone
+            // (6, 6) tap, whose right half meets zero weights: it keeps the in-row neighbour so that no lane reads past the slab)
+            if (!odd && p == 3 && (q >> 1) && rho + 1 < ROWS) { pos = v_base; row = rho + 1; }
+            const int hs = SWZ ? (hsel ^ ((pos >> 3) & 1) ^ ((row & 1) ? lp_par : 0)) : hsel;
+            return slab + (pos + row * LP + mt * 16) * CK + hs * 8;
+          };
+          auto a_step = [&](int odd, int p, int k) -> const T* { return odd ? a_ptr(1, p, ordO[k], mtO[k]) : a_ptr(0, p, ordE[k], mtE[k]); };
+          auto do_type = [&](int odd, int p, int nodd, int np, bool pre_next) {
+            const int S = odd ? NO : NE;
+#pragma unroll
+            for (int k = 0; k < NE; k++) {
+              if (k >= S) continue;
+              const int nx = k + 3;
+              if (nx < S) fa[nx % 4] = frag_ld_lds(a_step(odd, p, nx));
+              else if (pre_next) fa[nx % 4] = frag_ld_lds(a_step(nodd, np, nx - S));
+              __builtin_amdgcn_sched_barrier(0);
+              const int rho = odd ? ordO[k] : ordE[k], mt = odd ? mtO[k] : mtE[k];
+              if (odd) {
+#pragma unroll
+                for (int i = 2; i >= 0; i--) {
+                  const int orow = rho - (2 * i + 1);
+                  if (orow < 0 || orow >= RWO) continue;                 // compile-time after unrolling
+                  acc[od][orow][mt] = mma16(fa[k % 4], bO[i], acc[od][orow][mt]);
+                }
+              } else {
+#pragma unroll
+                for (int i = 3; i >= 0; i--) {
+                  const int orow = rho - 2 * i;
+                  if (orow < 0 || orow >= RWO) continue;
+                  acc[od][orow][mt] = mma16(fa[k % 4], bE[i], acc[od][orow][mt]);
+                }
+              }
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          };
+          static_assert(NE % 4 == 0 && NO % 4 == 0, "the fragment ring returns to slot 0 after every type");
+          // type order E_0 O_0 E_1 O_1 E_2 O_2 E_3: the tiles of the next type are requested while the current one is swept
+          load_bE(0);
+          fa[0] = frag_ld_lds(a_step(0, 0, 0)); fa[1] = frag_ld_lds(a_step(0, 0, 1)); fa[2] = frag_ld_lds(a_step(0, 0, 2));
+#pragma unroll 1
+          for (int p = 0; p < 3; p++) {
+            load_bO(p); __builtin_amdgcn_sched_barrier(0);
+            do_type(0, p, 1, p, true);
+            load_bE(p + 1); __builtin_amdgcn_sched_barrier(0);
+            do_type(1, p, 0, p + 1, true);
+          }
+          do_type(0, 3, 0, 0, false);
+        } else {
         const T* wbase = wq + ((int64_t)(kd * g.NCH + wch) * KWP) * KS * WT + lane_off;
         Frag8<T> b0[KS], b1[KS];
         auto load_b = [&](int kwp, Frag8<T>* bb) {
@@ -211,6 +297,7 @@ __global__ void __launch_bounds__(256, OCC) k_conv_cc16(const T* __restrict__ x,
           do_pair(kwp, b0, true);
           if (kwp + 2 < KWP) { load_b(kwp + 2, b0); __builtin_amdgcn_sched_barrier(0); }
           do_pair(kwp + 1, b1, kwp + 2 < KWP);
+        }
         }
       }
       }

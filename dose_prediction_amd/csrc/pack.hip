@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(256) k_pack_multi(const PackDesc* __restrict__
     total = (unsigned)(KS * (NP == 2 ? (KS + 1) / 2 : KS) * KS * ((x3cp ? 3 * x3cp : (P.b + 15)) / 16) * ((P.a * NP + 31) / 32) * 512);
   } else if (kind == PK_CONV_CC16) {
     const int KS = (int)P.c;
-    total = (unsigned)(KS * ((x3cp ? 3 * x3cp : (P.b + 15)) / 16) * ((KS + 1) / 2) * KS * 512);
+    total = (unsigned)(KS * ((x3cp ? 3 * x3cp : (P.b + 15)) / 16) * (KS == 7 ? 25 : ((KS + 1) / 2) * KS) * 512);
   } else total = (unsigned)(P.d ? P.a * P.c : 8 * P.b * P.c);
   const unsigned end = min(total, base + PACK_CHUNK);
   for (unsigned i = base + threadIdx.x; i < end; i += 256) {
@@ -112,15 +112,26 @@ __global__ void __launch_bounds__(256) k_pack_multi(const PackDesc* __restrict__
         v = tf ? w[((int64_t)ci * Cout + co) * taps + (taps - 1 - tap)] : w[((int64_t)co * Cin + ci) * taps + tap];
       }
     } else if (kind == PK_CONV_CC16) {
-      // dst[kd][chunk][kwp][kh][co 16][k 32]   (k_pack_w_cc16)
+      // KS = 3: dst[kd][chunk][kwp][kh][co 16][k 32]; KS = 7: dst[kd][chunk][slot 25][co 16][k 32], slot j = taps 2j | 2j + 1 in the
+      // linear order t = 7 kh + kw   (k_pack_w_cc16)
       const int Cout = (int)P.a, Cin = (int)P.b, KS = (int)P.c, tf = (int)P.e;
       const int KWP = (KS + 1) / 2, NCH = x3cp ? 3 * x3cp / 16 : (Cin + 15) / 16, taps = KS * KS * KS;
-      // thread order (kd, chunk, kh | co, ci | kw): see PK_CONV_TILED
       unsigned t = i;
-      const int kw = (int)(t % (2 * KWP)); t /= 2 * KWP; const int c16 = (int)(t & 15), co = (int)((t >> 4) & 15); t >>= 8;
-      const int kh = (int)(t % KS); t /= KS; const int ch = (int)(t % NCH); const int kd = (int)(t / NCH);
-      const int kwp = kw >> 1, k = ((kw & 1) << 4) + c16;
-      di = ((((unsigned)(kd * NCH + ch) * KWP + kwp) * KS + kh) << 9) + (co << 5) + k;
+      int kh, kw, c16, co, ch, kd;
+      if (KS == 7) {
+        // thread order (kd, chunk | co, ci | t 0..49): consecutive lanes walk the 49 (kh, kw) taps of one (co, ci, kd), 196 consecutive
+        // bytes of the source
+        const int tt = (int)(t % 50); t /= 50; c16 = (int)(t & 15); co = (int)((t >> 4) & 15); t >>= 8;
+        ch = (int)(t % NCH); kd = (int)(t / NCH);
+        kh = tt / 7; kw = tt >= 49 ? KS : tt % 7;
+        di = ((((unsigned)(kd * NCH + ch) * 25 + (tt >> 1))) << 9) + (co << 5) + ((tt & 1) << 4) + c16;
+      } else {
+        // thread order (kd, chunk, kh | co, ci | kw): see PK_CONV_TILED
+        kw = (int)(t % (2 * KWP)); t /= 2 * KWP; c16 = (int)(t & 15); co = (int)((t >> 4) & 15); t >>= 8;
+        kh = (int)(t % KS); t /= KS; ch = (int)(t % NCH); kd = (int)(t / NCH);
+        const int kwp = kw >> 1, k = ((kw & 1) << 4) + c16;
+        di = ((((unsigned)(kd * NCH + ch) * KWP + kwp) * KS + kh) << 9) + (co << 5) + k;
+      }
       int ci = ch * 16 + c16;
       if (x3cp) { part = ci / x3cp; ci -= part * x3cp; }
       if (kw < KS && co < Cout && ci < Cin) {

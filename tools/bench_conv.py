@@ -41,6 +41,7 @@ def main():
     ap.add_argument("what", nargs="?", default="all")
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--filter", default="")
+    ap.add_argument("--zeros", action="store_true", help="all-zero operands: the clock the chip holds without data toggling (DVFS diagnostic)")
     a = ap.parse_args()
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     if a.dtype == "fp32x3":
@@ -53,6 +54,8 @@ def main():
         x = torch.randn((N, S, S, S, ci), device=dev).to(dt)
         gy = torch.randn((N, S, S, S, co), device=dev).to(dt)
         w = (torch.randn((co, ci, k, k, k), device=dev) * (ci * k ** 3) ** -0.5).requires_grad_(True)
+        if a.zeros:
+            x.zero_(); gy.zero_(); w.data.zero_()
         fl = 2.0 * N * S ** 3 * ci * co * k ** 3
         line = f"{name:28s}"
         if a.what in ("fwd", "all"):
