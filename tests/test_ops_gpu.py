@@ -521,7 +521,10 @@ def test_fused_adam_matches_torch(amsgrad):
     (1, 64, 64, 64, 64, 2, 6, 16, 3), (1, 16, 16, 16, 8, 2, 5, 20, 3), (1, 8, 8, 8, 16, 3, 5, 6, 3),
     (1, 16, 16, 16, 16, 2, 34, 40, 7),       # (K-along-H weight gradient, second input behind the channel split)
     (1, 16, 16, 16, 16, 4, 34, 40, 3),       # (the depth-marching 3^3 weight gradient with a split input)
-    (2, 32, 32, 32, 64, 30, 29, 24, 3)])     # (one-column tiles, two channel-tile groups per block, no kd split)
+    (2, 32, 32, 32, 64, 30, 29, 24, 3),      # (one-column tiles, two channel-tile groups per block, no kd split)
+    (1, 16, 16, 16, 16, 5, 11, 96, 3),       # (W >= 96, Cout <= 16: the wave-private 3^3 kernel k_conv_w3, odd depth, ragged rows, split in and out)
+    (2, 16, 9, 16, 16, 2, 8, 128, 3),        # (... second operand padded to 16 channels)
+    (1, 16, 16, 16, 16, 2, 9, 96, 7)])       # (the 25-slot 7^3 sweep of k_conv_cc16 over a split input)
 def test_conv3d_virtual_concat(cfg, dtype):
     """conv3d((a, b)) == conv3d(cat(a, b)) of the oracle, forward and every gradient (dp_conv3d_tiled2 / dp_conv3d_wgrad_tiled2;
     the last config is too narrow for the tiled kernels and must take the materialised-cat fallback)."""
@@ -581,8 +584,11 @@ def _all_pack_users(dev, dtype):
     x9 = ndhwc(rnd((1, 9, 6, 6, 6), 72)).to(dev).to(dtype).requires_grad_(True)
     tok = rnd((2, 40, 96), 73).to(dev).to(dtype).requires_grad_(True)
     tok2 = rnd((2, 40, 100), 74).to(dev).to(dtype).requires_grad_(True)
+    x16w = ndhwc(rnd((1, 16, 2, 9, 96), 75)).to(dev).to(dtype).requires_grad_(True)
     users = [
         (mk((16, 16, 7, 7, 7), 1, 0.05), lambda w: ops.conv3d(x16, w, None, 1, 3, 1)),        # tiled, tap-paired (Cout <= 16)
+        (mk((16, 16, 7, 7, 7), 9, 0.05), lambda w: ops.conv3d(x16w, w, None, 1, 3, 1)),       # cc16 layout (W >= 96), 25 slots
+        (mk((8, 16, 3, 3, 3), 10), lambda w: ops.conv3d(x16w, w, None, 1, 1, 1)),             # cc16 layout, 3^3
         (mk((40, 24, 3, 3, 3), 2), lambda w: ops.conv3d(x24, w, None, 1, 1, 1)),              # tiled, two N tiles, ragged channels
         (mk((12, 9, 3, 3, 3), 3), lambda w: ops.conv3d(x9, w, None, 2, 1, 1)),                # generic (stride 2): modes 0 and 1
         (mk((12, 9, 3, 3, 3), 4), lambda w: ops.conv3d(x9, w, None, 1, 2, 2)),                # generic dilated: modes 0 and 2
