@@ -43,7 +43,8 @@ def parse():
     ap.add_argument("--no-cpu-full-forward", dest="cpu_full_forward", action="store_false",
                     help="skip the real 128^3 oracle forward of cpu_baseline (the 64^3 step stays: it is also the checker)")
     ap.add_argument("--cpu-steps", type=int, default=2, help="oracle steps timed for cpu_baseline (2 x ~6 s on the GPU box's host)")
-    ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph (GPU-bound either way)")
+    ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph (takes the launch thread out of the step)")
+    ap.add_argument("--graph-one-stream", action="store_true", help="with --graph: drop the side streams inside the capture (the behaviour of rounds 2-3, A/B)")
     ap.add_argument("--torch-adam", action="store_true", help="use torch.optim.Adam instead of the fused HIP Adam")
     ap.add_argument("--checkpoint", action="store_true", help="activation checkpointing of the four decoder blocks (BASELINE.json configs[4])")
     ap.add_argument("--roi", type=int, default=0, help="cascade: segmentation crop (sliding-window inference when smaller than the volume)")
@@ -88,6 +89,8 @@ def build_model(args, shape, dev):
         dose_prediction_amd.config.set_branch_stream(False)
     if args.no_wgrad_stream or args.no_side_stream:
         dose_prediction_amd.config.set_wgrad_stream(False)
+    if getattr(args, "graph_one_stream", False):
+        dose_prediction_amd.config.set_capture_side_streams(False)
     if getattr(args, "seg_mode", None):
         dose_prediction_amd.config.set_cascade_seg_mode(args.seg_mode)
     if args.model in ("pyfer", "cascade"):
@@ -534,8 +537,8 @@ def main():
         torch.cuda.synchronize()
 
     # Default: eager launches (the step is GPU-bound: ~950 kernels in ~30 ms).  --graph: after the eager warm-up the whole step
-    # (forward, loss, backward, capturable fused Adam with its packed-weight refresh) is captured ONCE into a HIP graph and the
-    # timed region replays it; every kernel still runs every step.
+    # (forward, loss, backward, capturable fused Adam with its packed-weight refresh) is captured ONCE into a HIP graph -- side
+    # streams included -- and the timed region replays it; every kernel still runs every step.
     graph = None
     side = torch.cuda.Stream() if (args.graph or args.own_stream) else None
     if use_graph:
@@ -586,7 +589,9 @@ def main():
             if opt is not None:
                 opt.zero_grad(set_to_none=True)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            # capture ON the stream the warm-up ran on: the package's side streams were chosen (and probed) for that stream, and with
+            # config.set_capture_side_streams (default on) their forks / joins become edges of the graph
+            with torch.cuda.graph(graph, stream=side):
                 static_loss = step()
             graph.replay()          # one untimed replay
             sync()

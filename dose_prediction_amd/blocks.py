@@ -146,7 +146,7 @@ class conv_3_1(nn.Module):
     def forward(self, x):
         """x: tensor or (a, b) pair = virtual torch.cat (the two first convolutions then read the operands directly)."""
         first = x[0] if isinstance(x, (tuple, list)) else x
-        if config.branch_stream() and first.is_cuda and not torch.cuda.is_current_stream_capturing():
+        if config.branch_stream() and first.is_cuda and config.branch_stream_allowed():
             # the latency- / fabric-bound 3x3x3 branch on a second stream beside the MFMA-bound 7x7x7 branch
             main = torch.cuda.current_stream(first.device)
             side = _branch_side_stream(first.device, main)

@@ -229,3 +229,28 @@ def set_wgrad_stream(on):
 
 def wgrad_stream():
     return _wgrad_stream
+
+
+_capture_side_streams = os.environ.get("DOSE_HIP_CAPTURE_SIDE_STREAMS", "1") != "0"
+
+
+def set_capture_side_streams(on):
+    """Keep the weight-gradient stream (and, as before, the transformer's stream) while a step is being CAPTURED into a HIP graph: the
+    forks (event recorded on the capturing stream, waited for on the side stream) and joins become dependency edges of the graph, so a
+    replay runs them side by side without the launch thread.  The 3x3x3 branch / small-block stream is NOT kept: with its many fork /
+    join pairs per pass hipStreamEndCapture of ROCm 7.2 dies with a segmentation fault (no HIP error is reported first; round 4,
+    `bench.py --graph`), so branch_stream_allowed() stays False inside a capture.  The side streams are the ones chosen (and probed for
+    hardware-queue collisions, streams.py) for the stream the capture runs on, so warm up eagerly ON that stream and pass it to
+    torch.cuda.graph(..., stream=...).  On by default; env DOSE_HIP_CAPTURE_SIDE_STREAMS=0 / set_capture_side_streams(False): one stream."""
+    global _capture_side_streams
+    _capture_side_streams = bool(on)
+
+
+def side_streams_allowed():
+    """False only while the current stream is capturing AND capture-time side streams are switched off."""
+    return _capture_side_streams or not torch.cuda.is_current_stream_capturing()
+
+
+def branch_stream_allowed():
+    """The 3x3x3 branch / small-block stream: never inside a capture (see set_capture_side_streams)."""
+    return not torch.cuda.is_current_stream_capturing()

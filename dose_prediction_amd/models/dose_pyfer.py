@@ -135,7 +135,7 @@ class small_blocks_beside:
         from .. import config
         self.run = run
         self.on = bool(config.branch_stream() and x_in.is_cuda and run.side is not None and run.part is None
-                       and not torch.cuda.is_current_stream_capturing())
+                       and config.branch_stream_allowed())
         self.dev = x_in.device
 
     def __enter__(self):

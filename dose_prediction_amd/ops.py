@@ -510,7 +510,7 @@ def _wg_fork(weight, wanted=True):
     caller's stream (switch off, CPU, stream capture, or the parameter already holds a .grad: AccumulateGrad would then add on the
     caller's stream what the other stream is still writing)."""
     from . import config
-    if not (wanted and config.wgrad_stream() and weight.is_cuda and weight.grad is None) or torch.cuda.is_current_stream_capturing():
+    if not (wanted and config.wgrad_stream() and weight.is_cuda and weight.grad is None) or not config.side_streams_allowed():
         return None
     from . import streams
     dev = weight.device

@@ -45,7 +45,13 @@ def side_streams(device, main, n=3):
     if got is not None and len(got) >= n:
         return got
     chosen, report = [], []
-    if _PROBE and not torch.cuda.is_current_stream_capturing():
+    if torch.cuda.is_current_stream_capturing():
+        # no probing inside a capture (it synchronises): reuse the streams probed for another caller's stream of this device
+        for (di, _h), prev in _CHOSEN.items():
+            if di == device.index:
+                chosen = [c for c in prev if c != main][:n]
+                break
+    elif _PROBE:
         spare = []
         for _ in range(16):
             c = torch.cuda.Stream(device=device)

@@ -617,6 +617,77 @@ def test_cu_partitioned_branches_match_the_single_stream_result():
             assert cmp_prefix(outs[tag][1][n].cpu(), outs["ref"][1][n].cpu()) < 1e-4, (tag, n)
 
 
+def test_captured_step_with_side_streams_replays_the_eager_steps():
+    """A whole training step (forward, loss, backward, capturable FusedAdam + pack refresh) captured into a HIP graph WITH the side
+    streams (config.set_capture_side_streams, round 4: forks / joins become graph edges) and replayed three times gives the parameters
+    three eager steps give from the same start; the capture really contains work of several streams (the eager twin runs on ONE stream)."""
+    import dose_prediction_amd
+    from dose_prediction_amd import losses, synth
+    from dose_prediction_amd.models.dose_pyfer import Model
+    from dose_prediction_amd.optim import FusedAdam
+    dev = _dev()
+    _set(torch.float32)
+    S = (32, 32, 32)
+
+    def mk():
+        torch.manual_seed(77)
+        net = Model(in_ch=9, out_ch=1, list_ch_A=[-1, 8, 16, 16, 32, 32], feature_size=8, img_size=S, num_layers=4, num_heads=6, act="mish").to(dev).train()
+        for n, p in net.named_parameters():
+            if "net_A" in n or "conv_out_A" in n:
+                p.requires_grad = False
+        params = [p for p in net.parameters() if p.requires_grad]
+        return net, FusedAdam(params, lr=1e-3, weight_decay=3e-5, amsgrad=True, capturable=True)
+    x, gt = synth.dose_input(1, S).to(dev), synth.dose_target(1, S).to(dev)
+
+    def step(net, opt):
+        opt.zero_grad(set_to_none=True)
+        loss = losses.gen_loss(net(x), gt, 10.0, 1.0, casecade=True, freez=True)
+        loss.backward()
+        opt.step()
+        return loss
+    try:
+        # eager twin, everything on one stream
+        for sw in (dose_prediction_amd.config.set_branch_stream, dose_prediction_amd.config.set_vit_side_stream, dose_prediction_amd.config.set_wgrad_stream):
+            sw(False)
+        net_e, opt_e = mk()
+        for _ in range(4):
+            le = step(net_e, opt_e)
+        torch.cuda.synchronize()
+        for sw in (dose_prediction_amd.config.set_branch_stream, dose_prediction_amd.config.set_vit_side_stream, dose_prediction_amd.config.set_wgrad_stream):
+            sw(True)
+        net_g, opt_g = mk()
+        cap = torch.cuda.Stream()
+        cap.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(cap):
+            step(net_g, opt_g)                     # eager warm-up on the capture stream (side streams chosen for it, packs built)
+        torch.cuda.current_stream().wait_stream(cap)
+        torch.cuda.synchronize()
+        opt_g.zero_grad(set_to_none=True)
+        graph = torch.cuda.CUDAGraph()
+        from dose_prediction_amd import streams
+        with torch.cuda.graph(graph, stream=cap):
+            lg = step(net_g, opt_g)
+        used = streams._CHOSEN.get((dev.index, cap.cuda_stream))
+        assert used and len({s.cuda_stream for s in used}) >= 2, "no side streams were chosen for the capture stream"
+        for _ in range(3):
+            graph.replay()
+        torch.cuda.synchronize()
+    finally:
+        for sw in (dose_prediction_amd.config.set_branch_stream, dose_prediction_amd.config.set_vit_side_stream, dose_prediction_amd.config.set_wgrad_stream):
+            sw(True)
+    assert torch.isfinite(lg).all()
+    assert abs(float(lg.detach()) - float(le.detach())) < 2e-3 * abs(float(le.detach())), (float(lg.detach()), float(le.detach()))
+    # Adam turns round-off-level gradient differences (atomics, stream order) into lr-sized steps of random sign, so the two runs are
+    # compared as whole update vectors: distance between the trained parameters / length of the eager run's own update (4 steps)
+    net0, _ = mk()
+    num = den = 0.0
+    for (n, a), (_, b), (_, c) in zip(net_g.named_parameters(), net_e.named_parameters(), net0.named_parameters()):
+        if a.requires_grad:
+            num += (a.detach() - b.detach()).double().pow(2).sum().item()
+            den += (b.detach() - c.detach()).double().pow(2).sum().item()
+    assert den > 0 and (num / den) ** 0.5 < 0.25, (num, den)
+
+
 def test_branch_streams_match_the_single_stream_result():
     """config.set_branch_stream (on by default since round 3): the 3x3x3 branch of every multi-scale block and the small up-sampling
     blocks of the encoder run on a further HIP stream beside the 7x7x7 branch / the 128^3 block.  Same outputs and gradients as with
