@@ -459,13 +459,11 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("DOSE_DDP_BACKEND", "nccl")      # nccl == RCCL on ROCm
         if backend == "nccl":
-            # RCCL's stream at NORMAL priority (DOSE_DDP_PRIO=1: high).  Round 3, 1-rank RCCL on one MI355X: 27.1 ms per step at normal
-            # priority against 32.2 at high priority once the weight gradients run on a stream of their own (a high-priority stream
-            # next to four busy ones costs the compute streams more than the collective gains; the same was seen with a
-            # high-priority weight-gradient stream: 25 -> 38 ms)
+            # RCCL's stream at NORMAL priority: a high-priority stream next to four busy compute streams costs them more than the
+            # collective gains (round 3, 1-rank RCCL: 27.1 ms per step against 32.2 at high priority)
             opts = None
             try:
-                opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=os.environ.get("DOSE_DDP_PRIO", "0") == "1")
+                opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=False)
             except Exception:
                 pass
             if opts is not None:

@@ -36,15 +36,11 @@ class SingleConv(nn.Module):
             nn.InstanceNorm3d(out_ch, affine=True),
             nn.ReLU(inplace=True))
 
-    def forward(self, x, lazy=False, next_conv=None):
-        """x: an NDHWC tensor, or a pair (a, b) standing for torch.cat((a, b), channels) (virtual concat); either may be an
-        ops.LazyNorm.  lazy=True: the caller guarantees that the result only feeds 3x3x3 convolutions through ops.conv3d -- where no
-        gradient is recorded the normalisation + ReLU may then be left to that convolution's staging path (ops.LazyNorm, opt-in).
+    def forward(self, x, next_conv=None):
+        """x: an NDHWC tensor, or a pair (a, b) standing for torch.cat((a, b), channels) (virtual concat).
         next_conv: the nn.Conv3d that is the ONLY consumer of the result (fp32x3: the normalisation writes its split operand)."""
         conv, norm = self.single_conv[0], self.single_conv[1]
         y, st = ops.conv3d(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0], conv.dilation[0], stats=True, bias_grad_zero=True)
-        if lazy and ops.lazy_norm_ok(y, norm.weight, norm.bias, "relu"):
-            return ops.norm_act_lazy(y, st, norm.weight, norm.bias, "relu", norm.eps)
         return ops.norm_act(y, "instance", norm.weight, norm.bias, act="relu", eps=norm.eps, stats=st, x3_split_for=next_conv)
 
 
@@ -58,11 +54,9 @@ class UpConv(nn.Module):
             nn.InstanceNorm3d(out_ch, affine=True),
             nn.ReLU(inplace=True))
 
-    def forward(self, x, lazy=False):
+    def forward(self, x):
         conv, norm = self.conv[0], self.conv[1]
-        y, st = ops.conv3d(ops.trilinear_up2(ops.dense(x)), conv.weight, conv.bias, 1, 1, 1, stats=True, bias_grad_zero=True)
-        if lazy and ops.lazy_norm_ok(y, norm.weight, norm.bias, "relu"):
-            return ops.norm_act_lazy(y, st, norm.weight, norm.bias, "relu", norm.eps)
+        y, st = ops.conv3d(ops.trilinear_up2(x), conv.weight, conv.bias, 1, 1, 1, stats=True, bias_grad_zero=True)
         return ops.norm_act(y, "instance", norm.weight, norm.bias, act="relu", eps=norm.eps, stats=st)
 
 

@@ -136,23 +136,6 @@ def vit_side_stream():
     return _vit_side_stream
 
 
-_vit_cus = int(os.environ.get("DOSE_HIP_VIT_CUS", "0"))
-
-
-def set_vit_cus(n):
-    """Compute units reserved for the transformer branch while it runs beside the 128^3 block (0: both streams see the whole chip).
-    A multiple of 8 (the same number of CUs on each of the 8 XCDs); env DOSE_HIP_VIT_CUS."""
-    global _vit_cus
-    n = int(n)
-    if n < 0 or n % 8 or n > 128:
-        raise ValueError("vit_cus must be a multiple of 8 in [0, 128]")
-    _vit_cus = n
-
-
-def vit_cus():
-    return _vit_cus
-
-
 _cascade_seg_mode = os.environ.get("DOSE_HIP_CASCADE_SEG_MODE", "fp32x3")
 
 
@@ -173,7 +156,15 @@ def cascade_seg_mode():
     return None if _cascade_seg_mode in (None, "same") else _cascade_seg_mode
 
 
-_x3_wgrad_terms = int(os.environ.get("DOSE_HIP_X3_WGRAD_TERMS", "1"))
+def _env_terms(name, default):
+    v = os.environ.get(name, str(default))
+    if v not in ("1", "3"):
+        raise ValueError(f"{name} must be 1 or 3, got {v!r}")
+    return int(v)
+
+
+_x3_wgrad_terms = _env_terms("DOSE_HIP_X3_WGRAD_TERMS", 1)
+_x3_linear_wgrad_terms = _env_terms("DOSE_HIP_X3_LINEAR_WGRAD_TERMS", 3)
 
 
 def set_x3_wgrad_terms(n):
@@ -194,6 +185,20 @@ def set_x3_wgrad_terms(n):
 
 def x3_wgrad_terms():
     return _x3_wgrad_terms
+
+
+def set_x3_linear_wgrad_terms(n):
+    """fp32x3 mode: split products in the weight gradients of the LINEAR layers (transformer, patch embedding).  Default 3:
+    their contraction runs over 1-2 k token rows, not over millions of voxels, so the averaging argument of set_x3_wgrad_terms does
+    not carry over, and the three products ride in the one grouped launch anyway (+0.3 ms per DOSE-PYFER step).  1 = x_hi gy_hi only."""
+    global _x3_linear_wgrad_terms
+    if n not in (1, 3):
+        raise ValueError("x3 weight-gradient terms must be 1 or 3")
+    _x3_linear_wgrad_terms = n
+
+
+def x3_linear_wgrad_terms():
+    return _x3_linear_wgrad_terms
 
 
 _branch_stream = os.environ.get("DOSE_HIP_BRANCH_STREAM", "1") != "0"

@@ -103,35 +103,10 @@ __device__ __forceinline__ v4f mma16(const Frag8<bf16_t>& a, const Frag8<bf16_t>
 __device__ __forceinline__ v4f mma16(const Frag8<f16_t>& a, const Frag8<f16_t>& b, v4f c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h, a.u), __builtin_bit_cast(v8h, b.u), c, 0, 0, 0);
 }
-// EXPERIMENT, off (-DDP_F32_SPLIT): fp32 operands as two bf16 terms each (hi = bf16(v), lo = bf16(v - hi): 16 significand bits,
-// residual <= 2^-18 |v|): the product a b ~ ah bh + ah bl + al bh on the bf16 matrix pipe (three K = 32 instructions instead of
-// eight K = 4 fp32 ones, fp32 accumulation).  Relative error of a product ~3e-6 rms against 6e-8 for the exact chain; every fp32
-// parity test still passes, but the step only gains 184 -> 125 ms: splitting per MFMA costs ~60 VALU instructions per triple (it
-// belongs into the LDS staging, with pre-split weights), and the parity mode keeps the exact fp32 FMA chain.
-struct Split8 { v4u hi, lo; };
-__device__ __forceinline__ Split8 split_bf16(const Frag8<float>& f) {
-  Split8 s;
-#pragma unroll
-  for (int r = 0; r < 4; r++) {
-    const float v0 = f.v[2 * r], v1 = f.v[2 * r + 1];
-    const bf16_t h0 = f2bf(v0), h1 = f2bf(v1);
-    const bf16_t l0 = f2bf(v0 - bf2f(h0)), l1 = f2bf(v1 - bf2f(h1));
-    s.hi[r] = (unsigned)h0 | ((unsigned)h1 << 16);
-    s.lo[r] = (unsigned)l0 | ((unsigned)l1 << 16);
-  }
-  return s;
-}
 __device__ __forceinline__ v4f mma16(const Frag8<float>& a, const Frag8<float>& b, v4f c) {
-#ifdef DP_F32_SPLIT
-  const Split8 sa = split_bf16(a), sb = split_bf16(b);
-  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, sa.lo), __builtin_bit_cast(v8bf, sb.hi), c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, sa.hi), __builtin_bit_cast(v8bf, sb.lo), c, 0, 0, 0);
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, sa.hi), __builtin_bit_cast(v8bf, sb.hi), c, 0, 0, 0);
-#else
 #pragma unroll
   for (int j = 0; j < 8; j++) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[j], b.v[j], c, 0, 0, 0);
   return c;
-#endif
 }
 
 // two ds_read_b64_tr_b16 at a lane address and OFF elements further: 8 consecutive voxels (k) of one column
@@ -210,24 +185,6 @@ __device__ __forceinline__ float act_bwd(float z, int act) {
   }
 }
 
-// Normalise + activate in the CONSUMER's staging (round 3; forward-only networks: the frozen C3D U-Net of DOSE-PYFER, c3d.py:11-38):
-// an input operand may be the PRE-normalisation output x_pre of the convolution in front; the staging path then stores
-// act(x_pre * scale[n][c] + shift[n][c]) into LDS (scale = rstd * gamma, shift = beta - mean * scale from dp_stats_finalize_ss), so
-// the normalised tensor is never written to or read from HBM.  Positions outside the volume stay zero (the padding pads the
-// normalised tensor).  16-bit storage, 3x3x3, fast (aligned, whole-chunk) staging only; ReLU / LeakyReLU / none.
-struct ConvPro { const float* sc; const float* sh; int ns; int act; };       // ns: elements between samples (0: one set for all)
-template <typename T>
-__device__ __forceinline__ v4u pro_apply(v4u t, const float* sc, const float* sh, int act) {
-  union { v4u raw; T e[8]; } w; w.raw = t;
-#pragma unroll
-  for (int i = 0; i < 8; i++) {
-    float z = ld_f(&w.e[i]) * sc[i] + sh[i];
-    z = act == DP_ACT_RELU ? fmaxf(z, 0.f) : (act == DP_ACT_LRELU ? (z >= 0.f ? z : 0.01f * z) : z);
-    st_f(&w.e[i], z);
-  }
-  return w.raw;
-}
-
 // conv_wgrad_hk.hip: weight gradient of the <= 16-output-channel 7x7x7 layers with K along H (shares the tap-major scratch and the
 // unpack kernel of dp_conv3d_wgrad_tiled2, which dispatches to it)
 struct WgHkGeom {
@@ -250,8 +207,7 @@ int cc16_pack(const float* w, void* dst, int Cout, int Cin, int k, int tf, int d
 int cc16_stat_blocks(int D, int H, int W);
 bool cc16_wide(const void* y, int ldy, const void* y2, int ldy2, int osplit, int dtype);
 int cc16_launch(const void* x, int ldx, const void* x2, int ldx2, int csplit, const void* wq, const float* bias, void* y, int ldy,
-                void* y2, int ldy2, int osplit, float* stat_part, int N, int D, int H, int W, int Cin, int Cout, int k, int dtype, hipStream_t s,
-                const ConvPro* pro1 = nullptr, const ConvPro* pro2 = nullptr);
+                void* y2, int ldy2, int osplit, float* stat_part, int N, int D, int H, int W, int Cin, int Cout, int k, int dtype, hipStream_t s);
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline int roundup8(int c) { return (c + 7) & ~7; }

@@ -33,7 +33,6 @@ struct Cc16Geom {
   // NCH = 3 * x3 chunks ([w_hi | w_hi | w_lo]).  Every x_hi slab is staged ONCE and swept with both of its weight blocks (chunk ch
   // and chunk 2 * x3 + ch); 0 = ordinary launch (one sweep per staged chunk).
   int x3;
-  ConvPro pro1, pro2;                     // normalise + activate while staging (operand 1 / operand 2 of a virtual concat); sc == nullptr: off
 };
 
 bool cc16_applicable(int Cin, int Cout, int k, int W) {
@@ -80,7 +79,7 @@ int cc16_pack(const float* w, void* dst, int Cout, int Cin, int k, int tf, int d
 
 // TO = type of the OUTPUT tensor: T, or float for DP_X3 launches (bf16 operands that are the hi / lo halves of fp32 values, see
 // dp_split_rows: the three partial products are separate 16-channel chunks of a 3x wider "virtual" input, the sum is kept in fp32)
-template <typename T, int KS, int DT, int OCC, typename TO, bool PRO = false>
+template <typename T, int KS, int DT, int OCC, typename TO>
 __global__ void __launch_bounds__(256, OCC) k_conv_cc16(const T* __restrict__ x, const T* __restrict__ wq, const float* __restrict__ bias,
                                                    TO* __restrict__ y, Cc16Geom g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -127,16 +126,6 @@ __global__ void __launch_bounds__(256, OCC) k_conv_cc16(const T* __restrict__ x,
         const T* xsrc = second ? (const T*)g.x2 : x;
         const int ldsrc = second ? g.ldx2 : g.ldx, c0 = ch * CK - (second ? g.csplit : 0);
         const T* xplane = xsrc + (((int64_t)n * g.D + z) * g.H) * (int64_t)g.W * ldsrc + c0 + st_half * 8;
-        float psc[8], psh[8]; int pact = 0; bool pon = false;
-        if constexpr (PRO) {
-          const ConvPro& P = second ? g.pro2 : g.pro1;
-          pon = P.sc != nullptr; pact = P.act;
-          if (pon) {
-            const float* a = P.sc + (int64_t)n * P.ns + c0 + st_half * 8; const float* bb = P.sh + (int64_t)n * P.ns + c0 + st_half * 8;
-#pragma unroll
-            for (int i = 0; i < 8; i++) { psc[i] = a[i]; psh[i] = bb[i]; }
-          }
-        }
         int lp = st_lp0, lr = st_lr0, v = tid >> 1;
         for (int p0 = 0; p0 < pieces; p0 += 256 * SU) {
           v4u buf[SU]; int vv[SU];
@@ -145,7 +134,6 @@ __global__ void __launch_bounds__(256, OCC) k_conv_cc16(const T* __restrict__ x,
             const int ih = h0 - PAD + lr, iw = w0 - PAD + lp;
             const bool ok = (p0 + j * 256 + tid < pieces) && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W;
             v4u t = *(const v4u*)(xplane + (ok ? (ih * g.W + iw) * ldsrc : 0));
-            if constexpr (PRO) { if (pon) t = pro_apply<T>(t, psc, psh, pact); }
             buf[j] = ok ? t : (v4u){0, 0, 0, 0};
             vv[j] = (p0 + j * 256 + tid < pieces) ? v : -1;
             v += 128; lp += 128;
@@ -388,17 +376,10 @@ __global__ void __launch_bounds__(256, OCC) k_conv_cc16(const T* __restrict__ x,
 
 int cc16_stat_blocks(int D, int H, int W) { return D * cdiv(H, 8) * cdiv(W, 128); }
 
-template <typename T, int KS, int DT, int OCC, typename TO, bool PRO = false>
+template <typename T, int KS, int DT, int OCC, typename TO>
 static int cc16_go_impl(const void* x, const void* wq, const float* bias, void* y, Cc16Geom g, hipStream_t s);
 template <typename T, int KS, typename TO = T>
 static int cc16_go(const void* x, const void* wq, const float* bias, void* y, Cc16Geom g, hipStream_t s) {
-  if (g.pro1.sc || g.pro2.sc) {
-    if constexpr (KS == 3 && sizeof(T) == 2 && sizeof(TO) == 2) {
-      // (one depth slice per block also for several chunks: the 16 scale / shift registers of the prologue do not fit beside 128
-      // accumulator registers)
-      return cc16_go_impl<T, KS, 1, 3, TO, true>(x, wq, bias, y, g, s);
-    } else { dp_set_error("conv_cc16: the normalising prologue exists for 3x3x3, 16-bit storage"); return 1; }
-  }
   // (fp32 fragments are twice as wide: one depth slice per block keeps the parity mode's register spills down)
   // 3x3x3 with one input chunk: one depth slice per block = 64 accumulator registers -> three blocks per CU, whose staging / sweep /
   // epilogue phases overlap (16->16 at 2 x 128^3: 112 -> 100 us; with two chunks the two variants tie)
@@ -411,13 +392,13 @@ static int cc16_go(const void* x, const void* wq, const float* bias, void* y, Cc
   }
   return cc16_go_impl<T, KS, (sizeof(T) == 4 ? 1 : 2), 2, TO>(x, wq, bias, y, g, s);
 }
-template <typename T, int KS, int DT, int OCC, typename TO, bool PRO>
+template <typename T, int KS, int DT, int OCC, typename TO>
 static int cc16_go_impl(const void* x, const void* wq, const float* bias, void* y, Cc16Geom g, hipStream_t s) {
   constexpr int ROWS = 8 + KS - 1, LP = (128 + KS - 1 + 7) & ~7;
   size_t smem = (size_t)ROWS * LP * 16 * sizeof(T);
   const size_t need = 4 * 2 * 32 * 16 * sizeof(TO) + 8 * 16 * sizeof(float);      // epilogue patches + statistics scratch
   if (smem < need) smem = need;
-  auto kern = k_conv_cc16<T, KS, DT, OCC, TO, PRO>;
+  auto kern = k_conv_cc16<T, KS, DT, OCC, TO>;
   if (smem > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) { dp_set_error("conv_cc16: cannot raise dynamic LDS to %zu: %s", smem, hipGetErrorString(e)); return 1; }
@@ -434,12 +415,9 @@ bool cc16_wide(const void* y, int ldy, const void* y2, int ldy2, int osplit, int
   return (ldy * es) % 16 == 0 && (((uintptr_t)y & 15) == 0) && (!y2 || ((ldy2 * es) % 16 == 0 && (((uintptr_t)y2 & 15) == 0) && osplit % epc == 0));
 }
 int cc16_launch(const void* x, int ldx, const void* x2, int ldx2, int csplit, const void* wq, const float* bias, void* y, int ldy,
-                void* y2, int ldy2, int osplit, float* stat_part, int N, int D, int H, int W, int Cin, int Cout, int k, int dtype, hipStream_t s,
-                const ConvPro* pro1, const ConvPro* pro2) {
+                void* y2, int ldy2, int osplit, float* stat_part, int N, int D, int H, int W, int Cin, int Cout, int k, int dtype, hipStream_t s) {
   Cc16Geom g;
   g.x3 = 0;
-  g.pro1 = pro1 ? *pro1 : ConvPro{nullptr, nullptr, 0, 0};
-  g.pro2 = pro2 ? *pro2 : ConvPro{nullptr, nullptr, 0, 0};
   if (dtype == DP_X3) {
     if (x2 || Cin % 48 || ldx < 2 * (Cin / 3)) { dp_set_error("conv_cc16: a DP_X3 launch takes ONE [x_hi | x_lo] tensor of 2/3 Cin channels (Cin = 3 x a multiple of 16)"); return 1; }
     g.x3 = Cin / 48;

@@ -74,7 +74,6 @@ struct TiledGeom {
   // DP_X3 launches (see Cc16Geom::x3 in conv_cc16.hip): the input holds 2 * x3 chunks [x_hi | x_lo], the packed weights NCH = 3 * x3
   // chunks [w_hi | w_hi | w_lo]; an x_hi slab is staged once and swept with weight chunks ch and 2 * x3 + ch.  0 = ordinary launch.
   int x3;
-  ConvPro pro1, pro2;  // normalise + activate while staging (common.h); sc == nullptr: off
 };
 
 // ---------------------------------------------------------------------------------------------- weight packing
@@ -147,7 +146,7 @@ extern "C" int dp_pack_conv_weight_tiled(const float* w, void* dst, int Cout, in
 // WN: waves along N.  1: the four waves are TWC columns x TRG row groups over the SAME NT channel tiles.  2 (W16 tiles on planes of
 // <= 16 rows, Cout >= 128: the 16^3 level of the decoder): two row groups x two channel-tile groups -- with four row groups of
 // 4 x 2 image rows half of every block's MFMAs fell on rows >= H (7^3 at 16^3: 0.67 PFLOP/s against 1.1-1.4 at the other levels).
-template <typename T, int KS, int NPAIR, int RW, int NT, int TWP, typename TO, int WN = 1, bool PRO = false>
+template <typename T, int KS, int NPAIR, int RW, int NT, int TWP, typename TO, int WN = 1>
 __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, const T* __restrict__ wq, const float* __restrict__ bias,
                                                     TO* __restrict__ y, float* __restrict__ ws, TiledGeom g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -230,16 +229,6 @@ __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, 
         const T* xsrc = second ? (const T*)g.x2 : x;
         const int ldsrc = second ? g.ldx2 : g.ldx, c0 = ch * CK - (second ? g.csplit : 0);
         const T* xplane = xsrc + (((int64_t)n * g.D + id) * g.H) * (int64_t)g.W * ldsrc + c0 + st_half * 8;
-        float psc[8], psh[8]; int pact = 0; bool pon = false;
-        if constexpr (PRO) {          // the operand is a pre-normalisation tensor: normalise + activate on the way into LDS (common.h)
-          const ConvPro& P = second ? g.pro2 : g.pro1;
-          pon = P.sc != nullptr; pact = P.act;
-          if (pon) {
-            const float* a = P.sc + (int64_t)n * P.ns + c0 + st_half * 8; const float* bb_ = P.sh + (int64_t)n * P.ns + c0 + st_half * 8;
-#pragma unroll
-            for (int i = 0; i < 8; i++) { psc[i] = a[i]; psh[i] = bb_[i]; }
-          }
-        }
         int lp = st_lp0, lr = st_lr0, v = tid >> 1;
         for (int p0 = 0; p0 < pieces; p0 += 256 * SU) {
           v4u buf[SU]; int vv[SU];
@@ -248,7 +237,6 @@ __global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, 
             const int ih = h0 - PAD + lr, iw = w0 - PAD + lp;
             const bool ok = (p0 + j * 256 + tid < pieces) && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W;
             v4u t = *(const v4u*)(xplane + (ok ? (ih * g.W + iw) * ldsrc : 0));     // 32-bit offset inside one (n, depth) plane
-            if constexpr (PRO) { if (pon) t = pro_apply<T>(t, psc, psh, pact); }
             buf[j] = ok ? t : (v4u){0, 0, 0, 0};
             vv[j] = (p0 + j * 256 + tid < pieces) ? v : -1;
             v += 128; lp += 128;
@@ -533,11 +521,11 @@ __global__ void k_conv_split_finish(float* __restrict__ ws, const float* __restr
   }
 }
 
-template <typename T, int KS, int NPAIR, int RW, int NT, int TWP, typename TO = T, int WN = 1, bool PRO = false>
+template <typename T, int KS, int NPAIR, int RW, int NT, int TWP, typename TO = T, int WN = 1>
 static int launch_tiled(const void* x, const void* wq, const float* bias, void* y, float* ws, TiledGeom g, int ygrid, hipStream_t s) {
   size_t smem = (size_t)g.LR * g.LP * 16 * sizeof(T);
   if (smem < 8 * 32 * 32 * sizeof(TO)) smem = 8 * 32 * 32 * sizeof(TO);     // the epilogue transposes through 2 patches per wave
-  auto kern = k_conv_tiled<T, KS, NPAIR, RW, NT, TWP, TO, WN, PRO>;
+  auto kern = k_conv_tiled<T, KS, NPAIR, RW, NT, TWP, TO, WN>;
   if (smem > 160 * 1024) { dp_set_error("conv3d_tiled: slab %zu B exceeds LDS", smem); return 1; }
   if (smem > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -631,7 +619,7 @@ extern "C" int dp_conv3d_tiled2(const void* x, int ldx, const void* x2, int ldx2
                                 int Cin, int Cout, int k, int dtype, void* stream);
 static int conv3d_tiled_impl(const void* x, int ldx, const void* x2, int ldx2, int csplit, const void* wq, const float* bias,
                              void* y, int ldy, void* y2, int ldy2, int osplit, float* ws, float* stat_part, int N, int D, int H, int W,
-                             int Cin, int Cout, int k, int dtype, void* stream, const ConvPro* pro1 = nullptr, const ConvPro* pro2 = nullptr);
+                             int Cin, int Cout, int k, int dtype, void* stream);
 extern "C" int dp_conv3d_tiled_stats(const void* x, int ldx, const void* x2, int ldx2, int csplit, const void* wq, const float* bias,
                                      void* y, int ldy, float* ws, float* stat_part, int N, int D, int H, int W, int Cin, int Cout, int k,
                                      int dtype, void* stream) {
@@ -647,48 +635,19 @@ extern "C" int dp_conv3d_tiled2(const void* x, int ldx, const void* x2, int ldx2
                                 int Cin, int Cout, int k, int dtype, void* stream) {
   return conv3d_tiled_impl(x, ldx, x2, ldx2, csplit, wq, bias, y, ldy, y2, ldy2, osplit, ws, nullptr, N, D, H, W, Cin, Cout, k, dtype, stream);
 }
-// conditions of the kernels' fast (aligned, whole-chunk) staging path: the normalising prologue has no guarded variant
-static bool tiled_fast_inputs(const void* x, int ldx, const void* x2, int ldx2, int csplit, int Cin, int H, int W) {
-  const int nch = (Cin + 15) / 16;
-  return nch * 16 <= (x2 ? csplit + ldx2 : ldx) && ldx % 8 == 0 && ((uintptr_t)x & 15) == 0 &&
-         (!x2 || (csplit % 16 == 0 && ldx2 % 8 == 0 && ((uintptr_t)x2 & 15) == 0)) && (int64_t)H * W * (ldx > ldx2 ? ldx : ldx2) < (1ll << 30);
-}
-extern "C" int dp_conv3d_tiled_pro_ok(const void* x, int ldx, const void* x2, int ldx2, int csplit, int H, int W, int Cin, int Cout, int k, int dtype) {
-  // (no prologue instantiation of the two-channel-group arrangements: shapes that take one keep the materialised normalisation, so
-  // that dp_conv3d_tiled_stat_blocks / _ws_elems describe every launch of a shape)
-  if (!cc16_applicable(Cin, Cout, k, W) && tiled_applicable(Cin, Cout, k, 1, k / 2, 1, W)) {
-    int rw, nt; int np = tiled_config(Cout, &rw, &nt);
-    if (np == 1 && nt == 2 && W > 16 && W <= 32) return 0;      // (the 8-row two-channel-group arrangement of one-column tiles, tiled_geometry)
-  }
-  return (k == 3 && (dtype == DP_BF16 || dtype == DP_F16) && tiled_applicable(Cin, Cout, k, 1, 1, 1, W) &&
-          tiled_fast_inputs(x, ldx, x2, ldx2, csplit, Cin, H, W)) ? 1 : 0;
-}
-extern "C" int dp_conv3d_tiled_pro(const void* x, int ldx, const void* x2, int ldx2, int csplit, const void* wq, const float* bias, void* y, int ldy,
-                                   float* ws, float* stat_part, const float* sc1, const float* sh1, int ns1, int act1, const float* sc2,
-                                   const float* sh2, int ns2, int act2, int N, int D, int H, int W, int Cin, int Cout, int k, int dtype, void* stream) {
-  if (!dp_conv3d_tiled_pro_ok(x, ldx, x2, ldx2, csplit, H, W, Cin, Cout, k, dtype))
-    DP_FAIL("conv3d_tiled_pro: needs k = 3, 16-bit storage and aligned whole-chunk inputs (dp_conv3d_tiled_pro_ok)");
-  for (int a : {act1, act2}) if (a != DP_ACT_NONE && a != DP_ACT_RELU && a != DP_ACT_LRELU) DP_FAIL("conv3d_tiled_pro: activation %d not supported in the prologue", a);
-  if ((sc1 && !sh1) || (sc2 && !sh2) || (sc2 && !x2)) DP_FAIL("conv3d_tiled_pro: inconsistent prologue arguments");
-  const ConvPro p1{sc1, sh1, ns1, act1}, p2{sc2, sh2, ns2, act2};
-  return conv3d_tiled_impl(x, ldx, x2, ldx2, csplit, wq, bias, y, ldy, nullptr, 0, 0, ws, stat_part, N, D, H, W, Cin, Cout, k, dtype, stream, &p1, &p2);
-}
 static int conv3d_tiled_impl(const void* x, int ldx, const void* x2, int ldx2, int csplit, const void* wq, const float* bias,
                              void* y, int ldy, void* y2, int ldy2, int osplit, float* ws, float* stat_part, int N, int D, int H, int W,
-                             int Cin, int Cout, int k, int dtype, void* stream, const ConvPro* pro1, const ConvPro* pro2) {
+                             int Cin, int Cout, int k, int dtype, void* stream) {
   if (!tiled_applicable(Cin, Cout, k, 1, k / 2, 1, W)) DP_FAIL("conv3d_tiled: shape not supported");
   if (x2 && (csplit <= 0 || csplit >= Cin || csplit % 8)) DP_FAIL("conv3d_tiled: input split must be a multiple of 8 inside (0, Cin)");
   if (y2 && (osplit <= 0 || osplit >= Cout || osplit % 8)) DP_FAIL("conv3d_tiled: output split must be a multiple of 8 inside (0, Cout)");
   if (cc16_applicable(Cin, Cout, k, W))
-    return cc16_launch(x, ldx, x2, ldx2, csplit, wq, bias, y, ldy, y2, ldy2, osplit, stat_part, N, D, H, W, Cin, Cout, k, dtype, STREAM, pro1, pro2);
+    return cc16_launch(x, ldx, x2, ldx2, csplit, wq, bias, y, ldy, y2, ldy2, osplit, stat_part, N, D, H, W, Cin, Cout, k, dtype, STREAM);
   int rw, nt; int np = tiled_config(Cout, &rw, &nt);
   TiledGeom g;
-  g.pro1 = pro1 ? *pro1 : ConvPro{nullptr, nullptr, 0, 0};
-  g.pro2 = pro2 ? *pro2 : ConvPro{nullptr, nullptr, 0, 0};
-  const bool pro = g.pro1.sc || g.pro2.sc;      // (no prologue instantiation of the WN = 2 arrangement: four row groups then)
   g.N = N; g.D = D; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.ldx = ldx; g.ldy = ldy;
   g.x2 = x2; g.ldx2 = ldx2; g.csplit = csplit; g.y2 = y2; g.ldy2 = ldy2; g.osplit = osplit;
-  int ygrid; bool w16; int wn; tiled_geometry(g, k, np, rw, nt, &ygrid, &w16, &wn, !pro);
+  int ygrid; bool w16; int wn; tiled_geometry(g, k, np, rw, nt, &ygrid, &w16, &wn);
   g.x3 = 0;
   if (dtype == DP_X3) {
     if (x2 || Cin % 48 || ldx < 2 * (Cin / 3)) DP_FAIL("conv3d_tiled: a DP_X3 launch takes ONE [x_hi | x_lo] tensor of 2/3 Cin channels (Cin = 3 x a multiple of 16)");
@@ -712,10 +671,6 @@ static int conv3d_tiled_impl(const void* x, int ldx, const void* x2, int ldx2, i
   hipStream_t s = STREAM;
 #define GO(TT, KS_, NP, RW_, NT_, TWP_) rc = x3 ? launch_tiled<bf16_t, KS_, NP, RW_, NT_, TWP_, float>(x, wq, bias, y, ws, g, ygrid, s) \
                                              : launch_tiled<TT, KS_, NP, RW_, NT_, TWP_>(x, wq, bias, y, ws, g, ygrid, s)
-#define GOP(TT, NP, RW_, NT_, TWP_) rc = launch_tiled<TT, 3, NP, RW_, NT_, TWP_, TT, 1, true>(x, wq, bias, y, ws, g, ygrid, s)
-#define BYTWP(TT, NP, RW_, NT_) do { if (g.TWC == 4) GOP(TT, NP, RW_, NT_, 4); else if (g.TWC == 2) GOP(TT, NP, RW_, NT_, 2); else GOP(TT, NP, RW_, NT_, 1); } while (0)
-#define BYCFGP(TT) do { if (np == 2) BYTWP(TT, 2, 9, 1); else if (nt == 1) { if (w16) GOP(TT, 1, 8, 1, 0); else BYTWP(TT, 1, 8, 1); } \
-                        else { if (w16) GOP(TT, 1, 4, 2, 0); else BYTWP(TT, 1, 4, 2); } } while (0)
 #define GOW2(TT, KS_) rc = x3 ? launch_tiled<bf16_t, KS_, 1, 4, 2, 0, float, 2>(x, wq, bias, y, ws, g, ygrid, s) \
                               : launch_tiled<TT, KS_, 1, 4, 2, 0, TT, 2>(x, wq, bias, y, ws, g, ygrid, s)
 #define BYTW(TT, KS_, NP, RW_, NT_) do { if (g.TWC == 4) GO(TT, KS_, NP, RW_, NT_, 4); else if (g.TWC == 2) GO(TT, KS_, NP, RW_, NT_, 2); \
@@ -726,10 +681,7 @@ static int conv3d_tiled_impl(const void* x, int ldx, const void* x2, int ldx2, i
                             else if (nt == 1) { if (w16) GO(TT, KS_, 1, 8, 1, 0); else BYTW(TT, KS_, 1, 8, 1); } \
                             else { if (w16 && wn == 2) GOW2(TT, KS_); else if (w16) GO(TT, KS_, 1, 4, 2, 0); else BYTW(TT, KS_, 1, 4, 2); } } while (0)
   const bool x3 = dtype == DP_X3;
-  if (pro) {
-    if (k != 3 || x3 || dtype == DP_F32) DP_FAIL("conv3d_tiled: the normalising prologue exists for 3x3x3, 16-bit storage");
-    if (dtype == DP_BF16) BYCFGP(bf16_t); else BYCFGP(f16_t);
-  } else if (dtype == DP_BF16 || x3) { if (k == 7) BYCFG(bf16_t, 7); else BYCFG(bf16_t, 3); }
+  if (dtype == DP_BF16 || x3) { if (k == 7) BYCFG(bf16_t, 7); else BYCFG(bf16_t, 3); }
   else if (dtype == DP_F16) { if (k == 7) BYCFG(f16_t, 7); else BYCFG(f16_t, 3); }
   else if (dtype == DP_F32) { if (k == 7) BYCFG(float, 7); else BYCFG(float, 3); }
   else DP_FAIL("conv3d_tiled: bad dtype");
@@ -737,9 +689,6 @@ static int conv3d_tiled_impl(const void* x, int ldx, const void* x2, int ldx2, i
 #undef BYTW
 #undef GOW2
 #undef GOW32
-#undef BYCFGP
-#undef BYTWP
-#undef GOP
 #undef GO
   if (rc) return rc;
   DP_CHECK_LAUNCH("conv3d_tiled"); return 0;

@@ -726,20 +726,3 @@ extern "C" int dp_im2col3d(const void* x, int ldx, void* col, int N, int Di, int
   DP_CHECK_LAUNCH("im2col3d"); return 0;
 }
 
-// ------------------------------------------------------------------------------------------------ CU-partitioned streams
-// A HIP stream whose kernels may only run on the compute units set in `mask` (bit b = CU b / 8 of XCD b % 8 on MI355X: the low V bits
-// are V / 8 CUs of every XCD).  The transformer branch is ~150 dependent small-grid launches; on an ordinary second stream its
-// workgroups only get CU slots at the tail of each full-chip kernel of the main stream, so the branch advances one launch per
-// main-stream kernel.  With the two branches on DISJOINT CU sets they really run side by side (models/dose_pyfer.py).
-extern "C" int dp_stream_create_cu_mask(const uint32_t* mask, int nwords, void** stream) {
-  if (!mask || nwords < 1 || !stream) DP_FAIL("stream_create_cu_mask: bad arguments");
-  hipStream_t s = nullptr;
-  hipError_t e = hipExtStreamCreateWithCUMask(&s, (uint32_t)nwords, mask);
-  if (e != hipSuccess) DP_FAIL("stream_create_cu_mask: %s", hipGetErrorString(e));
-  *stream = (void*)s; return 0;
-}
-extern "C" int dp_stream_destroy(void* stream) {
-  hipError_t e = hipStreamDestroy((hipStream_t)stream);
-  if (e != hipSuccess) DP_FAIL("stream_destroy: %s", hipGetErrorString(e));
-  return 0;
-}

@@ -189,16 +189,6 @@ __global__ void __launch_bounds__(256) k_stats_finalize(const float* __restrict_
   }
 }
 static inline int pick_cpb(int C) { return C >= 32 ? 32 : (C >= 16 ? 16 : 8); }
-// dp_stats_finalize that ALSO leaves scale = rstd * gamma and shift = beta - mean * scale as [groups][cpad] rows (cpad >= C; the caller
-// zero-fills the padding once): the operands of the normalising prologue of dp_conv3d_tiled_pro
-extern "C" int dp_stats_finalize_ss(const float* part, int N, int nblk, int C, int64_t V, int batch_mode, float eps, float* mean, float* rstd,
-                                    const float* gamma, const float* beta, float* scale, float* shift, int cpad, void* stream) {
-  if (!scale || !shift || cpad < C) DP_FAIL("stats_finalize_ss: scale / shift rows of at least C elements are required");
-  int cpb = pick_cpb(C);
-  hipLaunchKernelGGL(k_stats_finalize, dim3(cdiv(C, cpb), batch_mode ? 1 : N), dim3(256), 0, STREAM, part, N, nblk, C, V, batch_mode, eps, mean, rstd,
-                     (float*)nullptr, (float*)nullptr, 0.f, cpb, gamma, beta, scale, shift, cpad);
-  DP_CHECK_LAUNCH("stats_finalize_ss"); return 0;
-}
 extern "C" int dp_stats_finalize(const float* part, int N, int nblk, int C, int64_t V, int batch_mode, float eps, float* mean, float* rstd,
                                  float* running_mean, float* running_var, float momentum, void* stream) {
   int cpb = pick_cpb(C);

@@ -150,6 +150,7 @@ class GradAllReducer:
         self.work = []
         self._taken = set()
         self._streams = []
+        self._home = None                # (the stream of THIS pass's bucket launches, not of an earlier one)
 
     @_timed("launch")
     def _launch(self, bi, at_end=False):
@@ -189,6 +190,8 @@ class GradAllReducer:
         flat = self.flat[bi]
         if self.inplace[bi] and self.grad_ref[bi] is not None:
             flat = self.grad_ref[bi]
+            if flat.is_cuda:
+                flat.record_stream(torch.cuda.current_stream())      # (the in-place exchange runs on the launch stream)
         else:
             # pack the whole bucket with one multi-tensor copy (a copy_ per parameter was ~230 launches and as many Python
             # round trips inside the backward pass: +3 ms per step before any byte moved); converts to grad_dtype on the way
@@ -196,6 +199,12 @@ class GradAllReducer:
                     if getattr(p, "_dp_has_grad", False) and p.grad.data_ptr() != v.data_ptr()]     # (already in place: written there)
             if have:
                 torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+                if flat.is_cuda:
+                    #  the gradients were allocated on the streams that produced them and are read here on the launch
+                    # stream: the caching allocator must not hand their blocks out again before this copy has run
+                    cs = torch.cuda.current_stream()
+                    for _, g_ in have:
+                        g_.record_stream(cs)
         self.launched[bi] = True
         self.stats["launched_at_end" if at_end else "launched_in_backward"] += 1
         n = flat.numel()

@@ -34,9 +34,8 @@ class Encoder(nn.Module):
         outs = []
         for lvl in range(1, 6):
             blk = getattr(self, f"encoder_{lvl}")
-            # the first convolution's output feeds only the second one: its InstanceNorm + ReLU may be applied in that convolution's
-            # staging (ops.LazyNorm, forward-only networks); the level's output has several consumers and is written
-            x = blk[1](blk[0](x, lazy=True, next_conv=blk[1].single_conv[0]))
+            # the first convolution's output feeds only the second one (fp32x3: its normalisation writes that convolution's split operand)
+            x = blk[1](blk[0](x, next_conv=blk[1].single_conv[0]))
             outs.append(x)
         return outs
 
@@ -56,13 +55,13 @@ class Decoder(nn.Module):
     def forward(self, out_encoder):
         d = out_encoder[4]
         for lvl in (4, 3, 2, 1):
-            up = getattr(self, f"upconv_{lvl}")(d, lazy=True)                         # (only consumer: the concat convolution below)
+            up = getattr(self, f"upconv_{lvl}")(d)
             convs = getattr(self, f"decoder_conv_{lvl}")
-            d = convs[0]((up, out_encoder[lvl - 1]), lazy=len(convs) > 1,               # virtual torch.cat (c3d.py:103-113)
+            d = convs[0]((up, out_encoder[lvl - 1]),                                   # virtual torch.cat (c3d.py:103-113)
                          next_conv=convs[1].single_conv[0] if len(convs) > 1 else None)
             if len(convs) > 1:
                 d = convs[1](d)
-        return ops.dense(d)
+        return d
 
 
 class BaseUNet(nn.Module):

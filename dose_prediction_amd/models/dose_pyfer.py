@@ -19,20 +19,6 @@ def ensure_tuple_rep(v, n):
 _SIDE_STREAMS = {}
 
 
-def _cu_stream(device, lo, hi, total=256):
-    """A HIP stream restricted to compute units [lo, hi) of the mask numbering (bit b = CU b/8 of XCD b%8: every XCD contributes
-    the same share); dp_stream_create_cu_mask."""
-    import ctypes
-    from .. import _lib
-    words = (ctypes.c_uint32 * (total // 32))()
-    for b in range(lo, hi):
-        words[b >> 5] |= 1 << (b & 31)
-    out = ctypes.c_void_p()
-    with torch.cuda.device(device):
-        _lib.call("dp_stream_create_cu_mask", words, total // 32, ctypes.byref(out))
-    return torch.cuda.ExternalStream(out.value, device=device)
-
-
 class _SideRun:
     """Handle of a ViT forward running on the side stream: hidden(i) / final() make the CURRENT stream wait for exactly the
     producer they need (a per-block event), and register the tensor with the allocator for that stream.  With a CU partition
@@ -82,41 +68,23 @@ def run_vit_beside(vit, x_in, first=None, first_inputs=()):
     kernels on 128^3 .. 16^3 volumes; skip block k only waits for the transformer layer it reads.  Autograd replays each node on
     the stream of its forward pass, so the backward branches overlap the same way.
 
-    config.vit_cus() = V > 0: the two branches run on DISJOINT compute units -- the transformer on a stream masked to V CUs (V/8 per
-    XCD), `first` on a stream masked to the other 256 - V -- because on ordinary streams the transformer's workgroups only find free
-    CU slots at the tail of each full-chip kernel (kernel trace: the branch advances about one launch per main-stream kernel and its
-    backward pass ran with the main stream idle).  `first_inputs`: tensors `first` reads (allocator bookkeeping for its stream)."""
+    (Round 3 also built the two branches on DISJOINT compute units -- hipExtStreamCreateWithCUMask -- and measured it slower for every
+    split, 28-51 ms per step against 26.7: DESIGN section 5; removed in round 4.)  `first_inputs` is kept for source compatibility."""
     from .. import config
     if not (config.vit_side_stream() and x_in.is_cuda):
         out = first() if first is not None else None
         z, hidden = vit(x_in)
         return _SideRun(z, hidden, None, None, None), out
     main = torch.cuda.current_stream(x_in.device)
-    vcu = config.vit_cus()
-    key = (x_in.device.index, main.cuda_stream, vcu)
-    pair = _SIDE_STREAMS.get(key)
-    if pair is None:
-        if vcu > 0:
-            pair = (_cu_stream(x_in.device, 0, vcu), _cu_stream(x_in.device, vcu, 256))
-        else:
-            from .. import streams
-            pair = (streams.side_stream(x_in.device, main, streams.ROLE_VIT), None)
-        _SIDE_STREAMS[key] = pair
-    side, part = pair
+    key = (x_in.device.index, main.cuda_stream)
+    side = _SIDE_STREAMS.get(key)
+    if side is None:
+        from .. import streams
+        side = _SIDE_STREAMS[key] = streams.side_stream(x_in.device, main, streams.ROLE_VIT)
+    part = None
     fork = torch.cuda.Event()
     fork.record(main)
-    out = None
-    if first is not None:
-        if part is not None and not torch.cuda.is_current_stream_capturing():
-            part.wait_event(fork)
-            for t in (x_in,) + tuple(first_inputs):
-                if torch.is_tensor(t):
-                    t.record_stream(part)
-            with torch.cuda.stream(part):
-                out = first()
-        else:
-            part = None
-            out = first()
+    out = first() if first is not None else None
     side.wait_event(fork)
     x_in.record_stream(side)
     events = []

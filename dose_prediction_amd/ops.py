@@ -497,10 +497,10 @@ _STREAM_OBJ = {}
 
 def _current_stream_object(dev):
     """torch.cuda.current_stream(dev), cached by raw handle (the Stream constructor costs 8 us, this runs ~100 times per step)."""
-    ptr = _stream()
-    s = _STREAM_OBJ.get(ptr)
+    key = (dev.index, _stream())          # (the default stream has handle 0 on EVERY device: ADVICE r3)
+    s = _STREAM_OBJ.get(key)
     if s is None:
-        s = _STREAM_OBJ[ptr] = torch.cuda.current_stream(dev)
+        s = _STREAM_OBJ[key] = torch.cuda.current_stream(dev)
     return s
 
 
@@ -728,19 +728,7 @@ def conv3d(x, weight, bias=None, stride=1, pad=0, dil=1, stats=False, bias_grad_
     bias_grad_zero=True: the caller normalises y over batch statistics next (InstanceNorm, or BatchNorm in training mode), which
     makes the bias gradient identically zero: it is returned as exact zeros instead of a column sum of round-off."""
     if isinstance(x, (tuple, list)):
-        if isinstance(x[0], LazyNorm) or isinstance(x[1], LazyNorm):
-            k = weight.shape[2]
-            r = _conv3d_pro(x[0], x[1], weight, bias, stats) if (k == 3 and stride == 1 and dil == 1 and pad == 1) else None
-            if r is not None:
-                return r
-            x = (dense(x[0]), dense(x[1]))
         return conv3d_cat(x[0], x[1], weight, bias, stride, pad, dil, stats, bias_grad_zero)
-    if isinstance(x, LazyNorm):
-        k = weight.shape[2]
-        r = _conv3d_pro(x, None, weight, bias, stats) if (k == 3 and stride == 1 and dil == 1 and pad == 1) else None
-        if r is not None:
-            return r
-        x = x.dense()
     if _x3_conv_ok(x, None, weight, stride, pad, dil):
         return _x3_conv_call(x, None, weight, bias, stats, bias_grad_zero)
     if stats or bias_grad_zero:
@@ -908,114 +896,6 @@ def conv_transpose2x(x, weight):
 
 
 
-
-# ------------------------------------------------------------------------------------------------ normalise in the consumer (no-grad)
-class LazyNorm:
-    """conv -> InstanceNorm3d(+affine) -> ReLU / LeakyReLU whose result has NOT been written: the pre-normalisation tensor plus the
-    per-(sample, channel) scale / shift rows of dp_stats_finalize_ss.  A 3x3x3 tiled convolution that consumes it applies
-    act(x * scale + shift) while staging its input (dp_conv3d_tiled_pro); anything else calls dense(), which runs the ordinary fused
-    normalise kernel once and caches the tensor.  Only built where no gradient is recorded (the frozen C3D U-Net of DOSE-PYFER,
-    c3d.py:11-38 with train_light_pyfer.py:85-88): there is no backward for it."""
-
-    def __init__(self, x, mean, rstd, gamma, beta, sc, sh, act):
-        self.x, self.mean, self.rstd, self.gamma, self.beta, self.sc, self.sh, self.act = x, mean, rstd, gamma, beta, sc, sh, act
-        self._dense = None
-
-    shape = property(lambda self: self.x.shape)
-    dtype = property(lambda self: self.x.dtype)
-    device = property(lambda self: self.x.device)
-    is_cuda = property(lambda self: self.x.is_cuda)
-    requires_grad = False
-
-    def dense(self):
-        if self._dense is None:
-            x = self.x
-            rows, C, ldx = rows_ld(x)
-            N = x.shape[0]
-            y = torch.empty(x.shape, dtype=x.dtype, device=x.device)
-            _lib.call("dp_norm_act_fwd", _p(x), ldx, _p(self.mean), _p(self.rstd), C, _p(self.gamma), _p(self.beta), 0, 0, ACT[self.act],
-                      _p(y), C, N, rows // N, C, _dt(x), _stream())
-            self._dense = y
-        return self._dense
-
-
-def dense(x):
-    """The tensor behind x (materialising a LazyNorm)."""
-    return x.dense() if isinstance(x, LazyNorm) else x
-
-
-def lazy_norm_ok(y, gamma, beta, act):
-    """True when norm_act(y, 'instance', gamma, beta, act=act) may be left to its consumer: no gradient is recorded for it, 16-bit
-    storage, an activation the staging prologue evaluates."""
-    if not _LAZY_NORM["enabled"] or y.dtype not in (torch.bfloat16, torch.float16) or act not in (None, "none", "relu", "lrelu"):
-        return False
-    if torch.is_grad_enabled() and (y.requires_grad or (gamma is not None and gamma.requires_grad) or (beta is not None and beta.requires_grad)):
-        return False
-    return y.is_cuda and y.shape[-1] % 8 == 0
-
-
-# (off by default: measured 0.3-0.5 ms per DOSE-PYFER step slower than the separate normalise passes -- every staged element is
-# normalised ~3.5 times (three kd slabs + halo) and the two-chunk layers lose their two-depth-slice blocks; DESIGN section 5)
-_LAZY_NORM = {"enabled": os.environ.get("DOSE_HIP_LAZY_NORM", "0") != "0"}
-
-
-def norm_act_lazy(y, stats, gamma, beta, act, eps=1e-5):
-    """InstanceNorm statistics of y (from the convolution epilogue's partial rows) -> LazyNorm (the normalised tensor is not written)."""
-    y = as_rows(y)
-    rows, C, _ = rows_ld(y)
-    N = y.shape[0]
-    V = rows // N
-    if stats is None:
-        stats = _stats_partial(y)
-    nblk = stats.shape[1]
-    dev = y.device
-    cpad = (C + 15) // 16 * 16
-    mean = torch.empty((N, C), dtype=torch.float32, device=dev)
-    rstd = torch.empty((N, C), dtype=torch.float32, device=dev)
-    ss = (torch.zeros if cpad != C else torch.empty)((2, N, cpad), dtype=torch.float32, device=dev)
-    g32 = None if gamma is None else gamma.detach()
-    b32 = None if beta is None else beta.detach()
-    _lib.call("dp_stats_finalize_ss", _p(stats), N, nblk, C, V, 0, float(eps), _p(mean), _p(rstd), _p(g32), _p(b32), _p(ss[0]), _p(ss[1]), cpad,
-              _stream())
-    return LazyNorm(y, mean, rstd, g32, b32, ss[0], ss[1], act)
-
-
-def _conv3d_pro(xa, xb, weight, bias, want_stats):
-    """3x3x3 "same" convolution (no gradient recorded) whose operand(s) may be LazyNorm: dp_conv3d_tiled_pro; returns y or (y, part);
-    None when the launch is not supported (the caller then materialises the operands)."""
-    la, lb = isinstance(xa, LazyNorm), isinstance(xb, LazyNorm)
-    ta = as_rows(xa.x if la else xa)
-    tb = None if xb is None else as_rows(xb.x if lb else xb)
-    cout, cin, k = weight.shape[0], weight.shape[1], weight.shape[2]
-    N, D, H, W = ta.shape[:4]
-    _, cxa, lda = rows_ld(ta)
-    ldb = rows_ld(tb)[2] if tb is not None else 0
-    ca = cxa if tb is not None else cin
-    L = _lib.lib()
-    if tb is not None and not (0 < ca < cin and tb.shape[-1] >= cin - ca and ca % 16 == 0 and tuple(tb.shape[:4]) == (N, D, H, W) and tb.dtype == ta.dtype):
-        return None
-    if tb is None and cxa < cin:
-        return None
-    if not L.dp_conv3d_tiled_pro_ok(_p(ta), lda, _p(tb), ldb, ca if tb is not None else 0, H, W, cin, cout, k, _dt(ta)):
-        return None
-    te = _tiled_elems(cin, cout, k, 1, 1, 1, W)
-    if not te:
-        return None
-    wq = _pack_conv_tiled(weight, 0, ta.dtype, te, W)
-    y = torch.empty((N, D, H, W, cout), dtype=ta.dtype, device=ta.device)
-    nblk = L.dp_conv3d_tiled_stat_blocks(N, D, H, W, cin, cout, k, cout, _dt(ta)) if want_stats else 0
-    part = torch.empty((N, nblk, 2, cout), dtype=torch.float32, device=ta.device) if nblk else None
-    b32 = None if bias is None else bias.detach()
-
-    def pro(t):
-        if not isinstance(t, LazyNorm):
-            return (0, 0, 0, 0)
-        return (_p(t.sc), _p(t.sh), t.sc.shape[-1], ACT[t.act])
-    _lib.call("dp_conv3d_tiled_pro", _p(ta), lda, _p(tb), ldb, ca if tb is not None else 0, _p(wq), _p(b32), _p(y), cout,
-              _p(_tiled_ws(ta, N, D, H, W, cin, cout, k)), _p(part), *pro(xa), *pro(xb), N, D, H, W, cin, cout, k, _dt(ta), _stream())
-    if want_stats:
-        return y, (part if part is not None else _stats_partial(y))
-    return y
 
 # ------------------------------------------------------------------------------------------------ fp32x3 mode (csrc/x3.hip)
 DP_X3 = 3
@@ -1371,7 +1251,7 @@ class LinearX3(torch.autograd.Function):
             gw = _wgrad_buffer(weight, False)
             # K-stacked view: row (3 r + p) of the [3 rows][cp] matrix is block p of row r
             from . import config
-            if config.x3_wgrad_terms() == 1:
+            if config.x3_linear_wgrad_terms() == 1:
                 # gy_hi x_hi only: block 0 of every row of both operands (row pitch 3 cp)
                 if ctx.defer and _DEFER["enabled"] and rows <= 16384 and weight.grad is None and (not want_b or ctx.bias_ref.grad is None):
                     _defer_wgrad(gys, 3 * cpo, xs, 3 * cp, gw, None, nout, K, rows)

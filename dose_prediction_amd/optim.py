@@ -57,6 +57,15 @@ class FusedAdam(torch.optim.Optimizer):
         if self._found_inf is not None:
             self._found_inf.zero_()
 
+    def step_was_clean(self, reset=True):
+        """GradScaler-style use under a static loss scale: call after step(); False means some gradient elements were not
+        finite and THOSE elements were left untouched while the rest of the step was applied (torch's GradScaler would have skipped
+        the whole step) -- lower the loss scale (config.set_loss_scale) and carry on, or restore a checkpoint.  Synchronises."""
+        bad = self.found_inf()
+        if reset and bad:
+            self.reset_found_inf()
+        return not bad
+
     @staticmethod
     def _step_value(s):
         """state['step'] as written by this class (int), by torch.optim.Adam (0-dim float tensor) or by capturable mode."""

@@ -73,7 +73,7 @@ def side_streams(device, main, n=3):
 def root(stream):
     """The caller's stream a side stream was chosen for (the stream itself if it is not one of ours): code that runs ON a side stream
     (the 3x3x3 branch's backward, blocks inside the transformer branch) asks for the side streams of the same caller."""
-    return _ROOT.get(stream.cuda_stream, stream)
+    return _ROOT.get((stream.device.index, stream.cuda_stream), stream)
 
 
 def side_stream(device, main, role):
@@ -81,5 +81,5 @@ def side_stream(device, main, role):
     main = root(main)
     got = side_streams(device, main)
     for s in got:
-        _ROOT.setdefault(s.cuda_stream, main)
+        _ROOT.setdefault((s.device.index, s.cuda_stream), main)
     return got[role]

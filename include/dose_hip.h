@@ -114,10 +114,6 @@ int dp_stats_partial(const void* x, int ld, int N, int64_t V, int C, float* part
  * to row 0].  If running_mean != NULL (batch, training): running = (1-m)*running + m*stat (unbiased var). */
 int dp_stats_finalize(const float* part, int N, int nblk, int C, int64_t V, int batch_mode, float eps,
                       float* mean, float* rstd, float* running_mean, float* running_var, float momentum, void* stream);
-/* the same (no running statistics) that also writes scale = rstd * gamma and shift = beta - mean * scale as [groups][cpad] rows: the
- * operands of dp_conv3d_tiled_pro's normalising prologue (gamma / beta may be NULL). */
-int dp_stats_finalize_ss(const float* part, int N, int nblk, int C, int64_t V, int batch_mode, float eps, float* mean, float* rstd,
-                         const float* gamma, const float* beta, float* scale, float* shift, int cpad, void* stream);
 /* y = act( (x-mean)*rstd*gamma + beta + res ).  stat_stride_n = C for instance stats, 0 for batch/eval stats.
  * gamma/beta/res may be NULL.  replaces: norm + activation (+ residual add of MONAI UnetResBlock). */
 int dp_norm_act_fwd(const void* x, int ldx, const float* mean, const float* rstd, int stat_stride_n,
@@ -164,10 +160,6 @@ int dp_add_layernorm_fwd(const void* a, const void* b, void* sum, const float* g
 int dp_add_layernorm_bwd(const void* x, const void* gy, const void* gsum, const float* gamma, const float* mean, const float* rstd,
                          void* gx, float* dgamma, float* dbeta, int64_t rows, int C, int dtype, void* stream);
 
-/* ---- stream plumbing (no reference counterpart: the reference's two branches run one after the other on one stream) ----
- * A stream restricted to the compute units whose bits are set in mask[0..nwords) (MI355X: bit b = CU b/8 of XCD b%8). */
-int dp_stream_create_cu_mask(const uint32_t* mask, int nwords, void** stream);
-int dp_stream_destroy(void* stream);
 
 /* ---- matrix products (MFMA) ------------------------------------------------------------------- */
 /* C[b0][b1][m][n] = alpha * sum_k A[..][m][k] * B[..][n][k] (+ bias[n]) ; "NT" GEMM, both operands k-contiguous.
@@ -253,17 +245,6 @@ int dp_conv3d_tiled_stats(const void* x, int ldx, const void* x2, int ldx2, int 
                           int dtype, void* stream);
 int dp_conv3d_wgrad_tiled2(const void* x, int ldx, const void* x2, int ldx2, int csplit, const void* gy, int ldgy, float* dw, float* ws,
                            int N, int D, int H, int W, int Cin, int Cout, int k, int64_t s_co, int64_t s_ci, int64_t s_tap, int dtype, void* stream);
-/* dp_conv3d_tiled_stats (stat_part may be NULL) whose input operand(s) are PRE-normalisation tensors: the staging path stores
- * act(x * scale[n][c] + shift[n][c]) into LDS, so the nn.InstanceNorm3d + ReLU between two convolutions of a forward-only network is
- * never written to or read from HBM (replaces: c3d.SingleConv's norm + ReLU in front of the next convolution, c3d.py:15-19, when no
- * gradient is recorded: the frozen C3D U-Net of DOSE-PYFER).  sc1 / sh1: [N or 1][>= channels of operand 1] rows (ns1 elements apart,
- * 0 = one row for all samples) from dp_stats_finalize_ss, act1 in {DP_ACT_NONE, DP_ACT_RELU, DP_ACT_LRELU}; sc1 == NULL: operand 1 is
- * read as it is; the same for the second operand of a virtual concat.  k = 3, 16-bit storage, aligned whole-chunk inputs only:
- * dp_conv3d_tiled_pro_ok(...) tells (1 = supported). */
-int dp_conv3d_tiled_pro_ok(const void* x, int ldx, const void* x2, int ldx2, int csplit, int H, int W, int Cin, int Cout, int k, int dtype);
-int dp_conv3d_tiled_pro(const void* x, int ldx, const void* x2, int ldx2, int csplit, const void* wq, const float* bias, void* y, int ldy,
-                        float* ws, float* stat_part, const float* sc1, const float* sh1, int ns1, int act1, const float* sc2,
-                        const float* sh2, int ns2, int act2, int N, int D, int H, int W, int Cin, int Cout, int k, int dtype, void* stream);
 /* weight gradient (fp32, ACCUMULATES): for every tap t, co, ci:
  *   dw[co*s_co + ci*s_ci + t*s_tap] += sum_v gy[v][co + t*gy_tap_choff] * x[shift ? v*stride - pad + t*dil : v][ci]
  * replaces: autograd's conv/linear/conv-transpose weight gradients.  (v ranges over the gy voxels.) */
