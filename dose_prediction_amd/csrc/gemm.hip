@@ -4,6 +4,7 @@
 // Block = 4 waves (2x2), block tile 128x128x32, wave tile 64x64 (4x4 MFMA tiles, 64 accumulator VGPRs).
 // Global -> registers -> LDS with the next tile's loads in flight during the MFMA phase.
 #include "common.h"
+#include <stdlib.h>
 
 #define STREAM ((hipStream_t)stream)
 // BK: k-depth of one LDS stage (32 or 64).  LDP = padded LDS row (elements): keeps 16-B alignment, breaks the power-of-two stride.
@@ -211,6 +212,8 @@ static int gemm_nt_impl(const void* A, int64_t lda, int64_t sa0, int64_t sa1, co
   if (splitk > 1 && !out_f32) DP_FAIL("gemm_nt: split-K needs fp32 (atomic) output");
   int64_t big_blocks = (int64_t)cdiv(M, 128) * cdiv(N, 128) * nb0 * nb1 * splitk;
   bool small = big_blocks < 256 && N > 32;        // 64x64 tiles: 4x the blocks (skinny N keeps the 128-row tile: it is a row stream)
+  // (a 128 x 64 tile for the qkv / fc1 token GEMMs -- 288-384 blocks, a third less L2 -> LDS traffic -- was measured in round 4: 16.8 / 18.0 us
+  // against 14.9 / 15.7 for the 64 x 64 tiles: these launches are latency-, not traffic-bound)
   int bm = small ? 64 : 128, bn = small ? 64 : 128;
   dim3 g(cdiv(M, bm), cdiv(N, bn), nb0 * nb1 * splitk);
   if (g.y > 65535 || g.z > 65535) DP_FAIL("gemm_nt: grid too large");
@@ -336,6 +339,81 @@ __device__ __forceinline__ void gemm_tn_tile(const T* __restrict__ A, int64_t ld
     if (tid < 64 && m0 + tid < M) colsum[m0 + tid] = (red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]);
   }
 }
+// The same for a 128 x 128 output tile (round 4): a 64 x 64 tile fetches 16 KB of operands per 0.5 MFLOP, and the grouped launch of the
+// transformer's + patch embedding's weight gradients (33 k tiles x 16 k-slabs) pulled 8.4 GB through L2 -> LDS for 0.3 GB of operands:
+// it ran at the L2's rate (0.72 ms), not the matrix cores' (16.7 % MFMA-busy).  Four waves x (64 x 64) per block halve that traffic.
+// Whole tiles and aligned rows only (M, N multiples of 128, 16-byte rows): the caller picks the tile per problem.
+template <typename T>
+__device__ __forceinline__ void gemm_tn_tile128(const T* __restrict__ A, int64_t lda, const T* __restrict__ B, int64_t ldb, float* __restrict__ C,
+                                                int64_t ldc, int K, int m0, int n0, float* __restrict__ colsum, T* As, T* Bs) {
+  constexpr int BT = 128, BKT = 64, LDPT = BT + 8, CPRT = BT / 8, UT = BKT * CPRT / 256;     // 136-element LDS rows; 4 chunks per thread per operand
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1, r = lane & 15, q = lane >> 4;
+  const int ktiles = (K + BKT - 1) / BKT;
+  v4f acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
+  Frag8<T> ra[UT], rb[UT];
+  float csum = 0.f;
+  auto gload = [&](int kt) {
+#pragma unroll
+    for (int u = 0; u < UT; u++) {
+      const int c = tid + u * 256, row = c / CPRT, cc = (c % CPRT) * 8, k = kt * BKT + row;
+      if (k < K) { ra[u] = frag_ld_lds(A + (int64_t)k * lda + m0 + cc); rb[u] = frag_ld_lds(B + (int64_t)k * ldb + n0 + cc); }
+      else { ra[u] = frag_zero<T>(); rb[u] = frag_zero<T>(); }
+    }
+  };
+  const int i16 = lane & 15, tr_lane = (8 * q + (i16 >> 2)) * LDPT + 4 * (i16 & 3);
+  auto frag = [&](const T* img, int kk, int col0) {
+    if constexpr (sizeof(T) == 2) return tr_pair<4 * LDPT, T>(img + kk * LDPT + col0 + tr_lane);
+    else { Frag8<float> f;
+#pragma unroll
+      for (int j = 0; j < 8; j++) f.v[j] = img[(kk + 8 * q + j) * LDPT + col0 + r];
+      return f; }
+  };
+  gload(0);
+  for (int kt = 0; kt < ktiles; kt++) {
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < UT; u++) {
+      const int c = tid + u * 256, row = c / CPRT, cc = (c % CPRT) * 8;
+      frag_st_lds(As + row * LDPT + cc, ra[u]); frag_st_lds(Bs + row * LDPT + cc, rb[u]);
+    }
+    __syncthreads();
+    if (kt + 1 < ktiles) gload(kt + 1);
+    if (colsum) {                                  // block-uniform: thread t adds rows (t >> 7) * 32 .. + 31 of column t & 127
+      const int cc = tid & 127, r0 = (tid >> 7) * 32;
+#pragma unroll
+      for (int rr = 0; rr < 32; rr++) csum += ld_f(As + (r0 + rr) * LDPT + cc);
+    }
+#pragma unroll
+    for (int kk = 0; kk < BKT; kk += 32) {
+      Frag8<T> fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) { fa[i] = frag(As, kk, wm * 64 + i * 16); fb[i] = frag(Bs, kk, wn * 64 + i * 16); }
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = mma16(fa[i], fb[j], acc[i][j]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int col = n0 + wn * 64 + j * 16 + r;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int e = 0; e < 4; e++) C[(int64_t)(m0 + wm * 64 + i * 16 + q * 4 + e) * ldc + col] = acc[i][j][e];
+  }
+  if (colsum) {
+    __syncthreads();
+    float* red = (float*)As;
+    red[tid] = csum;
+    __syncthreads();
+    if (tid < 128) colsum[m0 + tid] = red[tid] + red[128 + tid];
+  }
+}
 template <typename T>
 __global__ void __launch_bounds__(256) k_gemm_tn(const T* __restrict__ A, int64_t lda, const T* __restrict__ B, int64_t ldb, float* __restrict__ C,
                                                  int64_t ldc, int M, int N, int K, int splitk) {
@@ -345,12 +423,13 @@ __global__ void __launch_bounds__(256) k_gemm_tn(const T* __restrict__ A, int64_
 }
 // Grouped form: ONE launch computes the weight (and bias) gradients of many Linear layers (the 8 transformer layers x 4 weights
 // + the patch embedding: every one a separate, latency-bound 25-us launch before).  table row p (12 x int64): A, B, C, colsum
-// pointers, lda, ldb, ldc, M, N, K, first tile id, tiles along M.  Tile ids are dealt problem-major, n-tile-major, m fastest.
+// pointers, lda, ldb, ldc, M, N, K, first tile id, tiles along M (| 1 << 32: 128 x 128 tiles instead of 64 x 64: M, N multiples of
+// 128, lda / ldb multiples of 8, 16-byte aligned operands).  Tile ids are dealt problem-major, n-tile-major, m fastest.
 struct TnProblem { const void* A; const void* B; float* C; float* colsum; int64_t lda, ldb, ldc, M, N, K, tile0, tiles_m; };
 template <typename T>
 __global__ void __launch_bounds__(256) k_gemm_tn_grouped(const TnProblem* __restrict__ tab, int nprob, int64_t total_tiles) {
-  __shared__ __attribute__((aligned(16))) T As[64 * 72];
-  __shared__ __attribute__((aligned(16))) T Bs[64 * 72];
+  __shared__ __attribute__((aligned(16))) T As[64 * 136];
+  __shared__ __attribute__((aligned(16))) T Bs[64 * 136];
   // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, consecutive TILES share an operand panel (the row tiles
   // of one 64-column panel of B: for the patch embedding 12 tiles x 128 KB of x).  Give every XCD a contiguous range of tiles, so
   // that a panel is fetched into ONE L2 instead of eight (FETCH_SIZE of the launch: 2.6 GB for 0.3 GB of operands, round 3).
@@ -364,7 +443,11 @@ __global__ void __launch_bounds__(256) k_gemm_tn_grouped(const TnProblem* __rest
   int p = 0;
   while (p + 1 < nprob && tab[p + 1].tile0 <= bid) p++;          // (uniform scalar loads; <= a few dozen problems)
   const TnProblem P = tab[p];
-  const int t = (int)(bid - P.tile0), tm = (int)P.tiles_m, mi = t % tm, ni = t / tm;
+  const int t = (int)(bid - P.tile0), tm = (int)(P.tiles_m & 0xffffffff), mi = t % tm, ni = t / tm;
+  if (P.tiles_m >> 32) {      // (bit 32 of tiles_m: the problem was tiled 128 x 128 -- whole tiles, aligned rows)
+    gemm_tn_tile128<T>((const T*)P.A, P.lda, (const T*)P.B, P.ldb, P.C, P.ldc, (int)P.K, mi * 128, ni * 128, (P.colsum && ni == 0) ? P.colsum : nullptr, As, Bs);
+    return;
+  }
   gemm_tn_tile<T>((const T*)P.A, P.lda, (const T*)P.B, P.ldb, P.C, P.ldc, (int)P.M, (int)P.N, (int)P.K, 1, mi * 64, ni * 64, 0,
                   (P.colsum && ni == 0) ? P.colsum : nullptr, As, Bs);
 }

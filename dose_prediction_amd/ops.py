@@ -1311,6 +1311,9 @@ def patch_embed_x3(x, C, p, weight, bias, splitk):
 _DEFER = {"pending": [], "queued": False, "host": None, "rot": 0, "enabled": os.environ.get("DOSE_HIP_DEFER_WGRAD", "1") != "0"}
 
 
+_TN_TILE128 = os.environ.get("DOSE_HIP_TN_TILE128", "1") != "0"
+
+
 def _alias(t):
     """A second tensor object on t's storage that is NOT a view of t: holding it keeps the memory alive without raising t's own
     reference count, so AccumulateGrad still adopts t as .grad without a copy (it clones a gradient somebody else holds), and
@@ -1354,8 +1357,13 @@ def flush_deferred(*_unused):
         for gy, ldg, x, ldx, gw, gb, nout, nin, rows, ev, _st in lst:
             if gw.dtype != torch.float32 or not gw.is_contiguous() or (gb is not None and not gb.is_contiguous()):
                 raise _lib.DoseHipError("deferred weight gradient: the gradient tensor is not a contiguous fp32 tensor")
-            tm, tn = -(-nout // 64), -(-nin // 64)
-            rows_tab.append((gy.data_ptr(), x.data_ptr(), gw.data_ptr(), 0 if gb is None else gb.data_ptr(), ldg, ldx, nin, nout, nin, rows, tile0, tm))
+            # 128 x 128 tiles where they are whole and the rows aligned (half the L2 -> LDS operand traffic of 64 x 64 tiles)
+            big = (_TN_TILE128 and nout % 128 == 0 and nin % 128 == 0 and ldg % 8 == 0 and ldx % 8 == 0 and gy.data_ptr() % 16 == 0
+                   and x.data_ptr() % 16 == 0)
+            ts = 128 if big else 64
+            tm, tn = -(-nout // ts), -(-nin // ts)
+            rows_tab.append((gy.data_ptr(), x.data_ptr(), gw.data_ptr(), 0 if gb is None else gb.data_ptr(), ldg, ldx, nin, nout, nin, rows, tile0,
+                             tm | ((1 << 32) if big else 0)))
             tile0 += tm * tn
             for t in (gw, gb):
                 if t is not None:

@@ -182,8 +182,9 @@ int dp_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C,
 /* Grouped form: one launch for the weight (and bias) gradients of many Linear layers (MONAI TransformerBlock x num_layers and the
  * patch embedding; autograd computes them one by one).  table: device array of rows {const T* A; const T* B; float* C;
  * float* colsum (or NULL); int64 lda, ldb, ldc, M, N, K, tile0, tiles_m}: C[m][n] = sum_k A[k][m] B[k][n] (A = gy [rows][out],
- * B = x [rows][in], C = dW [out][in]); colsum[m] = sum_k A[k][m] (the bias gradient).  64 x 64 tiles numbered from tile0 per
- * problem (n-tile-major, m fastest, tiles_m = ceil(M / 64)); total_tiles = sum over problems of ceil(M/64) * ceil(N/64). */
+ * B = x [rows][in], C = dW [out][in]); colsum[m] = sum_k A[k][m] (the bias gradient).  Tiles of T x T numbered from tile0 per
+ * problem (n-tile-major, m fastest, low 32 bits of tiles_m = ceil(M / T)); T = 64, or 128 when bit 32 of tiles_m is set (only for M, N
+ * multiples of 128, lda / ldb multiples of 8, 16-byte aligned operands); total_tiles = sum over problems of ceil(M/T) * ceil(N/T). */
 int dp_gemm_tn_grouped(const void* table, int nproblems, int64_t total_tiles, int dtype, void* stream);
 
 /* skinny pointwise (1x1x1) convolution over voxel rows, Cin <= 64 and Cout <= 32: y[v][co] = sum_ci x[v][ci] w[co*ldw + ci] (+bias).
