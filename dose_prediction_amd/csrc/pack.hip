@@ -17,6 +17,119 @@ struct PackDesc { const float* src; void* dst; int64_t kind, a, b, c, d, e; };
 // against activations split [x_hi | x_lo | x_hi] = 0b010).
 __device__ __forceinline__ float x3_part(float v, int lo) { const float h = bf2f(f2bf(v)); return lo ? v - h : h; }
 
+// Tiled convolution layouts (PK_CONV_TILED, PK_CONV_CC16; round 4): a chunk = FOUR destination columns (output channels of the
+// packed copy) x ONE 16-channel destination chunk x ALL taps.  Its source is 4 (16 when transposed) contiguous runs of the fp32
+// parameter -- 16 x taps (4 x taps) floats each -- which go through an LDS image [4 cols][taps][16 ch] and leave as whole 32- / 128-byte
+// pieces of the destination tiles.  The element-per-thread walk it replaces fetched 924 MB from HBM to write 223 MB (every 28-byte
+// run of seven kw taps pulled two sectors, and the (kd, kh) passes over one (co, ci) pair were a cache lifetime apart).
+__host__ __device__ inline int pk_conv_cols(int kind, int Cout, int KS, int NPAIR) {      // destination columns incl. padding
+  return kind == PK_CONV_CC16 ? 16 : ((Cout * NPAIR + 31) / 32) * 32 / NPAIR;
+}
+extern "C" int64_t dp_pack_chunks(int64_t kind_, int64_t a, int64_t b, int64_t c, int64_t d, int64_t e, int64_t dst_elems) {
+  const int kind = (int)(kind_ & 0xff), x3cp = (int)(kind_ >> 16);
+  (void)e;
+  if (kind == PK_MAT_T) return ((a + 63) / 64) * ((c + 127) / 128);
+  if (kind == PK_CONV_TILED || kind == PK_CONV_CC16) {
+    const int nch = x3cp ? 3 * x3cp / 16 : (int)((b + 15) / 16);
+    return (int64_t)(pk_conv_cols(kind, (int)a, (int)c, (int)d) / 4) * nch;
+  }
+  return (dst_elems + PACK_CHUNK - 1) / PACK_CHUNK;
+}
+
+template <typename T>
+__device__ __forceinline__ void pack_conv_lds(const PackDesc& P, unsigned ck, T* img) {
+  const float* __restrict__ w = P.src;
+  T* __restrict__ dst = (T*)P.dst;
+  const int kind = (int)(P.kind & 0xff), x3pat = (int)((P.kind >> 8) & 0xff), x3cp = (int)(P.kind >> 16);
+  const int Cout = (int)P.a, Cin = (int)P.b, KS = (int)P.c, NPAIR = kind == PK_CONV_TILED ? (int)P.d : 1, tf = (int)P.e;
+  const int taps = KS * KS * KS, NCH = x3cp ? 3 * x3cp / 16 : (Cin + 15) / 16;
+  const int ch = (int)(ck % (unsigned)NCH), co0 = (int)(ck / (unsigned)NCH) * 4;
+  int ci0 = ch * 16, lo = 0;
+  if (x3cp) { const int part = ci0 / x3cp; ci0 -= part * x3cp; lo = (x3pat >> part) & 1; }
+  const int tid = threadIdx.x;
+  // ---- source -> img[cc][tap][c] (element (cc * taps + tap) * 16 + c); the runs are read four floats at a time (16-byte requests at
+  // 4-byte alignment; 16 x taps and 4 x taps are multiples of 4 for taps = 27, 343)
+  // All 16 x 4 x taps floats of the chunk are (16 or 4) x taps / 4 four-float units; a thread requests its units in batches of 11
+  // BEFORE it touches LDS (one memory round trip per batch: a loop per run was 4-16 dependent round trips per block, 19 us each).
+  // The LDS image keeps the SOURCE order -- run-major, tap fastest: consecutive lanes write consecutive 8 bytes (an image in
+  // destination order put the lanes of a wave 128 bytes apart: two banks) -- and the transposition happens on the read side.
+  typedef float v4f_u __attribute__((ext_vector_type(4), aligned(4)));
+  const int rl = (tf ? 4 : 16) * taps;                         // floats per run
+  const int upr = rl / 4;                                      // units per run
+  const int nrun = tf ? 16 : 4, nunits = nrun * upr;
+  constexpr int UB = 11;
+  for (int u0 = 0; u0 < nunits; u0 += 256 * UB) {
+    v4f_u q4[UB];
+#pragma unroll
+    for (int b = 0; b < UB; b++) {
+      const int u = u0 + b * 256 + tid;
+      const int rn = u / upr, i = (u - rn * upr) * 4;
+      q4[b] = (v4f_u){0.f, 0.f, 0.f, 0.f};
+      if (u < nunits) {
+        // run rn: tf == 0: column co0 + rn, floats [ci0 .. ci0 + 15][tap]; tf == 1: channel ci0 + rn, floats [co0 .. co0 + 3][tap]
+        const int64_t base = tf ? ((int64_t)(ci0 + rn) * Cout + co0) * taps : ((int64_t)(co0 + rn) * Cin + ci0) * taps;
+        const int nv = tf ? ((ci0 + rn < Cin) ? min(4, Cout - co0) * taps : 0) : ((co0 + rn < Cout) ? min(16, Cin - ci0) * taps : 0);
+        if (i + 4 <= nv) q4[b] = *(const v4f_u*)(w + base + i);
+        else for (int j = 0; j < 4; j++) if (i + j < nv) q4[b][j] = w[base + i + j];
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < UB; b++) {
+      const int u = u0 + b * 256 + tid;
+      if (u >= nunits) continue;
+      T h[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) { float v = q4[b][j]; if (x3cp) v = x3_part(v, lo); st_f(&h[j], v); }
+      *(uint2*)(img + (int64_t)u * 4) = *(const uint2*)h;       // image element (run * rl + i): 4 two-byte elements, 8-byte aligned
+    }
+  }
+  __syncthreads();
+  // element (column cc, tap, channel c) of the image
+  auto at = [&](int cc, int tap, int c) -> unsigned {
+    const int idx = tf ? (c * rl + cc * taps + (taps - 1 - tap)) : (cc * rl + c * taps + tap);
+    return (unsigned)*(const unsigned short*)(img + idx);
+  };
+  auto piece = [&](int cc, int tap, int hv) -> v4u {           // channels hv * 8 .. + 7 of (cc, tap)
+    v4u v;
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = at(cc, tap, hv * 8 + 2 * k) | (at(cc, tap, hv * 8 + 2 * k + 1) << 16);
+    return v;
+  };
+  const v4u zero = (v4u){0, 0, 0, 0};
+  if (kind == PK_CONV_TILED) {
+    // dst[kd][jh][kw][chunk][ntile][col 32][ci 16]; NPAIR == 2: col = (kh & 1) * 16 + co % 16, ntile = co / 16 (kh = KS: zero padding)
+    const int JH = NPAIR == 2 ? (KS + 1) / 2 : KS, NTT = (Cout * NPAIR + 31) / 32, KHS = NPAIR == 2 ? 2 * JH : KS;
+    const int pieces = KS * KHS * KS * 8;                      // per (kd, kh slot, kw): 4 columns x 2 halves of 16 bytes
+    for (int i = tid; i < pieces; i += 256) {
+      const int hv = i & 1, cc = (i >> 1) & 3; int t = i >> 3;
+      const int kw = t % KS; t /= KS; const int khs = t % KHS, kd = t / KHS;
+      const int co = co0 + cc;
+      int jh, col, nt;
+      if (NPAIR == 2) { jh = khs >> 1; col = (khs & 1) * 16 + (co & 15); nt = co >> 4; } else { jh = khs; col = co & 31; nt = co >> 5; }
+      const int64_t di = ((((int64_t)((kd * JH + jh) * KS + kw) * NCH + ch) * NTT + nt) << 9) + (col << 4) + hv * 8;
+      *(v4u*)(dst + di) = khs < KS ? piece(cc, (kd * KS + khs) * KS + kw, hv) : zero;
+    }
+  } else if (KS == 7) {
+    // dst[kd][chunk][slot 25][co 16][k 32]: k < 16 tap t = 2 slot, k >= 16 tap 2 slot + 1 (t = 7 kh + kw; t = 49: zero)
+    const int pieces = 7 * 50 * 8;
+    for (int i = tid; i < pieces; i += 256) {
+      const int hv = i & 1, cc = (i >> 1) & 3; int t = i >> 3;
+      const int tt = t % 50, kd = t / 50;
+      const int64_t di = ((((int64_t)(kd * NCH + ch) * 25 + (tt >> 1))) << 9) + ((co0 + cc) << 5) + ((tt & 1) << 4) + hv * 8;
+      *(v4u*)(dst + di) = tt < 49 ? piece(cc, kd * 49 + tt, hv) : zero;
+    }
+  } else {
+    // dst[kd][chunk][kwp][kh][co 16][k 32]: k < 16 tap kw = 2 kwp, k >= 16 kw = 2 kwp + 1 (kw = KS: zero)
+    const int KWP = (KS + 1) / 2, pieces = KS * KWP * 2 * KS * 8;
+    for (int i = tid; i < pieces; i += 256) {
+      const int hv = i & 1, cc = (i >> 1) & 3; int t = i >> 3;
+      const int kh = t % KS; t /= KS; const int kw = t % (2 * KWP), kd = t / (2 * KWP);
+      const int64_t di = ((((int64_t)(kd * NCH + ch) * KWP + (kw >> 1)) * KS + kh) << 9) + ((co0 + cc) << 5) + ((kw & 1) << 4) + hv * 8;
+      *(v4u*)(dst + di) = kw < KS ? piece(cc, (kd * KS + kh) * KS + kw, hv) : zero;
+    }
+  }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) k_pack_multi(const PackDesc* __restrict__ tab, const int* __restrict__ chunk_t,
                                                     const int* __restrict__ chunk_i) {
@@ -25,25 +138,63 @@ __global__ void __launch_bounds__(256) k_pack_multi(const PackDesc* __restrict__
   const float* __restrict__ w = P.src;
   T* __restrict__ dst = (T*)P.dst;
   const int kind = (int)(P.kind & 0xff), x3pat = (int)((P.kind >> 8) & 0xff), x3cp = (int)(P.kind >> 16);
+  extern __shared__ __attribute__((aligned(16))) unsigned char pk_smem[];
+  if ((kind == PK_CONV_TILED || kind == PK_CONV_CC16) && sizeof(T) == 2) {
+    if constexpr (sizeof(T) == 2) pack_conv_lds<T>(P, ck, (T*)pk_smem);
+    return;
+  }
   if (kind == PK_MAT_T) {
     // dst[r][c] (rows a, valid columns b, pitch c) = src[c][r] (src is [b][a]); tile = 64 dst rows x 128 dst columns
-    __shared__ float tile[128][65];
+    // the tile is transposed on its way INTO LDS (as T, row pitch 130 elements = 65 words: conflict-free 2-byte writes), so that a
+    // destination row leaves as 16-byte pieces (the 2-byte global stores of round 2-3 ran at 1.7 TB/s)
+    constexpr int TP = 130;
+    T* tile = (T*)pk_smem;                               // [64 dst rows][TP]
     const unsigned rows = (unsigned)P.a, cols = (unsigned)P.b, pitch = (unsigned)P.c;
     const unsigned tc = (pitch + 127) / 128;
     const unsigned r0 = (ck / tc) * 64, c0 = (ck % tc) * 128;
-    for (unsigned i = threadIdx.x; i < 128 * 64; i += 256) {
-      const unsigned sr = i >> 6, sc = i & 63;          // src row = dst col, src col = dst row
-      float v = 0.f;
+    // 128 source rows x 64 floats = 2048 four-float units, 8 per thread, all requested before the first LDS write
+    typedef float v4f_u __attribute__((ext_vector_type(4), aligned(4)));
+    v4f_u q4[8]; unsigned lo8 = 0;
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+      const unsigned u = b * 256 + threadIdx.x, sr = u >> 4, sc = (u & 15) * 4;     // src row = dst col, src cols sc .. sc + 3 = dst rows
       unsigned cv = c0 + sr, part = 0;
       if (x3cp) { part = cv / (unsigned)x3cp; cv -= part * (unsigned)x3cp; }
-      if (cv < cols && part < 3 && r0 + sc < rows) v = w[(int64_t)cv * rows + r0 + sc];
-      if (x3cp) v = x3_part(v, (x3pat >> part) & 1);
-      tile[sr][sc] = v;
+      q4[b] = (v4f_u){0.f, 0.f, 0.f, 0.f};
+      if (cv < cols && part < 3) {
+        const float* src = w + (int64_t)cv * rows + r0 + sc;
+        if (r0 + sc + 4 <= rows) q4[b] = *(const v4f_u*)src;
+        else for (int j = 0; j < 4; j++) if (r0 + sc + j < rows) q4[b][j] = src[j];
+      }
+      if (x3cp && ((x3pat >> part) & 1)) lo8 |= 1u << b;
+    }
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+      const unsigned u = b * 256 + threadIdx.x, sr = u >> 4, sc = (u & 15) * 4;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        float v = q4[b][j];
+        if (x3cp) v = x3_part(v, (lo8 >> b) & 1);
+        st_f(tile + (sc + j) * TP + sr, v);
+      }
     }
     __syncthreads();
-    for (unsigned i = threadIdx.x; i < 64 * 128; i += 256) {
-      const unsigned dr = i >> 7, dc = i & 127;
-      if (r0 + dr < rows && c0 + dc < pitch) st_f(dst + (int64_t)(r0 + dr) * pitch + c0 + dc, tile[dc][dr]);
+    const bool vec = sizeof(T) == 2 && (pitch & 7) == 0 && (((uintptr_t)dst) & 15) == 0;
+    if (vec) {
+      for (unsigned i = threadIdx.x; i < 64 * 16; i += 256) {
+        const unsigned dr = i >> 4, dc = (i & 15) * 8;
+        if (r0 + dr < rows && c0 + dc < pitch) {
+          union { v4u raw; unsigned short e[8]; unsigned u[4]; } pk;
+          const unsigned* src32 = (const unsigned*)(tile + dr * TP + dc);        // (TP and dc even: 4-byte aligned)
+          pk.u[0] = src32[0]; pk.u[1] = src32[1]; pk.u[2] = src32[2]; pk.u[3] = src32[3];
+          *(v4u*)(dst + (int64_t)(r0 + dr) * pitch + c0 + dc) = pk.raw;
+        }
+      }
+    } else {
+      for (unsigned i = threadIdx.x; i < 64 * 128; i += 256) {
+        const unsigned dr = i >> 7, dc = i & 127;
+        if (r0 + dr < rows && c0 + dc < pitch) dst[(int64_t)(r0 + dr) * pitch + c0 + dc] = tile[dr * TP + dc];
+      }
     }
     return;
   }
@@ -154,7 +305,9 @@ __global__ void __launch_bounds__(256) k_pack_multi(const PackDesc* __restrict__
 extern "C" int dp_pack_chunk(void) { return PACK_CHUNK; }
 extern "C" int dp_pack_multi(const void* table, const int32_t* chunk_t, const int32_t* chunk_i, int nchunks, int dtype, void* stream) {
   if (nchunks <= 0) return 0;
-  DP_DISPATCH(dtype, hipLaunchKernelGGL(k_pack_multi<T>, dim3(nchunks), dim3(256), 0, STREAM, (const PackDesc*)table,
+  // dynamic LDS: the transposing matrix tile (128 x 65 floats) or the convolution image (4 x 343 x 16 two-byte elements)
+  constexpr size_t smem = 4 * 343 * 16 * 2 > 128 * 65 * 4 ? 4 * 343 * 16 * 2 : 128 * 65 * 4;
+  DP_DISPATCH(dtype, hipLaunchKernelGGL(k_pack_multi<T>, dim3(nchunks), dim3(256), smem, STREAM, (const PackDesc*)table,
                                         (const int*)chunk_t, (const int*)chunk_i));
   DP_CHECK_LAUNCH("pack_multi"); return 0;
 }

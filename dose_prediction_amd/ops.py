@@ -154,6 +154,13 @@ def adam_fusable_pack(p):
     return None, 0, 0, 0, 0
 
 
+def _pack_chunks(L, desc, dst, chunk):
+    """Blocks dp_pack_multi needs for one table row (dp_pack_chunks; fp32 destinations keep the element walk)."""
+    if dst.element_size() == 2 or (desc[0] & 0xff) == 2:
+        return int(L.dp_pack_chunks(desc[0], desc[1], desc[2], desc[3], desc[4], desc[5], dst.numel()))
+    return -(-dst.numel() // chunk)
+
+
 def refresh_packs(params, fused=None):
     """Rebuild, in ONE launch per storage type (dp_pack_multi), every packed copy of ``params`` that was used since the last
     refresh; called by FusedAdam.step() right after the update kernel, which changes the parameters through raw pointers
@@ -190,7 +197,7 @@ def refresh_packs(params, fused=None):
             for t, (p, d, desc) in enumerate(lst):
                 kind, a, b, c = desc[0], desc[1], desc[2], desc[3]
                 rows.append((p.data_ptr(), d.data_ptr()) + tuple(desc))
-                n = (-(-a // 64)) * (-(-c // 128)) if (kind & 0xff) == 2 else -(-d.numel() // chunk)
+                n = _pack_chunks(L, desc, d, chunk)
                 ct += [t] * n
                 ci += list(range(n))
             plan = (torch.tensor(rows, dtype=torch.int64, device=dev), torch.tensor(ct, dtype=torch.int32, device=dev),
@@ -905,7 +912,7 @@ _PAT_ACT, _PAT_W = 0b010, 0b100      # operand blocks [hi | lo | hi] against [hi
 def _pack_one(w, dst, desc):
     """Build ONE packed copy through dp_pack_multi (a one-row table): the x3 layouts only exist as dp_pack_multi kinds."""
     L = _lib.lib()
-    n = (-(-desc[1] // 64)) * (-(-desc[3] // 128)) if (desc[0] & 0xff) == 2 else -(-dst.numel() // L.dp_pack_chunk())
+    n = _pack_chunks(L, desc, dst, L.dp_pack_chunk())
     dev = w.device
     tab = torch.tensor([(w.data_ptr(), dst.data_ptr()) + tuple(desc)], dtype=torch.int64, device=dev)
     ct = torch.zeros((n,), dtype=torch.int32, device=dev)

@@ -297,6 +297,9 @@ int dp_adam_multi_dev(const void* table, const int32_t* chunk_t, const int32_t* 
  * 1 / 2, pitch c = 3 cp) is three blocks of cp virtual channels over the same zero-padded real ones; block p holds bf16(w) if
  * pattern bit p is 0, bf16(w - bf16(w)) if it is 1. */
 int dp_pack_chunk(void);
+/* number of chunks (blocks of dp_pack_multi) of one table row: kind 2: 64 x 128 transpose tiles; tiled convolution layouts (kinds 4, 6)
+ * with 16-bit destinations: (4 destination columns) x (16-channel chunks), all taps each; everything else: dp_pack_chunk() elements. */
+int64_t dp_pack_chunks(int64_t kind, int64_t a, int64_t b, int64_t c, int64_t d, int64_t e, int64_t dst_elems);
 int dp_conv3d_tiled_npair(int Cout);
 int dp_pack_multi(const void* table, const int32_t* chunk_t, const int32_t* chunk_i, int nchunks, int dtype, void* stream);
 

@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Which packed-weight layouts does the per-step refresh (dp_pack_multi) rebuild, how many bytes, and how long does each kind take
+alone?  (DOSE-PYFER bench model, one training step to populate the pack cache.)  usage: python tools/pack_probe.py [bf16|fp32x3]"""
+import collections
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from dose_prediction_amd import _lib, losses, ops, synth  # noqa: E402
+from dose_prediction_amd.optim import FusedAdam  # noqa: E402
+
+
+def main():
+    mode = sys.argv[1] if len(sys.argv) > 1 else "bf16"
+    sys.argv = [sys.argv[0], "--no-cpu-baseline", "--dtype", mode]
+    args = bench.parse()
+    dev = torch.device("cuda:0")
+    shape = (128, 128, 128)
+    net = bench.build_model(args, shape, dev)
+    params = [p for p in net.parameters() if p.requires_grad]
+    opt = FusedAdam(params, lr=1e-4, weight_decay=3e-5, betas=(0.9, 0.999), eps=1e-8, amsgrad=True)
+    x, gt = synth.dose_input(2, shape).to(dev), synth.dose_target(2, shape).to(dev)
+    for _ in range(2):
+        opt.zero_grad(set_to_none=True)
+        losses.gen_loss(net(x), gt, 10.0, 1.0, casecade=True, freez=True).backward()
+        opt.step()
+    opt.zero_grad(set_to_none=True)
+    losses.gen_loss(net(x), gt, 10.0, 1.0, casecade=True, freez=True).backward()
+    torch.cuda.synchronize()
+    L = _lib.lib()
+    chunk = L.dp_pack_chunk()
+    by = collections.defaultdict(list)
+    for p in params:
+        store = p.__dict__.get("_dp_packs") or {}
+        for key, ent in store.items():
+            dst, desc = ent[1], ent[2]
+            if desc is None or dst.data_ptr() == p.data_ptr() or not ent[3]:
+                continue
+            by[(desc[0] & 0xff, dst.dtype)].append((p, dst, desc))
+    names = {0: "cast", 1: "mat", 2: "mat_t", 3: "conv", 4: "conv_tiled", 5: "tconv", 6: "conv_cc16"}
+    for (kind, dt), lst in sorted(by.items()):
+        rows, ct, ci = [], [], []
+        for t, (p, d, desc) in enumerate(lst):
+            rows.append((p.data_ptr(), d.data_ptr()) + tuple(desc))
+            n = ops._pack_chunks(L, desc, d, chunk)
+            ct += [t] * n
+            ci += list(range(n))
+        tab = torch.tensor(rows, dtype=torch.int64, device=dev)
+        ctt, cit = torch.tensor(ct, dtype=torch.int32, device=dev), torch.tensor(ci, dtype=torch.int32, device=dev)
+        st = torch.cuda.current_stream().cuda_stream
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for it in range(3):
+            if it == 1:
+                e0.record()
+            _lib.call("dp_pack_multi", tab.data_ptr(), ctt.data_ptr(), cit.data_ptr(), len(ct), ops._DT[dt], st)
+        e1.record()
+        torch.cuda.synchronize()
+        src = sum(p.numel() * 4 for p, _, _ in lst)
+        dstb = sum(d.numel() * d.element_size() for _, d, _ in lst)
+        ms = e0.elapsed_time(e1) / 2
+        print(f"{names[kind]:10s} {str(dt):15s} {len(lst):4d} tensors {len(ct):7d} chunks  src {src / 1e6:7.1f} MB  dst {dstb / 1e6:7.1f} MB  {ms * 1e3:7.1f} us  "
+              f"{(src + dstb) / ms / 1e9:6.2f} TB/s")
+
+
+if __name__ == "__main__":
+    main()
