@@ -283,11 +283,52 @@ def _zero_bias_grad(bias):
     return pool["buf"][off:off + n].view(bias.shape)
 
 
+_PASS_ARENA = {}
+_PASS_ARENA_ON = os.environ.get("DOSE_HIP_PASS_ARENA", "1") != "0"      # (A/B switch)
+
+
+def _pass_zeros(shape, dev):
+    """A zero-filled fp32 tensor for an accumulator of the backward pass (LayerNorm's dgamma / dbeta, split-K weight gradients):
+    a slice of ONE arena per device and backward pass, filled by one launch at its first use (the pass used to issue ~30 five-microsecond
+    fill launches, each waiting its turn behind full-chip kernels on the critical stream: VERDICT r3 item 8).  The arena is a FRESH
+    tensor every pass -- gradients handed to autograd as views of it keep it alive, so accumulation over several backward passes is
+    safe -- sized by what the previous pass asked for; requests beyond it get their own torch.zeros.  Only call from backward functions."""
+    n = 1
+    for d in shape:
+        n *= int(d)
+    if dev.type != "cuda" or n == 0 or not _PASS_ARENA_ON:
+        return torch.zeros(shape, dtype=torch.float32, device=dev)
+    a = _PASS_ARENA.get(dev)
+    if a is None:
+        a = _PASS_ARENA[dev] = {"buf": None, "used": 0, "need": 0, "now": 0, "armed": False, "ev": None, "stream": None}
+    if not a["armed"]:
+        a["buf"] = torch.zeros((max(a["need"], 1 << 16),), dtype=torch.float32, device=dev)
+        a["used"], a["now"], a["armed"] = 0, 0, True
+        a["stream"] = torch.cuda.current_stream(dev)
+        a["ev"] = torch.cuda.Event()
+        a["ev"].record(a["stream"])
+
+        def _end(a=a):
+            a["armed"], a["need"], a["buf"] = False, max(a["need"], a["now"]), None
+        torch.autograd.Variable._execution_engine.queue_callback(_end)
+    step = (n + 63) // 64 * 64
+    a["now"] += step
+    if a["used"] + step > a["buf"].numel():
+        return torch.zeros(shape, dtype=torch.float32, device=dev)
+    t = a["buf"][a["used"]:a["used"] + n].view(shape)
+    a["used"] += step
+    cur = torch.cuda.current_stream(dev)
+    if cur != a["stream"]:
+        cur.wait_event(a["ev"])           # (the fill ran on the stream of the pass's first request)
+        a["buf"].record_stream(cur)
+    return t
+
+
 def _wgrad_buffer(weight, zero):
     f = GRAD_DEST.get(weight.data_ptr()) if GRAD_DEST else None
     buf = f() if f is not None else None
     if buf is None:
-        return (torch.zeros if zero else torch.empty)(weight.shape, dtype=torch.float32, device=weight.device)
+        return _pass_zeros(weight.shape, weight.device) if zero else torch.empty(weight.shape, dtype=torch.float32, device=weight.device)
     return buf.zero_() if zero else buf
 
 
@@ -888,7 +929,7 @@ class ConvTranspose2x(torch.autograd.Function):
                 # split so that the small output grid still fills the chip)
                 tiles = -(-8 * cout // 64) * -(-cin // 64)
                 sk = max(1, min(rows // 512, 512 // tiles))
-                tmp = (torch.zeros if sk > 1 else torch.empty)((8 * cout, cin), dtype=torch.float32, device=x.device)
+                tmp = _pass_zeros((8 * cout, cin), x.device) if sk > 1 else torch.empty((8 * cout, cin), dtype=torch.float32, device=x.device)
                 _lib.call("dp_gemm_tn", _p(gu), 8 * cout, _p(x), ldx, _p(tmp), cin, 8 * cout, cin, rows, sk, dtc, _stream())
                 gw = tmp.view(8, cout, cin).permute(2, 1, 0).contiguous().view(weight.shape)
             else:
@@ -1613,9 +1654,10 @@ def _norm_backward(x, mean, rstd, gamma, beta, res, kind, act, use_stats, ssn, g
     groups = N if kind == "instance" else 1
     s1 = torch.empty((groups, C), dtype=torch.float32, device=dev)
     s2 = torch.empty((groups, C), dtype=torch.float32, device=dev)
-    mk = torch.zeros if kind == "instance" else torch.empty          # instance mode accumulates over samples, batch mode overwrites
-    dgamma = mk((C,), dtype=torch.float32, device=dev) if need_gb else None
-    dbeta = mk((C,), dtype=torch.float32, device=dev) if need_gb else None
+    # (instance mode accumulates over samples, batch mode overwrites)
+    mk = (lambda shp: _pass_zeros(shp, dev)) if kind == "instance" else (lambda shp: torch.empty(shp, dtype=torch.float32, device=dev))
+    dgamma = mk((C,)) if need_gb else None
+    dbeta = mk((C,)) if need_gb else None
     if use_stats or need_gb:
         _lib.call("dp_norm_act_bwd_partial", _p(x), ldx, gy_ptr, ldg, _p(mean), _p(rstd), ssn, _p(g32), _p(b32), _p(res), ldr,
                   _act_code(act, x.dtype), N, V, C, _p(part), dtc, _stream())
@@ -1792,7 +1834,7 @@ class LayerNorm(torch.autograd.Function):
         C = x.shape[-1]
         rows = x.numel() // C
         gx = torch.empty_like(x)
-        dgb = torch.zeros((2, C), dtype=torch.float32, device=x.device)      # one fill for both (accumulated by atomics)
+        dgb = _pass_zeros((2, C), x.device)      # (accumulated by atomics)
         dg, db = dgb[0], dgb[1]
         _lib.call("dp_layernorm_bwd", _p(x), _p(gy), _p(gamma.detach()), _p(mean), _p(rstd), _p(gx), _p(dg), _p(db), rows, C,
                   _dt(x), _stream())
@@ -1831,7 +1873,7 @@ class AddLayerNorm(torch.autograd.Function):
         gz = gz.contiguous()
         gs = None if gs is None else gs.contiguous()
         gx = torch.empty_like(s)
-        dgb = torch.zeros((2, C), dtype=torch.float32, device=s.device)
+        dgb = _pass_zeros((2, C), s.device)
         if C <= 1024:
             _lib.call("dp_add_layernorm_bwd", _p(s), _p(gz), _p(gs), _p(gamma.detach()), _p(mean), _p(rstd), _p(gx), _p(dgb[0]), _p(dgb[1]),
                       rows, C, _dt(s), _stream())
