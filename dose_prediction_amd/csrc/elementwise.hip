@@ -1,5 +1,6 @@
 // Data-movement and elementwise kernels (HBM-bound; 16-byte vector accesses wherever rows allow).
 #include "common.h"
+#include <stdlib.h>
 #include <stdarg.h>
 #include <string.h>
 
@@ -377,6 +378,58 @@ __device__ __forceinline__ void trilinear_fwd_body(const T* __restrict__ x, int 
     frag_store<T>(y + (int64_t)ov * ldy + cg * 8, f, nv);
   }
 }
+// The same through LDS (round 4; 16-bit storage, C a multiple of 8 and <= 64: the 128^3 and 64^3 outputs of the C3D decoder).  One thread
+// per (output voxel, 8 channels) gathers its eight corners from global memory: 8 x the output bytes through the CU's load path (2.1 GB
+// for the 268 MB of the 32-channel 128^3 tensor: 156 us).  Here a block owns 2 x 8 x 32 output voxels, stages the <= 3 x 6 x 18 input
+// voxels they read once (16-byte pieces, coalesced rows) and takes the corners from LDS; the arithmetic (weights, order of the eight
+// FMAs) is trilinear_fwd_body's, so the results are bit-identical.
+template <typename T>
+__global__ void __launch_bounds__(256) k_trilinear_fwd_lds(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, int N, int D, int H, int W, int C) {
+  constexpr int TD = 2, TH = 8, TW = 32, ED = 3, EH = 6, EW = 18;
+  extern __shared__ __attribute__((aligned(16))) unsigned char tri_smem[];
+  T* img = (T*)tri_smem;                                    // [ED][EH][EW][C]
+  const int tid = threadIdx.x, cg8 = C >> 3;
+  const int tiles_w = (2 * W + TW - 1) / TW, tiles_h = (2 * H + TH - 1) / TH;
+  int b = blockIdx.x;
+  const int tw = b % tiles_w; b /= tiles_w; const int th = b % tiles_h; b /= tiles_h; const int odp = b % D, n = b / D;
+  const int od0 = odp * TD, oh0 = th * TH, ow0 = tw * TW;
+  const int od1 = min(od0 + TD, 2 * D) - 1, oh1 = min(oh0 + TH, 2 * H) - 1, ow1 = min(ow0 + TW, 2 * W) - 1;
+  int d_lo, h_lo, w_lo, t0, t1; float tf;
+  tri_coord(od0, D, d_lo, t1, tf); tri_coord(oh0, H, h_lo, t1, tf); tri_coord(ow0, W, w_lo, t1, tf);
+  int d_hi, h_hi, w_hi;
+  tri_coord(od1, D, t0, d_hi, tf); tri_coord(oh1, H, t0, h_hi, tf); tri_coord(ow1, W, t0, w_hi, tf);
+  const int ed = d_hi - d_lo + 1, eh = h_hi - h_lo + 1, ew = w_hi - w_lo + 1;      // <= ED, EH, EW
+  // stage: pieces (di, hi, wi, cg), cg fastest: a row of ew voxels is ew * C contiguous elements when ldx == C
+  const int pieces = ed * eh * ew * cg8;
+  for (int p = tid; p < pieces; p += 256) {
+    const int cg = p % cg8; int t = p / cg8;
+    const int wi = t % ew; t /= ew; const int hi = t % eh, di = t / eh;
+    const v4u v = *(const v4u*)(x + ((((int64_t)n * D + d_lo + di) * H + h_lo + hi) * W + w_lo + wi) * ldx + cg * 8);
+    *(v4u*)(img + (((di * EH + hi) * EW + wi) * cg8 + cg) * 8) = v;
+  }
+  __syncthreads();
+  const int items = TD * TH * TW * cg8;
+  for (int it = tid; it < items; it += 256) {
+    const int cg = it % cg8; int t = it / cg8;
+    const int owl = t % TW; t /= TW; const int ohl = t % TH, odl = t / TH;
+    const int od = od0 + odl, oh = oh0 + ohl, ow = ow0 + owl;
+    if (od > od1 || oh > oh1 || ow > ow1) continue;
+    int d0, d1, h0, h1, w0, w1; float fd, fh, fw;
+    tri_coord(od, D, d0, d1, fd); tri_coord(oh, H, h0, h1, fh); tri_coord(ow, W, w0, w1, fw);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int dd = ((k & 4) ? d1 : d0) - d_lo, hh = ((k & 2) ? h1 : h0) - h_lo, ww = ((k & 1) ? w1 : w0) - w_lo;
+      Frag8<T> in; in.u = *(const v4u*)(img + (((dd * EH + hh) * EW + ww) * cg8 + cg) * 8);
+      const float wgt = ((k & 4) ? fd : 1.f - fd) * ((k & 2) ? fh : 1.f - fh) * ((k & 1) ? fw : 1.f - fw);
+      float tt[8];
+      frag_unpack(in, tt);
+      for (int j = 0; j < 8; j++) acc[j] += wgt * tt[j];
+    }
+    Frag8<T> f; frag_pack(f, acc);
+    *(v4u*)(y + ((((int64_t)n * 2 * D + od) * 2 * H + oh) * 2 * W + ow) * ldy + cg * 8) = f.u;
+  }
+}
 template <typename T>
 __global__ void k_trilinear_fwd(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, int N, int D, int H, int W, int C) {
   const int cg8 = (C + 7) >> 3;
@@ -402,6 +455,17 @@ __global__ void k_trilinear_bwd(const T* __restrict__ gy, int ldgy, float* __res
   }
 }
 extern "C" int dp_trilinear_up2_fwd(const void* x, int ldx, void* y, int ldy, int N, int D, int H, int W, int C, int dtype, void* stream) {
+  static const int lds_on = [] { const char* e = getenv("DP_TRILINEAR_LDS"); return e ? atoi(e) : 1; }();
+  if (lds_on && (dtype == DP_BF16 || dtype == DP_F16) && C % 8 == 0 && C <= 64 && ldx % 8 == 0 && ldy % 8 == 0 && W >= 16 && H >= 4 &&
+      (((uintptr_t)x | (uintptr_t)y) & 15) == 0) {
+    const int64_t blocks = (int64_t)N * D * ((2 * H + 7) / 8) * ((2 * W + 31) / 32);
+    if (blocks < 2000000000LL) {
+      const size_t smem = (size_t)3 * 6 * 18 * C * 2;
+      if (dtype == DP_BF16) hipLaunchKernelGGL(k_trilinear_fwd_lds<bf16_t>, dim3((unsigned)blocks), dim3(256), smem, STREAM, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, N, D, H, W, C);
+      else hipLaunchKernelGGL(k_trilinear_fwd_lds<f16_t>, dim3((unsigned)blocks), dim3(256), smem, STREAM, (const f16_t*)x, ldx, (f16_t*)y, ldy, N, D, H, W, C);
+      DP_CHECK_LAUNCH("trilinear_fwd_lds"); return 0;
+    }
+  }
   int64_t total = (int64_t)N * 8 * D * H * W * ((C + 7) / 8);
   DP_DISPATCH(dtype, hipLaunchKernelGGL(k_trilinear_fwd<T>, dim3(grid_for(total, 256)), dim3(256), 0, STREAM, (const T*)x, ldx, (T*)y, ldy, N, D, H, W, C));
   DP_CHECK_LAUNCH("trilinear_fwd"); return 0;

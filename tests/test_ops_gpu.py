@@ -8,6 +8,8 @@ fp16 mode: the same protocol with fp16 rounding (2^-12): tolerance 1e-3 rel-L2.
 import copy
 import math
 
+import os
+
 import pytest
 import torch
 
@@ -475,6 +477,32 @@ def test_trilinear_cat_layout(dtype):
     check("y", yh, yr, dtype)
     check("gx", xh.grad, xr.grad, dtype)
     check("gs", sh.grad, sr.grad, dtype)
+
+
+@pytest.mark.parametrize("cfg", [(2, 32, 5, 9, 20), (1, 64, 3, 4, 16), (1, 8, 2, 33, 70), (1, 16, 7, 16, 32)])
+def test_trilinear_lds_path_matches_the_gather_kernel_bit_for_bit(cfg, monkeypatch):
+    """dp_trilinear_up2_fwd through LDS (16-bit storage, C <= 64: the C3D decoder's UpConv at the 128^3 / 64^3 levels, c3d.py:36) against
+    the oracle, and bit-identical to the one-thread-per-piece gather kernel it replaces (same weights, same FMA order)."""
+    import subprocess
+    import sys
+    from dose_prediction_amd import ops
+    dev = _dev()
+    N, C, D, H, W = cfg
+    for dtype in (torch.bfloat16, torch.float16):
+        x = q(rnd((N, C, D, H, W), 11), dtype)
+        yr = oracle.trilinear_up2(x.double())
+        xh = ndhwc(x).to(dev, dtype)
+        y = ops.trilinear_up2(xh)
+        check("y", ncdhw(y), yr, dtype)
+        # the gather kernel (DP_TRILINEAR_LDS=0 is read once per process: run it in a child)
+        code = ("import os, sys, torch; sys.path.insert(0, %r); os.environ['DP_TRILINEAR_LDS'] = '0'; from dose_prediction_amd import ops; "
+                "x = torch.load(sys.argv[1]).cuda(); torch.save(ops.trilinear_up2(x).cpu(), sys.argv[2])") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        import tempfile
+        with tempfile.TemporaryDirectory() as td:
+            torch.save(xh.cpu(), os.path.join(td, "x.pt"))
+            subprocess.check_call([sys.executable, "-c", code, os.path.join(td, "x.pt"), os.path.join(td, "y.pt")])
+            y0 = torch.load(os.path.join(td, "y.pt"))
+        assert torch.equal(y.cpu().view(torch.int16), y0.view(torch.int16)), (cfg, dtype)
 
 
 def test_argmax_onehot():
