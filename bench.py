@@ -671,6 +671,15 @@ def main():
                 fp32_leg["wgrad_three_products"] = w3
             finally:
                 dose_prediction_amd.config.set_x3_wgrad_terms(1)
+            # "exact forward, bf16-grade backward": one-product data gradients (config.set_x3_dgrad_terms(1), opt-in): the forward pass,
+            # hence every output / loss / metric, is the fp32x3 mode's; what the gradients lose is measured in DESIGN section 3
+            dose_prediction_amd.config.set_x3_dgrad_terms(1)
+            try:
+                d1 = time_mode("fp32x3", max(args.fp32_steps, 5))
+                d1["dtype"] = "fp32x3 forward (three products), data gradients from gy_hi w_hi alone (DP_X1 launches), weight gradients x_hi gy_hi"
+                fp32_leg["dgrad_one_product"] = d1
+            finally:
+                dose_prediction_amd.config.set_x3_dgrad_terms(3)
             if args.exact_fp32_leg:
                 ex = time_mode("fp32", args.fp32_steps)
                 ex["dtype"] = "fp32 storage, v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain)"

@@ -165,6 +165,7 @@ def _env_terms(name, default):
 
 _x3_wgrad_terms = _env_terms("DOSE_HIP_X3_WGRAD_TERMS", 1)
 _x3_linear_wgrad_terms = _env_terms("DOSE_HIP_X3_LINEAR_WGRAD_TERMS", 3)
+_x3_dgrad_terms = _env_terms("DOSE_HIP_X3_DGRAD_TERMS", 3)
 
 
 def set_x3_wgrad_terms(n):
@@ -185,6 +186,23 @@ def set_x3_wgrad_terms(n):
 
 def x3_wgrad_terms():
     return _x3_wgrad_terms
+
+
+def set_x3_dgrad_terms(n):
+    """fp32x3 mode: number of split products in the DATA gradients of the convolutions and Linear layers.  3 (default): like the forward
+    pass.  1: gy_hi w_hi only (a DP_X1 launch: the bf16 kernels on the hi halves, fp32 result) -- "exact forward, bf16-grade backward":
+    outputs, losses and validation metrics keep the mode's 1e-4 parity with the reference's fp32 path, the gradients that reach the
+    parameters carry the operand rounding of the bf16 mode (which accumulates along the backward chain, unlike the weight gradients'
+    own rounding: set_x3_wgrad_terms).  Opt-in because the trajectory of a training run is then the bf16 mode's, not the reference's;
+    the step is ~8 ms shorter (bench.py: fp32_mode.dgrad_one_product; measured gradient error: tools/x3_grad_probe.py)."""
+    global _x3_dgrad_terms
+    if n not in (1, 3):
+        raise ValueError("x3 data-gradient terms must be 1 or 3")
+    _x3_dgrad_terms = n
+
+
+def x3_dgrad_terms():
+    return _x3_dgrad_terms
 
 
 def set_x3_linear_wgrad_terms(n):

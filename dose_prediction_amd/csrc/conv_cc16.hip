@@ -411,7 +411,7 @@ static int cc16_go_impl(const void* x, const void* wq, const float* bias, void* 
 }
 
 bool cc16_wide(const void* y, int ldy, const void* y2, int ldy2, int osplit, int dtype) {
-  const int es = (dtype == DP_F32 || dtype == DP_X3) ? 4 : 2, epc = 16 / es;      // element size of the OUTPUT
+  const int es = (dtype == DP_F32 || dtype == DP_X3 || dtype == DP_X1) ? 4 : 2, epc = 16 / es;      // element size of the OUTPUT
   return (ldy * es) % 16 == 0 && (((uintptr_t)y & 15) == 0) && (!y2 || ((ldy2 * es) % 16 == 0 && (((uintptr_t)y2 & 15) == 0) && osplit % epc == 0));
 }
 int cc16_launch(const void* x, int ldx, const void* x2, int ldx2, int csplit, const void* wq, const float* bias, void* y, int ldy,
@@ -432,7 +432,7 @@ int cc16_launch(const void* x, int ldx, const void* x2, int ldx2, int csplit, co
   if (dtype == DP_BF16) rc = k == 7 ? cc16_go<bf16_t, 7>(x, wq, bias, y, g, s) : cc16_go<bf16_t, 3>(x, wq, bias, y, g, s);
   else if (dtype == DP_F16) rc = k == 7 ? cc16_go<f16_t, 7>(x, wq, bias, y, g, s) : cc16_go<f16_t, 3>(x, wq, bias, y, g, s);
   else if (dtype == DP_F32) rc = k == 7 ? cc16_go<float, 7>(x, wq, bias, y, g, s) : cc16_go<float, 3>(x, wq, bias, y, g, s);
-  else if (dtype == DP_X3) rc = k == 7 ? cc16_go<bf16_t, 7, float>(x, wq, bias, y, g, s) : cc16_go<bf16_t, 3, float>(x, wq, bias, y, g, s);
+  else if (dtype == DP_X3 || dtype == DP_X1) rc = k == 7 ? cc16_go<bf16_t, 7, float>(x, wq, bias, y, g, s) : cc16_go<bf16_t, 3, float>(x, wq, bias, y, g, s);
   else { dp_set_error("conv_cc16: bad dtype"); return 1; }
   if (rc) return rc;
   DP_CHECK_LAUNCH("conv_cc16"); return 0;

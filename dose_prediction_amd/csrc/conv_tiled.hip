@@ -597,7 +597,7 @@ extern "C" int dp_conv3d_tiled_ws_elems(int N, int D, int H, int W, int Cin, int
 }
 
 static bool tiled_wide(const TiledGeom& g, const void* y, int dtype) {
-  const int es = (dtype == DP_F32 || dtype == DP_X3) ? 4 : 2, epc = 16 / es;      // element size of the OUTPUT
+  const int es = (dtype == DP_F32 || dtype == DP_X3 || dtype == DP_X1) ? 4 : 2, epc = 16 / es;      // element size of the OUTPUT
   return !g.splitkd && (g.ldy * es) % 16 == 0 && (((uintptr_t)y & 15) == 0) &&
          (!g.y2 || ((g.ldy2 * es) % 16 == 0 && (((uintptr_t)g.y2 & 15) == 0) && g.osplit % epc == 0));
 }
@@ -680,7 +680,7 @@ static int conv3d_tiled_impl(const void* x, int ldx, const void* x2, int ldx2, i
 #define BYCFG(TT, KS_) do { if (np == 2) BYTW(TT, KS_, 2, 9, 1); else if (!w16 && wn == 2) GOW32(TT, KS_); \
                             else if (nt == 1) { if (w16) GO(TT, KS_, 1, 8, 1, 0); else BYTW(TT, KS_, 1, 8, 1); } \
                             else { if (w16 && wn == 2) GOW2(TT, KS_); else if (w16) GO(TT, KS_, 1, 4, 2, 0); else BYTW(TT, KS_, 1, 4, 2); } } while (0)
-  const bool x3 = dtype == DP_X3;
+  const bool x3 = dtype == DP_X3 || dtype == DP_X1;          // (float output; g.x3 says whether the operands are split)
   if (dtype == DP_BF16 || x3) { if (k == 7) BYCFG(bf16_t, 7); else BYCFG(bf16_t, 3); }
   else if (dtype == DP_F16) { if (k == 7) BYCFG(f16_t, 7); else BYCFG(f16_t, 3); }
   else if (dtype == DP_F32) { if (k == 7) BYCFG(float, 7); else BYCFG(float, 3); }

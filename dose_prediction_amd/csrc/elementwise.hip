@@ -633,9 +633,106 @@ __global__ void __launch_bounds__(256) k_pointwise_rows(const T* __restrict__ x,
     }
   }
 }
+// The same row stream on the matrix cores (round 4; north_star: "MFMA ... for the 1x1x1 pointwise convs where they really are dense
+// GEMMs"): with 32-64 input and 16-32 output channels the VALU version spends 512-2048 FMAs per voxel (the 64 -> 32 mixer of the 64^3
+// level: 88 us for 100 MB) -- one v_mfma_f32_16x16x32 does 16 output channels x 16 voxels x 32 inputs.  No LDS at all: the weights are
+// the A operand (rows = output channels, held in registers for the whole launch), a tile of 16 voxels is the B operand and the fragment
+// of a lane IS one 16-byte global load (voxel lane % 16, channels 8 (lane / 16) .. + 7 of a 32-channel chunk).  The C layout then gives
+// a lane four consecutive output rows of ONE voxel; with 32 outputs the weight rows are dealt to the two MFMA tiles so that those rows
+// are channels 8q .. 8q+3 (tile 0) and 8q+4 .. 8q+7 (tile 1) -- the lane's eight results are one 16-byte store.  U tiles per trip are
+// requested before the first MFMA.
+template <typename T> __device__ __forceinline__ unsigned pw_pack2(float a, float b) {
+  T lo, hi; st_f(&lo, a); st_f(&hi, b);
+  return (unsigned)__builtin_bit_cast(unsigned short, lo) | ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16);
+}
+template <typename T, int KC, int NT>
+__global__ void __launch_bounds__(256) k_pointwise_mfma(const T* __restrict__ x, int ldx, const T* __restrict__ w, int ldw, const float* __restrict__ bias,
+                                                        T* __restrict__ y, int ldy, int64_t rows, int Cin, int Cout) {
+  constexpr int U = 4;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 15, q = lane >> 4;
+  Frag8<T> aw[NT][KC];
+  unsigned keep[KC][4];                                       // dword masks of the channels < Cin (input padding may hold anything)
+#pragma unroll
+  for (int kc = 0; kc < KC; kc++) {
+    const int k0 = kc * 32 + q * 8;
+#pragma unroll
+    for (int d = 0; d < 4; d++) keep[kc][d] = (k0 + 2 * d + 1 < Cin) ? 0xffffffffu : (k0 + 2 * d < Cin) ? 0x0000ffffu : 0u;
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+      const int co = NT == 2 ? 8 * (r >> 2) + 4 * nt + (r & 3) : r;
+      aw[nt][kc] = (co < Cout && k0 < Cin) ? frag_load(w + (int64_t)co * ldw + k0, min(8, Cin - k0)) : frag_zero<T>();
+    }
+  }
+  const int c0 = NT == 2 ? 8 * q : 4 * q;                     // the lane's first output channel
+  float bv[NT][4];
+#pragma unroll
+  for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+    for (int e = 0; e < 4; e++) bv[nt][e] = (bias && c0 + 4 * nt + e < Cout) ? bias[c0 + 4 * nt + e] : 0.f;
+  const bool ragged = (Cin & 31) != 0;
+  const int64_t ntiles = (rows + 15) / 16, wave = (int64_t)blockIdx.x * 4 + wv, nwaves = (int64_t)gridDim.x * 4;
+  for (int64_t t0 = wave * U; t0 < ntiles; t0 += nwaves * U) {
+    Frag8<T> b[U][KC];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      int64_t v = (t0 + u) * 16 + r; v = v < rows ? v : rows - 1;      // (tail rows re-read the last voxel: never stored)
+#pragma unroll
+      for (int kc = 0; kc < KC; kc++) b[u][kc].u = *(const v4u*)(x + v * ldx + (keep[kc][0] ? kc * 32 + q * 8 : 0));   // (chunks beyond Cin: any valid address, masked below)
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int64_t v = (t0 + u) * 16 + r;
+      if (ragged)
+#pragma unroll
+        for (int d = 0; d < 4; d++) b[u][KC - 1].u[d] &= keep[KC - 1][d];
+      v4f acc[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++) {
+        acc[nt] = (v4f){bv[nt][0], bv[nt][1], bv[nt][2], bv[nt][3]};
+#pragma unroll
+        for (int kc = 0; kc < KC; kc++) acc[nt] = mma16(aw[nt][kc], b[u][kc], acc[nt]);
+      }
+      if (v >= rows) continue;
+      T* yo = y + v * ldy + c0;
+      if (c0 + 4 * NT <= Cout) {
+        if constexpr (NT == 2) {
+          v4u o; o.x = pw_pack2<T>(acc[0][0], acc[0][1]); o.y = pw_pack2<T>(acc[0][2], acc[0][3]); o.z = pw_pack2<T>(acc[1][0], acc[1][1]); o.w = pw_pack2<T>(acc[1][2], acc[1][3]);
+          *(v4u*)yo = o;
+        } else {
+          uint2 o; o.x = pw_pack2<T>(acc[0][0], acc[0][1]); o.y = pw_pack2<T>(acc[0][2], acc[0][3]);
+          *(uint2*)yo = o;
+        }
+      } else {
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+          for (int e = 0; e < 4; e++) if (c0 + 4 * nt + e < Cout) st_f(yo + 4 * nt + e, acc[nt][e]);
+      }
+    }
+  }
+}
+
 extern "C" int dp_pointwise_rows(const void* x, int ldx, const void* w, int ldw, const float* bias, void* y, int ldy, int64_t rows, int Cin, int Cout,
                                  int dtype, void* stream) {
   if (Cin > 64 || Cout > 32 || Cin < 1 || Cout < 1) DP_FAIL("pointwise_rows: needs Cin <= 64 and Cout <= 32");
+  {
+    // matrix-core path: 16-bit storage, >= 16 input channels (below that the VALU stream is already at the HBM rate), rows readable in
+    // 16-byte pieces up to Cin rounded up to 8 (what lies beyond Cin is masked in registers)
+    static const int mfma_on = [] { const char* e = getenv("DP_POINTWISE_MFMA"); return e ? atoi(e) : 1; }();
+    const int kp = (Cin + 31) / 32 * 32;
+    if (mfma_on && (dtype == DP_BF16 || dtype == DP_F16) && Cin >= 16 && Cout > 8 && (Cin + 7) / 8 * 8 <= ldx && ldx % 8 == 0 && ldy % 8 == 0 && ldw >= Cin &&
+        (((uintptr_t)x | (uintptr_t)y) & 15) == 0 && rows >= 16) {
+      const int kc = kp / 32, nt = Cout > 16 ? 2 : 1;
+      const int64_t tiles = (rows + 15) / 16;
+      int g = (int)((tiles + 15) / 16 < 2048 ? (tiles + 15) / 16 : 2048);
+#define GOM(TT, KC_, NT_) hipLaunchKernelGGL((k_pointwise_mfma<TT, KC_, NT_>), dim3(g), dim3(256), 0, STREAM, (const TT*)x, ldx, (const TT*)w, ldw, bias, (TT*)y, ldy, rows, Cin, Cout)
+#define GOMT(TT) do { if (kc == 1 && nt == 1) GOM(TT, 1, 1); else if (kc == 1) GOM(TT, 1, 2); else if (nt == 1) GOM(TT, 2, 1); else GOM(TT, 2, 2); } while (0)
+      if (dtype == DP_BF16) GOMT(bf16_t); else GOMT(f16_t);
+#undef GOMT
+#undef GOM
+      DP_CHECK_LAUNCH("pointwise_mfma"); return 0;
+    }
+  }
   int g = grid_for(rows, 256, 256 * 32);
 #define GO(CO) DP_DISPATCH(dtype, hipLaunchKernelGGL((k_pointwise_rows<T, CO>), dim3(g), dim3(256), 0, STREAM, (const T*)x, ldx, (const T*)w, ldw, bias, (T*)y, ldy, rows, Cin, Cout))
   if (Cout <= 8) GO(8); else if (Cout <= 16) GO(16); else GO(32);

@@ -410,13 +410,16 @@ def _cast_vec(v, dtype):
 
 
 # ------------------------------------------------------------------------------------------------ raw helpers
+_PW_MAXK = int(os.environ.get("DOSE_HIP_PW_MAXK", "64"))
+
+
 def gemm_nt(A, B, out, bias=None, alpha=1.0, M=None, N=None, K=None, batch=(1, 1), sa=(0, 0), sb=(0, 0), sc=(0, 0),
             lda=None, ldb=None, ldc=None, splitk=1):
     """out[m][n] = alpha * sum_k A[m][k] B[n][k] (+bias).  A, B share dtype; out dtype float32 => fp32 output."""
     out_f32 = 1 if (out.dtype == torch.float32 and A.dtype != torch.float32) or splitk > 1 else 0
     if splitk > 1 and out.dtype != torch.float32:
         raise ValueError("split-K needs an fp32 output")
-    if (batch == (1, 1) and splitk == 1 and not out_f32 and alpha == 1.0 and M >= 32768 and K <= 64 and N <= 32
+    if (batch == (1, 1) and splitk == 1 and not out_f32 and alpha == 1.0 and M >= 32768 and K <= _PW_MAXK and N <= 32
             and out.dtype == A.dtype):
         # millions of voxel rows x a handful of channels: HBM-bound row stream, not a GEMM
         _lib.call("dp_pointwise_rows", _p(A), lda, _p(B), ldb, _p(bias), _p(out), ldc, M, K, N, _dt(A), _stream())
@@ -947,6 +950,7 @@ def conv_transpose2x(x, weight):
 
 # ------------------------------------------------------------------------------------------------ fp32x3 mode (csrc/x3.hip)
 DP_X3 = 3
+DP_X1 = 4
 _PAT_ACT, _PAT_W = 0b010, 0b100      # operand blocks [hi | lo | hi] against [hi | hi | lo]: hi*hi + lo*hi + hi*lo
 
 
@@ -1152,16 +1156,24 @@ class Conv3dX3(torch.autograd.Function):
         gxa = gxb = gw = gb = None
         tok = _wg_fork(weight, need_w)
         if need_x:
-            if L.dp_conv3d_tiled_weight_elems(3 * cpo, cin, k, 1, pad, 1, W):
-                wq = _pack_conv_tiled_x3(weight, 1, cpo, W)
-                ws = _tiled_ws(gy, N, D, H, W, 3 * cpo, cin, k)
+            from . import config as _cfg
+            one = _cfg.x3_dgrad_terms() == 1 and _tiled_elems(cout, cin, k, 1, pad, 1, W) > 0
+            if one or L.dp_conv3d_tiled_weight_elems(3 * cpo, cin, k, 1, pad, 1, W):
+                if one:
+                    # config.set_x3_dgrad_terms(1): gy_hi against the ordinary bf16 data-gradient pack, fp32 result (a DP_X1 launch)
+                    wq = _pack_conv_tiled(weight, 1, torch.bfloat16, _tiled_elems(cout, cin, k, 1, pad, 1, W), W)
+                    kc, kdt = cout, DP_X1
+                else:
+                    wq = _pack_conv_tiled_x3(weight, 1, cpo, W)
+                    kc, kdt = 3 * cpo, DP_X3
+                ws = _tiled_ws(gy, N, D, H, W, kc, cin, k)
                 if cxb is None or ca % 8:
                     cx1 = cxa if cxb is None else cin            # (a concat split that is not a multiple of 8: one tensor, sliced below)
                     gx = torch.empty((N, D, H, W, cx1), dtype=torch.float32, device=dev)
                     if cx1 > cin:
                         gx.zero_()
                     _lib.call("dp_conv3d_tiled2", _p(gys), 2 * cpo, 0, 0, 0, _p(wq), 0, _p(gx), cx1, 0, 0, 0, _p(ws),
-                              N, D, H, W, 3 * cpo, cin, k, DP_X3, _stream())
+                              N, D, H, W, kc, cin, k, kdt, _stream())
                     if cxb is None:
                         gxa = gx
                     else:
@@ -1173,7 +1185,7 @@ class Conv3dX3(torch.autograd.Function):
                     if cxb > cin - ca:
                         gxb.zero_()
                     _lib.call("dp_conv3d_tiled2", _p(gys), 2 * cpo, 0, 0, 0, _p(wq), 0, _p(gxa), ca, _p(gxb), cxb, ca, _p(ws),
-                              N, D, H, W, 3 * cpo, cin, k, DP_X3, _stream())
+                              N, D, H, W, kc, cin, k, kdt, _stream())
             else:
                 # fewer than 8 input channels (no tiled kernel computes so narrow an output): the exact-fp32 gather kernel
                 wt = _pack_conv(weight, 2, torch.float32)
@@ -1293,7 +1305,9 @@ class LinearX3(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             wt = _pack_mat_x3(weight, True, cpo, _PAT_ACT)             # [in][w_hi | w_lo | w_hi]
             gx = torch.empty(xshape, dtype=torch.float32, device=dev)
-            gemm_nt(gys, wt, gx, M=rows, N=K, K=3 * cpo, lda=3 * cpo, ldb=3 * cpo, ldc=K)
+            from . import config as _cfg
+            # (config.set_x3_dgrad_terms(1): block 0 of both operands alone, gy_hi w_hi)
+            gemm_nt(gys, wt, gx, M=rows, N=K, K=cpo if _cfg.x3_dgrad_terms() == 1 else 3 * cpo, lda=3 * cpo, ldb=3 * cpo, ldc=K)
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             gw = _wgrad_buffer(weight, False)

@@ -24,6 +24,10 @@
  *     accumulators written as fp32 OUTPUT.  x / wq are bf16, y / y2 are float.  In a DP_X3 launch `Cin` = 3 cp (cp a multiple of
  *     16) is the contraction axis of the packed weights, `x` is the [x_hi | x_lo] tensor of 2 cp channels (x2 must be NULL): the
  *     kernels stage every x_hi chunk once and sweep it against both of its weight blocks.
+ *     DP_X1 (4), accepted by dp_conv3d_tiled / dp_conv3d_tiled2 only: bf16 operands, fp32 OUTPUT, ONE product -- the data gradient
+ *     of an fp32x3 convolution from gy_hi and w_hi alone (config.set_x3_dgrad_terms(1): the forward pass keeps its three products,
+ *     the backward pass has the accuracy of the bf16 mode).  x is typically the hi half of a [hi | lo] tensor (ldx = 2 cp), Cin the
+ *     real channel count, wq the ordinary bf16 pack.
  *   - every function returns 0 on success, non-zero on error; dp_last_error() gives the message.
  *   - no function allocates, frees or synchronises: workspaces are caller-provided.
  */
@@ -34,7 +38,7 @@
 extern "C" {
 #endif
 
-enum { DP_F32 = 0, DP_BF16 = 1, DP_F16 = 2, DP_X3 = 3 };
+enum { DP_F32 = 0, DP_BF16 = 1, DP_F16 = 2, DP_X3 = 3, DP_X1 = 4 };
 /* DP_ACT_MISH_FAST (fp32 storage only, used by the fp32x3 mode): Mish through the hardware exp2 / rcp approximations (~1e-7
  * relative, far below that mode's 4e-6 operator error) instead of the correctly rounded expf / divisions of DP_ACT_MISH. */
 enum { DP_ACT_NONE = 0, DP_ACT_RELU = 1, DP_ACT_LRELU = 2, DP_ACT_MISH = 3, DP_ACT_GELU = 4, DP_ACT_MISH_FAST = 5 };

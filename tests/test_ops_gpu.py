@@ -94,6 +94,14 @@ DTYPES = [torch.float32, torch.bfloat16, torch.float16]
     (1, 64, 2, 16, 32, 64, 1, 1, 0, 1, False),
     (1, 32, 16, 32, 32, 40, 1, 1, 0, 1, True),    # conv_3_1 mixer (tiled k = 1 weight gradient)
     (1, 25, 16, 32, 32, 40, 1, 1, 0, 1, True),
+    # the matrix-core row stream (k_pointwise_mfma: > 16 input channels, 16-bit storage): one / two 32-channel chunks x one / two
+    # 16-row output tiles, a ragged number of output channels, a voxel count that is not a multiple of the 16-voxel tile
+    (1, 64, 32, 32, 32, 40, 1, 1, 0, 1, True),
+    (1, 64, 16, 32, 32, 40, 1, 1, 0, 1, False),
+    (1, 32, 32, 33, 31, 35, 1, 1, 0, 1, True),
+    (2, 32, 24, 16, 31, 35, 1, 1, 0, 1, True),
+    (1, 64, 12, 32, 32, 40, 1, 1, 0, 1, True),
+    (1, 16, 32, 32, 32, 40, 1, 1, 0, 1, True),    # (16 inputs: half a chunk, the input-gradient shape of the 32 -> 16 mixer)
     # 7^3 weight gradient with K along H (conv_wgrad_hk.hip: <= 16 output channels, planes >= 32 x 32): exact / ragged tiles, two
     # input-channel tiles, a partial second channel tile, fewer than 16 output channels
     (1, 16, 16, 2, 32, 32, 7, 1, 3, 1, True),
@@ -143,6 +151,27 @@ def test_conv3d(cfg, dtype):
     check("gw", wh.grad, wr.grad, dtype)
     if has_b:
         check("gb", bh.grad, br.grad, dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("cin,cout,ldx", [(25, 16, 64), (40, 24, 64), (33, 32, 64), (64, 32, 64), (16, 32, 16), (25, 16, 32), (40, 32, 40), (20, 16, 24)])
+def test_pointwise_rows_ragged_channels_ignore_the_row_padding(cin, cout, ldx, dtype):
+    """dp_pointwise_rows on rows wider than Cin (pitch a multiple of 32): the matrix-core path reads whole 32-channel chunks and must
+    mask what lies beyond Cin -- the padding here holds NaN / Inf.  Output rows are slices of a wider buffer whose other columns stay."""
+    from dose_prediction_amd import ops
+    dev = _dev()
+    rows, ldy = 32768 + 7, 40
+    x = q(rnd((rows, cin), 1), dtype)
+    w = q(rnd((cout, cin), 2, cin ** -0.5), dtype)
+    b = rnd((cout,), 3, 0.1)
+    xb = torch.full((rows, ldx), float("nan"), dtype=dtype, device=dev)
+    xb[:, cin:cin + 2] = float("inf")
+    xb[:, :cin] = x.to(dev, dtype)
+    yb = torch.full((rows, ldy), 7.0, dtype=dtype, device=dev)
+    ops.gemm_nt(xb, w.to(dev, dtype).contiguous(), yb, bias=b.to(dev), M=rows, N=cout, K=cin, lda=ldx, ldb=cin, ldc=ldy)
+    yr = x.double() @ w.double().t() + b.double()
+    check("y", yb[:, :cout], yr, dtype)
+    assert bool((yb[:, cout:] == 7.0).all())
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

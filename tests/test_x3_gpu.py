@@ -150,6 +150,55 @@ def test_x3_single_product_weight_gradients(cfg):
     check("linear gb", bh.grad, blr.grad, scale=20.0)
 
 
+@pytest.mark.parametrize("cfg", [(2, 32, 16, 16, 3, 33, 70, 7), (1, 16, 0, 16, 5, 32, 32, 3), (1, 64, 0, 40, 2, 33, 32, 7), (2, 16, 0, 16, 2, 9, 130, 7),
+                                 (1, 16, 0, 16, 3, 9, 130, 3), (1, 128, 64, 80, 4, 4, 16, 7), (2, 25, 16, 16, 4, 20, 100, 3), (1, 3, 0, 16, 2, 9, 32, 7)])
+def test_x3_single_product_data_gradients(cfg):
+    """config.set_x3_dgrad_terms(1) (opt-in: exact forward, bf16-grade backward): the forward pass is untouched (3e-5), the data
+    gradient is gy_hi w_hi through a DP_X1 launch of the bf16 kernels -- inside the bf16 operator tolerance and clearly not the
+    three-product result; weight gradients as configured (three products under this file's fixture).  Linear layers likewise."""
+    import dose_prediction_amd
+    from dose_prediction_amd import ops
+    dev = _dev()
+    dose_prediction_amd.config.set_x3_dgrad_terms(1)
+    try:
+        N, Cin, ca, Cout, D, H, W, k = cfg
+        x = rnd((N, Cin, D, H, W), 1) * 1.3 + 0.2
+        w = rnd((Cout, Cin, k, k, k), 2, (Cin * k ** 3) ** -0.5)
+        xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+        yr = oracle.conv3d(xr, wr, None, 1, k // 2, 1)
+        r = rnd(yr.shape, 4)
+        (yr * r.double()).sum().backward()
+        wh = w.to(dev).requires_grad_(True)
+        if ca:
+            xa, xb = ndhwc(x[:, :ca]).to(dev).requires_grad_(True), ndhwc(x[:, ca:]).to(dev).requires_grad_(True)
+            yh = ops.conv3d((xa, xb), wh, None, 1, k // 2, 1)
+        else:
+            xa = ndhwc(x).to(dev).requires_grad_(True)
+            yh = ops.conv3d(xa, wh, None, 1, k // 2, 1)
+        yh.backward(ndhwc(r).to(dev))
+        gx = torch.cat((xa.grad, xb.grad), -1) if ca else xa.grad
+        check("y", ncdhw(yh), yr)
+        check("gw", wh.grad, wr.grad)
+        e = rel_l2(ncdhw(gx).cpu(), xr.grad)
+        if Cin >= 8:
+            assert 1e-4 < e < 6e-3, e      # (two operand roundings of 2^-9 / sqrt(3) each; 3e-5 would mean three products ran)
+        else:
+            assert e < 3e-5, e             # (fewer than 8 input channels: the exact gather kernel whatever the setting)
+        xl, wl = rnd((2, 512, 768), 5), rnd((96, 768), 6, 768 ** -0.5)
+        xlr, wlr = xl.double().requires_grad_(True), wl.double().requires_grad_(True)
+        rl = rnd((2, 512, 96), 8)
+        (torch.nn.functional.linear(xlr, wlr) * rl.double()).sum().backward()
+        xh, wh2 = xl.to(dev).requires_grad_(True), wl.to(dev).requires_grad_(True)
+        yl = ops.linear(xh, wh2, None)
+        yl.backward(rl.to(dev))
+        torch.cuda.synchronize()
+        check("linear y", yl, torch.nn.functional.linear(xl.double(), wl.double()))
+        check("linear gw", wh2.grad, wlr.grad)
+        assert 1e-4 < rel_l2(xh.grad.cpu(), xlr.grad) < 6e-3
+    finally:
+        dose_prediction_amd.config.set_x3_dgrad_terms(3)
+
+
 def test_x3_conv3d_with_statistics_and_padded_rows():
     """conv3d(..., stats=True) in x3 mode: the epilogue statistics equal those of the stored fp32 output; an input whose rows are
     wider than Cin (zero-padded boundary tensor) uses its first Cin channels only."""
