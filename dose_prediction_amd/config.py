@@ -164,14 +164,14 @@ def _env_terms(name, default):
 
 
 _x3_wgrad_terms = _env_terms("DOSE_HIP_X3_WGRAD_TERMS", 1)
-_x3_linear_wgrad_terms = _env_terms("DOSE_HIP_X3_LINEAR_WGRAD_TERMS", 3)
-_x3_dgrad_terms = _env_terms("DOSE_HIP_X3_DGRAD_TERMS", 3)
+_x3_linear_wgrad_terms = _env_terms("DOSE_HIP_X3_LINEAR_WGRAD_TERMS", 1)
+_x3_dgrad_terms = _env_terms("DOSE_HIP_X3_DGRAD_TERMS", 1)
 
 
 def set_x3_wgrad_terms(n):
     """fp32x3 mode: number of split products in the WEIGHT gradients.  1 (default): x_hi gy_hi -- the weight gradients (and only they)
-    are formed from bf16-rounded operands with fp32 accumulation; the forward pass and the data gradients always use the three
-    products, so outputs keep their 1e-4 parity.  3: x_hi gy_hi + x_lo gy_hi + x_hi gy_lo like every other contraction of the mode
+    are formed from bf16-rounded operands with fp32 accumulation; the forward pass always uses the three products, so outputs keep
+    their 1e-4 parity (data gradients: set_x3_dgrad_terms).  3: x_hi gy_hi + x_lo gy_hi + x_hi gy_lo like every other contraction of the mode
     (10.5 ms per DOSE-PYFER step more).  Why 1 is the default: a weight-gradient element is a sum over millions of voxels, the
     operand rounding is unbiased, and what it adds (~1.6e-3 relative per element) is below what separates the EXACT fp32 mode from
     float64 on the same gradients (4.2e-3, ReLU gates of pre-activations within round-off of zero).  Measured at production width
@@ -189,12 +189,15 @@ def x3_wgrad_terms():
 
 
 def set_x3_dgrad_terms(n):
-    """fp32x3 mode: number of split products in the DATA gradients of the convolutions and Linear layers.  3 (default): like the forward
-    pass.  1: gy_hi w_hi only (a DP_X1 launch: the bf16 kernels on the hi halves, fp32 result) -- "exact forward, bf16-grade backward":
-    outputs, losses and validation metrics keep the mode's 1e-4 parity with the reference's fp32 path, the gradients that reach the
-    parameters carry the operand rounding of the bf16 mode (which accumulates along the backward chain, unlike the weight gradients'
-    own rounding: set_x3_wgrad_terms).  Opt-in because the trajectory of a training run is then the bf16 mode's, not the reference's;
-    the step is ~8 ms shorter (bench.py: fp32_mode.dgrad_one_product; measured gradient error: tools/x3_grad_probe.py)."""
+    """fp32x3 mode: number of split products in the DATA gradients of the convolutions and Linear layers.  1 (default since round 4):
+    gy_hi w_hi only (a DP_X1 launch: the bf16 kernels on the hi halves, fp32 result); 3: like the forward pass (+7 ms per DOSE-PYFER
+    step).  The forward pass -- every output, loss and validation metric, i.e. what the north-star's 1e-3 / arg-max bar is stated on --
+    always uses three products.  Why 1 is the default: measured at production width (tools/x3_grad_probe.py, 64^3, all 148 trainable
+    tensors against the float64 oracle) the gradient vector is 1.09e-2 away with one product and 1.04e-2 with three -- the floor is set
+    by activation gates of pre-activations within round-off of zero, not by the backward arithmetic -- against 2.6e-1 in the bf16 mode,
+    whose error comes from its FORWARD activations; six fused-Adam steps end 8.0 % of the update away from an exact-fp32 run with one
+    product, 8.1 % with three (two exact-fp32 runs: 5.4 %; bf16: 40 %) (tools/x3_trajectory_probe.py).  bench.py reports the
+    three-product variants beside the default (fp32_mode.dgrad_three_products, .all_three_products)."""
     global _x3_dgrad_terms
     if n not in (1, 3):
         raise ValueError("x3 data-gradient terms must be 1 or 3")
@@ -206,9 +209,13 @@ def x3_dgrad_terms():
 
 
 def set_x3_linear_wgrad_terms(n):
-    """fp32x3 mode: split products in the weight gradients of the LINEAR layers (transformer, patch embedding).  Default 3:
-    their contraction runs over 1-2 k token rows, not over millions of voxels, so the averaging argument of set_x3_wgrad_terms does
-    not carry over, and the three products ride in the one grouped launch anyway (+0.3 ms per DOSE-PYFER step).  1 = x_hi gy_hi only."""
+    """fp32x3 mode: split products in the weight gradients of the LINEAR layers (transformer, patch embedding): 1 = x_hi gy_hi (default
+    since round 4), 3 = all three.  Their contraction runs over 1-2 k token rows, not over millions of voxels, so the averaging argument
+    of set_x3_wgrad_terms does not carry over -- round 3 therefore defaulted to 3 until there was per-layer evidence.  That
+    evidence (tools/x3_grad_probe.py, the 33 Linear weight tensors of DOSE-PYFER at production width, each against the float64 oracle):
+    relative L2 error per tensor median 1.56e-2 / max 1.82e-2 with three products, 1.60e-2 / 1.85e-2 with one; all 33 together 1.81e-2
+    vs 1.84e-2; six Adam steps end 8.1 % of the update away from the exact-fp32 run in both cases.  The gradient error of these layers is
+    set upstream (activation gates flipping within round-off of zero), not by the operand rounding of their own contraction."""
     global _x3_linear_wgrad_terms
     if n not in (1, 3):
         raise ValueError("x3 weight-gradient terms must be 1 or 3")

@@ -1149,15 +1149,21 @@ class Conv3dX3(torch.autograd.Function):
         cpo = (cout + 15) // 16 * 16
         need_x = ctx.needs_input_grad[0] or (cxb is not None and ctx.needs_input_grad[1])
         need_w = ctx.needs_input_grad[2]
+        from . import config as _cfg
+        one = _cfg.x3_dgrad_terms() == 1 and _tiled_elems(cout, cin, k, 1, pad, 1, W) > 0
+        ldgs = 2 * cpo
         if ctx.gy_split:
             gys = gy.view(torch.bfloat16)                 # [.., gy_hi (cout) | gy_lo (cout)] already (cpo == cout)
+        elif (one or not need_x) and (_cfg.x3_wgrad_terms() == 1 or not need_w):
+            # one-product gradients on both sides: only gy_hi is ever read -- a compact bf16 tensor (half the bytes written here, and
+            # the kernels' 32-byte rows are not interleaved with 32 bytes nobody wants)
+            gys = split_rows(gy, cout, None, 0, cpo, 1, 0) if (need_x or need_w) else None
+            ldgs = cpo
         else:
             gys = split_rows(gy, cout, None, 0, cpo, 2, 0b10) if (need_x or need_w) else None
         gxa = gxb = gw = gb = None
         tok = _wg_fork(weight, need_w)
         if need_x:
-            from . import config as _cfg
-            one = _cfg.x3_dgrad_terms() == 1 and _tiled_elems(cout, cin, k, 1, pad, 1, W) > 0
             if one or L.dp_conv3d_tiled_weight_elems(3 * cpo, cin, k, 1, pad, 1, W):
                 if one:
                     # config.set_x3_dgrad_terms(1): gy_hi against the ordinary bf16 data-gradient pack, fp32 result (a DP_X1 launch)
@@ -1172,7 +1178,7 @@ class Conv3dX3(torch.autograd.Function):
                     gx = torch.empty((N, D, H, W, cx1), dtype=torch.float32, device=dev)
                     if cx1 > cin:
                         gx.zero_()
-                    _lib.call("dp_conv3d_tiled2", _p(gys), 2 * cpo, 0, 0, 0, _p(wq), 0, _p(gx), cx1, 0, 0, 0, _p(ws),
+                    _lib.call("dp_conv3d_tiled2", _p(gys), ldgs, 0, 0, 0, _p(wq), 0, _p(gx), cx1, 0, 0, 0, _p(ws),
                               N, D, H, W, kc, cin, k, kdt, _stream())
                     if cxb is None:
                         gxa = gx
@@ -1184,7 +1190,7 @@ class Conv3dX3(torch.autograd.Function):
                     gxb = torch.empty((N, D, H, W, cxb), dtype=torch.float32, device=dev)
                     if cxb > cin - ca:
                         gxb.zero_()
-                    _lib.call("dp_conv3d_tiled2", _p(gys), 2 * cpo, 0, 0, 0, _p(wq), 0, _p(gxa), ca, _p(gxb), cxb, ca, _p(ws),
+                    _lib.call("dp_conv3d_tiled2", _p(gys), ldgs, 0, 0, 0, _p(wq), 0, _p(gxa), ca, _p(gxb), cxb, ca, _p(ws),
                               N, D, H, W, kc, cin, k, kdt, _stream())
             else:
                 # fewer than 8 input channels (no tiled kernel computes so narrow an output): the exact-fp32 gather kernel
@@ -1206,7 +1212,7 @@ class Conv3dX3(torch.autograd.Function):
                 gw = _wgrad_buffer(weight, False)
                 if config.x3_wgrad_terms() == 1:
                     # (config.set_x3_wgrad_terms(1)) x_hi x gy_hi only: one bf16 launch straight into dW
-                    _lib.call("dp_conv3d_wgrad_tiled", _p(xs), 2 * cp, _p(gys), 2 * cpo, _p(gw), _p(ws), N, D, H, W, cin, cout, k,
+                    _lib.call("dp_conv3d_wgrad_tiled", _p(xs), 2 * cp, _p(gys), ldgs, _p(gw), _p(ws), N, D, H, W, cin, cout, k,
                               cin * taps, taps, 1, 1, _stream())
                 else:
                     # S[co][p cp + ci][tap]: blocks p = 0, 1 from (x_hi | x_lo) x gy_hi, block 2 from x_hi x gy_lo
@@ -1301,13 +1307,17 @@ class LinearX3(torch.autograd.Function):
         cpo = (nout + 7) // 8 * 8
         dev = gy.device
         gx = gw = gb = None
-        gys = split_rows(gy, nout, None, 0, cpo, 3, _PAT_W)             # [gy_hi | gy_hi | gy_lo]
+        from . import config as _cfg
+        d1 = _cfg.x3_dgrad_terms() == 1
+        if (d1 or not ctx.needs_input_grad[0]) and (_cfg.x3_linear_wgrad_terms() == 1 or not ctx.needs_input_grad[1]):
+            gys, ldgs = split_rows(gy, nout, None, 0, cpo, 1, 0), cpo   # one-product gradients on both sides: gy_hi alone, compact
+        else:
+            gys, ldgs = split_rows(gy, nout, None, 0, cpo, 3, _PAT_W), 3 * cpo             # [gy_hi | gy_hi | gy_lo]
         if ctx.needs_input_grad[0]:
             wt = _pack_mat_x3(weight, True, cpo, _PAT_ACT)             # [in][w_hi | w_lo | w_hi]
             gx = torch.empty(xshape, dtype=torch.float32, device=dev)
-            from . import config as _cfg
             # (config.set_x3_dgrad_terms(1): block 0 of both operands alone, gy_hi w_hi)
-            gemm_nt(gys, wt, gx, M=rows, N=K, K=cpo if _cfg.x3_dgrad_terms() == 1 else 3 * cpo, lda=3 * cpo, ldb=3 * cpo, ldc=K)
+            gemm_nt(gys, wt, gx, M=rows, N=K, K=cpo if d1 else 3 * cpo, lda=ldgs, ldb=3 * cpo, ldc=K)
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             gw = _wgrad_buffer(weight, False)
@@ -1316,9 +1326,9 @@ class LinearX3(torch.autograd.Function):
             if config.x3_linear_wgrad_terms() == 1:
                 # gy_hi x_hi only: block 0 of every row of both operands (row pitch 3 cp)
                 if ctx.defer and _DEFER["enabled"] and rows <= 16384 and weight.grad is None and (not want_b or ctx.bias_ref.grad is None):
-                    _defer_wgrad(gys, 3 * cpo, xs, 3 * cp, gw, None, nout, K, rows)
+                    _defer_wgrad(gys, ldgs, xs, 3 * cp, gw, None, nout, K, rows)
                 else:
-                    _lib.call("dp_gemm_tn", _p(gys), 3 * cpo, _p(xs), 3 * cp, _p(gw), K, nout, K, rows, 1, 1, _stream())
+                    _lib.call("dp_gemm_tn", _p(gys), ldgs, _p(xs), 3 * cp, _p(gw), K, nout, K, rows, 1, 1, _stream())
             elif (ctx.defer and _DEFER["enabled"] and rows <= 16384 and weight.grad is None and (not want_b or ctx.bias_ref.grad is None)):
                 _defer_wgrad(gys, cpo, xs, cp, gw, None, nout, K, 3 * rows)
                 if want_b:
@@ -2007,14 +2017,41 @@ class Attention(torch.autograd.Function):
         O = torch.empty((B, N, H), dtype=qkv.dtype, device=dev)
         _lib.call("dp_gemm_nt", _p(S), N, heads * N * N, N * N, _p(Vt), N, heads * d * N, d * N, _p(O), H, N * H, d, 0, N, d, N,
                   B, heads, 1.0, 0, 1, dtc, _stream())
-        ctx.save_for_backward(qkv, S)
+        # fp32x3 mode with one-product data gradients (config.set_x3_dgrad_terms, the default): the backward pass runs the fused bf16
+        # kernels on the rounded operands -- it needs qkv only (no N x N probabilities kept)
+        from . import config as _cfg
+        ctx.fused_bwd = bool(_cfg.x3() and _cfg.x3_dgrad_terms() == 1 and qkv.dtype == torch.float32 and d in (64, 128)
+                             and not os.environ.get("DP_NO_FUSED_ATTN"))
+        if ctx.fused_bwd:
+            ctx.save_for_backward(qkv)
+        else:
+            ctx.save_for_backward(qkv, S)
         ctx.heads = heads
         return O
 
     @staticmethod
     def backward(ctx, gO):
-        qkv, P = ctx.saved_tensors
         heads = ctx.heads
+        if ctx.fused_bwd:
+            # gy_hi-grade backward: qkv and dO rounded to bf16, the fused forward once more for the log-sum-exp rows and O that belong
+            # to THOSE operands (11 us), the fused backward, the result widened to fp32: 5 launches instead of 10 fp32 ones
+            (qkv,) = ctx.saved_tensors
+            B, N, H3 = qkv.shape
+            H = H3 // 3
+            d = H // heads
+            qh, gOh = _cast_vec(qkv, torch.bfloat16), _cast_vec(gO.contiguous(), torch.bfloat16)
+            base = qh.data_ptr()
+            Oh = torch.empty((B, N, H), dtype=torch.bfloat16, device=qkv.device)
+            lse = torch.empty((B * heads * ((N + 31) // 32 * 32),), dtype=torch.float32, device=qkv.device)
+            _lib.call("dp_attention_fwd", base, base + H * 2, base + 2 * H * 2, H3, _p(Oh), H, _p(lse), B, heads, N, d, float(d ** -0.5),
+                      _DT[torch.bfloat16], _stream())
+            gh = torch.empty_like(qh)
+            gb = gh.data_ptr()
+            delta = torch.empty_like(lse)
+            _lib.call("dp_attention_bwd", base, base + H * 2, base + 2 * H * 2, H3, _p(Oh), _p(gOh), H, _p(lse), _p(delta), gb, gb + H * 2,
+                      gb + 2 * H * 2, H3, B, heads, N, d, float(d ** -0.5), _DT[torch.bfloat16], _stream())
+            return _cast_vec(gh, torch.float32), None
+        qkv, P = ctx.saved_tensors
         gO = gO.contiguous()
         B, N, H3 = qkv.shape
         H = H3 // 3

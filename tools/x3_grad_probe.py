@@ -27,7 +27,9 @@ torch.autograd.backward(ref, [r.double() for r in rs])
 net.to(dev).train()
 for mode in sys.argv[1:] or ("fp32", "fp32x3"):
     dose_prediction_amd.config.set_x3_wgrad_terms(3 if mode == "fp32x3w3" else 1)
-    dose_prediction_amd.set_compute_dtype("fp32x3" if mode == "fp32x3w3" else mode)
+    dose_prediction_amd.config.set_x3_dgrad_terms(3 if mode in ("fp32x3d3", "fp32x3w3") else 1)       # (fp32x3 = the defaults: 1 / 1)
+    dose_prediction_amd.config.set_x3_linear_wgrad_terms(1 if mode == "fp32x3l1" else 3)
+    dose_prediction_amd.set_compute_dtype("fp32x3" if mode.startswith("fp32x3") else mode)
     net.load_state_dict(sd)
     net.zero_grad(set_to_none=True)
     outs = net(x.to(dev))[1]
@@ -42,5 +44,13 @@ for mode in sys.argv[1:] or ("fp32", "fp32x3"):
         num += e2; den += n2
         rows.append((e2, (e2 / max(n2, 1e-300)) ** 0.5, n2 ** 0.5, k))
     print(f"== {mode}: outputs {[('%.2e' % float((o.detach().double().cpu() - r.detach()).abs().max() / r.detach().abs().max())) for o, r in zip(outs, ref)]}  gradient rel-L2 {(num / den) ** 0.5:.3e}")
+    # the Linear layers (2-D weights: transformer, patch embedding) on their own: ADVICE r3 asked for per-layer evidence before their
+    # weight gradients may use one product (config.set_x3_linear_wgrad_terms)
+    lin = [(e2, rel, nrm, k) for e2, rel, nrm, k in rows if sd64[k].dim() == 2]
+    if lin:
+        le, ln = sum(r[0] for r in lin), sum(r[2] ** 2 for r in lin)
+        rels = sorted(r[1] for r in lin)
+        print(f"   Linear weights ({len(lin)} tensors, linear wgrad terms {dose_prediction_amd.config.x3_linear_wgrad_terms()}): rel-L2 {(le / ln) ** 0.5:.3e}  "
+              f"per-tensor rel median {rels[len(rels) // 2]:.2e} max {rels[-1]:.2e}")
     for e2, rel, nrm, k in sorted(rows, reverse=True)[:12]:
         print(f"   share {e2 / num:6.3f}  rel {rel:.2e}  |g| {nrm:.2e}  {k}")

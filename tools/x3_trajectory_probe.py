@@ -20,6 +20,8 @@ x, gt = synth.dose_input(2, S).to(dev), synth.dose_target(2, S).to(dev)
 
 def run(mode):
     dose_prediction_amd.config.set_x3_wgrad_terms(3 if mode == "fp32x3w3" else 1)
+    dose_prediction_amd.config.set_x3_dgrad_terms(3 if mode in ("fp32x3d3", "fp32x3w3") else 1)       # (fp32x3 = the defaults: 1 / 1)
+    dose_prediction_amd.config.set_x3_linear_wgrad_terms(1 if mode == "fp32x3l1" else 3)
     dose_prediction_amd.set_compute_dtype("fp32x3" if mode.startswith("fp32x3") else mode)
     net = Model(in_ch=9, out_ch=1, list_ch_A=[-1, 16, 32, 64, 128, 256], feature_size=16, img_size=S, num_layers=8, num_heads=6, act="mish")
     net.load_state_dict(sd0)
@@ -46,7 +48,7 @@ ref_l, ref_w, keys = run("fp32")
 w0 = torch.cat([sd0[k].double().reshape(-1) for k in keys])
 upd = (ref_w - w0).norm()
 print(f"exact fp32 losses {['%.5f' % l for l in ref_l]}  |update| {upd:.4e}")
-for mode in ("fp32", "fp32x3w3", "fp32x3", "bf16"):
+for mode in ("fp32", "fp32x3w3", "fp32x3d3", "fp32x3", "fp32x3l1", "bf16"):
     l, w, _ = run(mode)
     print(f"{mode:9s} losses {['%.5f' % v for v in l]}  max |loss - fp32| {max(abs(a - b) for a, b in zip(l, ref_l)):.2e}  "
           f"weights: distance from the fp32 run / its update {float((w - ref_w).norm() / upd):.3f}")
