@@ -1326,7 +1326,10 @@ class LinearX3(torch.autograd.Function):
             if config.x3_linear_wgrad_terms() == 1:
                 # gy_hi x_hi only: block 0 of every row of both operands (row pitch 3 cp)
                 if ctx.defer and _DEFER["enabled"] and rows <= 16384 and weight.grad is None and (not want_b or ctx.bias_ref.grad is None):
-                    _defer_wgrad(gys, ldgs, xs, 3 * cp, gw, None, nout, K, rows)
+                    # (the bias gradient rides in the same problem: column sums of the gy_hi operand)
+                    gb = torch.empty((nout,), dtype=torch.float32, device=dev) if want_b else None
+                    _defer_wgrad(gys, ldgs, xs, 3 * cp, gw, gb, nout, K, rows)
+                    want_b = False
                 else:
                     _lib.call("dp_gemm_tn", _p(gys), ldgs, _p(xs), 3 * cp, _p(gw), K, nout, K, rows, 1, 1, _stream())
             elif (ctx.defer and _DEFER["enabled"] and rows <= 16384 and weight.grad is None and (not want_b or ctx.bias_ref.grad is None)):

@@ -153,7 +153,7 @@ def test_x3_single_product_weight_gradients(cfg):
     torch.cuda.synchronize()
     check("linear gx", xh.grad, xlr.grad)
     assert 1e-4 < rel_l2(wh2.grad.cpu(), wlr.grad) < 6e-3
-    check("linear gb", bh.grad, blr.grad, scale=20.0)
+    assert rel_l2(bh.grad.cpu(), blr.grad) < 6e-3          # (column sums of the gy_hi operand, inside the grouped launch)
 
 
 @pytest.mark.parametrize("cfg", [(2, 32, 16, 16, 3, 33, 70, 7), (1, 16, 0, 16, 5, 32, 32, 3), (1, 64, 0, 40, 2, 33, 32, 7), (2, 16, 0, 16, 2, 9, 130, 7),
