@@ -25,7 +25,11 @@ __global__ void __launch_bounds__(256) k_gemm_nt(const T* __restrict__ A, int64_
                                                  float alpha, int out_f32, int splitk, T* __restrict__ aux, int64_t ldaux, int epi) {
   constexpr int BM = 32 * TI, BN = 32 * TJ, WMR = 16 * TI, WNR = 16 * TJ, LDP = BK + 8, CPR = BK / 8;   // CPR: 16-byte chunks per row
   constexpr int UA = BM * CPR / 256 > 0 ? BM * CPR / 256 : 1, UB = BN * CPR / 256 > 0 ? BN * CPR / 256 : 1;   // chunks per thread
-  __shared__ __attribute__((aligned(16))) T smem[(BM + BN) * LDP];
+  // fp32 results leave through an LDS tile too (round 4): NPF passes of BM / NPF rows x (BN + 4) floats
+  constexpr int NPF = TI == 4 ? 2 : 1, CPF = BN + 4;
+  constexpr int OPB = (BM + BN) * LDP * (int)sizeof(T), F32B = (BM / NPF) * CPF * 4, SMB = OPB > F32B ? OPB : F32B;
+  __shared__ __attribute__((aligned(16))) char smem_raw[SMB];
+  T* const smem = (T*)smem_raw;
   T* const As = smem; T* const Bs = smem + BM * LDP;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
   const int r = lane & 15, q = lane >> 4;
@@ -180,6 +184,38 @@ __global__ void __launch_bounds__(256) k_gemm_nt(const T* __restrict__ A, int64_
       }
     }
     PROBE(32);
+    return;
+  }
+  // Interior tiles with an fp32 output (the fp32x3 mode's Linear layers, the exact-fp32 ConvTranspose / attention GEMMs): the same
+  // transposition through LDS, 16-byte stores of four floats (the scattered version wrote 4-byte elements 64 bytes at a time: the
+  // 524 288 x 128 x 32 ConvTranspose GEMM of the fp32 modes ran at 1.3 TB/s of output)
+  if ((out_f32 || sizeof(T) == 4) && splitk == 1 && epi == 0 && m0 + BM <= M && n0 + BN <= N && (ldc & 3) == 0 && ((sc0 | sc1) & 3) == 0 &&
+      (((uintptr_t)Cv) & 15) == 0) {
+    float* tile = (float*)smem_raw;
+    float* Cb = (float*)Cv + coff + (int64_t)m0 * ldc + n0;
+    constexpr int PR = BM / NPF;
+#pragma unroll
+    for (int ps = 0; ps < NPF; ps++) {
+      __syncthreads();
+      if (NPF == 1 || wm == ps) {
+        const int rbase = NPF == 1 ? wm * WMR : 0;
+#pragma unroll
+        for (int j = 0; j < TJ; j++) {
+          const int col = wn * WNR + j * 16 + r;
+          const float bv = bias ? bias[n0 + col] : 0.f;
+#pragma unroll
+          for (int i = 0; i < TI; i++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) tile[(rbase + i * 16 + q * 4 + e) * CPF + col] = alpha * acc[i][j][e] + bv;
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < PR * BN / 4 / 256; u++) {
+        const int c = tid + u * 256, row = c / (BN / 4), cc = (c % (BN / 4)) * 4;
+        *(v4f*)(Cb + (int64_t)(ps * PR + row) * ldc + cc) = *(const v4f*)(tile + row * CPF + cc);
+      }
+    }
     return;
   }
 #pragma unroll
