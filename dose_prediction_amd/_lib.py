@@ -72,8 +72,12 @@ PROFILE_NAMES = ("dp_conv3d", "dp_conv3d_tiled", "dp_conv3d_tiled2", "dp_conv3d_
                  "dp_gemm_nt", "dp_gemm_tn")
 
 
+# entry points that may answer 3 = "not this kernel's shape, nothing launched" (the caller then takes its general path)
+SOFT_DECLINE = ("dp_tconv2x_fwd",)
+
+
 def call(name, *args):
-    """Call an int-returning entry point; raise DoseHipError(dp_last_error()) on a non-zero status."""
+    """Call an int-returning entry point; raise DoseHipError(dp_last_error()) on a non-zero status (3 is returned for SOFT_DECLINE names)."""
     L = lib()
     if PROFILE is not None and name in PROFILE_NAMES:
         import torch
@@ -84,6 +88,6 @@ def call(name, *args):
         PROFILE.append((name, args, e0, e1))
     else:
         rc = getattr(L, name)(*args)
-    if rc != 0:
+    if rc != 0 and not (rc == 3 and name in SOFT_DECLINE):
         raise DoseHipError(f"{name} failed (rc={rc}): {L.dp_last_error().decode()}")
     return rc

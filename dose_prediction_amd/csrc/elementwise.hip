@@ -645,11 +645,25 @@ template <typename T> __device__ __forceinline__ unsigned pw_pack2(float a, floa
   T lo, hi; st_f(&lo, a); st_f(&hi, b);
   return (unsigned)__builtin_bit_cast(unsigned short, lo) | ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16);
 }
+// Generalised in the same round to every skinny row GEMM of the step (grid.y walks the output columns in tiles of 16 NT, up to 128
+// input channels): ConvTranspose 2 x 2 x 2 forward (K = Cin, 8 Cout columns) and data gradient (K = 8 Cout), the data gradients of
+// the mixers -- the generic 128 x 128-tile GEMM moved 0.9-1.7 TB/s on these shapes.  ShuffleGeom: ConvTranspose forward with the
+// 2 x 2 x 2 pixel shuffle in the store: column group g = 4a + 2b + c (cg channels each) of input voxel (n, d, h, w) IS output voxel
+// (n, 2d + a, 2h + b, 2w + c) -- the [voxels][8 Cout] intermediate and its shuffle pass (a read and a write of the whole upsampled
+// tensor) do not exist.
+struct ShuffleGeom { int cg, D, H, W; float rW, rH, rD; };
+__device__ __forceinline__ unsigned div_small(unsigned v, unsigned d, float rd) {      // v / d for v < 2^24 (one multiply + fix-ups)
+  unsigned qv = (unsigned)((float)v * rd);
+  if (qv * d > v) qv--;
+  if ((qv + 1) * d <= v) qv++;
+  return qv;
+}
 template <typename T, int KC, int NT>
 __global__ void __launch_bounds__(256) k_pointwise_mfma(const T* __restrict__ x, int ldx, const T* __restrict__ w, int ldw, const float* __restrict__ bias,
-                                                        T* __restrict__ y, int ldy, int64_t rows, int Cin, int Cout) {
-  constexpr int U = 4;
+                                                        T* __restrict__ y, int ldy, int64_t rows, int Cin, int Cout, ShuffleGeom sg) {
+  constexpr int U = KC >= 3 ? 2 : 4;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 15, q = lane >> 4;
+  const int n0 = blockIdx.y * 16 * NT;
   Frag8<T> aw[NT][KC];
   unsigned keep[KC][4];                                       // dword masks of the channels < Cin (input padding may hold anything)
 #pragma unroll
@@ -659,16 +673,19 @@ __global__ void __launch_bounds__(256) k_pointwise_mfma(const T* __restrict__ x,
     for (int d = 0; d < 4; d++) keep[kc][d] = (k0 + 2 * d + 1 < Cin) ? 0xffffffffu : (k0 + 2 * d < Cin) ? 0x0000ffffu : 0u;
 #pragma unroll
     for (int nt = 0; nt < NT; nt++) {
-      const int co = NT == 2 ? 8 * (r >> 2) + 4 * nt + (r & 3) : r;
+      const int co = n0 + (NT == 2 ? 8 * (r >> 2) + 4 * nt + (r & 3) : r);
       aw[nt][kc] = (co < Cout && k0 < Cin) ? frag_load(w + (int64_t)co * ldw + k0, min(8, Cin - k0)) : frag_zero<T>();
     }
   }
-  const int c0 = NT == 2 ? 8 * q : 4 * q;                     // the lane's first output channel
+  const int c0 = n0 + (NT == 2 ? 8 * q : 4 * q);              // the lane's first output channel
   float bv[NT][4];
 #pragma unroll
   for (int nt = 0; nt < NT; nt++)
 #pragma unroll
     for (int e = 0; e < 4; e++) bv[nt][e] = (bias && c0 + 4 * nt + e < Cout) ? bias[c0 + 4 * nt + e] : 0.f;
+  // pixel-shuffle store: the lane's channels all belong to one (a, b, c) group
+  const int grp = sg.cg ? c0 / sg.cg : 0, cs = sg.cg ? c0 - grp * sg.cg : c0;
+  const int ga = grp >> 2, gb = (grp >> 1) & 1, gc = grp & 1;
   const bool ragged = (Cin & 31) != 0;
   const int64_t ntiles = (rows + 15) / 16, wave = (int64_t)blockIdx.x * 4 + wv, nwaves = (int64_t)gridDim.x * 4;
   for (int64_t t0 = wave * U; t0 < ntiles; t0 += nwaves * U) {
@@ -693,7 +710,13 @@ __global__ void __launch_bounds__(256) k_pointwise_mfma(const T* __restrict__ x,
         for (int kc = 0; kc < KC; kc++) acc[nt] = mma16(aw[nt][kc], b[u][kc], acc[nt]);
       }
       if (v >= rows) continue;
-      T* yo = y + v * ldy + c0;
+      int64_t orow = v;
+      if (sg.cg) {
+        const unsigned vv = (unsigned)v, q1 = div_small(vv, sg.W, sg.rW), ww = vv - q1 * sg.W, q2 = div_small(q1, sg.H, sg.rH), hh = q1 - q2 * sg.H,
+                       nn = div_small(q2, sg.D, sg.rD), dd = q2 - nn * sg.D;
+        orow = (((int64_t)nn * 2 * sg.D + 2 * dd + ga) * 2 * sg.H + 2 * hh + gb) * 2 * sg.W + 2 * ww + gc;
+      }
+      T* yo = y + orow * ldy + cs;
       if (c0 + 4 * NT <= Cout) {
         if constexpr (NT == 2) {
           v4u o; o.x = pw_pack2<T>(acc[0][0], acc[0][1]); o.y = pw_pack2<T>(acc[0][2], acc[0][3]); o.z = pw_pack2<T>(acc[1][0], acc[1][1]); o.w = pw_pack2<T>(acc[1][2], acc[1][3]);
@@ -712,27 +735,49 @@ __global__ void __launch_bounds__(256) k_pointwise_mfma(const T* __restrict__ x,
   }
 }
 
+// Shapes the matrix-core row kernel takes: 16-bit storage, 16 <= Cin <= 128, more than 8 output columns, rows readable in 16-byte
+// pieces up to Cin rounded up to 8, 16-byte aligned output rows (pointer alignment is checked at the launch).
+extern "C" int dp_rows_mfma_ok(int ldx, int ldw, int ldy, int Cin, int Cout, int dtype) {
+  static const int mfma_on = [] { const char* e = getenv("DP_POINTWISE_MFMA"); return e ? atoi(e) : 1; }();
+  return mfma_on && (dtype == DP_BF16 || dtype == DP_F16) && Cin >= 16 && Cin <= 128 && Cout > 8 && (Cin + 7) / 8 * 8 <= ldx && ldx % 8 == 0 && ldy % 8 == 0 &&
+         ldw >= Cin;
+}
+static int rows_mfma_launch(const void* x, int ldx, const void* w, int ldw, const float* bias, void* y, int ldy, int64_t rows, int Cin, int Cout, int dtype,
+                            ShuffleGeom sg, hipStream_t s) {
+  const int kc = (Cin + 31) / 32, nt = Cout > 16 ? 2 : 1, ny = (Cout + 16 * nt - 1) / (16 * nt);
+  const int64_t tiles = (rows + 15) / 16;
+  int64_t g = (tiles + 15) / 16; if (g * ny > 4096) g = (4096 + ny - 1) / ny; if (g < 1) g = 1;
+#define GOM(TT, KC_, NT_) hipLaunchKernelGGL((k_pointwise_mfma<TT, KC_, NT_>), dim3((unsigned)g, ny), dim3(256), 0, s, (const TT*)x, ldx, (const TT*)w, ldw, bias, (TT*)y, ldy, rows, Cin, Cout, sg)
+#define GOMK(TT, NT_) do { if (kc == 1) GOM(TT, 1, NT_); else if (kc == 2) GOM(TT, 2, NT_); else if (kc == 3) GOM(TT, 3, NT_); else GOM(TT, 4, NT_); } while (0)
+#define GOMT(TT) do { if (nt == 1) GOMK(TT, 1); else GOMK(TT, 2); } while (0)
+  if (dtype == DP_BF16) GOMT(bf16_t); else GOMT(f16_t);
+#undef GOMT
+#undef GOMK
+#undef GOM
+  return 0;
+}
+// nn.ConvTranspose3d(kernel 2, stride 2, bias = False) forward in ONE launch (base_blocks.py:118-127): w = the [(abc, co)][ldw >= Cin]
+// pack of dp_pack_multi / _pack_tconv, y the NDHWC tensor of the (2D, 2H, 2W) volume.  Needs dp_rows_mfma_ok(ldx, ldw, ldy, Cin,
+// 8 Cout, dtype), Cout % 8 == 0 and N D H W < 2^24; returns 3 ("not this kernel's shape") otherwise without launching.
+extern "C" int dp_tconv2x_fwd(const void* x, int ldx, const void* w, int ldw, void* y, int ldy, int N, int D, int H, int W, int Cin, int Cout, int dtype,
+                              void* stream) {
+  const int64_t rows = (int64_t)N * D * H * W;
+  if (rows <= 0) return 0;
+  if (!dp_rows_mfma_ok(ldx, ldw, ldy, Cin, 8 * Cout, dtype) || Cout % 8 || rows >= (1 << 24) || (((uintptr_t)x | (uintptr_t)y) & 15) != 0) return 3;
+  ShuffleGeom sg; sg.cg = Cout; sg.D = D; sg.H = H; sg.W = W; sg.rW = 1.f / (float)W; sg.rH = 1.f / (float)H; sg.rD = 1.f / (float)D;
+  rows_mfma_launch(x, ldx, w, ldw, nullptr, y, ldy, rows, Cin, 8 * Cout, dtype, sg, STREAM);
+  DP_CHECK_LAUNCH("tconv2x_fwd"); return 0;
+}
+
 extern "C" int dp_pointwise_rows(const void* x, int ldx, const void* w, int ldw, const float* bias, void* y, int ldy, int64_t rows, int Cin, int Cout,
                                  int dtype, void* stream) {
-  if (Cin > 64 || Cout > 32 || Cin < 1 || Cout < 1) DP_FAIL("pointwise_rows: needs Cin <= 64 and Cout <= 32");
-  {
-    // matrix-core path: 16-bit storage, >= 16 input channels (below that the VALU stream is already at the HBM rate), rows readable in
-    // 16-byte pieces up to Cin rounded up to 8 (what lies beyond Cin is masked in registers)
-    static const int mfma_on = [] { const char* e = getenv("DP_POINTWISE_MFMA"); return e ? atoi(e) : 1; }();
-    const int kp = (Cin + 31) / 32 * 32;
-    if (mfma_on && (dtype == DP_BF16 || dtype == DP_F16) && Cin >= 16 && Cout > 8 && (Cin + 7) / 8 * 8 <= ldx && ldx % 8 == 0 && ldy % 8 == 0 && ldw >= Cin &&
-        (((uintptr_t)x | (uintptr_t)y) & 15) == 0 && rows >= 16) {
-      const int kc = kp / 32, nt = Cout > 16 ? 2 : 1;
-      const int64_t tiles = (rows + 15) / 16;
-      int g = (int)((tiles + 15) / 16 < 2048 ? (tiles + 15) / 16 : 2048);
-#define GOM(TT, KC_, NT_) hipLaunchKernelGGL((k_pointwise_mfma<TT, KC_, NT_>), dim3(g), dim3(256), 0, STREAM, (const TT*)x, ldx, (const TT*)w, ldw, bias, (TT*)y, ldy, rows, Cin, Cout)
-#define GOMT(TT) do { if (kc == 1 && nt == 1) GOM(TT, 1, 1); else if (kc == 1) GOM(TT, 1, 2); else if (nt == 1) GOM(TT, 2, 1); else GOM(TT, 2, 2); } while (0)
-      if (dtype == DP_BF16) GOMT(bf16_t); else GOMT(f16_t);
-#undef GOMT
-#undef GOM
-      DP_CHECK_LAUNCH("pointwise_mfma"); return 0;
-    }
+  if (Cin < 1 || Cout < 1) DP_FAIL("pointwise_rows: empty channel count");
+  if (dp_rows_mfma_ok(ldx, ldw, ldy, Cin, Cout, dtype) && (((uintptr_t)x | (uintptr_t)y) & 15) == 0 && rows >= 16) {
+    ShuffleGeom sg; sg.cg = 0; sg.D = sg.H = sg.W = 1; sg.rW = sg.rH = sg.rD = 1.f;
+    rows_mfma_launch(x, ldx, w, ldw, bias, y, ldy, rows, Cin, Cout, dtype, sg, STREAM);
+    DP_CHECK_LAUNCH("pointwise_mfma"); return 0;
   }
+  if (Cin > 64 || Cout > 32) DP_FAIL("pointwise_rows: outside the matrix-core kernel's shapes (dp_rows_mfma_ok) the row stream needs Cin <= 64 and Cout <= 32");
   int g = grid_for(rows, 256, 256 * 32);
 #define GO(CO) DP_DISPATCH(dtype, hipLaunchKernelGGL((k_pointwise_rows<T, CO>), dim3(g), dim3(256), 0, STREAM, (const T*)x, ldx, (const T*)w, ldw, bias, (T*)y, ldy, rows, Cin, Cout))
   if (Cout <= 8) GO(8); else if (Cout <= 16) GO(16); else GO(32);

@@ -419,11 +419,13 @@ def gemm_nt(A, B, out, bias=None, alpha=1.0, M=None, N=None, K=None, batch=(1, 1
     out_f32 = 1 if (out.dtype == torch.float32 and A.dtype != torch.float32) or splitk > 1 else 0
     if splitk > 1 and out.dtype != torch.float32:
         raise ValueError("split-K needs an fp32 output")
-    if (batch == (1, 1) and splitk == 1 and not out_f32 and alpha == 1.0 and M >= 32768 and K <= _PW_MAXK and N <= 32
-            and out.dtype == A.dtype):
-        # millions of voxel rows x a handful of channels: HBM-bound row stream, not a GEMM
-        _lib.call("dp_pointwise_rows", _p(A), lda, _p(B), ldb, _p(bias), _p(out), ldc, M, K, N, _dt(A), _stream())
-        return
+    if batch == (1, 1) and splitk == 1 and not out_f32 and alpha == 1.0 and M >= 32768 and out.dtype == A.dtype:
+        # millions of voxel rows x a handful of channels: a row stream, not a tiled GEMM -- the matrix-core row kernel where it applies
+        # (16-bit storage, up to 128 input channels: pointwise convolutions, ConvTranspose data gradients), the VALU stream otherwise
+        if ((K <= _PW_MAXK and N <= 32) or (A.dtype != torch.float32 and K <= 128 and _p(A) % 16 == 0 and _p(out) % 16 == 0
+                                            and _lib.lib().dp_rows_mfma_ok(lda, ldb, ldc, K, N, _dt(A)))):
+            _lib.call("dp_pointwise_rows", _p(A), lda, _p(B), ldb, _p(bias), _p(out), ldc, M, K, N, _dt(A), _stream())
+            return
     _lib.call("dp_gemm_nt", _p(A), lda, sa[0], sa[1], _p(B), ldb, sb[0], sb[1], _p(out), ldc, sc[0], sc[1], _p(bias),
               M, N, K, batch[0], batch[1], float(alpha), out_f32, splitk, _dt(A), _stream())
 
@@ -892,10 +894,16 @@ class ConvTranspose2x(torch.autograd.Function):
         N, D, H, W = x.shape[:4]
         cin, cout = weight.shape[0], weight.shape[1]
         wp = _pack_tconv(weight, False, x.dtype)
-        tmp = torch.empty((rows, 8 * cout), dtype=x.dtype, device=x.device)
-        gemm_nt(x, wp, tmp, M=rows, N=8 * cout, K=cin, lda=ldx, ldb=wp.shape[-1], ldc=8 * cout)
         y = torch.empty((N, 2 * D, 2 * H, 2 * W, cout), dtype=x.dtype, device=x.device)
-        _lib.call("dp_pixel_shuffle2", _p(tmp), _p(y), N, D, H, W, cout, cout, _dt(x), _stream())
+        # one launch where the matrix-core row kernel takes the shape (the pixel shuffle is its store pattern) ...
+        rc = 3
+        if rows >= 32768 and x.dtype != torch.float32:
+            rc = _lib.call("dp_tconv2x_fwd", _p(x), ldx, _p(wp), wp.shape[-1], _p(y), cout, N, D, H, W, cin, cout, _dt(x), _stream())
+        if rc == 3:
+            # ... else the GEMM into a [voxels][8 Cout] intermediate and the shuffle pass
+            tmp = torch.empty((rows, 8 * cout), dtype=x.dtype, device=x.device)
+            gemm_nt(x, wp, tmp, M=rows, N=8 * cout, K=cin, lda=ldx, ldb=wp.shape[-1], ldc=8 * cout)
+            _lib.call("dp_pixel_shuffle2", _p(tmp), _p(y), N, D, H, W, cout, cout, _dt(x), _stream())
         ctx.save_for_backward(x, weight)
         return y
 

@@ -191,11 +191,23 @@ int dp_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C,
  * multiples of 128, lda / ldb multiples of 8, 16-byte aligned operands); total_tiles = sum over problems of ceil(M/T) * ceil(N/T). */
 int dp_gemm_tn_grouped(const void* table, int nproblems, int64_t total_tiles, int dtype, void* stream);
 
-/* skinny pointwise (1x1x1) convolution over voxel rows, Cin <= 64 and Cout <= 32: y[v][co] = sum_ci x[v][ci] w[co*ldw + ci] (+bias).
- * HBM-bound row stream on the vector ALU.  replaces: nn.Conv3d k1 at the 128^3 / 64^3 levels (blocks_MDUNet.py:146,
- * dose_pyfer.py:292,353) forward, and their data gradient with a transposed weight matrix. */
+/* skinny row GEMM over voxel rows: y[v][co] = sum_ci x[v][ci] w[co*ldw + ci] (+bias).  Two kernels:
+ *   - the matrix-core row kernel (k_pointwise_mfma: weights as the MFMA A operand in registers, a lane's B fragment one 16-byte
+ *     global load, no LDS, 16-byte stores) for the shapes dp_rows_mfma_ok() accepts -- 16-bit storage, 16 <= Cin <= 128, Cout > 8,
+ *     16-byte aligned rows;
+ *   - otherwise an HBM-bound row stream on the vector ALU, Cin <= 64 and Cout <= 32 (every dtype).
+ * replaces: nn.Conv3d k1 at the 128^3 / 64^3 levels (blocks_MDUNet.py:146, dose_pyfer.py:292,353) forward and their data gradient
+ * with a transposed weight matrix; the ConvTranspose3d k2 s2 data gradient (base_blocks.py:118-127). */
 int dp_pointwise_rows(const void* x, int ldx, const void* w, int ldw, const float* bias, void* y, int ldy, int64_t rows, int Cin, int Cout,
                       int dtype, void* stream);
+int dp_rows_mfma_ok(int ldx, int ldw, int ldy, int Cin, int Cout, int dtype);
+/* nn.ConvTranspose3d(kernel 2, stride 2, bias=False) forward in ONE launch (base_blocks.py:118-127; MONAI UnetrPrUpBlock): the row
+ * GEMM [voxels x Cin] x [Cin x 8 Cout] with the 2x2x2 pixel shuffle in its store.  w: [(abc, co)][ldw] (dp_pack_multi kind 1 / 2 of the
+ * permuted weight), y: NDHWC of the (2D, 2H, 2W) volume, pitch ldy.  Returns 3 WITHOUT launching when the shape is outside the kernel
+ * (dp_rows_mfma_ok(ldx, ldw, ldy, Cin, 8 Cout, dtype), Cout % 8 == 0, N D H W < 2^24, 16-byte aligned x / y): the caller then runs
+ * dp_gemm_nt + dp_pixel_shuffle2. */
+int dp_tconv2x_fwd(const void* x, int ldx, const void* w, int ldw, void* y, int ldy, int N, int D, int H, int W, int Cin, int Cout, int dtype,
+                   void* stream);
 /* Weight + bias gradient of that skinny pointwise conv (the deep-supervision heads, dose_pyfer.py:330-350; autograd of
  * nn.Conv3d k=1): dw[co*s_co + ci] = sum_v gy[v][co] x[v][ci] (fp32), db[co] = sum_v gy[v][co] (db may be NULL).
  * Cin in {<=8, 16, 32, 64}, Cout <= 16.  ws: fp32 workspace of dp_pointwise_wgrad_ws_elems() elements (0 = unsupported

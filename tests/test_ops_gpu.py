@@ -189,7 +189,12 @@ def test_conv3d_channel_slice_and_padding(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cfg", [(2, 48, 8, 2, 1, 1), (1, 32, 16, 4, 4, 4), (1, 768, 128, 2, 2, 2), (1, 6, 3, 3, 3, 3)])
+@pytest.mark.parametrize("cfg", [(2, 48, 8, 2, 1, 1), (1, 32, 16, 4, 4, 4), (1, 768, 128, 2, 2, 2), (1, 6, 3, 3, 3, 3),
+                                 # >= 32768 voxels: the one-launch forward (dp_tconv2x_fwd, pixel shuffle in the store) and the matrix-core row
+                                 # kernel for the data gradient (K = 8 Cout up to 128): one / two / four 32-channel chunks, ragged Cin, a non-cubic
+                                 # volume whose extents are not powers of two, Cout = 8 (8-byte stores), and a shape outside (Cout = 12)
+                                 (2, 32, 16, 32, 32, 32), (1, 64, 16, 32, 32, 40), (1, 128, 16, 32, 32, 32), (2, 40, 8, 24, 28, 36),
+                                 (1, 32, 12, 32, 32, 40), (1, 96, 32, 32, 32, 32)])
 def test_conv_transpose(cfg, dtype):
     from dose_prediction_amd import ops
     dev = _dev()
