@@ -645,7 +645,7 @@ template <typename T> __device__ __forceinline__ unsigned pw_pack2(float a, floa
   T lo, hi; st_f(&lo, a); st_f(&hi, b);
   return (unsigned)__builtin_bit_cast(unsigned short, lo) | ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16);
 }
-// Generalised in the same round to every skinny row GEMM of the step (grid.y walks the output columns in tiles of 16 NT, up to 128
+// Generalised in the same round to every skinny row GEMM of the step (grid.y walks the output columns in tiles of 16 NT, up to 256
 // input channels): ConvTranspose 2 x 2 x 2 forward (K = Cin, 8 Cout columns) and data gradient (K = 8 Cout), the data gradients of
 // the mixers -- the generic 128 x 128-tile GEMM moved 0.9-1.7 TB/s on these shapes.  ShuffleGeom: ConvTranspose forward with the
 // 2 x 2 x 2 pixel shuffle in the store: column group g = 4a + 2b + c (cg channels each) of input voxel (n, d, h, w) IS output voxel
@@ -661,7 +661,7 @@ __device__ __forceinline__ unsigned div_small(unsigned v, unsigned d, float rd) 
 template <typename T, int KC, int NT>
 __global__ void __launch_bounds__(256) k_pointwise_mfma(const T* __restrict__ x, int ldx, const T* __restrict__ w, int ldw, const float* __restrict__ bias,
                                                         T* __restrict__ y, int ldy, int64_t rows, int Cin, int Cout, ShuffleGeom sg) {
-  constexpr int U = KC >= 3 ? 2 : 4;
+  constexpr int U = KC >= 5 ? 1 : KC >= 3 ? 2 : 4;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 15, q = lane >> 4;
   const int n0 = blockIdx.y * 16 * NT;
   Frag8<T> aw[NT][KC];
@@ -735,11 +735,11 @@ __global__ void __launch_bounds__(256) k_pointwise_mfma(const T* __restrict__ x,
   }
 }
 
-// Shapes the matrix-core row kernel takes: 16-bit storage, 16 <= Cin <= 128, more than 8 output columns, rows readable in 16-byte
+// Shapes the matrix-core row kernel takes: 16-bit storage, 16 <= Cin <= 256, more than 8 output columns, rows readable in 16-byte
 // pieces up to Cin rounded up to 8, 16-byte aligned output rows (pointer alignment is checked at the launch).
 extern "C" int dp_rows_mfma_ok(int ldx, int ldw, int ldy, int Cin, int Cout, int dtype) {
   static const int mfma_on = [] { const char* e = getenv("DP_POINTWISE_MFMA"); return e ? atoi(e) : 1; }();
-  return mfma_on && (dtype == DP_BF16 || dtype == DP_F16) && Cin >= 16 && Cin <= 128 && Cout > 8 && (Cin + 7) / 8 * 8 <= ldx && ldx % 8 == 0 && ldy % 8 == 0 &&
+  return mfma_on && (dtype == DP_BF16 || dtype == DP_F16) && Cin >= 16 && Cin <= 256 && Cout > 8 && (Cin + 7) / 8 * 8 <= ldx && ldx % 8 == 0 && ldy % 8 == 0 &&
          ldw >= Cin;
 }
 static int rows_mfma_launch(const void* x, int ldx, const void* w, int ldw, const float* bias, void* y, int ldy, int64_t rows, int Cin, int Cout, int dtype,
@@ -748,7 +748,8 @@ static int rows_mfma_launch(const void* x, int ldx, const void* w, int ldw, cons
   const int64_t tiles = (rows + 15) / 16;
   int64_t g = (tiles + 15) / 16; if (g * ny > 4096) g = (4096 + ny - 1) / ny; if (g < 1) g = 1;
 #define GOM(TT, KC_, NT_) hipLaunchKernelGGL((k_pointwise_mfma<TT, KC_, NT_>), dim3((unsigned)g, ny), dim3(256), 0, s, (const TT*)x, ldx, (const TT*)w, ldw, bias, (TT*)y, ldy, rows, Cin, Cout, sg)
-#define GOMK(TT, NT_) do { if (kc == 1) GOM(TT, 1, NT_); else if (kc == 2) GOM(TT, 2, NT_); else if (kc == 3) GOM(TT, 3, NT_); else GOM(TT, 4, NT_); } while (0)
+#define GOMK(TT, NT_) do { if (kc == 1) GOM(TT, 1, NT_); else if (kc == 2) GOM(TT, 2, NT_); else if (kc == 3) GOM(TT, 3, NT_); else if (kc == 4) GOM(TT, 4, NT_); \
+                            else GOM(TT, 8, NT_); } while (0)      /* (5-8 chunks: the eight-chunk instance, absent chunks masked) */
 #define GOMT(TT) do { if (nt == 1) GOMK(TT, 1); else GOMK(TT, 2); } while (0)
   if (dtype == DP_BF16) GOMT(bf16_t); else GOMT(f16_t);
 #undef GOMT

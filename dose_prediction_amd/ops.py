@@ -421,8 +421,8 @@ def gemm_nt(A, B, out, bias=None, alpha=1.0, M=None, N=None, K=None, batch=(1, 1
         raise ValueError("split-K needs an fp32 output")
     if batch == (1, 1) and splitk == 1 and not out_f32 and alpha == 1.0 and M >= 32768 and out.dtype == A.dtype:
         # millions of voxel rows x a handful of channels: a row stream, not a tiled GEMM -- the matrix-core row kernel where it applies
-        # (16-bit storage, up to 128 input channels: pointwise convolutions, ConvTranspose data gradients), the VALU stream otherwise
-        if ((K <= _PW_MAXK and N <= 32) or (A.dtype != torch.float32 and K <= 128 and _p(A) % 16 == 0 and _p(out) % 16 == 0
+        # (16-bit storage, up to 256 input channels: pointwise convolutions, ConvTranspose data gradients), the VALU stream otherwise
+        if ((K <= _PW_MAXK and N <= 32) or (A.dtype != torch.float32 and K <= 256 and _p(A) % 16 == 0 and _p(out) % 16 == 0
                                             and _lib.lib().dp_rows_mfma_ok(lda, ldb, ldc, K, N, _dt(A)))):
             _lib.call("dp_pointwise_rows", _p(A), lda, _p(B), ldb, _p(bias), _p(out), ldc, M, K, N, _dt(A), _stream())
             return

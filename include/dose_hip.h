@@ -193,7 +193,7 @@ int dp_gemm_tn_grouped(const void* table, int nproblems, int64_t total_tiles, in
 
 /* skinny row GEMM over voxel rows: y[v][co] = sum_ci x[v][ci] w[co*ldw + ci] (+bias).  Two kernels:
  *   - the matrix-core row kernel (k_pointwise_mfma: weights as the MFMA A operand in registers, a lane's B fragment one 16-byte
- *     global load, no LDS, 16-byte stores) for the shapes dp_rows_mfma_ok() accepts -- 16-bit storage, 16 <= Cin <= 128, Cout > 8,
+ *     global load, no LDS, 16-byte stores) for the shapes dp_rows_mfma_ok() accepts -- 16-bit storage, 16 <= Cin <= 256, Cout > 8,
  *     16-byte aligned rows;
  *   - otherwise an HBM-bound row stream on the vector ALU, Cin <= 64 and Cout <= 32 (every dtype).
  * replaces: nn.Conv3d k1 at the 128^3 / 64^3 levels (blocks_MDUNet.py:146, dose_pyfer.py:292,353) forward and their data gradient

@@ -194,7 +194,7 @@ def test_conv3d_channel_slice_and_padding(dtype):
                                  # kernel for the data gradient (K = 8 Cout up to 128): one / two / four 32-channel chunks, ragged Cin, a non-cubic
                                  # volume whose extents are not powers of two, Cout = 8 (8-byte stores), and a shape outside (Cout = 12)
                                  (2, 32, 16, 32, 32, 32), (1, 64, 16, 32, 32, 40), (1, 128, 16, 32, 32, 32), (2, 40, 8, 24, 28, 36),
-                                 (1, 32, 12, 32, 32, 40), (1, 96, 32, 32, 32, 32)])
+                                 (1, 32, 12, 32, 32, 40), (1, 96, 32, 32, 32, 32), (1, 256, 24, 32, 32, 32)])
 def test_conv_transpose(cfg, dtype):
     from dose_prediction_amd import ops
     dev = _dev()
