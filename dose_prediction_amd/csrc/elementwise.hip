@@ -735,10 +735,105 @@ __global__ void __launch_bounds__(256) k_pointwise_mfma(const T* __restrict__ x,
   }
 }
 
+// The fp32x3 mode's twin (dtype DP_X3 / DP_X1): fp32 rows and fp32 weights in HBM, split into bf16 halves IN REGISTERS (a lane's B
+// fragment is two 16-byte loads of eight floats -> x_hi, x_lo), three products x_hi w_hi + x_lo w_hi + x_hi w_lo (DP_X3: forward
+// passes) or x_hi w_hi alone (DP_X1: the one-product data gradients), fp32 results as 16-byte stores.  Replaces the exact-fp32 tiled
+// GEMM on the skinny shapes (ConvTranspose forward / data gradient, mixer data gradients: 0.16-0.26 ms launches at 1.3 TB/s).
+__device__ __forceinline__ void split8(const float* v, int nv, Frag8<bf16_t>& hi, Frag8<bf16_t>& lo) {
+#pragma unroll
+  for (int d = 0; d < 4; d++) {
+    const float a = 2 * d < nv ? v[2 * d] : 0.f, b = 2 * d + 1 < nv ? v[2 * d + 1] : 0.f;
+    const bf16_t ah = f2bf(a), bh = f2bf(b);
+    hi.u[d] = (unsigned)ah | ((unsigned)bh << 16);
+    lo.u[d] = (unsigned)f2bf(a - bf2f(ah)) | ((unsigned)f2bf(b - bf2f(bh)) << 16);
+  }
+}
+template <int KC, int NT>
+__global__ void __launch_bounds__(256) k_rows_mfma_f32(const float* __restrict__ x, int ldx, const float* __restrict__ w, int ldw, const float* __restrict__ bias,
+                                                       float* __restrict__ y, int ldy, int64_t rows, int Cin, int Cout, int terms, ShuffleGeom sg) {
+  constexpr int U = KC >= 3 ? 1 : 2;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 15, q = lane >> 4;
+  const int n0 = blockIdx.y * 16 * NT;
+  Frag8<bf16_t> awh[NT][KC], awl[NT][KC];
+  int nvk[KC];                                                // valid channels of the lane's eight in chunk kc
+#pragma unroll
+  for (int kc = 0; kc < KC; kc++) {
+    const int k0 = kc * 32 + q * 8;
+    nvk[kc] = Cin - k0 < 0 ? 0 : (Cin - k0 > 8 ? 8 : Cin - k0);
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+      const int co = n0 + (NT == 2 ? 8 * (r >> 2) + 4 * nt + (r & 3) : r);
+      float wv8[8];
+#pragma unroll
+      for (int e = 0; e < 8; e++) wv8[e] = (co < Cout && e < nvk[kc]) ? w[(int64_t)co * ldw + k0 + e] : 0.f;
+      split8(wv8, 8, awh[nt][kc], awl[nt][kc]);
+    }
+  }
+  const int c0 = n0 + (NT == 2 ? 8 * q : 4 * q);
+  float bv[NT][4];
+#pragma unroll
+  for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+    for (int e = 0; e < 4; e++) bv[nt][e] = (bias && c0 + 4 * nt + e < Cout) ? bias[c0 + 4 * nt + e] : 0.f;
+  const int grp = sg.cg ? c0 / sg.cg : 0, cs = sg.cg ? c0 - grp * sg.cg : c0;
+  const int ga = grp >> 2, gb = (grp >> 1) & 1, gc = grp & 1;
+  const bool three = terms == 3;
+  const int64_t ntiles = (rows + 15) / 16, wave = (int64_t)blockIdx.x * 4 + wv, nwaves = (int64_t)gridDim.x * 4;
+  for (int64_t t0 = wave * U; t0 < ntiles; t0 += nwaves * U) {
+    v4f raw[U][KC][2];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      int64_t v = (t0 + u) * 16 + r; v = v < rows ? v : rows - 1;
+#pragma unroll
+      for (int kc = 0; kc < KC; kc++) {
+        const float* p = x + v * ldx + (nvk[kc] ? kc * 32 + q * 8 : 0);      // (chunks beyond Cin: any valid address, zeroed by the split)
+        raw[u][kc][0] = *(const v4f*)p; raw[u][kc][1] = *(const v4f*)(p + 4);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int64_t v = (t0 + u) * 16 + r;
+      v4f acc[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++) acc[nt] = (v4f){bv[nt][0], bv[nt][1], bv[nt][2], bv[nt][3]};
+#pragma unroll
+      for (int kc = 0; kc < KC; kc++) {
+        const float f8[8] = {raw[u][kc][0][0], raw[u][kc][0][1], raw[u][kc][0][2], raw[u][kc][0][3], raw[u][kc][1][0], raw[u][kc][1][1], raw[u][kc][1][2], raw[u][kc][1][3]};
+        Frag8<bf16_t> bh, bl;
+        split8(f8, nvk[kc], bh, bl);
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) {
+          acc[nt] = mma16(awh[nt][kc], bh, acc[nt]);
+          if (three) { acc[nt] = mma16(awh[nt][kc], bl, acc[nt]); acc[nt] = mma16(awl[nt][kc], bh, acc[nt]); }
+        }
+      }
+      if (v >= rows) continue;
+      int64_t orow = v;
+      if (sg.cg) {
+        const unsigned vv = (unsigned)v, q1 = div_small(vv, sg.W, sg.rW), ww = vv - q1 * sg.W, q2 = div_small(q1, sg.H, sg.rH), hh = q1 - q2 * sg.H,
+                       nn = div_small(q2, sg.D, sg.rD), dd = q2 - nn * sg.D;
+        orow = (((int64_t)nn * 2 * sg.D + 2 * dd + ga) * 2 * sg.H + 2 * hh + gb) * 2 * sg.W + 2 * ww + gc;
+      }
+      float* yo = y + orow * ldy + cs;
+      if (c0 + 4 * NT <= Cout) {
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) *(v4f*)(yo + 4 * nt) = acc[nt];
+      } else {
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+          for (int e = 0; e < 4; e++) if (c0 + 4 * nt + e < Cout) yo[4 * nt + e] = acc[nt][e];
+      }
+    }
+  }
+}
+
 // Shapes the matrix-core row kernel takes: 16-bit storage, 16 <= Cin <= 256, more than 8 output columns, rows readable in 16-byte
 // pieces up to Cin rounded up to 8, 16-byte aligned output rows (pointer alignment is checked at the launch).
 extern "C" int dp_rows_mfma_ok(int ldx, int ldw, int ldy, int Cin, int Cout, int dtype) {
   static const int mfma_on = [] { const char* e = getenv("DP_POINTWISE_MFMA"); return e ? atoi(e) : 1; }();
+  if (dtype == DP_X3 || dtype == DP_X1)      // fp32 rows, split in registers: up to 128 input channels, rows readable / writable in 16-byte pieces
+    return mfma_on && Cin >= 16 && Cin <= 128 && Cout > 8 && (Cin + 7) / 8 * 8 <= ldx && ldx % 4 == 0 && ldy % 4 == 0 && ldw >= Cin;
   return mfma_on && (dtype == DP_BF16 || dtype == DP_F16) && Cin >= 16 && Cin <= 256 && Cout > 8 && (Cin + 7) / 8 * 8 <= ldx && ldx % 8 == 0 && ldy % 8 == 0 &&
          ldw >= Cin;
 }
@@ -751,7 +846,12 @@ static int rows_mfma_launch(const void* x, int ldx, const void* w, int ldw, cons
 #define GOMK(TT, NT_) do { if (kc == 1) GOM(TT, 1, NT_); else if (kc == 2) GOM(TT, 2, NT_); else if (kc == 3) GOM(TT, 3, NT_); else if (kc == 4) GOM(TT, 4, NT_); \
                             else GOM(TT, 8, NT_); } while (0)      /* (5-8 chunks: the eight-chunk instance, absent chunks masked) */
 #define GOMT(TT) do { if (nt == 1) GOMK(TT, 1); else GOMK(TT, 2); } while (0)
-  if (dtype == DP_BF16) GOMT(bf16_t); else GOMT(f16_t);
+#define GOF(KC_, NT_) hipLaunchKernelGGL((k_rows_mfma_f32<KC_, NT_>), dim3((unsigned)g, ny), dim3(256), 0, s, (const float*)x, ldx, (const float*)w, ldw, bias, (float*)y, ldy, rows, Cin, Cout, dtype == DP_X3 ? 3 : 1, sg)
+#define GOFK(NT_) do { if (kc == 1) GOF(1, NT_); else if (kc == 2) GOF(2, NT_); else if (kc == 3) GOF(3, NT_); else GOF(4, NT_); } while (0)
+  if (dtype == DP_X3 || dtype == DP_X1) { if (nt == 1) GOFK(1); else GOFK(2); }
+  else if (dtype == DP_BF16) GOMT(bf16_t); else GOMT(f16_t);
+#undef GOFK
+#undef GOF
 #undef GOMT
 #undef GOMK
 #undef GOM

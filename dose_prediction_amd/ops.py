@@ -414,8 +414,10 @@ _PW_MAXK = int(os.environ.get("DOSE_HIP_PW_MAXK", "64"))
 
 
 def gemm_nt(A, B, out, bias=None, alpha=1.0, M=None, N=None, K=None, batch=(1, 1), sa=(0, 0), sb=(0, 0), sc=(0, 0),
-            lda=None, ldb=None, ldc=None, splitk=1):
-    """out[m][n] = alpha * sum_k A[m][k] B[n][k] (+bias).  A, B share dtype; out dtype float32 => fp32 output."""
+            lda=None, ldb=None, ldc=None, splitk=1, x3_terms=None):
+    """out[m][n] = alpha * sum_k A[m][k] B[n][k] (+bias).  A, B share dtype; out dtype float32 => fp32 output.
+    x3_terms (fp32 operands in the fp32x3 mode only): 3 / 1 = the caller accepts split-bf16 products (three: forward passes, one: the
+    one-product data gradients) where the matrix-core row kernel takes the shape; None = exact fp32 arithmetic."""
     out_f32 = 1 if (out.dtype == torch.float32 and A.dtype != torch.float32) or splitk > 1 else 0
     if splitk > 1 and out.dtype != torch.float32:
         raise ValueError("split-K needs an fp32 output")
@@ -426,8 +428,23 @@ def gemm_nt(A, B, out, bias=None, alpha=1.0, M=None, N=None, K=None, batch=(1, 1
                                             and _lib.lib().dp_rows_mfma_ok(lda, ldb, ldc, K, N, _dt(A)))):
             _lib.call("dp_pointwise_rows", _p(A), lda, _p(B), ldb, _p(bias), _p(out), ldc, M, K, N, _dt(A), _stream())
             return
+        xdt = {3: DP_X3, 1: DP_X1}.get(x3_terms)
+        if (xdt is not None and A.dtype == torch.float32 and K <= 128 and _p(A) % 16 == 0 and _p(out) % 16 == 0
+                and _lib.lib().dp_rows_mfma_ok(lda, ldb, ldc, K, N, xdt)):
+            # fp32x3: fp32 rows split into bf16 halves in registers (k_rows_mfma_f32) instead of the exact-fp32 tiled GEMM
+            _lib.call("dp_pointwise_rows", _p(A), lda, _p(B), ldb, _p(bias), _p(out), ldc, M, K, N, xdt, _stream())
+            return
     _lib.call("dp_gemm_nt", _p(A), lda, sa[0], sa[1], _p(B), ldb, sb[0], sb[1], _p(out), ldc, sc[0], sc[1], _p(bias),
               M, N, K, batch[0], batch[1], float(alpha), out_f32, splitk, _dt(A), _stream())
+
+
+def _x3_terms(forward):
+    """Split products a contraction may use in the CURRENT mode: None outside fp32x3 (exact arithmetic of the storage type), 3 for a
+    forward pass, config.x3_dgrad_terms() for a data gradient."""
+    from . import config
+    if not config.x3():
+        return None
+    return 3 if forward else config.x3_dgrad_terms()
 
 
 def colsum_into(gy2d_rows, ld, rows, C, db, dtype_code):
@@ -653,7 +670,7 @@ class Conv3d(torch.autograd.Function):
                           N, Di, Hi, Wi, cin, cout, k, _dt(x), _stream())
         elif k == 1 and stride == 1 and pad == 0:
             wp = _pack_conv(weight, 0, x.dtype)
-            gemm_nt(x, wp, y, bias=b32, M=rows, N=cout, K=cin, lda=ldx, ldb=wp.shape[-1], ldc=cout)
+            gemm_nt(x, wp, y, bias=b32, M=rows, N=cout, K=cin, lda=ldx, ldb=wp.shape[-1], ldc=cout, x3_terms=_x3_terms(True))
         elif N * Do * Ho * Wo <= 16384 and cin >= 32 and N * Do * Ho * Wo * k ** 3 * cin <= (1 << 26):
             # few output voxels, many channels (deep C3D stages): gather once, then ONE GEMM with K = taps * Cin
             wp = _pack_conv(weight, 0, x.dtype)                  # [Cout][tap][CinP]
@@ -695,7 +712,7 @@ class Conv3d(torch.autograd.Function):
                 gx.zero_()
             if k == 1 and stride == 1 and pad == 0:
                 wt = _pack_conv(weight, 1, x.dtype)          # [Cin][1][CoutP]
-                gemm_nt(gy, wt, gx, M=grows, N=cin, K=cout, lda=ldg, ldb=wt.shape[-1], ldc=cx)
+                gemm_nt(gy, wt, gx, M=grows, N=cin, K=cout, lda=ldg, ldb=wt.shape[-1], ldc=cx, x3_terms=_x3_terms(False))
             elif stride == 1 and _tiled_elems(cout, cin, k, 1, dil * (k - 1) - pad, dil, Wo):
                 te = _tiled_elems(cout, cin, k, 1, dil * (k - 1) - pad, dil, Wo)
                 wq = _pack_conv_tiled(weight, 1, x.dtype, te, Wo)
@@ -897,8 +914,9 @@ class ConvTranspose2x(torch.autograd.Function):
         y = torch.empty((N, 2 * D, 2 * H, 2 * W, cout), dtype=x.dtype, device=x.device)
         # one launch where the matrix-core row kernel takes the shape (the pixel shuffle is its store pattern) ...
         rc = 3
-        if rows >= 32768 and x.dtype != torch.float32:
-            rc = _lib.call("dp_tconv2x_fwd", _p(x), ldx, _p(wp), wp.shape[-1], _p(y), cout, N, D, H, W, cin, cout, _dt(x), _stream())
+        if rows >= 32768 and (x.dtype != torch.float32 or _x3_terms(True)):
+            rc = _lib.call("dp_tconv2x_fwd", _p(x), ldx, _p(wp), wp.shape[-1], _p(y), cout, N, D, H, W, cin, cout,
+                           DP_X3 if x.dtype == torch.float32 else _dt(x), _stream())
         if rc == 3:
             # ... else the GEMM into a [voxels][8 Cout] intermediate and the shuffle pass
             tmp = torch.empty((rows, 8 * cout), dtype=x.dtype, device=x.device)
@@ -924,7 +942,7 @@ class ConvTranspose2x(torch.autograd.Function):
             gx = torch.empty((N, D, H, W, cx), dtype=x.dtype, device=x.device)
             if cx > cin:
                 gx.zero_()
-            gemm_nt(gu, wt, gx, M=rows, N=cin, K=8 * cout, lda=8 * cout, ldb=wt.shape[-1], ldc=cx)
+            gemm_nt(gu, wt, gx, M=rows, N=cin, K=8 * cout, lda=8 * cout, ldb=wt.shape[-1], ldc=cx, x3_terms=_x3_terms(False))
         if ctx.needs_input_grad[1]:
             wse = _lib.lib().dp_conv3d_wgrad_tiled_ws_elems(cin, 8 * cout, 1, 1, 0, 1, 1, W) if (USE_TILED and rows >= 32768) else 0
             if wse:

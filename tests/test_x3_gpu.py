@@ -286,6 +286,45 @@ def test_x3_linear(cfg):
             check("gb", bh.grad, br.grad)
 
 
+@pytest.mark.parametrize("cfg", [("tconv", 2, 32, 16, 32, 32, 32), ("tconv", 1, 64, 16, 32, 32, 40), ("tconv", 2, 40, 8, 24, 28, 36),
+                                 ("tconv", 1, 128, 16, 32, 32, 32), ("tconv", 1, 32, 12, 32, 32, 40), ("pw", 1, 96, 48, 32, 32, 40),
+                                 ("pw", 1, 32, 64, 32, 32, 40), ("pw", 2, 72, 24, 16, 31, 35)])
+def test_x3_row_kernel_conv_transpose_and_wide_pointwise(cfg):
+    """The skinny row GEMMs of the mode on fp32 rows split in registers (k_rows_mfma_f32, dtype codes DP_X3 / DP_X1): ConvTranspose
+    2x2x2 forward in one launch (pixel shuffle in the store) and its data gradient, pointwise convolutions wider than the VALU row
+    stream takes.  Three products: the mode's 3e-5; one-product data gradients (the default): bf16 operator tolerance."""
+    import dose_prediction_amd
+    from dose_prediction_amd import ops
+    dev = _dev()
+    kind, N, Cin, Cout, D, H, W = cfg
+    x = rnd((N, Cin, D, H, W), 1) * 1.3 + 0.2
+    if kind == "tconv":
+        w = rnd((Cin, Cout, 2, 2, 2), 2, Cin ** -0.5)
+        f_ref = lambda xx, ww: oracle.conv_transpose3d_k2s2(xx, ww)
+        f_hip = lambda xx, ww: ops.conv_transpose2x(xx, ww)
+    else:
+        w = rnd((Cout, Cin, 1, 1, 1), 2, Cin ** -0.5)
+        f_ref = lambda xx, ww: oracle.conv3d(xx, ww, None, 1, 0, 1)
+        f_hip = lambda xx, ww: ops.conv3d(xx, ww, None, 1, 0, 1)
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    yr = f_ref(xr, wr)
+    r = rnd(yr.shape, 3)
+    (yr * r.double()).sum().backward()
+    for terms in (3, 1):
+        dose_prediction_amd.config.set_x3_dgrad_terms(terms)
+        xh, wh = ndhwc(x).to(dev).requires_grad_(True), w.to(dev).requires_grad_(True)
+        yh = f_hip(xh, wh)
+        yh.backward(ndhwc(r).to(dev))
+        check(f"y ({terms})", ncdhw(yh), yr)
+        check(f"gw ({terms})", wh.grad, wr.grad)
+        e = rel_l2(ncdhw(xh.grad).cpu(), xr.grad)
+        k_dgrad = 8 * Cout if kind == "tconv" else Cout
+        if terms == 3 or k_dgrad > 128 or k_dgrad < 16 or (k_dgrad <= 64 and Cin <= 32):
+            assert e < TOL_L2, e          # (three products, or a contraction outside the row kernel / inside the exact VALU row stream)
+        else:
+            assert 1e-4 < e < 6e-3, e
+
+
 @pytest.mark.parametrize("cfg", [(2, 512, 6, 128), (1, 77, 12, 64)])
 def test_x3_attention_backward_three_vs_one_product(cfg):
     """softmax(q k^T d^-1/2) v on fp32 qkv: the forward pass is the exact-fp32 GEMM + row-softmax path in both settings; with
