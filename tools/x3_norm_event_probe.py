@@ -1,0 +1,42 @@
+"""Rare discrete events in ops.norm_act forward + backward (fp32 storage; MODE=fp32x3 selects the fast Mish): repeated on fixed data."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import dose_prediction_amd  # noqa: E402
+from dose_prediction_amd import ops  # noqa: E402
+
+dose_prediction_amd.set_compute_dtype(os.environ.get("MODE", "fp32x3"))
+dev = torch.device("cuda:0")
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+torch.manual_seed(7)
+for kind in ("instance", "batch"):
+    for act in ("mish", "relu", "lrelu", None):
+        for C in (4, 8, 16):
+            for with_res in (False, True):
+                shape = (2, 32, 16, 16, C)
+                x, r = torch.randn(shape, device=dev), torch.randn(shape, device=dev)
+                res = torch.randn(shape, device=dev) if with_res else None
+                gam = torch.randn(C, device=dev) if kind == "batch" else None
+                bet = torch.randn(C, device=dev) if kind == "batch" else None
+                ref, ev, worst = None, 0, 0.0
+                for it in range(reps):
+                    xa = x.clone().requires_grad_(True)
+                    ra = res.clone().requires_grad_(True) if with_res else None
+                    ga = gam.clone().requires_grad_(True) if gam is not None else None
+                    ba = bet.clone().requires_grad_(True) if bet is not None else None
+                    y = ops.norm_act(xa, kind, ga, ba, None, None, training=True, res=ra, act=act)
+                    y.backward(r)
+                    cur = [y.detach(), xa.grad] + ([ra.grad] if with_res else []) + ([ga.grad, ba.grad] if ga is not None else [])
+                    if ref is None:
+                        ref = [t.clone() for t in cur]
+                        continue
+                    d = max(float((a - b).norm() / (b.norm() + 1e-30)) for a, b in zip(cur, ref))
+                    worst = max(worst, d)
+                    ev += d > 1e-5
+                if ev or worst > 0:
+                    print(f"norm_act {kind} {act} C={C} res={with_res}: events {ev} of {reps - 1}; largest difference {worst:.1e}")
+print("done")
