@@ -21,19 +21,33 @@ __global__ void __launch_bounds__(256) k_split_rows(const float* __restrict__ a,
                                                     bf16_t* __restrict__ dst, int cp, int parts, int pattern, int64_t rows, int ppr_shift) {
   const int ppr = cp >> 3;
   const int64_t total = rows * ppr;
-  const bool va = ((lda & 3) == 0) && (((uintptr_t)a & 15) == 0) && ((ca & 7) == 0);
-  const bool vb = !b || (((ldb & 3) == 0) && (((uintptr_t)b & 15) == 0));
+  // 16-byte loads wherever the eight elements lie inside the source's row PITCH (not only inside its used channels): a 25-channel
+  // input stored with pitch 32 is read in whole pieces and masked in registers (round 4: the scalar path took 0.31 ms for the
+  // network input where the aligned 32-channel case takes 0.21)
+  const bool va = ((lda & 3) == 0) && (((uintptr_t)a & 15) == 0);
+  const bool vb = b && ((ldb & 3) == 0) && (((uintptr_t)b & 15) == 0);
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t row = ppr_shift >= 0 ? (i >> ppr_shift) : i / ppr;
     const int c0 = (int)(i - row * ppr) * 8;
     float v[8];
-    if (c0 + 8 <= ca && va) {
+    if (c0 < ca && va && c0 + 8 <= lda) {
       const v4f p0 = *(const v4f*)(a + row * lda + c0), p1 = *(const v4f*)(a + row * lda + c0 + 4);
       v[0] = p0[0]; v[1] = p0[1]; v[2] = p0[2]; v[3] = p0[3]; v[4] = p1[0]; v[5] = p1[1]; v[6] = p1[2]; v[7] = p1[3];
-    } else if (c0 >= ca && c0 + 8 <= ca + cb && vb && va) {
+      if (c0 + 8 > ca) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          const int c = c0 + j;
+          if (c >= ca) v[j] = c < ca + cb ? b[row * ldb + (c - ca)] : 0.f;
+        }
+      }
+    } else if (c0 >= ca && c0 < ca + cb && vb && ((c0 - ca) & 3) == 0 && c0 - ca + 8 <= ldb) {
       const float* s = b + row * ldb + (c0 - ca);
       const v4f p0 = *(const v4f*)s, p1 = *(const v4f*)(s + 4);
       v[0] = p0[0]; v[1] = p0[1]; v[2] = p0[2]; v[3] = p0[3]; v[4] = p1[0]; v[5] = p1[1]; v[6] = p1[2]; v[7] = p1[3];
+      if (c0 + 8 > ca + cb) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) if (c0 + j >= ca + cb) v[j] = 0.f;
+      }
     } else {
 #pragma unroll
       for (int j = 0; j < 8; j++) {
