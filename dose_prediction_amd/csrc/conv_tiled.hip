@@ -146,8 +146,11 @@ extern "C" int dp_pack_conv_weight_tiled(const float* w, void* dst, int Cout, in
 // WN: waves along N.  1: the four waves are TWC columns x TRG row groups over the SAME NT channel tiles.  2 (W16 tiles on planes of
 // <= 16 rows, Cout >= 128: the 16^3 level of the decoder): two row groups x two channel-tile groups -- with four row groups of
 // 4 x 2 image rows half of every block's MFMAs fell on rows >= H (7^3 at 16^3: 0.67 PFLOP/s against 1.1-1.4 at the other levels).
+#ifndef DP_TILED_MINB8
+#define DP_TILED_MINB8 2
+#endif
 template <typename T, int KS, int NPAIR, int RW, int NT, int TWP, typename TO, int WN = 1>
-__global__ void __launch_bounds__(256, 2) k_conv_tiled(const T* __restrict__ x, const T* __restrict__ wq, const float* __restrict__ bias,
+__global__ void __launch_bounds__(256, (RW == 8 ? DP_TILED_MINB8 : 2)) k_conv_tiled(const T* __restrict__ x, const T* __restrict__ wq, const float* __restrict__ bias,
                                                     TO* __restrict__ y, float* __restrict__ ws, TiledGeom g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* slab = (T*)smem_raw;
