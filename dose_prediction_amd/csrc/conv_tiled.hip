@@ -149,8 +149,11 @@ extern "C" int dp_pack_conv_weight_tiled(const float* w, void* dst, int Cout, in
 #ifndef DP_TILED_MINB8
 #define DP_TILED_MINB8 2
 #endif
+#ifndef DP_TILED_MINB4
+#define DP_TILED_MINB4 2
+#endif
 template <typename T, int KS, int NPAIR, int RW, int NT, int TWP, typename TO, int WN = 1>
-__global__ void __launch_bounds__(256, (RW == 8 ? DP_TILED_MINB8 : 2)) k_conv_tiled(const T* __restrict__ x, const T* __restrict__ wq, const float* __restrict__ bias,
+__global__ void __launch_bounds__(256, (RW == 8 ? DP_TILED_MINB8 : DP_TILED_MINB4)) k_conv_tiled(const T* __restrict__ x, const T* __restrict__ wq, const float* __restrict__ bias,
                                                     TO* __restrict__ y, float* __restrict__ ws, TiledGeom g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* slab = (T*)smem_raw;
