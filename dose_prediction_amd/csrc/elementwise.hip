@@ -899,16 +899,41 @@ __global__ void __launch_bounds__(256) k_pointwise_wgrad_rows(const T* __restric
 #pragma unroll
   for (int c = 0; c < COUT; c++) { accb[c] = 0.f; for (int j = 0; j < 8; j++) acc[c][j] = 0.f; }
   const int nv = min(8, Cin - chunk * 8);
-  for (int64_t r = (int64_t)blockIdx.x * RPI + roff; r < rows; r += (int64_t)gridDim.x * RPI) {
-    float t[8];
-    frag_unpack(frag_load(x + r * ldx + chunk * 8, nv), t);
-    const T* g = gy + r * ldgy;
+  // U rows per trip with every load issued before the first FMA, the gy row as 16-byte pieces (round 4: one row per trip with COUT
+  // scalar 2-byte loads was a dependent load -> FMA chain: 1.2 TB/s on the 7-OAR head of OAR-TRANSEG, 165 us for 201 MB)
+  constexpr int U = COUT >= 16 ? 2 : 4, GP = (COUT + 7) / 8;
+  const int64_t stride = (int64_t)gridDim.x * RPI;
+  for (int64_t r0 = (int64_t)blockIdx.x * RPI + roff; r0 < rows; r0 += stride * U) {
+    Frag8<T> xf[U], gf[U][GP];
 #pragma unroll
-    for (int c = 0; c < COUT; c++) {
-      float gv = c < Cout ? ld_f(g + c) : 0.f;
-      accb[c] += gv;
+    for (int u = 0; u < U; u++) {
+      const int64_t r = r0 + u * stride;
+      const bool ok = r < rows;
+      xf[u] = ok ? frag_load(x + r * ldx + chunk * 8, nv) : frag_zero<T>();
 #pragma unroll
-      for (int j = 0; j < 8; j++) acc[c][j] += gv * t[j];
+      for (int p8 = 0; p8 < GP; p8++) {
+        const int ng = min(8, Cout - p8 * 8);
+        gf[u][p8] = (ok && ng > 0) ? frag_load(gy + r * ldgy + p8 * 8, ng) : frag_zero<T>();
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      float t[8];
+      frag_unpack(xf[u], t);
+#pragma unroll
+      for (int p8 = 0; p8 < GP; p8++) {
+        float gvv[8];
+        frag_unpack(gf[u][p8], gvv);
+#pragma unroll
+        for (int cc = 0; cc < 8; cc++) {
+          const int c = p8 * 8 + cc;
+          if (c < COUT) {
+            accb[c] += gvv[cc];
+#pragma unroll
+            for (int j = 0; j < 8; j++) acc[c][j] += gvv[cc] * t[j];
+          }
+        }
+      }
     }
   }
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -956,7 +981,7 @@ extern "C" int dp_pointwise_wgrad_rows(const void* x, int ldx, const void* gy, i
   if (!ws) DP_FAIL("pointwise_wgrad_rows: workspace missing");
   int g = pw_wgrad_grid(rows, Cin), E = Cout * (Cin + 1);
 #define GO(CO) DP_DISPATCH(dtype, hipLaunchKernelGGL((k_pointwise_wgrad_rows<T, CO>), dim3(g), dim3(256), 0, STREAM, (const T*)x, ldx, (const T*)gy, ldgy, ws, rows, Cin, Cout, lg))
-  if (Cout <= 1) GO(1); else if (Cout <= 4) GO(4); else GO(16);
+  if (Cout <= 1) GO(1); else if (Cout <= 4) GO(4); else if (Cout <= 8) GO(8); else GO(16);
 #undef GO
   hipLaunchKernelGGL(k_pointwise_wgrad_finish, dim3(E), dim3(64), 0, STREAM, (const float*)ws, g, E, Cin, Cout, dw, s_co, db);
   DP_CHECK_LAUNCH("pointwise_wgrad_rows"); return 0;
