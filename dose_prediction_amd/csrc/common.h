@@ -123,6 +123,12 @@ __device__ __forceinline__ Frag8<T16> tr_pair(const T16* a) {
   return f;
 }
 
+// streaming weight gradient of the skinny row GEMMs (elementwise.hip), used by dp_conv3d_wgrad_tiled2 for k = 1
+bool wgrad_rows_ok(int ldx, int ldgy, int64_t rows, int Cin, int Cout, int dtype);
+int64_t wgrad_rows_ws_elems(int Cin, int Cout);
+int wgrad_rows_launch(const void* x, int ldx, const void* gy, int ldgy, float* dw, int64_t s_co, int64_t s_ci, float* part, int64_t rows, int Cin, int Cout,
+                      int dtype, int rezero, hipStream_t s);
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a release fence over ALL address spaces, which on
 // gfx9 is s_waitcnt vmcnt(0): every global load still in flight (the software-prefetched next tile) is drained at each
 // barrier.  Use this one when the barrier only publishes LDS data and the kernel has no global producer/consumer pair.

@@ -1282,7 +1282,8 @@ static inline bool wgt_applicable(int Cin, int Cout, int k, int stride, int pad,
 extern "C" int dp_conv3d_wgrad_tiled_ws_elems(int Cin, int Cout, int k, int stride, int pad, int dil, int shift, int W) {
   if (!wgt_applicable(Cin, Cout, k, stride, pad, dil, shift, W)) return 0;
   const int64_t base = (int64_t)k * k * k * Cin * Cout, hk = wgrad_hk_ws_elems(Cin, Cout, k);
-  const int64_t n = base > hk ? base : hk;
+  int64_t n = base > hk ? base : hk;
+  if (k == 1 && Cin <= 64 && Cout <= 32) { const int64_t rw = wgrad_rows_ws_elems(Cin, Cout); if (rw > n) n = rw; }   // per-block partials of k_wgrad_rows
   return n > 2000000000LL ? 0 : (int)n;
 }
 
@@ -1348,6 +1349,11 @@ extern "C" int dp_conv3d_wgrad_tiled2(const void* x, int ldx, const void* x2, in
                 (W <= tw || W % tw == 0);
     if (!fast) fprintf(stderr, "[dp slow] wgrad_tiled k=%d Cin=%d Cout=%d %dx%dx%d ldx=%d ldx2=%d csplit=%d ldgy=%d: some channel tiles stage GUARDED\n", k, Cin, Cout,
                        D, H, W, ldx, ldx2, csplit, ldgy);
+  }
+  if (k == 1 && !x2 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)gy & 15) == 0 && wgrad_rows_ok(ldx, ldgy, (int64_t)N * D * H * W, Cin, Cout, dtype)) {
+    // millions of voxel rows x a few dozen channels: the streaming kernel of elementwise.hip (deterministic two-stage sum, dW written directly)
+    wgrad_rows_launch(x, ldx, gy, ldgy, dw, s_co, s_ci, ws, (int64_t)N * D * H * W, Cin, Cout, dtype, g_scratch_zeroed, s);
+    DP_CHECK_LAUNCH("wgrad_rows"); return 0;
   }
   int rc = 0;
   const bool aligned = ldx % 8 == 0 && ldgy % 8 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)gy & 15) == 0 &&

@@ -987,6 +987,147 @@ extern "C" int dp_pointwise_wgrad_rows(const void* x, int ldx, const void* gy, i
   DP_CHECK_LAUNCH("pointwise_wgrad_rows"); return 0;
 }
 
+// Weight gradient of the skinny row GEMMs on the matrix cores (round 4): dW[co][ci] = sum_v gy[v][co] x[v][ci] over millions of voxel rows
+// -- the 1x1x1 mixers at the 128^3 / 64^3 levels (up to 32 output and 64 input channels).  The tiled weight-gradient kernel
+// (k_wgrad_tiled<T,1,1,1>: 64-voxel tiles, block-wide barriers) read these operands at 2.1-2.4 TB/s.  Here every WAVE runs its own
+// pipeline over 32-row slabs: 16-byte global loads of the slab after next are in flight while the current one goes through a
+// wave-private LDS image (rows as they lie in memory) and comes back as k-major MFMA fragments (ds_read_b64_tr_b16, the map of
+// gemm_tn_tile); no block barrier until the end, where the four waves' accumulators meet in LDS and the block writes ONE partial
+// [Cout][Cin] to the workspace.  A second small kernel adds the partials in a fixed order (deterministic), writes dW with the caller's
+// strides and hands the workspace back zeroed.
+template <typename T, int MT, int NT>
+__global__ void __launch_bounds__(256) k_wgrad_rows(const T* __restrict__ x, int ldx, const T* __restrict__ gy, int ldgy, float* __restrict__ part,
+                                                    int64_t rows, int Cin, int Cout) {
+  constexpr int GP = MT * 16 + 8, XP = NT * 16 + 8;            // LDS row pitches in elements (16-byte rows)
+  constexpr int WSZ = 32 * GP + 32 * XP;
+  __shared__ __attribute__((aligned(16))) T lds[4 * WSZ];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, q = lane >> 4, i16 = lane & 15;
+  T* gimg = lds + wv * WSZ; T* ximg = gimg + 32 * GP;
+  // 16-byte pieces of a slab: gy 32 rows x 2 MT pieces, x 32 rows x 2 NT pieces; piece p = lane + 64 i
+  int grow[MT], gcc[MT], xrow[NT], xcc[NT];
+#pragma unroll
+  for (int i = 0; i < MT; i++) { const int p = lane + 64 * i; grow[i] = p / (2 * MT); gcc[i] = (p % (2 * MT)) * 8; }
+#pragma unroll
+  for (int i = 0; i < NT; i++) { const int p = lane + 64 * i; xrow[i] = p / (2 * NT); xcc[i] = (p % (2 * NT)) * 8; }
+  const int64_t nslab = (rows + 31) / 32, wave = (int64_t)blockIdx.x * 4 + wv, nwaves = (int64_t)gridDim.x * 4;
+  v4f acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; m++)
+#pragma unroll
+    for (int n = 0; n < NT; n++) acc[m][n] = (v4f){0.f, 0.f, 0.f, 0.f};
+  v4u rg0[MT], rx0[NT], rg1[MT], rx1[NT];                      // two slabs in flight per wave
+  auto gload = [&](int64_t sl, v4u* rg, v4u* rx) __attribute__((always_inline)) {
+    const int64_t r0 = sl * 32;
+#pragma unroll
+    for (int i = 0; i < MT; i++) {
+      const int64_t r = r0 + grow[i];
+      const bool ok = r < rows && gcc[i] < Cout;                // (columns beyond Cout: zero rows of dW that are never stored)
+      const v4u v = *(const v4u*)(gy + (ok ? r * ldgy + gcc[i] : 0));
+      rg[i] = ok ? v : (v4u){0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int i = 0; i < NT; i++) {
+      const int64_t r = r0 + xrow[i];
+      const bool ok = r < rows && xcc[i] < Cin;
+      const v4u v = *(const v4u*)(x + (ok ? r * ldx + xcc[i] : 0));
+      rx[i] = ok ? v : (v4u){0, 0, 0, 0};
+    }
+  };
+  const int trg = (8 * q + (i16 >> 2)) * GP + 4 * (i16 & 3), trx = (8 * q + (i16 >> 2)) * XP + 4 * (i16 & 3);
+  auto step = [&](int64_t nxt, v4u* rg, v4u* rx) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < MT; i++) *(v4u*)(gimg + grow[i] * GP + gcc[i]) = rg[i];
+#pragma unroll
+    for (int i = 0; i < NT; i++) *(v4u*)(ximg + xrow[i] * XP + xcc[i]) = rx[i];
+    if (nxt < nslab) gload(nxt, rg, rx);                        // this register set's next slab flies during the LDS round trip and the MFMAs
+    __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier();
+    Frag8<T> fa[MT], fb[NT];
+#pragma unroll
+    for (int m = 0; m < MT; m++) fa[m] = tr_pair<4 * GP, T>(gimg + m * 16 + trg);
+#pragma unroll
+    for (int n = 0; n < NT; n++) fb[n] = tr_pair<4 * XP, T>(ximg + n * 16 + trx);
+#pragma unroll
+    for (int m = 0; m < MT; m++)
+#pragma unroll
+      for (int n = 0; n < NT; n++) acc[m][n] = mma16(fa[m], fb[n], acc[m][n]);
+    __builtin_amdgcn_wave_barrier();
+  };
+  if (wave < nslab) gload(wave, rg0, rx0);
+  if (wave + nwaves < nslab) gload(wave + nwaves, rg1, rx1);
+  for (int64_t sl = wave; sl < nslab; sl += 2 * nwaves) {
+    step(sl + 2 * nwaves, rg0, rx0);
+    if (sl + nwaves < nslab) step(sl + 3 * nwaves, rg1, rx1);
+  }
+  // the four waves' tiles meet in LDS (the images are dead): C layout col (ci) = lane & 15, row (co) = 4 (lane >> 4) + e
+  __syncthreads();
+  float* red = (float*)lds;                                    // [wave][MT*16][NT*16] floats: 4 * MT * NT * 256 * 4 B <= the image space?
+  constexpr int TILE = MT * 16 * NT * 16;
+  static_assert(4 * TILE * 4 <= 4 * WSZ * (int)sizeof(T) || TILE * 4 <= 4 * WSZ * (int)sizeof(T), "reduction space");
+  constexpr bool ALL4 = 4 * TILE * 4 <= 4 * WSZ * (int)sizeof(T);
+  if constexpr (ALL4) {
+#pragma unroll
+    for (int m = 0; m < MT; m++)
+#pragma unroll
+      for (int n = 0; n < NT; n++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) red[wv * TILE + (m * 16 + 4 * q + e) * (NT * 16) + n * 16 + i16] = acc[m][n][e];
+    __syncthreads();
+    float* dst = part + (int64_t)blockIdx.x * Cout * Cin;
+    for (int o = tid; o < Cout * Cin; o += 256) {
+      const int co = o / Cin, ci = o - co * Cin, a = co * (NT * 16) + ci;
+      dst[o] = red[a] + red[TILE + a] + red[2 * TILE + a] + red[3 * TILE + a];
+    }
+  } else {
+    // large tiles: the waves take turns adding into one tile
+    for (int w = 0; w < 4; w++) {
+      if (wv == w) {
+#pragma unroll
+        for (int m = 0; m < MT; m++)
+#pragma unroll
+          for (int n = 0; n < NT; n++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+              float* p_ = red + (m * 16 + 4 * q + e) * (NT * 16) + n * 16 + i16;
+              *p_ = (w ? *p_ : 0.f) + acc[m][n][e];
+            }
+      }
+      __syncthreads();
+    }
+    float* dst = part + (int64_t)blockIdx.x * Cout * Cin;
+    for (int o = tid; o < Cout * Cin; o += 256) { const int co = o / Cin, ci = o - co * Cin; dst[o] = red[co * (NT * 16) + ci]; }
+  }
+}
+__global__ void __launch_bounds__(64) k_wgrad_rows_finish(float* __restrict__ part, int nblk, int E, int Cin, float* __restrict__ dw, int64_t s_co, int64_t s_ci,
+                                                          int rezero) {
+  const int e = blockIdx.x;
+  float a = 0.f;
+  for (int b = threadIdx.x; b < nblk; b += 64) { a += part[(int64_t)b * E + e]; if (rezero) part[(int64_t)b * E + e] = 0.f; }
+  a = wave_sum(a);
+  if (threadIdx.x == 0) { const int co = e / Cin, ci = e - co * Cin; dw[co * s_co + ci * s_ci] = a; }
+}
+static int wgrad_rows_blocks(int64_t rows) { const int64_t slabs = (rows + 31) / 32; int64_t g = slabs / 16; return (int)(g > 1024 ? 1024 : (g < 1 ? 1 : g)); }
+// shapes the streaming weight-gradient kernel takes (16-bit storage; alignment of the pointers is checked by the caller)
+bool wgrad_rows_ok(int ldx, int ldgy, int64_t rows, int Cin, int Cout, int dtype) {
+  static const int on = [] { const char* e = getenv("DP_WGRAD_ROWS"); return e ? atoi(e) : 1; }();
+  return on && (dtype == DP_BF16 || dtype == DP_F16) && rows >= 32768 && Cin >= 8 && Cin <= 64 && Cout >= 8 && Cout <= 32 && Cout % 8 == 0 &&
+         ldx % 8 == 0 && ldgy % 8 == 0 && (Cin + 7) / 8 * 8 <= ldx && Cout <= ldgy;      // (wider outputs -- ConvTranspose's 8 Cout -- measured slower than the tiled kernel: 16 MB of partials)
+}
+int64_t wgrad_rows_ws_elems(int Cin, int Cout) { return (int64_t)1024 * Cin * Cout; }
+// dw[co * s_co + ci * s_ci] = sum_v gy[v][co] x[v][ci]; part: wgrad_rows_ws_elems() floats (zeroed on return when `rezero`)
+int wgrad_rows_launch(const void* x, int ldx, const void* gy, int ldgy, float* dw, int64_t s_co, int64_t s_ci, float* part, int64_t rows, int Cin, int Cout,
+                      int dtype, int rezero, hipStream_t s) {
+  const int mt = (Cout + 15) / 16, nt = (Cin + 15) / 16, g = wgrad_rows_blocks(rows);
+#define GOW(TT, MT_, NT_) hipLaunchKernelGGL((k_wgrad_rows<TT, MT_, NT_>), dim3(g), dim3(256), 0, s, (const TT*)x, ldx, (const TT*)gy, ldgy, part, rows, Cin, Cout)
+#define GOWN(TT, MT_) do { if (nt == 1) GOW(TT, MT_, 1); else if (nt == 2) GOW(TT, MT_, 2); else GOW(TT, MT_, 4); } while (0)
+#define GOWM(TT) do { if (mt == 1) GOWN(TT, 1); else GOWN(TT, 2); } while (0)
+  if (dtype == DP_BF16) GOWM(bf16_t); else GOWM(f16_t);
+#undef GOWM
+#undef GOWN
+#undef GOW
+  hipLaunchKernelGGL(k_wgrad_rows_finish, dim3(Cout * Cin), dim3(64), 0, s, part, g, Cout * Cin, Cin, dw, s_co, s_ci, rezero);
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------------ sliding-window stitching
 // MONAI sliding_window_inference (constant blend mode), call site train_light_linked_model.py:152-153: window predictions are
 // summed into an fp32 volume with a per-voxel visit count, then divided.  One thread per (window voxel, 8-channel chunk).

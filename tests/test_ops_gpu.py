@@ -102,6 +102,12 @@ DTYPES = [torch.float32, torch.bfloat16, torch.float16]
     (2, 32, 24, 16, 31, 35, 1, 1, 0, 1, True),
     (1, 64, 12, 32, 32, 40, 1, 1, 0, 1, True),
     (1, 16, 32, 32, 32, 40, 1, 1, 0, 1, True),    # (16 inputs: half a chunk, the input-gradient shape of the 32 -> 16 mixer)
+    # k_wgrad_rows (streaming matrix-core weight gradient of the row GEMMs): 8 / 24 / 40 / 64 inputs, 8 .. 128 outputs, a row count
+    # that is not a multiple of the 32-row slab
+    (1, 8, 8, 32, 32, 40, 1, 1, 0, 1, True),
+    (1, 24, 40, 33, 31, 35, 1, 1, 0, 1, False),
+    (2, 40, 128, 16, 32, 40, 1, 1, 0, 1, True),
+    (1, 64, 64, 32, 32, 40, 1, 1, 0, 1, True),
     # 7^3 weight gradient with K along H (conv_wgrad_hk.hip: <= 16 output channels, planes >= 32 x 32): exact / ragged tiles, two
     # input-channel tiles, a partial second channel tile, fewer than 16 output channels
     (1, 16, 16, 2, 32, 32, 7, 1, 3, 1, True),
