@@ -1105,7 +1105,10 @@ __global__ void __launch_bounds__(64) k_wgrad_rows_finish(float* __restrict__ pa
   a = wave_sum(a);
   if (threadIdx.x == 0) { const int co = e / Cin, ci = e - co * Cin; dw[co * s_co + ci * s_ci] = a; }
 }
-static int wgrad_rows_blocks(int64_t rows) { const int64_t slabs = (rows + 31) / 32; int64_t g = slabs / 16; return (int)(g > 1024 ? 1024 : (g < 1 ? 1 : g)); }
+static int wgrad_rows_blocks(int64_t rows) {
+  static const int cap = [] { const char* e = getenv("DP_WGRAD_ROWS_BLOCKS"); return e ? (atoi(e) < 1024 ? atoi(e) : 1024) : 256; }();      // (one block per CU: 1024 blocks 0.120 ms, 512 / 256 blocks 0.105 for 32 -> 16 at 2 x 128^3 -- the finish pass reads fewer partials)
+  const int64_t slabs = (rows + 31) / 32; int64_t g = slabs / 16; return (int)(g > cap ? cap : (g < 1 ? 1 : g));
+}
 // shapes the streaming weight-gradient kernel takes (16-bit storage; alignment of the pointers is checked by the caller)
 bool wgrad_rows_ok(int ldx, int ldgy, int64_t rows, int Cin, int Cout, int dtype) {
   static const int on = [] { const char* e = getenv("DP_WGRAD_ROWS"); return e ? atoi(e) : 1; }();
