@@ -246,7 +246,7 @@ def check_transeg_128(args, threads):
 
 
 def cpu_baseline_transeg(args):
-    """OAR-TRANSEG counterpart of cpu_baseline(): the oracle's forward + cross-entropy + backward at cpu_size^3, and the HIP path
+    """OAR-TRANSEG counterpart of cpu_baseline(): the oracle's forward + DiceCE loss + backward at cpu_size^3, and the HIP path
     checked on the same sample (logit rel-err, arg-max mismatch count -- SURVEY 8d)."""
     import oracle
     import dose_prediction_amd
@@ -271,11 +271,11 @@ def cpu_baseline_transeg(args):
         for v in sd.values():
             v.grad = None
         logits = oracle.oar_transeg(sd, x, num_heads=12, training=True)
-        torch.nn.functional.cross_entropy(logits, lab).backward()
+        oracle.dice_ce_loss(logits, lab[:, None]).backward()       # DiceCELoss(to_onehot_y=True, softmax=True): train_light_transeg.py:148
     dt = (time.time() - t0) / nstep
     scale = (S / 128.0) ** 3
     res = {"value": scale / dt, "unit": "128^3-equivalent volumes/s (fwd+bwd)", "cores": threads, "kind": "port",
-           "sample": f"{nstep} step(s) (forward + cross-entropy + backward) of the fp32 CPU oracle on one {S}^3 volume: {dt:.2f} s per step "
+           "sample": f"{nstep} step(s) (forward + DiceCE loss + backward) of the fp32 CPU oracle on one {S}^3 volume: {dt:.2f} s per step "
                      f"with {threads} torch threads on {cores} host cores; scaled by voxel count ({scale:.4f})", "seconds": dt * nstep}
     try:
         dev = torch.device("cuda", torch.cuda.current_device())
@@ -508,7 +508,9 @@ def main():
         gt = synth.dose_target(B, shape, seed=5678 + rank).to(dev)
     else:
         x = synth.ct_input(B, shape, seed=1234 + rank).to(dev)
-        gt = torch.randint(0, 8, (B,) + shape, generator=torch.Generator().manual_seed(5678 + rank)).to(dev)
+        # labels as the reference's loader hands them over: [B, 1, D, H, W] float class indices (train_light_transeg.py:194)
+        gt = torch.randint(0, 8, (B, 1) + shape, generator=torch.Generator().manual_seed(5678 + rank)).float().to(dev)
+        seg_loss = losses.DiceCELoss(to_onehot_y=True, softmax=True)        # train_light_transeg.py:148
 
     def step():
         if opt is not None:
@@ -523,7 +525,7 @@ def main():
         if args.model in ("pyfer", "cascade"):
             loss = losses.gen_loss(out, gt, 10.0, 1.0, casecade=True, freez=True)
         else:
-            loss = torch.nn.functional.cross_entropy(out, gt)
+            loss = seg_loss(out, gt)
         loss.backward()
         if opt is not None:
             opt.step()
@@ -661,7 +663,7 @@ def main():
             fp32_leg = time_mode("fp32x3", max(args.fp32_steps, 5))
             fp32_leg.update({"dtype": "fp32x3: fp32 storage, bf16 MFMA on split operands (x_hi w_hi + x_lo w_hi + x_hi w_lo) in the forward pass, fp32 "
                                       "accumulation; data gradients from gy_hi w_hi, weight gradients from x_hi gy_hi (config.set_x3_dgrad_terms / "
-                                      "set_x3_wgrad_terms, default 1; Linear weight gradients three products)",
+                                      "set_x3_wgrad_terms / set_x3_linear_wgrad_terms, all default 1)",
                              "note": "the fast mode that meets the north-star's 1e-3 / arg-max parity bar (check_vs_oracle.fp32x3), which is stated on "
                                      "OUTPUTS: the forward pass always uses three products.  dgrad_three_products / all_three_products: the same with "
                                      "three-product data gradients / data and weight gradients (gradient vector vs float64 1.09e-2 / 1.04e-2 / 1.03e-2, "
@@ -673,11 +675,13 @@ def main():
                 d3["dtype"] = "fp32x3 with three split products in the data gradients as well (the default of rounds 2-3)"
                 fp32_leg["dgrad_three_products"] = d3
                 cfg_.set_x3_wgrad_terms(3)
+                cfg_.set_x3_linear_wgrad_terms(3)
                 w3 = time_mode("fp32x3", max(args.fp32_steps, 5))
-                w3["dtype"] = "fp32x3 with three split products in every contraction: forward, data gradients, weight gradients"
+                w3["dtype"] = "fp32x3 with three split products in every contraction: forward, data gradients, convolution AND Linear weight gradients"
                 fp32_leg["all_three_products"] = w3
             finally:
                 cfg_.set_x3_wgrad_terms(1)
+                cfg_.set_x3_linear_wgrad_terms(1)
                 cfg_.set_x3_dgrad_terms(1)
             if args.exact_fp32_leg:
                 ex = time_mode("fp32", args.fp32_steps)

@@ -284,3 +284,45 @@ def side_streams_allowed():
 def branch_stream_allowed():
     """The 3x3x3 branch / small-block stream: never inside a capture (see set_capture_side_streams)."""
     return not torch.cuda.is_current_stream_capturing()
+
+
+_deterministic = False
+
+
+def set_deterministic(on):
+    """Bit-reproducible passes on demand (the reference's CPU path is bit-repeatable, the parity gates run under this).
+    By default a handful of reductions meet in fp32 atomics, whose order -- hence the last bit of the sum -- differs from run to run:
+    split-kd convolutions of small volumes, split-K GEMMs (patch embedding), the tap-major scratch of the 7^3 / 3^3 weight-gradient
+    kernels, the generic weight gradient, LayerNorm's dgamma / dbeta, the trilinear up-sampling's backward scatter.  With the switch
+    on each of them takes a fixed-order path (csrc: dp_set_deterministic -- unsplit launches, one scratch slab per voxel share added
+    in share order by the unpack pass, per-block partial rows + an fp64 combine, a gather instead of the scatter); everything else
+    (per-block statistics partials, the 3^3 marching weight gradient, the row-stream weight gradients, the grouped transformer
+    weight-gradient launch, losses) was order-fixed already.  Same arithmetic, same tolerances; a DOSE-PYFER 128^3 bf16 step costs
+    a few per cent more.  Process-wide (the flag lives in libdose_hip.so); off by default, env
+    DOSE_HIP_DETERMINISTIC=1 switches it on at import."""
+    global _deterministic
+    from . import _lib
+    _lib.lib().dp_set_deterministic(1 if on else 0)
+    _deterministic = bool(on)
+
+
+def deterministic():
+    return _deterministic
+
+
+class deterministic_as:
+    """Context: run a region with set_deterministic(on)."""
+
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        self.prev = _deterministic
+        set_deterministic(self.on)
+
+    def __exit__(self, *a):
+        set_deterministic(self.prev)
+
+
+if os.environ.get("DOSE_HIP_DETERMINISTIC", "0") == "1":
+    set_deterministic(True)

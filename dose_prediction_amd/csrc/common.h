@@ -199,6 +199,8 @@ struct WgHkGeom {
   const void* x2; int ldx2, csplit;   // virtual concat of the input
   int dbg;                            // experiments only (env DP_DBG): 1 = no staging, 2 = no sweep, 4 = no epilogue
   float* dw; int64_t s_co, s_ci, s_tap; int rezero;     // destination of the finish pass (3^3: per-block slabs instead of atomics)
+  int64_t slab;                       // 7^3, deterministic mode: voxel share yb accumulates into scratch slab yb (slab elements apart); 0 = one shared scratch
+  int max_slabs; int* nslab_out;      // ... at most max_slabs shares; *nslab_out = the number used (what the unpack pass has to add up)
 };
 bool wgrad_hk_applicable(int Cout, int k, int H, int W, int dtype);
 int64_t wgrad_hk_ws_elems(int Cin, int Cout, int k);     // fp32 scratch elements the K-along-H kernels may use (0: no extra need)
@@ -216,4 +218,11 @@ int cc16_launch(const void* x, int ldx, const void* x2, int ldx2, int csplit, co
                 void* y2, int ldy2, int osplit, float* stat_part, int N, int D, int H, int W, int Cin, int Cout, int k, int dtype, hipStream_t s);
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// dp_set_deterministic (elementwise.hip): 1 = every reduction that normally meets in fp32 atomics takes a fixed-order path instead, so that
+// two runs on the same inputs are bit-identical (split-kd convolutions run unsplit, split-K GEMMs unsplit, the weight-gradient kernels write one
+// scratch slab per voxel share and the unpack pass adds the slabs in order, LayerNorm's dgamma / dbeta go through per-block partial rows).
+int dp_det();
+// slabs of `base` fp32 elements the tap-major weight-gradient scratch holds in deterministic mode (<= 32 Mi elements in total)
+static inline int det_slabs(int64_t base) { int64_t n = (32ll << 20) / (base > 0 ? base : 1); return n < 1 ? 1 : (n > 512 ? 512 : (int)n); }
 static inline int roundup8(int c) { return (c + 7) & ~7; }

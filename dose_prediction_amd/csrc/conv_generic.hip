@@ -175,6 +175,7 @@ template <> __device__ __forceinline__ Frag8<float> ld_kmajor<float>(const float
 struct WgGeom {
   int N, Di, Hi, Wi, Do, Ho, Wo, Cin, Cout, k, stride, pad, dil, shift, choff, ldx, ldgy;
   int64_t s_co, s_ci, s_tap;
+  int64_t vpb;         // output voxels per block (WG_VOX; deterministic mode: all of them, swept by ONE wave per (tap, channel block))
 };
 
 template <typename T>
@@ -191,14 +192,15 @@ __global__ void __launch_bounds__(256) k_wgrad_generic(const T* __restrict__ x, 
   const int nco = min(WG_CB, g.Cout - co0), nci = min(WG_CB, g.Cin - ci0);
   const int tco = (nco + 15) >> 4, tci = (nci + 15) >> 4;
   const int64_t Vtot = (int64_t)g.N * g.Do * g.Ho * g.Wo;
-  const int64_t vbeg = (int64_t)blockIdx.x * WG_VOX, vend = min(Vtot, vbeg + WG_VOX);
+  const int64_t vbeg = (int64_t)blockIdx.x * g.vpb, vend = min(Vtot, vbeg + g.vpb);
+  const int vstep = 32 * (blockDim.x >> 6);
   T* mx = sx[wv]; T* mg = sg[wv];
   v4f acc[4][4];
 #pragma unroll
   for (int a = 0; a < 4; a++)
 #pragma unroll
     for (int b = 0; b < 4; b++) acc[a][b] = (v4f){0.f, 0.f, 0.f, 0.f};
-  for (int64_t v0 = vbeg + wv * 32; v0 < vend; v0 += 128) {
+  for (int64_t v0 = vbeg + wv * 32; v0 < vend; v0 += vstep) {
     // stage 32 voxels x WG_CB channels of gy and x: 32*CPR chunks each, CPR/2 per lane
 #pragma unroll
     for (int u = 0; u < CPR / 2; u++) {
@@ -256,12 +258,14 @@ extern "C" int dp_conv3d_wgrad(const void* x, int ldx, const void* gy, int ldgy,
                                int64_t s_tap, int dtype, void* stream) {
   int rc = dp_wgrad_tiled_try(x, ldx, gy, ldgy, dw, N, Di, Hi, Wi, Do, Ho, Wo, Cin, Cout, k, stride, pad, dil, shift, gy_tap_choff, s_co, s_ci, s_tap, dtype, stream);
   if (rc >= 0) return rc;
-  WgGeom g = {N, Di, Hi, Wi, Do, Ho, Wo, Cin, Cout, k, stride, pad, dil, shift, gy_tap_choff, ldx, ldgy, s_co, s_ci, s_tap};
   int64_t Vtot = (int64_t)N * Do * Ho * Wo;
+  // deterministic mode: every dW element is one wave's accumulator, added ONCE to the (zeroed) destination -- no atomics meet
+  const bool det = dp_det() != 0;
+  WgGeom g = {N, Di, Hi, Wi, Do, Ho, Wo, Cin, Cout, k, stride, pad, dil, shift, gy_tap_choff, ldx, ldgy, s_co, s_ci, s_tap, det ? Vtot : (int64_t)WG_VOX};
   int taps = k * k * k;
   int cb = dtype != DP_F32 ? WgCfg<bf16_t>::CB : WgCfg<float>::CB;
-  dim3 grid(cdiv(Vtot, WG_VOX), taps, cdiv(Cout, cb) * cdiv(Cin, cb));
+  dim3 grid(det ? 1 : cdiv(Vtot, WG_VOX), taps, cdiv(Cout, cb) * cdiv(Cin, cb));
   if (grid.y > 65535 || grid.z > 65535) DP_FAIL("wgrad: grid too large (taps %d)", taps);
-  DP_DISPATCH(dtype, hipLaunchKernelGGL(k_wgrad_generic<T>, grid, dim3(256), 0, STREAM, (const T*)x, (const T*)gy, dw, g));
+  DP_DISPATCH(dtype, hipLaunchKernelGGL(k_wgrad_generic<T>, grid, dim3(det ? 64 : 256), 0, STREAM, (const T*)x, (const T*)gy, dw, g));
   DP_CHECK_LAUNCH("wgrad_generic"); return 0;
 }

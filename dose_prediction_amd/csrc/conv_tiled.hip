@@ -38,16 +38,9 @@ __device__ __forceinline__ v16f mma32(const Frag8<f16_t>& a, const Frag8<f16_t>&
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, a.u), __builtin_bit_cast(v8h, b.u), c, 0, 0, 0);
 }
 __device__ __forceinline__ v16f mma32(const Frag8<float>& a, const Frag8<float>& b, v16f c) {
-#ifdef DP_F32_SPLIT
-  const Split8 sa = split_bf16(a), sb = split_bf16(b);
-  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, sa.lo), __builtin_bit_cast(v8bf, sb.hi), c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, sa.hi), __builtin_bit_cast(v8bf, sb.lo), c, 0, 0, 0);
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, sa.hi), __builtin_bit_cast(v8bf, sb.hi), c, 0, 0, 0);
-#else
 #pragma unroll
   for (int j = 0; j < 8; j++) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[j], b.v[j], c, 0, 0, 0);
   return c;
-#endif
 }
 
 struct TiledGeom {
@@ -584,7 +577,7 @@ static void tiled_geometry(TiledGeom& g, int k, int np, int rw, int& nt, int* yg
   *ygrid = cdiv(g.NTT, nt * wn);
   int64_t blocks = (int64_t)g.N * g.D * g.tiles_h * g.tiles_w * *ygrid;
   const int split_below = (!*w16 && wn == 2) ? 200 : 400;   // (the 8-row arrangement is there to AVOID the split: 256 blocks are enough)
-  g.splitkd = (np == 1 && blocks < split_below) ? 1 : 0;    // small volumes: one block per kd, fp32 atomic accumulation
+  g.splitkd = (np == 1 && blocks < split_below && !dp_det()) ? 1 : 0;    // small volumes: one block per kd, fp32 atomic accumulation (deterministic mode: unsplit)
   // ... and, when even k blocks per tile leave the chip half empty, per share of the input chunks (>= 4 chunks per share)
   g.chsplit = 1;
   if (g.splitkd) { while (blocks * k * g.chsplit < 400 && g.NCH / (g.chsplit * 2) >= 4) g.chsplit *= 2; }
@@ -722,6 +715,7 @@ struct WgtGeom {
   int tiles_h, tiles_w, MT, NTn, KHG, ydim, zdim;
   const void* x2; int ldx2, csplit;   // virtual concat of the input (see TiledGeom)
   int dbg;             // experiments only (env DP_DBG): 1 = skip staging, 2 = skip the MFMA sweep, 3 = both, 4 = also skip the epilogue
+  int64_t slab;        // deterministic mode: voxel share yb adds into ITS OWN scratch slab (yb * slab elements further; every address then has one contributor and k_wgrad_unpack adds the slabs in order); 0 = one shared scratch
 };
 
 template <typename T, int KS, int NPAIR, int MPAIR>
@@ -1042,6 +1036,7 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_tiled(const T* __restrict__ x,
   int co, kh;
   if (NPAIR == 2) { co = nt * 16 + (ncol & 15); kh = 2 * jh + (ncol >> 4); } else { co = nt * 32 + ncol; kh = jh; }
   if (kh >= KS || co >= g.Cout) return;
+  dwt += ((int64_t)yb * C::WCH + chw) * g.slab;          // (deterministic mode: one slab per voxel share AND per wave group that shares its taps)
 #pragma unroll
   for (int k = 0; k < C::KWT; k++)
 #pragma unroll
@@ -1205,6 +1200,7 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_cc16(const T* __restrict__ x, 
     cu = nu; ctw = ntw;
   }
   if (g.dbg & 4) return;
+  dwt += (int64_t)yb * g.slab;
   // C/D of the 16x16 MFMA: col (co) = lane&15, row (ci) = 4*(lane>>4) + e
 #pragma unroll
   for (int kk = 0; kk < C::KPW; kk++) {
@@ -1225,7 +1221,7 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_cc16(const T* __restrict__ x, 
 }
 
 template <typename T, int KS, int NT16>
-static int launch_wg16(const void* x, const void* gy, float* ws, WgtGeom g, hipStream_t s) {
+static int launch_wg16(const void* x, const void* gy, float* ws, WgtGeom g, hipStream_t s, int max_slabs, int* nslab) {
   using C = Wg16Cfg<T, KS, NT16>;
   auto kern = k_wgrad_cc16<T, KS, NT16>;
   if (C::SMEM > 48 * 1024) {
@@ -1245,14 +1241,15 @@ static int launch_wg16(const void* x, const void* gy, float* ws, WgtGeom g, hipS
   int want = (ncu * occ) / (KS * zdim); if (want < 1) want = 1;
   int ydim = units < want ? units : want;
   // (always rounding to a multiple of 8 for the XCD-aware decode: 0.84 -> 0.81 ms on 16->16, nothing on 32->16; rounding up: 1.5x slower)
+  if (max_slabs && ydim > max_slabs) ydim = max_slabs;
   if (ydim >= 8 && (ydim & 7) * 20 <= ydim) ydim &= ~7;
-  g.ydim = ydim; g.zdim = zdim;
+  g.ydim = ydim; g.zdim = zdim; *nslab = max_slabs ? ydim : 1;
   hipLaunchKernelGGL(kern, dim3(KS * ydim * zdim), dim3(256), C::SMEM, s, (const T*)x, (const T*)gy, ws, g);
   return 0;
 }
 
 __global__ void __launch_bounds__(256) k_wgrad_unpack(float* __restrict__ dwt, float* __restrict__ dw, int taps, int Cin, int Cout, int64_t s_co, int64_t s_ci,
-                                                      int64_t s_tap, int rezero) {
+                                                      int64_t s_tap, int rezero, int nslab, int64_t slab) {
   // [tap][ci][co] scratch -> dw[co*s_co + ci*s_ci + tap*s_tap] as an LDS-tiled transpose of 32 taps x 32 (ci, co) pairs: reads are
   // 128-byte runs along co, writes 128-byte runs along the taps (either side alone is a 4-byte scatter: 207 us for 343 x 256 x 128).
   __shared__ float tile[32][33];
@@ -1263,8 +1260,15 @@ __global__ void __launch_bounds__(256) k_wgrad_unpack(float* __restrict__ dwt, f
   for (int r = 0; r < 4; r++) {
     const int tap = tap0 + ty + 8 * r; const int64_t pr = pair0 + tx;
     const bool in = tap < taps && pr < pairs;
-    tile[ty + 8 * r][tx] = in ? dwt[(int64_t)tap * pairs + pr] : 0.f;
-    if (in && rezero) dwt[(int64_t)tap * pairs + pr] = 0.f;
+    // (deterministic mode: the voxel shares' slabs added in share order)
+    float v = 0.f;
+    if (in) {
+      float* a = dwt + (int64_t)tap * pairs + pr;
+      v = *a;
+      if (rezero) *a = 0.f;
+      for (int sl = 1; sl < nslab; sl++) { v += a[sl * slab]; if (rezero) a[sl * slab] = 0.f; }
+    }
+    tile[ty + 8 * r][tx] = v;
   }
   __syncthreads();
 #pragma unroll
@@ -1281,14 +1285,15 @@ static inline bool wgt_applicable(int Cin, int Cout, int k, int stride, int pad,
 // fp32 scratch elements needed by dp_conv3d_wgrad_tiled (0: shape not supported, use dp_conv3d_wgrad)
 extern "C" int dp_conv3d_wgrad_tiled_ws_elems(int Cin, int Cout, int k, int stride, int pad, int dil, int shift, int W) {
   if (!wgt_applicable(Cin, Cout, k, stride, pad, dil, shift, W)) return 0;
-  const int64_t base = (int64_t)k * k * k * Cin * Cout, hk = wgrad_hk_ws_elems(Cin, Cout, k);
+  int64_t base = (int64_t)k * k * k * Cin * Cout; const int64_t hk = wgrad_hk_ws_elems(Cin, Cout, k);
+  if (dp_det()) base *= det_slabs(base);               // one slab per voxel share (see WgtGeom::slab)
   int64_t n = base > hk ? base : hk;
   if (k == 1 && Cin <= 64 && Cout <= 32) { const int64_t rw = wgrad_rows_ws_elems(Cin, Cout); if (rw > n) n = rw; }   // per-block partials of k_wgrad_rows
   return n > 2000000000LL ? 0 : (int)n;
 }
 
 template <typename T, int KS, int NPAIR, int MPAIR>
-static int launch_wgt(const void* x, const void* gy, float* ws, WgtGeom g, hipStream_t s) {
+static int launch_wgt(const void* x, const void* gy, float* ws, WgtGeom g, hipStream_t s, int max_slabs, int* nslab) {
   using C = WgtCfg<T, KS, NPAIR, MPAIR>;
   auto kern = k_wgrad_tiled<T, KS, NPAIR, MPAIR>;
   if (C::SMEM > 48 * 1024) {
@@ -1311,8 +1316,12 @@ static int launch_wgt(const void* x, const void* gy, float* ws, WgtGeom g, hipSt
   int ydim = units < want ? units : want;
   // multiple of 8 => XCD-aware decode in the kernel; only when rounding down idles <= 5 % of the block slots (the locality is
   // worth a few per cent, an empty eighth of the chip is not)
+  if (max_slabs) {
+    if (max_slabs < C::WCH) { dp_set_error("wgrad_tiled: deterministic scratch too small for this shape"); return 1; }
+    if (ydim > max_slabs / C::WCH) ydim = max_slabs / C::WCH;
+  }
   if (ydim >= 8 && (ydim & 7) * 20 <= ydim) ydim &= ~7;
-  g.ydim = ydim; g.zdim = zdim;
+  g.ydim = ydim; g.zdim = zdim; *nslab = max_slabs ? ydim * C::WCH : 1;
   dim3 grid(KS * ydim * zdim, 1, 1);
   hipLaunchKernelGGL(kern, grid, dim3(256), C::SMEM, s, (const T*)x, (const T*)gy, ws, g);
   return 0;
@@ -1332,12 +1341,15 @@ extern "C" int dp_conv3d_wgrad_tiled2(const void* x, int ldx, const void* x2, in
   if (k == 1 && H * (int64_t)D * N > 2000000000LL) DP_FAIL("wgrad_tiled: too many rows");
   hipStream_t s = STREAM;
   int taps = k * k * k;
+  const int64_t base = (int64_t)taps * Cin * Cout;
+  const int max_slabs = dp_det() ? det_slabs(base) : 0;
+  int nslab = 1;
   if (!g_scratch_zeroed) {
-    hipError_t me = hipMemsetAsync(ws, 0, (size_t)taps * Cin * Cout * sizeof(float), s);
+    hipError_t me = hipMemsetAsync(ws, 0, (size_t)base * (max_slabs ? max_slabs : 1) * sizeof(float), s);
     if (me != hipSuccess) DP_FAIL("wgrad_tiled: memset failed: %s", hipGetErrorString(me));
   }
   WgtGeom g; g.N = N; g.D = D; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.ldx = ldx; g.ldgy = ldgy;
-  g.x2 = x2; g.ldx2 = ldx2; g.csplit = csplit;
+  g.x2 = x2; g.ldx2 = ldx2; g.csplit = csplit; g.slab = max_slabs ? base : 0;
   { const char* e = getenv("DP_DBG"); g.dbg = e ? atoi(e) : 0; }
   const int np = (Cout <= 16 && k > 1) ? 2 : 1, mp = (Cin <= 16 && k > 1) ? 2 : 1;
   if (getenv("DP_DEBUG_SLOW")) {
@@ -1366,6 +1378,7 @@ extern "C" int dp_conv3d_wgrad_tiled2(const void* x, int ldx, const void* x2, in
     WgHkGeom hg; hg.N = N; hg.D = D; hg.H = H; hg.W = W; hg.Cin = Cin; hg.Cout = Cout; hg.ldx = ldx; hg.ldgy = ldgy;
     hg.tiles_h = hg.tiles_w = hg.MT = hg.NTn = hg.ydim = 0; hg.dbg = g.dbg; hg.x2 = x2; hg.ldx2 = ldx2; hg.csplit = csplit;
     hg.dw = dw; hg.s_co = s_co; hg.s_ci = s_ci; hg.s_tap = s_tap; hg.rezero = g_scratch_zeroed;
+    hg.slab = g.slab; hg.max_slabs = max_slabs; hg.nslab_out = &nslab;
     int finished = 0;
     rc = wgrad_hk_launch(x, gy, ws, hg, k, dtype, s, &finished);
     if (rc > 0) return rc;
@@ -1375,23 +1388,23 @@ extern "C" int dp_conv3d_wgrad_tiled2(const void* x, int ldx, const void* x2, in
   }
   if (hk_done) {
   } else if (cc16 && np == 2) {           // Cout <= 16: one tap per 16x16x32 MFMA, no tap-pairing padding
-    if (dtype == DP_BF16) rc = k == 7 ? launch_wg16<bf16_t, 7, 1>(x, gy, ws, g, s) : launch_wg16<bf16_t, 3, 1>(x, gy, ws, g, s);
-    else rc = k == 7 ? launch_wg16<f16_t, 7, 1>(x, gy, ws, g, s) : launch_wg16<f16_t, 3, 1>(x, gy, ws, g, s);
+    if (dtype == DP_BF16) rc = k == 7 ? launch_wg16<bf16_t, 7, 1>(x, gy, ws, g, s, max_slabs, &nslab) : launch_wg16<bf16_t, 3, 1>(x, gy, ws, g, s, max_slabs, &nslab);
+    else rc = k == 7 ? launch_wg16<f16_t, 7, 1>(x, gy, ws, g, s, max_slabs, &nslab) : launch_wg16<f16_t, 3, 1>(x, gy, ws, g, s, max_slabs, &nslab);
   } else if (cc16 && mp == 2 && Cout <= 32) {   // Cin <= 16, Cout <= 32: two 16-wide N tiles share every x window (kw pairing wasted an eighth)
-    if (dtype == DP_BF16) rc = k == 7 ? launch_wg16<bf16_t, 7, 2>(x, gy, ws, g, s) : launch_wg16<bf16_t, 3, 2>(x, gy, ws, g, s);
-    else rc = k == 7 ? launch_wg16<f16_t, 7, 2>(x, gy, ws, g, s) : launch_wg16<f16_t, 3, 2>(x, gy, ws, g, s);
+    if (dtype == DP_BF16) rc = k == 7 ? launch_wg16<bf16_t, 7, 2>(x, gy, ws, g, s, max_slabs, &nslab) : launch_wg16<bf16_t, 3, 2>(x, gy, ws, g, s, max_slabs, &nslab);
+    else rc = k == 7 ? launch_wg16<f16_t, 7, 2>(x, gy, ws, g, s, max_slabs, &nslab) : launch_wg16<f16_t, 3, 2>(x, gy, ws, g, s, max_slabs, &nslab);
   } else {
-#define GO(TT, KS_) do { if (np == 2 && mp == 2) rc = launch_wgt<TT, KS_, 2, 2>(x, gy, ws, g, s); else if (np == 2) rc = launch_wgt<TT, KS_, 2, 1>(x, gy, ws, g, s); \
-                         else if (mp == 2) rc = launch_wgt<TT, KS_, 1, 2>(x, gy, ws, g, s); else rc = launch_wgt<TT, KS_, 1, 1>(x, gy, ws, g, s); } while (0)
-  if (dtype == DP_BF16) { if (k == 7) GO(bf16_t, 7); else if (k == 3) GO(bf16_t, 3); else rc = launch_wgt<bf16_t, 1, 1, 1>(x, gy, ws, g, s); }
-  else if (dtype == DP_F16) { if (k == 7) GO(f16_t, 7); else if (k == 3) GO(f16_t, 3); else rc = launch_wgt<f16_t, 1, 1, 1>(x, gy, ws, g, s); }
-  else if (dtype == DP_F32) { if (k == 7) GO(float, 7); else if (k == 3) GO(float, 3); else rc = launch_wgt<float, 1, 1, 1>(x, gy, ws, g, s); }
+#define GO(TT, KS_) do { if (np == 2 && mp == 2) rc = launch_wgt<TT, KS_, 2, 2>(x, gy, ws, g, s, max_slabs, &nslab); else if (np == 2) rc = launch_wgt<TT, KS_, 2, 1>(x, gy, ws, g, s, max_slabs, &nslab); \
+                         else if (mp == 2) rc = launch_wgt<TT, KS_, 1, 2>(x, gy, ws, g, s, max_slabs, &nslab); else rc = launch_wgt<TT, KS_, 1, 1>(x, gy, ws, g, s, max_slabs, &nslab); } while (0)
+  if (dtype == DP_BF16) { if (k == 7) GO(bf16_t, 7); else if (k == 3) GO(bf16_t, 3); else rc = launch_wgt<bf16_t, 1, 1, 1>(x, gy, ws, g, s, max_slabs, &nslab); }
+  else if (dtype == DP_F16) { if (k == 7) GO(f16_t, 7); else if (k == 3) GO(f16_t, 3); else rc = launch_wgt<f16_t, 1, 1, 1>(x, gy, ws, g, s, max_slabs, &nslab); }
+  else if (dtype == DP_F32) { if (k == 7) GO(float, 7); else if (k == 3) GO(float, 3); else rc = launch_wgt<float, 1, 1, 1>(x, gy, ws, g, s, max_slabs, &nslab); }
   else DP_FAIL("wgrad_tiled: bad dtype");
 #undef GO
   }
   if (rc) return rc;
   DP_CHECK_LAUNCH("wgrad_tiled");
   int64_t pairs = (int64_t)Cin * Cout;
-  hipLaunchKernelGGL(k_wgrad_unpack, dim3((unsigned)((pairs + 31) / 32), (taps + 31) / 32), dim3(256), 0, s, ws, dw, taps, Cin, Cout, s_co, s_ci, s_tap, g_scratch_zeroed);
+  hipLaunchKernelGGL(k_wgrad_unpack, dim3((unsigned)((pairs + 31) / 32), (taps + 31) / 32), dim3(256), 0, s, ws, dw, taps, Cin, Cout, s_co, s_ci, s_tap, g_scratch_zeroed, nslab, base);
   DP_CHECK_LAUNCH("wgrad_unpack"); return 0;
 }

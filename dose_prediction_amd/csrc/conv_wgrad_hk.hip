@@ -208,6 +208,7 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_hk(const T* __restrict__ x, co
   // C/D of the 16x16 MFMA: col (co) = lane&15, row (ci) = 4*(lane>>4) + e
   const int co = nt * 16 + (lane & 15);
   if (co >= g.Cout) return;
+  dwt += (int64_t)yb * g.slab;            // (deterministic mode: one scratch slab per voxel share)
   auto flush = [&]<typename R>(R) {
     static_for<0, R::NR>([&](auto r_) {
       constexpr int r = decltype(r_)::value;
@@ -257,8 +258,10 @@ int launch_hk(const void* x, const void* gy, float* ws, WgHkGeom g, hipStream_t 
   // depth-fastest walk above): 0.66 GB and 0.18 GB; the launches take the same time (they are matrix-bound either way) and leave
   // 12 GB per step of fabric traffic to the kernels on the other streams.  DP_HK_ROUND8=0: the old rule.
   static const int round8 = [] { const char* e = getenv("DP_HK_ROUND8"); return e ? atoi(e) : 1; }();
+  if (g.max_slabs && ydim > g.max_slabs) ydim = g.max_slabs;
   if (ydim >= 8 && ((ydim & 7) * 20 <= ydim || round8)) ydim &= ~7;
   g.ydim = ydim;
+  if (g.nslab_out) *g.nslab_out = g.max_slabs ? ydim : 1;
   hipLaunchKernelGGL(kern, dim3(KS * ydim * g.MT * g.NTn), dim3(256), C::SMEM, s, (const T*)x, (const T*)gy, ws, g);
   return 0;
 }

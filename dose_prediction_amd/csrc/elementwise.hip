@@ -11,6 +11,11 @@ void dp_set_error(const char* fmt, ...) {
 }
 extern "C" const char* dp_last_error(void) { return g_err; }
 extern "C" int dp_version(void) { return 100; }
+// Deterministic mode (process-wide; see common.h dp_det()).
+static int g_deterministic = 0;
+int dp_det() { return g_deterministic; }
+extern "C" int dp_set_deterministic(int on) { g_deterministic = on ? 1 : 0; return 0; }
+extern "C" int dp_get_deterministic(void) { return g_deterministic; }
 
 #define STREAM ((hipStream_t)stream)
 static inline int grid_for(int64_t work, int block, int cap = 256 * 16) {
@@ -470,7 +475,53 @@ extern "C" int dp_trilinear_up2_fwd(const void* x, int ldx, void* y, int ldy, in
   DP_DISPATCH(dtype, hipLaunchKernelGGL(k_trilinear_fwd<T>, dim3(grid_for(total, 256)), dim3(256), 0, STREAM, (const T*)x, ldx, (T*)y, ldy, N, D, H, W, C));
   DP_CHECK_LAUNCH("trilinear_fwd"); return 0;
 }
+// The same as a GATHER (deterministic mode): one thread per input element walks the <= 8 output coordinates per axis that can read it
+// (src = o (n - 1) / (2n - 1) ~ o / 2: outputs 2i - 3 .. 2i + 4 cover every case), with the very weights the forward pass computes, and
+// adds them in a fixed order; gx is OVERWRITTEN.
+template <typename T>
+__global__ void k_trilinear_bwd_gather(const T* __restrict__ gy, int ldgy, float* __restrict__ gx, int N, int D, int H, int W, int C) {
+  const int64_t IV = (int64_t)N * D * H * W, total = IV * C;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C); int64_t v = i / C;
+    const int w = (int)(v % W); v /= W; const int h = (int)(v % H); v /= H; const int d = (int)(v % D); const int64_t n = v / D;
+    float wd[8], wh[8], ww[8];
+    auto weights = [](int idx, int n_in, float* out) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const int o = 2 * idx - 3 + j;
+        float wsum = 0.f;
+        if (o >= 0 && o < 2 * n_in) {
+          int i0, i1; float f; tri_coord(o, n_in, i0, i1, f);
+          if (i0 == idx) wsum += 1.f - f;
+          if (i1 == idx) wsum += f;
+        }
+        out[j] = wsum;
+      }
+    };
+    weights(d, D, wd); weights(h, H, wh); weights(w, W, ww);
+    float acc = 0.f;
+    for (int a = 0; a < 8; a++) {
+      if (wd[a] == 0.f) continue;
+      const int od = 2 * d - 3 + a;
+      for (int b = 0; b < 8; b++) {
+        if (wh[b] == 0.f) continue;
+        const int oh = 2 * h - 3 + b;
+        for (int e = 0; e < 8; e++) {
+          if (ww[e] == 0.f) continue;
+          const int ow = 2 * w - 3 + e;
+          acc += wd[a] * wh[b] * ww[e] * ld_f(gy + ((((int64_t)n * 2 * D + od) * 2 * H + oh) * 2 * W + ow) * ldgy + c);
+        }
+      }
+    }
+    gx[i] = acc;
+  }
+}
 extern "C" int dp_trilinear_up2_bwd(const void* gy, int ldgy, float* gx, int N, int D, int H, int W, int C, int dtype, void* stream) {
+  if (dp_det()) {
+    const int64_t tot = (int64_t)N * D * H * W * C;
+    DP_DISPATCH(dtype, hipLaunchKernelGGL(k_trilinear_bwd_gather<T>, dim3(grid_for(tot, 256)), dim3(256), 0, STREAM, (const T*)gy, ldgy, gx, N, D, H, W, C));
+    DP_CHECK_LAUNCH("trilinear_bwd_gather"); return 0;
+  }
   int64_t total = (int64_t)N * 8 * D * H * W * C;
   DP_DISPATCH(dtype, hipLaunchKernelGGL(k_trilinear_bwd<T>, dim3(grid_for(total, 256)), dim3(256), 0, STREAM, (const T*)gy, ldgy, gx, N, D, H, W, C));
   DP_CHECK_LAUNCH("trilinear_bwd"); return 0;
@@ -699,9 +750,13 @@ __global__ void __launch_bounds__(256) k_pointwise_mfma(const T* __restrict__ x,
 #pragma unroll
     for (int u = 0; u < U; u++) {
       const int64_t v = (t0 + u) * 16 + r;
+      // (the masks are all-ones / all-zeros except in the chunk that holds channel Cin - 1, which for the eight-chunk instance serving
+      // 5-7 real chunks is not chunk KC - 1: every chunk from the last real one on is masked -- ADVICE r4)
       if (ragged)
 #pragma unroll
-        for (int d = 0; d < 4; d++) b[u][KC - 1].u[d] &= keep[KC - 1][d];
+        for (int kc = (KC == 8 ? 4 : KC - 1); kc < KC; kc++)
+#pragma unroll
+          for (int d = 0; d < 4; d++) b[u][kc].u[d] &= keep[kc][d];
       v4f acc[NT];
 #pragma unroll
       for (int nt = 0; nt < NT; nt++) {

@@ -139,3 +139,154 @@ extern "C" int dp_resample_gt(const float* dose, const float* mask, float* out_d
   hipLaunchKernelGGL(k_resample_gt, dim3((unsigned)g), dim3(256), 0, STREAM, dose, mask, out_dose, out_mask, N, Di, Hi, Wi, Do, Ho, Wo);
   DP_CHECK_LAUNCH("resample_gt"); return 0;
 }
+
+// ================================================================================================ DiceCE (OAR-TRANSEG's training loss)
+// MONAI 0.7.0 DiceCELoss(to_onehot_y=True, softmax=True) as the reference builds it (OARSegmentation/train_light_transeg.py:148, called
+// at :196 / :212 on the network's logits [B][C][D][H][W] and the label volume [B][1][D][H][W]):
+//   p = softmax(logits, channel);  onehot = one_hot(label);
+//   dice = mean over (b, c) of 1 - (2 I_bc + smooth_nr) / (G_bc + P_bc + smooth_dr),  I = sum_v onehot p, G = sum_v onehot, P = sum_v p
+//   ce   = nn.CrossEntropyLoss(reduction="mean")(logits, label) = mean over (b, v) of -log p[label]
+//   loss = lambda_dice dice + lambda_ce ce                                   (include_background, no squared_pred / jaccard / batch)
+// Forward: ONE pass over the logits (softmax, CE term and the three Dice sums per voxel; 1 + 3 C partial sums per block, combined in a
+// fixed order by the finish kernel, which also leaves the per-(b, c) coefficients of the backward pass in `stats`).  Backward: ONE more
+// pass that recomputes the softmax and writes d loss / d logits.  The ATen composition this replaces in the benchmark's C3 step
+// (cross_entropy alone: log_softmax + nll_loss forward / backward, 4 launches, 0.53 ms at 2 x 128^3) had no Dice term at all.
+#define DCE_BLOCK 256
+#define DCE_VOX 4096        // voxels per block
+enum { DCE_LBL_F32 = 0, DCE_LBL_I64 = 1, DCE_LBL_I32 = 2, DCE_LBL_U8 = 3 };
+__device__ __forceinline__ int dce_label(const void* lab, int kind, int64_t i) {
+  switch (kind) {
+    case DCE_LBL_F32: return (int)((const float*)lab)[i];
+    case DCE_LBL_I64: return (int)((const int64_t*)lab)[i];
+    case DCE_LBL_I32: return ((const int*)lab)[i];
+    default: return (int)((const unsigned char*)lab)[i];
+  }
+}
+// stats layout: [0] loss, [1] dice, [2] ce, [3] lambda_ce / (B V), then per (b, c): [4 + 2 (b C + c)] = u_bc, [+1] = w_bc with
+//   d(lambda_dice dice) / d p_c(b, v) = u_bc - w_bc [label(b, v) == c]
+template <int CM>
+__global__ void __launch_bounds__(DCE_BLOCK) k_dice_ce_partial(const float* __restrict__ z, const void* __restrict__ lab, int lkind, int C, int64_t V, int nblk,
+                                                               float* __restrict__ part) {
+  __shared__ float red[DCE_BLOCK / 64][1 + 3 * CM];
+  const int b = blockIdx.y, blk = blockIdx.x;
+  const float* zb = z + (int64_t)b * C * V;
+  const int64_t v0 = (int64_t)blk * DCE_VOX, v1 = min(V, v0 + DCE_VOX);
+  float ce = 0.f, I[CM], G[CM], P[CM];
+#pragma unroll
+  for (int c = 0; c < CM; c++) I[c] = G[c] = P[c] = 0.f;
+  for (int64_t v = v0 + threadIdx.x; v < v1; v += DCE_BLOCK) {
+    const int t = dce_label(lab, lkind, (int64_t)b * V + v);
+    float l[CM], m = -INFINITY, zt = 0.f;
+#pragma unroll
+    for (int c = 0; c < CM; c++) { l[c] = c < C ? zb[(int64_t)c * V + v] : -INFINITY; m = fmaxf(m, l[c]); if (c == t) zt = l[c]; }
+    float S = 0.f;
+#pragma unroll
+    for (int c = 0; c < CM; c++) { l[c] = c < C ? expf(l[c] - m) : 0.f; S += l[c]; }
+    const float rS = 1.f / S;
+    if (t >= 0 && t < C) ce += (m + logf(S)) - zt;        // -log softmax[t] in its log-sum-exp form
+#pragma unroll
+    for (int c = 0; c < CM; c++) {
+      const float p = l[c] * rS;
+      P[c] += p;
+      if (c == t) { I[c] += p; G[c] += 1.f; }
+    }
+  }
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  ce = wave_sum(ce);
+  if (lane == 0) red[wv][0] = ce;
+#pragma unroll
+  for (int c = 0; c < CM; c++) {
+    const float a = wave_sum(I[c]), g = wave_sum(G[c]), p = wave_sum(P[c]);
+    if (lane == 0) { red[wv][1 + c] = a; red[wv][1 + CM + c] = g; red[wv][1 + 2 * CM + c] = p; }
+  }
+  __syncthreads();
+  float* out = part + ((int64_t)b * nblk + blk) * (1 + 3 * CM);
+  for (int j = threadIdx.x; j < 1 + 3 * CM; j += DCE_BLOCK) out[j] = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
+}
+template <int CM>
+__global__ void __launch_bounds__(64) k_dice_ce_finish(const float* __restrict__ part, int B, int C, int64_t V, int nblk, float snr, float sdr, float ld, float lc,
+                                                       float* __restrict__ stats) {
+  // one wave; lane j < 1 + 3 CM owns partial column j of sample b (fixed order over the blocks, fp64)
+  __shared__ double tot[1 + 3 * CM];
+  __shared__ double acc[2];
+  if (threadIdx.x == 0) { acc[0] = 0.0; acc[1] = 0.0; }
+  for (int b = 0; b < B; b++) {
+    __syncthreads();
+    if (threadIdx.x < 1 + 3 * CM) {
+      double s = 0.0;
+      const float* p = part + (int64_t)b * nblk * (1 + 3 * CM) + threadIdx.x;
+      for (int k = 0; k < nblk; k++) s += p[(int64_t)k * (1 + 3 * CM)];
+      tot[threadIdx.x] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      acc[1] += tot[0];
+      for (int c = 0; c < C; c++) {
+        const double I = tot[1 + c], den = tot[1 + CM + c] + tot[1 + 2 * CM + c] + (double)sdr, num = 2.0 * I + (double)snr;
+        acc[0] += 1.0 - num / den;
+        stats[4 + 2 * (b * C + c)] = (float)((double)ld / ((double)B * C) * num / (den * den));
+        stats[4 + 2 * (b * C + c) + 1] = (float)((double)ld / ((double)B * C) * 2.0 / den);
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double dice = acc[0] / ((double)B * C), ce = acc[1] / ((double)B * (double)V);
+    stats[0] = (float)((double)ld * dice + (double)lc * ce); stats[1] = (float)dice; stats[2] = (float)ce;
+    stats[3] = (float)((double)lc / ((double)B * (double)V));
+  }
+}
+template <int CM>
+__global__ void __launch_bounds__(256) k_dice_ce_bwd(const float* __restrict__ z, const void* __restrict__ lab, int lkind, int C, int64_t V,
+                                                     const float* __restrict__ stats, const float* __restrict__ gup, float* __restrict__ gz) {
+  const int b = blockIdx.y;
+  const float* zb = z + (int64_t)b * C * V; float* gb = gz + (int64_t)b * C * V;
+  float u[CM], w[CM];
+#pragma unroll
+  for (int c = 0; c < CM; c++) { u[c] = c < C ? stats[4 + 2 * (b * C + c)] : 0.f; w[c] = c < C ? stats[4 + 2 * (b * C + c) + 1] : 0.f; }
+  const float g0 = gup[0], cs = stats[3];
+  for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < V; v += (int64_t)gridDim.x * blockDim.x) {
+    float l[CM], m = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < CM; c++) { l[c] = c < C ? zb[(int64_t)c * V + v] : -INFINITY; m = fmaxf(m, l[c]); }
+    float S = 0.f;
+#pragma unroll
+    for (int c = 0; c < CM; c++) { l[c] = c < C ? expf(l[c] - m) : 0.f; S += l[c]; }
+    const float rS = 1.f / S;
+    const int t = dce_label(lab, lkind, (int64_t)b * V + v);
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < CM; c++) { l[c] *= rS; s += (u[c] - (c == t ? w[c] : 0.f)) * l[c]; }
+#pragma unroll
+    for (int c = 0; c < CM; c++)
+      if (c < C) gb[(int64_t)c * V + v] = g0 * (l[c] * ((u[c] - (c == t ? w[c] : 0.f)) - s) + cs * (l[c] - (c == t ? 1.f : 0.f)));
+  }
+}
+extern "C" int64_t dp_dice_ce_ws_elems(int B, int C, int64_t V) {
+  const int cm = C <= 8 ? 8 : 16;
+  return (int64_t)B * ((V + DCE_VOX - 1) / DCE_VOX) * (1 + 3 * cm);
+}
+extern "C" int64_t dp_dice_ce_stats_elems(int B, int C) { return 4 + 2 * (int64_t)B * C; }
+extern "C" int dp_dice_ce_fwd(const float* logits, const void* labels, int label_kind, int B, int C, int64_t V, float smooth_nr, float smooth_dr,
+                              float lambda_dice, float lambda_ce, float* ws, float* stats, void* stream) {
+  if (B < 1 || C < 2 || C > 16 || V < 1) DP_FAIL("dice_ce: need B >= 1, 2 <= C <= 16, V >= 1 (got %d, %d, %lld)", B, C, (long long)V);
+  if (label_kind < 0 || label_kind > 3) DP_FAIL("dice_ce: label kind %d (0 float32, 1 int64, 2 int32, 3 uint8)", label_kind);
+  const int64_t nblk = (V + DCE_VOX - 1) / DCE_VOX;
+  if (nblk > 2000000000LL || B > 65535) DP_FAIL("dice_ce: tensor too large");
+  if (C <= 8) {
+    hipLaunchKernelGGL(k_dice_ce_partial<8>, dim3((unsigned)nblk, B), dim3(DCE_BLOCK), 0, STREAM, logits, labels, label_kind, C, V, (int)nblk, ws);
+    hipLaunchKernelGGL(k_dice_ce_finish<8>, dim3(1), dim3(64), 0, STREAM, (const float*)ws, B, C, V, (int)nblk, smooth_nr, smooth_dr, lambda_dice, lambda_ce, stats);
+  } else {
+    hipLaunchKernelGGL(k_dice_ce_partial<16>, dim3((unsigned)nblk, B), dim3(DCE_BLOCK), 0, STREAM, logits, labels, label_kind, C, V, (int)nblk, ws);
+    hipLaunchKernelGGL(k_dice_ce_finish<16>, dim3(1), dim3(64), 0, STREAM, (const float*)ws, B, C, V, (int)nblk, smooth_nr, smooth_dr, lambda_dice, lambda_ce, stats);
+  }
+  DP_CHECK_LAUNCH("dice_ce_fwd"); return 0;
+}
+extern "C" int dp_dice_ce_bwd(const float* logits, const void* labels, int label_kind, int B, int C, int64_t V, const float* stats, const float* gup,
+                              float* glogits, void* stream) {
+  if (B < 1 || C < 2 || C > 16 || V < 1 || B > 65535) DP_FAIL("dice_ce_bwd: bad shape");
+  int64_t g = (V + 255) / 256; if (g > 8192) g = 8192;
+  if (C <= 8) hipLaunchKernelGGL(k_dice_ce_bwd<8>, dim3((unsigned)g, B), dim3(256), 0, STREAM, logits, labels, label_kind, C, V, stats, gup, glogits);
+  else hipLaunchKernelGGL(k_dice_ce_bwd<16>, dim3((unsigned)g, B), dim3(256), 0, STREAM, logits, labels, label_kind, C, V, stats, gup, glogits);
+  DP_CHECK_LAUNCH("dice_ce_bwd"); return 0;
+}

@@ -485,13 +485,20 @@ __global__ void __launch_bounds__(256) k_norm_bwd_finalize(const float* __restri
   const int n0 = batch_mode ? 0 : gidx, n1 = batch_mode ? N : gidx + 1;
   double s1, s2;
   combine_partials<0>(part, n0, n1, nblk, C, c0, cpb, s1, s2, red);
+  // dgamma / dbeta are sums over ALL samples.  Batch mode has ONE statistics group: its sums ARE dgamma / dbeta.  Instance mode: the
+  // block of sample 0 combines the partial rows of every sample once more, in the same fixed order (round 5: one fp32 atomic per sample
+  // used to meet here -- order-dependent for N > 2).  Either way a plain store: the caller need not zero them.
+  double t1 = s1, t2 = s2;
+  const bool owner = batch_mode || gidx == 0;
+  if (!batch_mode && gidx == 0 && N > 1 && (dgamma || dbeta)) {          // (block-uniform)
+    __syncthreads();
+    combine_partials<0>(part, 0, N, nblk, C, c0, cpb, t1, t2, red);
+  }
   const int c = c0 + threadIdx.x;
   if (threadIdx.x >= cpb || c >= C) return;
   s1o[gidx * C + c] = (float)s1; s2o[gidx * C + c] = (float)s2;
-  // dgamma / dbeta are sums over ALL samples: one add per statistics group (N is small)
-  // batch mode has ONE statistics group: its sums ARE dgamma / dbeta (plain store: the caller need not zero them)
-  if (dgamma) { if (batch_mode) dgamma[c] = (float)s2; else atomicAdd(dgamma + c, (float)s2); }
-  if (dbeta) { if (batch_mode) dbeta[c] = (float)s1; else atomicAdd(dbeta + c, (float)s1); }
+  if (dgamma && owner) dgamma[c] = (float)t2;
+  if (dbeta && owner) dbeta[c] = (float)t1;
 }
 extern "C" int dp_norm_bwd_finalize(const float* part, int N, int nblk, int C, int batch_mode, float* s1, float* s2, float* dgamma, float* dbeta, void* stream) {
   int cpb = pick_cpb(C);
@@ -591,7 +598,8 @@ __global__ void k_layernorm_bwd(const T* __restrict__ x, const T* __restrict__ g
 template <typename T>
 __global__ void __launch_bounds__(256) k_layernorm_bwd_reg(const T* __restrict__ x, const T* __restrict__ gy, const T* __restrict__ gres,
                                 const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd, T* __restrict__ gx,
-                                float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t rows, int C, int rows_per_block) {
+                                float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t rows, int C, int rows_per_block,
+                                float* __restrict__ part = nullptr) {
   __shared__ float sm[4][2][1024];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   float gam[16], ag[16], ab[16];
@@ -621,8 +629,10 @@ __global__ void __launch_bounds__(256) k_layernorm_bwd_reg(const T* __restrict__
   for (int i = 0; i < 16; i++) { int c = lane + 64 * i; sm[wv][0][c] = ag[i]; sm[wv][1][c] = ab[i]; }
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += 256) {
-    atomicAdd(dgamma + c, sm[0][0][c] + sm[1][0][c] + sm[2][0][c] + sm[3][0][c]);
-    atomicAdd(dbeta + c, sm[0][1][c] + sm[1][1][c] + sm[2][1][c] + sm[3][1][c]);
+    const float dg = sm[0][0][c] + sm[1][0][c] + sm[2][0][c] + sm[3][0][c], db = sm[0][1][c] + sm[1][1][c] + sm[2][1][c] + sm[3][1][c];
+    if (part) {      // deterministic mode: one partial row pair per block ([blk][0] = dbeta, [blk][1] = dgamma), combined by k_norm_bwd_finalize
+      part[((int64_t)blockIdx.x * 2) * C + c] = db; part[((int64_t)blockIdx.x * 2 + 1) * C + c] = dg;
+    } else { atomicAdd(dgamma + c, dg); atomicAdd(dbeta + c, db); }
   }
 }
 extern "C" int dp_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int64_t rows, int C,
@@ -651,6 +661,21 @@ extern "C" int dp_layernorm_bwd(const void* x, const void* gy, const float* gamm
   DP_DISPATCH(dtype, hipLaunchKernelGGL(k_layernorm_bwd<T>, dim3(cdiv(rows, rpb)), dim3(256), 2 * C * sizeof(float), STREAM, (const T*)x, (const T*)gy, gamma,
                                         mean, rstd, (T*)gx, dgamma, dbeta, rows, C, rpb));
   DP_CHECK_LAUNCH("layernorm_bwd"); return 0;
+}
+// Deterministic LayerNorm backward (config.set_deterministic): the blocks' dgamma / dbeta partial sums go to `part`
+// (dp_layernorm_bwd_parts(rows, C) x 2 x C floats) and are combined in a fixed order (fp64) instead of meeting in fp32 atomics; dgamma / dbeta
+// are OVERWRITTEN.  gsum may be NULL (plain LayerNorm) or the residual-path gradient (fused add + LayerNorm).  C <= 1024.
+static inline int ln_bwd_rpb(int64_t rows) { return rows >= 8192 ? 16 : (rows >= 2048 ? 8 : 4); }
+extern "C" int dp_layernorm_bwd_parts(int64_t rows, int C) { (void)C; return cdiv(rows, ln_bwd_rpb(rows)); }
+extern "C" int dp_add_layernorm_bwd_det(const void* x, const void* gy, const void* gsum, const float* gamma, const float* mean, const float* rstd, void* gx,
+                                        float* part, float* dgamma, float* dbeta, int64_t rows, int C, int dtype, void* stream) {
+  if (C > 1024) DP_FAIL("add_layernorm_bwd_det: C > 1024 not supported");
+  if (!part || !dgamma || !dbeta) DP_FAIL("add_layernorm_bwd_det: part / dgamma / dbeta missing");
+  const int rpb = ln_bwd_rpb(rows), nblk = cdiv(rows, rpb);
+  DP_DISPATCH(dtype, hipLaunchKernelGGL(k_layernorm_bwd_reg<T>, dim3(nblk), dim3(256), 0, STREAM, (const T*)x, (const T*)gy, (const T*)gsum,
+                                        gamma, mean, rstd, (T*)gx, dgamma, dbeta, rows, C, rpb, part));
+  DP_CHECK_LAUNCH("add_layernorm_bwd_det");
+  return dp_norm_bwd_finalize(part, 1, nblk, C, 1, dbeta, dgamma, nullptr, nullptr, stream);      // s1 = sum of rows [.][0] = dbeta, s2 = dgamma
 }
 // backward of the fused residual add + LayerNorm: gx = gsum + LayerNorm'(gy)  (C <= 1024)
 extern "C" int dp_add_layernorm_bwd(const void* x, const void* gy, const void* gsum, const float* gamma, const float* mean, const float* rstd, void* gx,

@@ -30,7 +30,8 @@ __global__ void __launch_bounds__(256) k_split_rows(const float* __restrict__ a,
     const int64_t row = ppr_shift >= 0 ? (i >> ppr_shift) : i / ppr;
     const int c0 = (int)(i - row * ppr) * 8;
     float v[8];
-    if (c0 < ca && va && c0 + 8 <= lda) {
+    // (the last row of a channel-sliced source may end before its pitch does: whole pieces there only inside the used channels)
+    if (c0 < ca && va && c0 + 8 <= lda && (c0 + 8 <= ca || row + 1 < rows)) {
       const v4f p0 = *(const v4f*)(a + row * lda + c0), p1 = *(const v4f*)(a + row * lda + c0 + 4);
       v[0] = p0[0]; v[1] = p0[1]; v[2] = p0[2]; v[3] = p0[3]; v[4] = p1[0]; v[5] = p1[1]; v[6] = p1[2]; v[7] = p1[3];
       if (c0 + 8 > ca) {
@@ -40,7 +41,7 @@ __global__ void __launch_bounds__(256) k_split_rows(const float* __restrict__ a,
           if (c >= ca) v[j] = c < ca + cb ? b[row * ldb + (c - ca)] : 0.f;
         }
       }
-    } else if (c0 >= ca && c0 < ca + cb && vb && ((c0 - ca) & 3) == 0 && c0 - ca + 8 <= ldb) {
+    } else if (c0 >= ca && c0 < ca + cb && vb && ((c0 - ca) & 3) == 0 && c0 - ca + 8 <= ldb && (c0 + 8 <= ca + cb || row + 1 < rows)) {
       const float* s = b + row * ldb + (c0 - ca);
       const v4f p0 = *(const v4f*)s, p1 = *(const v4f*)(s + 4);
       v[0] = p0[0]; v[1] = p0[1]; v[2] = p0[2]; v[3] = p0[3]; v[4] = p1[0]; v[5] = p1[1]; v[6] = p1[2]; v[7] = p1[3];

@@ -65,3 +65,22 @@ def l1_loss(pred, gt, freez=True, casecade=True):
         return _masked_l1(pred, dose, mask)
     lb = _masked_l1(pred[1] if not isinstance(pred[1], (list, tuple)) else pred[1][0], dose, mask)
     return lb if freez else 0.5 * _masked_l1(pred[0], dose, mask) + lb
+
+
+class DiceCELoss(torch.nn.Module):
+    """Drop-in for ``monai.losses.DiceCELoss`` as OAR-TRANSEG uses it (OARSegmentation/train_light_transeg.py:148:
+    ``DiceCELoss(to_onehot_y=True, softmax=True)``; called on (logits [B, 8, D, H, W], labels [B, 1, D, H, W]) at :196 / :212), on the
+    fused HIP kernels (ops.dice_ce).  Constructor arguments outside that use are rejected rather than silently ignored."""
+
+    def __init__(self, include_background=True, to_onehot_y=False, sigmoid=False, softmax=False, other_act=None, squared_pred=False,
+                 jaccard=False, reduction="mean", smooth_nr=1e-5, smooth_dr=1e-5, batch=False, ce_weight=None, lambda_dice=1.0,
+                 lambda_ce=1.0):
+        super().__init__()
+        if not (to_onehot_y and softmax) or sigmoid or other_act is not None or squared_pred or jaccard or batch or ce_weight is not None \
+                or not include_background or reduction != "mean":
+            raise ValueError("HIP path implements DiceCELoss(to_onehot_y=True, softmax=True) with MONAI's other defaults (the reference's use)")
+        self.smooth_nr, self.smooth_dr, self.lambda_dice, self.lambda_ce = float(smooth_nr), float(smooth_dr), float(lambda_dice), float(lambda_ce)
+
+    def forward(self, input, target):
+        from . import ops
+        return ops.dice_ce(input, target, self.smooth_nr, self.smooth_dr, self.lambda_dice, self.lambda_ce)

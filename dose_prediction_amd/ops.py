@@ -273,11 +273,13 @@ def _zero_bias_grad(bias):
             return torch.zeros(bias.shape, dtype=torch.float32, device=dev)
         off = pool["slots"][key] = pool["used"]
         pool["used"] += (n + 63) // 64 * 64
-    if not pool.get("armed"):
+    task = _graph_task_id()
+    if not pool.get("armed") or pool.get("task") != task:
         # first hand-out of this backward pass: wipe the pool (one 256 KB fill), so that whatever was written into a previous step's
-        # .grad in place (a regulariser's grad.add_, a NaN from clip_grad_norm_) cannot survive into this step
+        # .grad in place (a regulariser's grad.add_, a NaN from clip_grad_norm_) cannot survive into this step; a pass
+        # that raised before its end-of-backward callback leaves "armed" behind -- the pass id tells
         pool["buf"].zero_()
-        pool["armed"] = True
+        pool["armed"], pool["task"] = True, task
         torch.autograd.Variable._execution_engine.queue_callback(lambda: pool.__setitem__("armed", False))
     # a FRESH view object every time: autograd adopts it as .grad without a copy only if nobody else holds the tensor object
     return pool["buf"][off:off + n].view(bias.shape)
@@ -285,6 +287,8 @@ def _zero_bias_grad(bias):
 
 _PASS_ARENA = {}
 _PASS_ARENA_ON = os.environ.get("DOSE_HIP_PASS_ARENA", "1") != "0"      # (A/B switch)
+_PASS_ARENA_MAX_ELEMS = 1 << 20
+_graph_task_id = getattr(torch._C, "_current_graph_task_id", lambda: -1)      # id of the running backward pass (-1 outside one)
 
 
 def _pass_zeros(shape, dev):
@@ -298,12 +302,20 @@ def _pass_zeros(shape, dev):
         n *= int(d)
     if dev.type != "cuda" or n == 0 or not _PASS_ARENA_ON:
         return torch.zeros(shape, dtype=torch.float32, device=dev)
+    if n > _PASS_ARENA_MAX_ELEMS:
+        # (a gradient adopted as a view of the arena pins the WHOLE arena until every such gradient is released: big accumulators --
+        # split-K dW buffers of tens of MB -- get their own allocation)
+        return torch.zeros(shape, dtype=torch.float32, device=dev)
     a = _PASS_ARENA.get(dev)
     if a is None:
-        a = _PASS_ARENA[dev] = {"buf": None, "used": 0, "need": 0, "now": 0, "armed": False, "ev": None, "stream": None}
+        a = _PASS_ARENA[dev] = {"buf": None, "used": 0, "need": 0, "now": 0, "armed": False, "ev": None, "stream": None, "task": None}
+    task = _graph_task_id()
+    if a["armed"] and a["task"] != task:
+        # the pass that armed the arena never reached its end-of-backward callback (it raised): start over
+        a["armed"], a["buf"] = False, None
     if not a["armed"]:
         a["buf"] = torch.zeros((max(a["need"], 1 << 16),), dtype=torch.float32, device=dev)
-        a["used"], a["now"], a["armed"] = 0, 0, True
+        a["used"], a["now"], a["armed"], a["task"] = 0, 0, True, task
         a["stream"] = torch.cuda.current_stream(dev)
         a["ev"] = torch.cuda.Event()
         a["ev"].record(a["stream"])
@@ -1707,10 +1719,9 @@ def _norm_backward(x, mean, rstd, gamma, beta, res, kind, act, use_stats, ssn, g
     groups = N if kind == "instance" else 1
     s1 = torch.empty((groups, C), dtype=torch.float32, device=dev)
     s2 = torch.empty((groups, C), dtype=torch.float32, device=dev)
-    # (instance mode accumulates over samples, batch mode overwrites)
-    mk = (lambda shp: _pass_zeros(shp, dev)) if kind == "instance" else (lambda shp: torch.empty(shp, dtype=torch.float32, device=dev))
-    dgamma = mk((C,)) if need_gb else None
-    dbeta = mk((C,)) if need_gb else None
+    # (dp_norm_bwd_finalize overwrites both in either mode: the sample-0 block of an instance normalisation combines every sample's rows)
+    dgamma = torch.empty((C,), dtype=torch.float32, device=dev) if need_gb else None
+    dbeta = torch.empty((C,), dtype=torch.float32, device=dev) if need_gb else None
     if use_stats or need_gb:
         _lib.call("dp_norm_act_bwd_partial", _p(x), ldx, gy_ptr, ldg, _p(mean), _p(rstd), ssn, _p(g32), _p(b32), _p(res), ldr,
                   _act_code(act, x.dtype), N, V, C, _p(part), dtc, _stream())
@@ -1887,6 +1898,9 @@ class LayerNorm(torch.autograd.Function):
         C = x.shape[-1]
         rows = x.numel() // C
         gx = torch.empty_like(x)
+        if _deterministic():
+            dgb = _layernorm_bwd_det(x, gy, None, gamma, mean, rstd, gx, rows, C)
+            return gx, dgb[0], dgb[1], None
         dgb = _pass_zeros((2, C), x.device)      # (accumulated by atomics)
         dg, db = dgb[0], dgb[1]
         _lib.call("dp_layernorm_bwd", _p(x), _p(gy), _p(gamma.detach()), _p(mean), _p(rstd), _p(gx), _p(dg), _p(db), rows, C,
@@ -1896,6 +1910,22 @@ class LayerNorm(torch.autograd.Function):
 
 def layer_norm(x, gamma, beta, eps=1e-5):
     return LayerNorm.apply(x, gamma, beta, eps)
+
+
+def _deterministic():
+    from . import config
+    return config.deterministic()
+
+
+def _layernorm_bwd_det(x, gy, gsum, gamma, mean, rstd, gx, rows, C):
+    """config.set_deterministic: LayerNorm backward with dgamma / dbeta through per-block partial rows and a fixed-order combine
+    (dp_add_layernorm_bwd_det) instead of fp32 atomics; returns the [2, C] tensor (dgamma, dbeta)."""
+    nblk = _lib.lib().dp_layernorm_bwd_parts(rows, C)
+    part = torch.empty((nblk, 2, C), dtype=torch.float32, device=x.device)
+    dgb = torch.empty((2, C), dtype=torch.float32, device=x.device)
+    _lib.call("dp_add_layernorm_bwd_det", _p(x), _p(gy), _p(gsum), _p(gamma.detach()), _p(mean), _p(rstd), _p(gx), _p(part), _p(dgb[0]), _p(dgb[1]),
+              rows, C, _dt(x), _stream())
+    return dgb
 
 
 class AddLayerNorm(torch.autograd.Function):
@@ -1926,6 +1956,9 @@ class AddLayerNorm(torch.autograd.Function):
         gz = gz.contiguous()
         gs = None if gs is None else gs.contiguous()
         gx = torch.empty_like(s)
+        if _deterministic():
+            dgb = _layernorm_bwd_det(s, gz, gs, gamma, mean, rstd, gx, rows, C)
+            return gx, gx, dgb[0], dgb[1], None
         dgb = _pass_zeros((2, C), s.device)
         if C <= 1024:
             _lib.call("dp_add_layernorm_bwd", _p(s), _p(gz), _p(gs), _p(gamma.detach()), _p(mean), _p(rstd), _p(gx), _p(dgb[0]), _p(dgb[1]),
@@ -2286,6 +2319,51 @@ class MaskedL1(torch.autograd.Function):
 
 def masked_l1(pred, gt, mask, huber_delta=0.0):
     return MaskedL1.apply(pred, gt, mask, huber_delta)
+
+
+_LABEL_KIND = {torch.float32: 0, torch.int64: 1, torch.int32: 2, torch.uint8: 3}
+
+
+class DiceCE(torch.autograd.Function):
+    """monai.losses.DiceCELoss(to_onehot_y=True, softmax=True) (OARSegmentation/train_light_transeg.py:148,196): one fused pass over the
+    logits forward (softmax, cross-entropy term, the three Dice sums per class) and one backward (dp_dice_ce_fwd / _bwd).
+    logits: fp32 [B, C, D, H, W] (the module boundary's NCDHW tensor); labels: [B, 1, D, H, W] or [B, D, H, W] class indices stored
+    as float32 (the reference's loader), int64, int32 or uint8.  Returns the 0-dim fp32 loss."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, smooth_nr, smooth_dr, lambda_dice, lambda_ce):
+        _chk_dev(logits, labels)
+        if logits.dtype != torch.float32:
+            raise _lib.DoseHipError("dice_ce takes the fp32 logits of the module boundary")
+        logits = logits.contiguous()
+        B, C = logits.shape[:2]
+        V = logits.numel() // (B * C)
+        if labels.dtype not in _LABEL_KIND:
+            labels = labels.to(torch.int32)
+        labels = labels.contiguous()
+        if labels.numel() != B * V:
+            raise ValueError("dice_ce: labels must hold one class index per voxel ([B, 1, ...] or [B, ...])")
+        L = _lib.lib()
+        ws = torch.empty((L.dp_dice_ce_ws_elems(B, C, V),), dtype=torch.float32, device=logits.device)
+        stats = torch.empty((L.dp_dice_ce_stats_elems(B, C),), dtype=torch.float32, device=logits.device)
+        _lib.call("dp_dice_ce_fwd", _p(logits), _p(labels), _LABEL_KIND[labels.dtype], B, C, V, float(smooth_nr), float(smooth_dr),
+                  float(lambda_dice), float(lambda_ce), _p(ws), _p(stats), _stream())
+        ctx.save_for_backward(logits, labels, stats)
+        return stats[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, labels, stats = ctx.saved_tensors
+        B, C = logits.shape[:2]
+        V = logits.numel() // (B * C)
+        gz = torch.empty_like(logits)
+        gup = g.contiguous().float().reshape(1)
+        _lib.call("dp_dice_ce_bwd", _p(logits), _p(labels), _LABEL_KIND[labels.dtype], B, C, V, _p(stats), _p(gup), _p(gz), _stream())
+        return gz, None, None, None, None, None
+
+
+def dice_ce(logits, labels, smooth_nr=1e-5, smooth_dr=1e-5, lambda_dice=1.0, lambda_ce=1.0):
+    return DiceCE.apply(logits, labels, smooth_nr, smooth_dr, lambda_dice, lambda_ce)
 
 
 def dose_score(pred, gt, mask, scale=70.0):

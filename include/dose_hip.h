@@ -45,6 +45,14 @@ enum { DP_ACT_NONE = 0, DP_ACT_RELU = 1, DP_ACT_LRELU = 2, DP_ACT_MISH = 3, DP_A
 
 const char* dp_last_error(void);
 int dp_version(void);
+/* Deterministic mode (process-wide, default off): 1 = every reduction that normally meets in fp32 atomics takes a fixed-order path, so two
+ * runs on the same inputs are BIT-IDENTICAL, as the reference's CPU path is (the parity gates run under it): split-kd convolutions run
+ * unsplit, split-K GEMMs unsplit, the tiled / K-along-H weight-gradient kernels accumulate one scratch slab per voxel share which the unpack
+ * pass adds in share order (dp_conv3d_wgrad_tiled_ws_elems grows accordingly), the generic weight gradient runs one wave per result tile,
+ * dp_trilinear_up2_bwd gathers instead of scattering; LayerNorm's dgamma / dbeta need dp_add_layernorm_bwd_det.  Queries made before a
+ * switch (workspace sizes, statistics blocks) do not carry over: ask again. */
+int dp_set_deterministic(int on);
+int dp_get_deterministic(void);
 
 /* ---- layout / data movement ---------------------------------------------------------------- */
 /* replaces: the implicit NCDHW layout of every torch op; entry `input_.to(device)` network_trainer.py:188.
@@ -141,8 +149,8 @@ int dp_norm_act_cat_bwd_apply(const void* xa, int lda, const float* mean_a, cons
 int dp_norm_act_bwd_partial(const void* x, int ldx, const void* gy, int ldgy, const float* mean, const float* rstd,
                             int stat_stride_n, const float* gamma, const float* beta, const void* res, int ldr, int act,
                             int N, int64_t V, int C, float* part, int dtype, void* stream);
-/* combine partials: s1,s2 float [groups][C] (groups = N instance, 1 batch); dgamma/dbeta if non-NULL: accumulated (+=, one
- * add per sample) in instance mode, OVERWRITTEN in batch mode (one statistics group: no zero-fill needed). */
+/* combine partials: s1,s2 float [groups][C] (groups = N instance, 1 batch); dgamma/dbeta if non-NULL: the sums over ALL samples,
+ * OVERWRITTEN in both modes (fixed-order fp64 combination of the partial rows: no atomics, no zero-fill needed). */
 int dp_norm_bwd_finalize(const float* part, int N, int nblk, int C, int batch_mode, float* s1, float* s2,
                          float* dgamma, float* dbeta, void* stream);
 /* backward pass 2: gx = gamma*rstd*(g - s1/M - xhat*s2/M) (use_stats) or gamma*rstd*g (eval BN);
@@ -163,6 +171,11 @@ int dp_add_layernorm_fwd(const void* a, const void* b, void* sum, const float* g
                          int64_t rows, int C, float eps, int dtype, void* stream);
 int dp_add_layernorm_bwd(const void* x, const void* gy, const void* gsum, const float* gamma, const float* mean, const float* rstd,
                          void* gx, float* dgamma, float* dbeta, int64_t rows, int C, int dtype, void* stream);
+/* the deterministic form of both LayerNorm backward passes (dp_set_deterministic; gsum may be NULL): per-block dgamma / dbeta partial rows
+ * in `part` (dp_layernorm_bwd_parts(rows, C) x 2 x C floats), combined in a fixed order; dgamma / dbeta are OVERWRITTEN.  C <= 1024. */
+int dp_layernorm_bwd_parts(int64_t rows, int C);
+int dp_add_layernorm_bwd_det(const void* x, const void* gy, const void* gsum, const float* gamma, const float* mean, const float* rstd,
+                             void* gx, float* part, float* dgamma, float* dbeta, int64_t rows, int C, int dtype, void* stream);
 
 
 /* ---- matrix products (MFMA) ------------------------------------------------------------------- */
@@ -385,6 +398,19 @@ int dp_masked_huber_bwd(const float* pred, const float* gt, const float* mask, c
  * align_corners=True), mask like mode="nearest-exact"; fp32 single-channel volumes [N][D][H][W]. */
 int dp_resample_gt(const float* dose, const float* mask, float* out_dose, float* out_mask, int N, int Di, int Hi, int Wi, int Do, int Ho,
                    int Wo, void* stream);
+/* replaces: monai.losses.DiceCELoss(to_onehot_y=True, softmax=True) -- OAR-TRANSEG's training / validation loss
+ * (OARSegmentation/train_light_transeg.py:148,196,212): logits fp32 [B][C][V] (NCDHW, V = D H W), labels [B][V] class indices stored as
+ * float32 (label_kind 0, what the reference's loader delivers), int64 (1), int32 (2) or uint8 (3); 2 <= C <= 16.
+ *   loss = lambda_dice * mean_{b,c}(1 - (2 I + smooth_nr) / (G + P + smooth_dr)) + lambda_ce * mean_{b,v}(-log softmax[label])
+ * with I = sum_v onehot p, G = sum_v onehot, P = sum_v p (MONAI 0.7.0 defaults: smooth 1e-5, lambdas 1, include_background, no squared /
+ * jaccard / batch).  ws: dp_dice_ce_ws_elems floats; stats: dp_dice_ce_stats_elems floats = {loss, dice, ce, ...coefficients the backward
+ * pass reads}.  Backward: glogits fp32 [B][C][V] = gup[0] * d loss / d logits (softmax recomputed; gup on the device). */
+int64_t dp_dice_ce_ws_elems(int B, int C, int64_t V);
+int64_t dp_dice_ce_stats_elems(int B, int C);
+int dp_dice_ce_fwd(const float* logits, const void* labels, int label_kind, int B, int C, int64_t V, float smooth_nr, float smooth_dr,
+                   float lambda_dice, float lambda_ce, float* ws, float* stats, void* stream);
+int dp_dice_ce_bwd(const float* logits, const void* labels, int label_kind, int B, int C, int64_t V, const float* stats, const float* gup,
+                   float* glogits, void* stream);
 /* out = (mask < 1 || pred < 0) ? 0 : scale * pred   (train_light_pyfer.py:166-172, scale = 70 Gy) */
 int dp_dose_postprocess(const float* pred, const float* mask, float* out, int64_t n, float scale, void* stream);
 

@@ -10,7 +10,7 @@ import torch.nn.functional as F
 
 __all__ = [
     "conv3d", "conv_transpose3d_k2s2", "instance_norm", "batch_norm", "layer_norm", "activation",
-    "trilinear_up2", "linear", "gelu", "attention", "patchify", "bf16_round", "storage", "store", "store_weight",
+    "trilinear_up2", "linear", "gelu", "attention", "patchify", "bf16_round", "storage", "store", "store_weight", "dice_ce_loss",
 ]
 
 
@@ -182,3 +182,23 @@ def patchify(x, p=16):
     h, w, d = S0 // p, S1 // p, S2 // p
     x = x.view(B, C, h, p, w, p, d, p).permute(0, 2, 4, 6, 3, 5, 7, 1)
     return x.reshape(B, h * w * d, p * p * p * C)
+
+
+def dice_ce_loss(logits, labels, smooth_nr=1e-5, smooth_dr=1e-5, lambda_dice=1.0, lambda_ce=1.0):
+    """MONAI 0.7.0 ``DiceCELoss(to_onehot_y=True, softmax=True)`` as OAR-TRANSEG builds and calls it
+    (OARSegmentation/train_light_transeg.py:148, 196, 212): logits [B, C, ...], labels [B, 1, ...] (class indices, any dtype).
+    DiceLoss.forward with the defaults (include_background, no squared_pred / jaccard / batch, reduction="mean"):
+    input = softmax(logits, 1); target = one_hot(labels); reduce over the SPATIAL axes only; f = 1 - (2 I + smooth_nr) /
+    (ground + pred + smooth_dr); mean over batch and channel.  DiceCELoss.ce: nn.CrossEntropyLoss(reduction="mean") on
+    squeeze(labels, 1).long().  total = lambda_dice * dice + lambda_ce * ce.  [parity unpinned: MONAI absent; the CE half is torch's
+    own F.cross_entropy, the Dice half is checked against a per-class loop in tests/test_oracle_leaves_cpu.py]"""
+    C = logits.shape[1]
+    lab = labels.reshape(labels.shape[0], *labels.shape[2:]).long()
+    p = torch.softmax(logits, 1)
+    onehot = torch.nn.functional.one_hot(lab, C).movedim(-1, 1).to(p.dtype)
+    axes = list(range(2, logits.dim()))
+    inter = (onehot * p).sum(axes)
+    den = onehot.sum(axes) + p.sum(axes)
+    dice = (1.0 - (2.0 * inter + smooth_nr) / (den + smooth_dr)).mean()
+    ce = torch.nn.functional.cross_entropy(logits, lab)
+    return lambda_dice * dice + lambda_ce * ce

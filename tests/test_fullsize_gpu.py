@@ -358,8 +358,8 @@ def _transeg(dev, shape, seed=8765):
 
 
 def test_c3_transeg_training_steps_128_bf16():
-    """BASELINE.json configs[2]: OAR-TRANSEG at 128^3, bf16 storage, batch 2 on one GPU -- forward (logits [2, 8, 128^3]) + cross
-    entropy + backward + fused Adam, four steps: every gradient finite, every parameter that the graph reaches receives one, the loss
+    """BASELINE.json configs[2]: OAR-TRANSEG at 128^3, bf16 storage, batch 2 on one GPU -- forward (logits [2, 8, 128^3]) + DiceCE
+    loss (train_light_transeg.py:148) + backward + fused Adam, four steps: every gradient finite, every parameter that the graph reaches receives one, the loss
     falls.  (The 1 -> 16 first convolution and the 16 -> 8 head are checked against the oracle at this size in
     test_conv_sampled_oracle_full_size; 12-head d = 64 attention at B = 2, N = 512 in test_ops_gpu.test_fused_attention_full_size.)"""
     import dose_prediction_amd
@@ -371,13 +371,15 @@ def test_c3_transeg_training_steps_128_bf16():
         net = _transeg(dev, S).train()
         opt = FusedAdam(net.parameters(), lr=1e-4, weight_decay=1e-5)
         x = synth.ct_input(2, S).to(dev)
-        lab = torch.randint(0, 8, (2,) + S, generator=torch.Generator().manual_seed(5678)).to(dev)
+        lab = torch.randint(0, 8, (2, 1) + S, generator=torch.Generator().manual_seed(5678)).float().to(dev)
+        from dose_prediction_amd.losses import DiceCELoss
+        seg_loss = DiceCELoss(to_onehot_y=True, softmax=True)          # the reference's loss: train_light_transeg.py:148
         hist = []
         for it in range(4):
             opt.zero_grad(set_to_none=True)
             logits = net(x)
             assert logits.shape == (2, 8) + S and logits.dtype == torch.float32
-            loss = torch.nn.functional.cross_entropy(logits, lab)
+            loss = seg_loss(logits, lab)
             loss.backward()
             if it == 0:
                 missing = [k for k, p in net.named_parameters() if p.grad is None]
@@ -386,7 +388,7 @@ def test_c3_transeg_training_steps_128_bf16():
             assert all(torch.isfinite(p.grad).all() for p in net.parameters() if p.grad is not None)
             opt.step()
             hist.append(loss.item())
-        print(f"[c3] cross-entropy {hist}")
+        print(f"[c3] DiceCE {hist}")
         assert all(h == h and h < 1e3 for h in hist) and hist[-1] < hist[0], hist
         assert not opt.found_inf()
     finally:

@@ -25,6 +25,19 @@ def _set(dtype):
     dose_prediction_amd.set_compute_dtype(dtype)
 
 
+@pytest.fixture(autouse=True)
+def _golden_gates_run_deterministically(request):
+    """The reference-golden network tests (test_g*) run with config.set_deterministic(True): the reference's CPU path is bit-repeatable,
+    so its parity gates are run on the order-fixed reductions; everything else in this file runs with the default."""
+    import dose_prediction_amd
+    on = request.node.name.startswith(("test_g1_", "test_g2_", "test_g4_", "test_g7_"))
+    if on and torch.cuda.is_available():
+        dose_prediction_amd.config.set_deterministic(True)
+    yield
+    if on and torch.cuda.is_available():
+        dose_prediction_amd.config.set_deterministic(False)
+
+
 def _load(mod, sd):
     missing, unexpected = mod.load_state_dict(sd, strict=True), None
     return mod
@@ -449,8 +462,10 @@ def test_gradient_allreduce_single_rank_rccl_is_identity():
                 assert e < 5e-3, (step, k, e)
 
 
-def test_gradient_allreduce_two_ranks_matches_the_mean_of_local_gradients():
-    """World size 2 on the GPU (gloo, both ranks on this box's one GPU; tests/ddp_gpu_worker.py): with bucket boundaries that fall
+@pytest.mark.parametrize("grad_dtype", ["fp32", "bf16"])
+def test_gradient_allreduce_two_ranks_matches_the_mean_of_local_gradients(grad_dtype):
+    """World size 2 on the GPU (tests/ddp_gpu_worker.py: RCCL with one GPU per rank when the box has two, else gloo with both ranks on
+    this box's one GPU; fp32 buckets incl. the in-place chunked exchange of tensors above the bucket size, and bf16 buckets): with bucket boundaries that fall
     between deferred Linear weights and their biases (such a bucket used to be exchanged before the grouped weight-gradient
     launch had written it), every gradient after the exchange equals the mean of the two ranks' local gradients, over three passes."""
     import os
@@ -458,11 +473,12 @@ def test_gradient_allreduce_two_ranks_matches_the_mean_of_local_gradients():
     import sys
     _dev()
     here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ)
+    env = dict(os.environ, DDP_TEST_GRAD_DTYPE=grad_dtype)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29547", os.path.join(here, "ddp_gpu_worker.py")], env=env, capture_output=True, text=True, timeout=900)
+                        "--master-port", "29547" if grad_dtype == "fp32" else "29548", os.path.join(here, "ddp_gpu_worker.py")], env=env,
+                       capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "DDP_GPU_WORKER_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 

@@ -160,7 +160,8 @@ def test_conv3d(cfg, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("cin,cout,ldx", [(25, 16, 64), (40, 24, 64), (33, 32, 64), (64, 32, 64), (16, 32, 16), (25, 16, 32), (40, 32, 40), (20, 16, 24)])
+@pytest.mark.parametrize("cin,cout,ldx", [(25, 16, 64), (40, 24, 64), (33, 32, 64), (64, 32, 64), (16, 32, 16), (25, 16, 32), (40, 32, 40), (20, 16, 24),
+                                          (132, 16, 256), (164, 32, 192), (200, 24, 224), (160, 16, 256)])   # (eight-chunk instance with 5-7 real chunks: ADVICE r4)
 def test_pointwise_rows_ragged_channels_ignore_the_row_padding(cin, cout, ldx, dtype):
     """dp_pointwise_rows on rows wider than Cin (pitch a multiple of 32): the matrix-core path reads whole 32-channel chunks and must
     mask what lies beyond Cin -- the padding here holds NaN / Inf.  Output rows are slices of a wider buffer whose other columns stay."""

@@ -90,3 +90,28 @@ def test_storage_emulation_is_identity_without_context_and_rounds_within():
         with oracle.storage(None):
             assert torch.equal(oracle.store(x), x)
     assert torch.equal(oracle.store(x), x)
+
+
+def test_dice_ce_restatement_matches_a_per_class_loop_and_torch_cross_entropy():
+    """oracle.dice_ce_loss (MONAI 0.7.0 DiceCELoss(to_onehot_y=True, softmax=True), train_light_transeg.py:148): the cross-entropy half
+    is torch's own F.cross_entropy; the Dice half is re-derived here as an explicit loop over (sample, class) from the published
+    formula 1 - (2 sum(p y) + 1e-5) / (sum(y) + sum(p) + 1e-5), mean over samples and classes (background included)."""
+    B, C, S = 2, 8, (5, 6, 7)
+    z = _rnd((B, C) + S, 21)
+    lab = torch.randint(0, C, (B, 1) + S, generator=torch.Generator().manual_seed(22)).double()
+    zr = z.clone().requires_grad_(True)
+    p = torch.softmax(zr, 1)
+    dice = 0.0
+    for b in range(B):
+        for c in range(C):
+            y = (lab[b, 0] == c).double()
+            dice = dice + (1.0 - (2.0 * (p[b, c] * y).sum() + 1e-5) / (y.sum() + p[b, c].sum() + 1e-5))
+    ref = dice / (B * C) + torch.nn.functional.cross_entropy(zr, lab[:, 0].long())
+    zo = z.clone().requires_grad_(True)
+    got = oracle.dice_ce_loss(zo, lab)
+    assert abs(float(got) - float(ref)) < 1e-12
+    ref.backward()
+    got.backward()
+    assert rel_err(zo.grad, zr.grad) < 1e-11
+    # labels without the channel axis and integer labels are the same thing
+    assert abs(float(oracle.dice_ce_loss(z, lab[:, 0].long()[:, None])) - float(ref)) < 1e-12
