@@ -286,7 +286,7 @@ def branch_stream_allowed():
     return not torch.cuda.is_current_stream_capturing()
 
 
-_deterministic = False
+_deterministic = 0
 
 
 def set_deterministic(on):
@@ -302,12 +302,15 @@ def set_deterministic(on):
     DOSE_HIP_DETERMINISTIC=1 switches it on at import."""
     global _deterministic
     from . import _lib
-    _lib.lib().dp_set_deterministic(1 if on else 0)
-    _deterministic = bool(on)
+    # (an int other than 0 / 1 is a mask of single sites, for experiments -- tools/determinism_probe.py: 1 split-kd convolutions, 2 split-K
+    # GEMMs, 4 tiled weight gradients, 8 generic weight gradient, 16 trilinear backward, 32 LayerNorm dgamma / dbeta)
+    mask = 0x7fffffff if on is True or on == 1 else int(on or 0)
+    _lib.lib().dp_set_deterministic(mask)
+    _deterministic = mask
 
 
-def deterministic():
-    return _deterministic
+def deterministic(site=0x7fffffff):
+    return bool(_deterministic & site)
 
 
 class deterministic_as:

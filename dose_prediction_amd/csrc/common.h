@@ -222,7 +222,8 @@ static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 // dp_set_deterministic (elementwise.hip): 1 = every reduction that normally meets in fp32 atomics takes a fixed-order path instead, so that
 // two runs on the same inputs are bit-identical (split-kd convolutions run unsplit, split-K GEMMs unsplit, the weight-gradient kernels write one
 // scratch slab per voxel share and the unpack pass adds the slabs in order, LayerNorm's dgamma / dbeta go through per-block partial rows).
-int dp_det();
+int dp_det(int site = 0x7fffffff);        // site: DET_* bit(s); experiments (tools/determinism_probe.py) switch single sites on through dp_set_deterministic(mask)
+enum { DET_SPLITKD = 1, DET_SPLITK = 2, DET_WGRAD = 4, DET_WGRAD_GENERIC = 8, DET_TRILINEAR = 16 };
 // slabs of `base` fp32 elements the tap-major weight-gradient scratch holds in deterministic mode (<= 32 Mi elements in total)
 static inline int det_slabs(int64_t base) { int64_t n = (32ll << 20) / (base > 0 ? base : 1); return n < 1 ? 1 : (n > 512 ? 512 : (int)n); }
 static inline int roundup8(int c) { return (c + 7) & ~7; }

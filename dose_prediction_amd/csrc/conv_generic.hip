@@ -260,7 +260,7 @@ extern "C" int dp_conv3d_wgrad(const void* x, int ldx, const void* gy, int ldgy,
   if (rc >= 0) return rc;
   int64_t Vtot = (int64_t)N * Do * Ho * Wo;
   // deterministic mode: every dW element is one wave's accumulator, added ONCE to the (zeroed) destination -- no atomics meet
-  const bool det = dp_det() != 0;
+  const bool det = dp_det(DET_WGRAD_GENERIC) != 0;
   WgGeom g = {N, Di, Hi, Wi, Do, Ho, Wo, Cin, Cout, k, stride, pad, dil, shift, gy_tap_choff, ldx, ldgy, s_co, s_ci, s_tap, det ? Vtot : (int64_t)WG_VOX};
   int taps = k * k * k;
   int cb = dtype != DP_F32 ? WgCfg<bf16_t>::CB : WgCfg<float>::CB;

@@ -577,7 +577,7 @@ static void tiled_geometry(TiledGeom& g, int k, int np, int rw, int& nt, int* yg
   *ygrid = cdiv(g.NTT, nt * wn);
   int64_t blocks = (int64_t)g.N * g.D * g.tiles_h * g.tiles_w * *ygrid;
   const int split_below = (!*w16 && wn == 2) ? 200 : 400;   // (the 8-row arrangement is there to AVOID the split: 256 blocks are enough)
-  g.splitkd = (np == 1 && blocks < split_below && !dp_det()) ? 1 : 0;    // small volumes: one block per kd, fp32 atomic accumulation (deterministic mode: unsplit)
+  g.splitkd = (np == 1 && blocks < split_below && !dp_det(DET_SPLITKD)) ? 1 : 0;    // small volumes: one block per kd, fp32 atomic accumulation (deterministic mode: unsplit)
   // ... and, when even k blocks per tile leave the chip half empty, per share of the input chunks (>= 4 chunks per share)
   g.chsplit = 1;
   if (g.splitkd) { while (blocks * k * g.chsplit < 400 && g.NCH / (g.chsplit * 2) >= 4) g.chsplit *= 2; }
@@ -1286,7 +1286,7 @@ static inline bool wgt_applicable(int Cin, int Cout, int k, int stride, int pad,
 extern "C" int dp_conv3d_wgrad_tiled_ws_elems(int Cin, int Cout, int k, int stride, int pad, int dil, int shift, int W) {
   if (!wgt_applicable(Cin, Cout, k, stride, pad, dil, shift, W)) return 0;
   int64_t base = (int64_t)k * k * k * Cin * Cout; const int64_t hk = wgrad_hk_ws_elems(Cin, Cout, k);
-  if (dp_det()) base *= det_slabs(base);               // one slab per voxel share (see WgtGeom::slab)
+  if (dp_det(DET_WGRAD)) base *= det_slabs(base);               // one slab per voxel share (see WgtGeom::slab)
   int64_t n = base > hk ? base : hk;
   if (k == 1 && Cin <= 64 && Cout <= 32) { const int64_t rw = wgrad_rows_ws_elems(Cin, Cout); if (rw > n) n = rw; }   // per-block partials of k_wgrad_rows
   return n > 2000000000LL ? 0 : (int)n;
@@ -1342,7 +1342,7 @@ extern "C" int dp_conv3d_wgrad_tiled2(const void* x, int ldx, const void* x2, in
   hipStream_t s = STREAM;
   int taps = k * k * k;
   const int64_t base = (int64_t)taps * Cin * Cout;
-  const int max_slabs = dp_det() ? det_slabs(base) : 0;
+  const int max_slabs = dp_det(DET_WGRAD) ? det_slabs(base) : 0;
   int nslab = 1;
   if (!g_scratch_zeroed) {
     hipError_t me = hipMemsetAsync(ws, 0, (size_t)base * (max_slabs ? max_slabs : 1) * sizeof(float), s);

@@ -13,8 +13,8 @@ extern "C" const char* dp_last_error(void) { return g_err; }
 extern "C" int dp_version(void) { return 100; }
 // Deterministic mode (process-wide; see common.h dp_det()).
 static int g_deterministic = 0;
-int dp_det() { return g_deterministic; }
-extern "C" int dp_set_deterministic(int on) { g_deterministic = on ? 1 : 0; return 0; }
+int dp_det(int site) { return (g_deterministic & site) != 0; }
+extern "C" int dp_set_deterministic(int on) { g_deterministic = on == 1 ? 0x7fffffff : on; return 0; }     // (1 = everything; other values: a mask of DET_* sites, experiments only)
 extern "C" int dp_get_deterministic(void) { return g_deterministic; }
 
 #define STREAM ((hipStream_t)stream)
@@ -517,7 +517,7 @@ __global__ void k_trilinear_bwd_gather(const T* __restrict__ gy, int ldgy, float
   }
 }
 extern "C" int dp_trilinear_up2_bwd(const void* gy, int ldgy, float* gx, int N, int D, int H, int W, int C, int dtype, void* stream) {
-  if (dp_det()) {
+  if (dp_det(DET_TRILINEAR)) {
     const int64_t tot = (int64_t)N * D * H * W * C;
     DP_DISPATCH(dtype, hipLaunchKernelGGL(k_trilinear_bwd_gather<T>, dim3(grid_for(tot, 256)), dim3(256), 0, STREAM, (const T*)gy, ldgy, gx, N, D, H, W, C));
     DP_CHECK_LAUNCH("trilinear_bwd_gather"); return 0;

@@ -246,7 +246,7 @@ static int gemm_nt_impl(const void* A, int64_t lda, int64_t sa0, int64_t sa1, co
   if (M <= 0 || N <= 0 || K <= 0) DP_FAIL("gemm_nt: empty problem %d %d %d", M, N, K);
   if (splitk < 1) splitk = 1;
   if (splitk > 1 && !out_f32) DP_FAIL("gemm_nt: split-K needs fp32 (atomic) output");
-  if (dp_det()) splitk = 1;            // deterministic mode: no atomic meeting of K shares (the whole K axis in one block per tile)
+  if (dp_det(DET_SPLITK)) splitk = 1;            // deterministic mode: no atomic meeting of K shares (the whole K axis in one block per tile)
   int64_t big_blocks = (int64_t)cdiv(M, 128) * cdiv(N, 128) * nb0 * nb1 * splitk;
   bool small = big_blocks < 256 && N > 32;        // 64x64 tiles: 4x the blocks (skinny N keeps the 128-row tile: it is a row stream)
   // (a 128 x 64 tile for the qkv / fc1 token GEMMs -- 288-384 blocks, a third less L2 -> LDS traffic -- was measured in round 4: 16.8 / 18.0 us
@@ -492,7 +492,7 @@ __global__ void __launch_bounds__(256) k_gemm_tn_grouped(const TnProblem* __rest
 extern "C" int dp_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int M, int N, int K, int splitk,
                           int dtype, void* stream) {
   if (M <= 0 || N <= 0 || K <= 0) DP_FAIL("gemm_tn: empty problem %d %d %d", M, N, K);
-  if (splitk < 1 || dp_det()) splitk = 1;      // (deterministic mode: unsplit)
+  if (splitk < 1 || dp_det(DET_SPLITK)) splitk = 1;      // (deterministic mode: unsplit)
   dim3 g(cdiv(M, 64), cdiv(N, 64), splitk);
   if (g.y > 65535 || g.z > 65535) DP_FAIL("gemm_tn: grid too large");
   DP_DISPATCH(dtype, hipLaunchKernelGGL(k_gemm_tn<T>, g, dim3(256), 0, STREAM, (const T*)A, lda, (const T*)B, ldb, C, ldc, M, N, K, splitk));

@@ -1914,7 +1914,7 @@ def layer_norm(x, gamma, beta, eps=1e-5):
 
 def _deterministic():
     from . import config
-    return config.deterministic()
+    return config.deterministic(32)
 
 
 def _layernorm_bwd_det(x, gy, gsum, gamma, mean, rstd, gx, rows, C):

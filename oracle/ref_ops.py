@@ -10,7 +10,7 @@ import torch.nn.functional as F
 
 __all__ = [
     "conv3d", "conv_transpose3d_k2s2", "instance_norm", "batch_norm", "layer_norm", "activation",
-    "trilinear_up2", "linear", "gelu", "attention", "patchify", "bf16_round", "storage", "store", "store_weight", "dice_ce_loss", "grad_noise",
+    "trilinear_up2", "linear", "gelu", "attention", "patchify", "bf16_round", "storage", "store", "store_weight", "dice_ce_loss", "grad_noise", "round_bits",
 ]
 
 
@@ -63,8 +63,15 @@ _GRAD_NOISE = None
 
 
 class grad_noise:
-    def __init__(self, eps, seed=0):
-        self.cfg = (float(eps), torch.Generator().manual_seed(int(seed)))
+    """bits: additionally round every stored gradient to that many significand bits AFTER the perturbation (8 = the operand grid of the
+    fp32x3 mode's one-product backward pass and of the bf16 mode, 16 = its three-product backward pass).  A rounding to u = 2^-bits turns
+    a perturbation of relative size d into one of size ~sqrt(d u) (the elements within d of a rounding boundary flip by a whole u), so a
+    CHAIN of such roundings drives any perturbation, however small, to the grid's own noise level within a few layers."""
+
+    def __init__(self, eps, seed=0, bits=None, fwd_eps=0.0):
+        """fwd_eps: the same relative perturbation on the FORWARD value of every stored tensor (round-off that reaches the activation
+        gates: a ReLU / LeakyReLU pre-activation within fwd_eps of zero flips, and the gradient field around it changes by O(1))."""
+        self.cfg = (float(eps), torch.Generator().manual_seed(int(seed)), bits, float(fwd_eps))
 
     def __enter__(self):
         global _GRAD_NOISE
@@ -76,17 +83,26 @@ class grad_noise:
         _GRAD_NOISE = self.prev
 
 
+def round_bits(t, bits):
+    """t rounded to `bits` significand bits (round to nearest; bits = 8: the bf16 grid, 16: a [hi | lo] bf16 pair, 24: fp32)."""
+    m, e = torch.frexp(t)
+    return torch.ldexp(torch.round(m * (2.0 ** bits)) / (2.0 ** bits), e)
+
+
 class _Noise(torch.autograd.Function):
     @staticmethod
     def forward(ctx, t, cfg):
         ctx.cfg = cfg
+        if cfg[3]:
+            return t * (1 + cfg[3] * (torch.rand(t.shape, generator=cfg[1], dtype=t.dtype) * 2 - 1))
         return t.view_as(t)
 
     @staticmethod
     def backward(ctx, g):
-        eps, gen = ctx.cfg
+        eps, gen, bits, _ = ctx.cfg
         u = torch.rand(g.shape, generator=gen, dtype=g.dtype) * 2 - 1
-        return g * (1 + eps * u), None
+        g = g * (1 + eps * u)
+        return (g if bits is None else round_bits(g, bits)), None
 
 
 def store(t):
