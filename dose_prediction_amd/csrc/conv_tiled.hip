@@ -1327,6 +1327,8 @@ static int launch_wgt(const void* x, const void* gy, float* ws, WgtGeom g, hipSt
   return 0;
 }
 
+// shape test of the streaming pointwise weight-gradient kernel (k = 1); dtype DP_X1: fp32 rows, dW = x_hi gy_hi (the fp32x3 mode)
+extern "C" int dp_conv3d_wgrad_rows_ok(int ldx, int ldgy, int64_t rows, int Cin, int Cout, int dtype) { return wgrad_rows_ok(ldx, ldgy, rows, Cin, Cout, dtype) ? 1 : 0; }
 // ws: fp32 scratch of dp_conv3d_wgrad_tiled_ws_elems() elements (need not be initialised).  OVERWRITES dw (need not be initialised).
 extern "C" int dp_conv3d_wgrad_tiled2(const void* x, int ldx, const void* x2, int ldx2, int csplit, const void* gy, int ldgy, float* dw, float* ws,
                                       int N, int D, int H, int W, int Cin, int Cout, int k, int64_t s_co, int64_t s_ci, int64_t s_tap, int dtype, void* stream);
@@ -1362,6 +1364,8 @@ extern "C" int dp_conv3d_wgrad_tiled2(const void* x, int ldx, const void* x2, in
     if (!fast) fprintf(stderr, "[dp slow] wgrad_tiled k=%d Cin=%d Cout=%d %dx%dx%d ldx=%d ldx2=%d csplit=%d ldgy=%d: some channel tiles stage GUARDED\n", k, Cin, Cout,
                        D, H, W, ldx, ldx2, csplit, ldgy);
   }
+  if (dtype == DP_X1 && !(k == 1 && !x2 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)gy & 15) == 0 && wgrad_rows_ok(ldx, ldgy, (int64_t)N * D * H * W, Cin, Cout, dtype)))
+    DP_FAIL("wgrad_tiled: DP_X1 (fp32 rows, one bf16 product) is the pointwise row kernel's shape class only (dp_conv3d_wgrad_rows_ok)");
   if (k == 1 && !x2 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)gy & 15) == 0 && wgrad_rows_ok(ldx, ldgy, (int64_t)N * D * H * W, Cin, Cout, dtype)) {
     // millions of voxel rows x a few dozen channels: the streaming kernel of elementwise.hip (deterministic two-stage sum, dW written directly)
     wgrad_rows_launch(x, ldx, gy, ldgy, dw, s_co, s_ci, ws, (int64_t)N * D * H * W, Cin, Cout, dtype, g_scratch_zeroed, s);

@@ -77,6 +77,19 @@ __device__ __forceinline__ void ncdhw_to_ndhwc_body(const float* __restrict__ sr
         continue;
       }
     }
+    if constexpr (sizeof(T) == 4) {
+      // fp32 rows (parity / fp32x3 modes): four channels -> one 16-byte store (round 5: the 4-byte stores ran the 9 -> 16 channel entry
+      // conversion of a 2 x 128^3 input at 1 TB/s, 0.45 ms where the bf16 path takes 0.05)
+      if ((cpad & 3) == 0 && (ld & 3) == 0 && (((uintptr_t)dst) & 15) == 0) {
+        for (int c0 = 0; c0 < cpad; c0 += 4) {
+          v4f t;
+#pragma unroll
+          for (int j = 0; j < 4; j++) t[j] = (c0 + j < C) ? s[(int64_t)(c0 + j) * V] : 0.f;
+          *(v4f*)((float*)d + c0) = t;
+        }
+        continue;
+      }
+    }
     for (int c = 0; c < cpad; c++) st_f(d + c, c < C ? s[(int64_t)c * V] : 0.f);
   }
 }
@@ -1050,8 +1063,24 @@ extern "C" int dp_pointwise_wgrad_rows(const void* x, int ldx, const void* gy, i
 // gemm_tn_tile); no block barrier until the end, where the four waves' accumulators meet in LDS and the block writes ONE partial
 // [Cout][Cin] to the workspace.  A second small kernel adds the partials in a fixed order (deterministic), writes dW with the caller's
 // strides and hands the workspace back zeroed.
-template <typename T, int MT, int NT>
-__global__ void __launch_bounds__(256) k_wgrad_rows(const T* __restrict__ x, int ldx, const T* __restrict__ gy, int ldgy, float* __restrict__ part,
+// S = the type the rows have in memory: T, or float (the fp32x3 mode's one-product weight gradient, DP_X1: fp32 rows rounded to bf16
+// between the global load and the LDS image -- dW = x_hi gy_hi without a cast pass over either tensor).
+template <typename S> struct RowPiece { v4u v; };
+template <> struct RowPiece<float> { v4f a, b; };
+template <typename T, typename S> __device__ __forceinline__ RowPiece<S> row_piece_load(const S* p, bool ok) {
+  RowPiece<S> r;
+  if constexpr (sizeof(S) == 4) { const v4f a = *(const v4f*)p, b = *(const v4f*)(p + 4); r.a = ok ? a : (v4f){0.f, 0.f, 0.f, 0.f}; r.b = ok ? b : (v4f){0.f, 0.f, 0.f, 0.f}; }
+  else { const v4u v = *(const v4u*)p; r.v = ok ? v : (v4u){0, 0, 0, 0}; }
+  return r;
+}
+template <typename T, typename S> __device__ __forceinline__ v4u row_piece_bits(const RowPiece<S>& r) {
+  if constexpr (sizeof(S) == 4) {
+    return (v4u){(unsigned)f2bf(r.a[0]) | ((unsigned)f2bf(r.a[1]) << 16), (unsigned)f2bf(r.a[2]) | ((unsigned)f2bf(r.a[3]) << 16),
+                 (unsigned)f2bf(r.b[0]) | ((unsigned)f2bf(r.b[1]) << 16), (unsigned)f2bf(r.b[2]) | ((unsigned)f2bf(r.b[3]) << 16)};
+  } else return r.v;
+}
+template <typename T, int MT, int NT, typename S = T>
+__global__ void __launch_bounds__(256) k_wgrad_rows(const S* __restrict__ x, int ldx, const S* __restrict__ gy, int ldgy, float* __restrict__ part,
                                                     int64_t rows, int Cin, int Cout) {
   constexpr int GP = MT * 16 + 8, XP = NT * 16 + 8;            // LDS row pitches in elements (16-byte rows)
   constexpr int WSZ = 32 * GP + 32 * XP;
@@ -1070,30 +1099,28 @@ __global__ void __launch_bounds__(256) k_wgrad_rows(const T* __restrict__ x, int
   for (int m = 0; m < MT; m++)
 #pragma unroll
     for (int n = 0; n < NT; n++) acc[m][n] = (v4f){0.f, 0.f, 0.f, 0.f};
-  v4u rg0[MT], rx0[NT], rg1[MT], rx1[NT];                      // two slabs in flight per wave
-  auto gload = [&](int64_t sl, v4u* rg, v4u* rx) __attribute__((always_inline)) {
+  RowPiece<S> rg0[MT], rx0[NT], rg1[MT], rx1[NT];              // two slabs in flight per wave
+  auto gload = [&](int64_t sl, RowPiece<S>* rg, RowPiece<S>* rx) __attribute__((always_inline)) {
     const int64_t r0 = sl * 32;
 #pragma unroll
     for (int i = 0; i < MT; i++) {
       const int64_t r = r0 + grow[i];
       const bool ok = r < rows && gcc[i] < Cout;                // (columns beyond Cout: zero rows of dW that are never stored)
-      const v4u v = *(const v4u*)(gy + (ok ? r * ldgy + gcc[i] : 0));
-      rg[i] = ok ? v : (v4u){0, 0, 0, 0};
+      rg[i] = row_piece_load<T, S>(gy + (ok ? r * ldgy + gcc[i] : 0), ok);
     }
 #pragma unroll
     for (int i = 0; i < NT; i++) {
       const int64_t r = r0 + xrow[i];
       const bool ok = r < rows && xcc[i] < Cin;
-      const v4u v = *(const v4u*)(x + (ok ? r * ldx + xcc[i] : 0));
-      rx[i] = ok ? v : (v4u){0, 0, 0, 0};
+      rx[i] = row_piece_load<T, S>(x + (ok ? r * ldx + xcc[i] : 0), ok);
     }
   };
   const int trg = (8 * q + (i16 >> 2)) * GP + 4 * (i16 & 3), trx = (8 * q + (i16 >> 2)) * XP + 4 * (i16 & 3);
-  auto step = [&](int64_t nxt, v4u* rg, v4u* rx) __attribute__((always_inline)) {
+  auto step = [&](int64_t nxt, RowPiece<S>* rg, RowPiece<S>* rx) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < MT; i++) *(v4u*)(gimg + grow[i] * GP + gcc[i]) = rg[i];
+    for (int i = 0; i < MT; i++) *(v4u*)(gimg + grow[i] * GP + gcc[i]) = row_piece_bits<T, S>(rg[i]);
 #pragma unroll
-    for (int i = 0; i < NT; i++) *(v4u*)(ximg + xrow[i] * XP + xcc[i]) = rx[i];
+    for (int i = 0; i < NT; i++) *(v4u*)(ximg + xrow[i] * XP + xcc[i]) = row_piece_bits<T, S>(rx[i]);
     if (nxt < nslab) gload(nxt, rg, rx);                        // this register set's next slab flies during the LDS round trip and the MFMAs
     __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier();
     Frag8<T> fa[MT], fb[NT];
@@ -1167,6 +1194,9 @@ static int wgrad_rows_blocks(int64_t rows) {
 // shapes the streaming weight-gradient kernel takes (16-bit storage; alignment of the pointers is checked by the caller)
 bool wgrad_rows_ok(int ldx, int ldgy, int64_t rows, int Cin, int Cout, int dtype) {
   static const int on = [] { const char* e = getenv("DP_WGRAD_ROWS"); return e ? atoi(e) : 1; }();
+  if (dtype == DP_X1)        // fp32 rows, rounded to bf16 in registers (the fp32x3 mode's one-product weight gradients): 16-byte pieces of four floats
+    return on && rows >= 32768 && Cin >= 8 && Cin <= 64 && Cout >= 8 && Cout <= 32 && Cout % 8 == 0 && ldx % 4 == 0 && ldgy % 4 == 0 &&
+           (Cin + 7) / 8 * 8 <= ldx && Cout <= ldgy;
   return on && (dtype == DP_BF16 || dtype == DP_F16) && rows >= 32768 && Cin >= 8 && Cin <= 64 && Cout >= 8 && Cout <= 32 && Cout % 8 == 0 &&
          ldx % 8 == 0 && ldgy % 8 == 0 && (Cin + 7) / 8 * 8 <= ldx && Cout <= ldgy;      // (wider outputs -- ConvTranspose's 8 Cout -- measured slower than the tiled kernel: 16 MB of partials)
 }
@@ -1178,7 +1208,12 @@ int wgrad_rows_launch(const void* x, int ldx, const void* gy, int ldgy, float* d
 #define GOW(TT, MT_, NT_) hipLaunchKernelGGL((k_wgrad_rows<TT, MT_, NT_>), dim3(g), dim3(256), 0, s, (const TT*)x, ldx, (const TT*)gy, ldgy, part, rows, Cin, Cout)
 #define GOWN(TT, MT_) do { if (nt == 1) GOW(TT, MT_, 1); else if (nt == 2) GOW(TT, MT_, 2); else GOW(TT, MT_, 4); } while (0)
 #define GOWM(TT) do { if (mt == 1) GOWN(TT, 1); else GOWN(TT, 2); } while (0)
-  if (dtype == DP_BF16) GOWM(bf16_t); else GOWM(f16_t);
+#define GOW32(MT_, NT_) hipLaunchKernelGGL((k_wgrad_rows<bf16_t, MT_, NT_, float>), dim3(g), dim3(256), 0, s, (const float*)x, ldx, (const float*)gy, ldgy, part, rows, Cin, Cout)
+#define GOWN32(MT_) do { if (nt == 1) GOW32(MT_, 1); else if (nt == 2) GOW32(MT_, 2); else GOW32(MT_, 4); } while (0)
+  if (dtype == DP_X1) { if (mt == 1) GOWN32(1); else GOWN32(2); }
+  else if (dtype == DP_BF16) GOWM(bf16_t); else GOWM(f16_t);
+#undef GOWN32
+#undef GOW32
 #undef GOWM
 #undef GOWN
 #undef GOW

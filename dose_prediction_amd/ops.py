@@ -776,8 +776,15 @@ class Conv3d(torch.autograd.Function):
             gw = _wgrad_buffer(weight, not wse)
             if wse:
                 ws = _zero_scratch(x.device, wse)
+                wdt = dtc
+                if k == 1 and dtc == 0 and _p(x) % 16 == 0 and _p(gy) % 16 == 0:
+                    # fp32x3 with one-product weight gradients (config.set_x3_wgrad_terms(1), the default): the mixers' dW = x_hi gy_hi on the
+                    # streaming row kernel, fp32 rows rounded to bf16 in registers (the exact-fp32 tiled kernel took 0.4-0.5 ms at 2 x 128^3)
+                    from . import config
+                    if config.x3() and config.x3_wgrad_terms() == 1 and _lib.lib().dp_conv3d_wgrad_rows_ok(ldx, ldg, grows, cin, cout, DP_X1):
+                        wdt = DP_X1
                 _lib.call("dp_conv3d_wgrad_tiled", _p(x), ldx, _p(gy), ldg, _p(gw), _p(ws), N, Di, Hi, Wi, cin, cout, k,
-                          cin * taps, taps, 1, dtc, _stream())
+                          cin * taps, taps, 1, wdt, _stream())
             else:
                 wgrad(x, ldx, gy, ldg, gw, (N, Di, Hi, Wi, Do, Ho, Wo), cin, cout, k, stride, pad, dil, 1, 0,
                       cin * taps, taps, 1, dtc)

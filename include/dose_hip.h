@@ -289,6 +289,11 @@ int dp_conv3d_wgrad(const void* x, int ldx, const void* gy, int ldgy, float* dw,
  * [Cout][Cin][taps] index space is written); neither dw nor ws need be initialised.  (k = 3: the scratch also holds the per-block
  * partial sums of the depth-marching kernel, 512 x 27 x 256 floats, so that no atomics are needed.) */
 int dp_conv3d_wgrad_tiled_ws_elems(int Cin, int Cout, int k, int stride, int pad, int dil, int shift, int W);
+/* 1 when dp_conv3d_wgrad_tiled(k = 1) takes the streaming row kernel for these rows (>= 32768 rows, 8 <= Cin <= 64, Cout in {8 .. 32}).
+ * dtype DP_X1 (accepted by dp_conv3d_wgrad_tiled for exactly these shapes): x and gy are FP32 rows and dW = x_hi gy_hi -- both operands
+ * rounded to bf16 between the global load and the LDS image: the fp32x3 mode's one-product weight gradient of the 1x1x1 mixers
+ * (blocks_MDUNet.py:146) without a cast pass and without the exact-fp32 tiled kernel. */
+int dp_conv3d_wgrad_rows_ok(int ldx, int ldgy, int64_t rows, int Cin, int Cout, int dtype);
 int dp_conv3d_wgrad_tiled(const void* x, int ldx, const void* gy, int ldgy, float* dw, float* ws, int N, int D, int H, int W,
                           int Cin, int Cout, int k, int64_t s_co, int64_t s_ci, int64_t s_tap, int dtype, void* stream);
 

@@ -24,6 +24,19 @@ SHAPES = [
 ]
 
 
+# row lengths other than 128: the 96^3 crop of the segmentation network (OARSegmentation/config.py:24, the cascade's
+# sliding-window roi, train_light_linked_model.py:152-154) and the 192-wide volume of BASELINE configs[4]; (D, H, W) tuples
+SHAPES_W = [
+    ("c7 16->16 @2x128^3", 2, 16, 16, (128, 128, 128), 7), ("c7 16->16 @4x96^3", 4, 16, 16, (96, 96, 96), 7), ("c7 16->16 @128x192x192", 1, 16, 16, (128, 192, 192), 7),
+    ("c7 32->16 @2x128^3", 2, 32, 16, (128, 128, 128), 7), ("c7 32->16 @4x96^3", 4, 32, 16, (96, 96, 96), 7), ("c7 32->16 @128x192x192", 1, 32, 16, (128, 192, 192), 7),
+    ("c3 16->16 @2x128^3", 2, 16, 16, (128, 128, 128), 3), ("c3 16->16 @4x96^3", 4, 16, 16, (96, 96, 96), 3), ("c3 16->16 @128x192x192", 1, 16, 16, (128, 192, 192), 3),
+    ("c7 16->32 @2x128^3", 2, 16, 32, (128, 128, 128), 7), ("c7 16->32 @4x96^3", 4, 16, 32, (96, 96, 96), 7), ("c7 16->32 @128x192x192", 1, 16, 32, (128, 192, 192), 7),
+    ("c7 64->32 @2x64^3", 2, 64, 32, (64, 64, 64), 7), ("c7 64->32 @4x48^3", 4, 64, 32, (48, 48, 48), 7), ("c7 64->32 @64x96x96", 1, 64, 32, (64, 96, 96), 7),
+    ("c7 32->32 @2x64^3", 2, 32, 32, (64, 64, 64), 7), ("c7 32->32 @4x48^3", 4, 32, 32, (48, 48, 48), 7), ("c7 32->32 @64x96x96", 1, 32, 32, (64, 96, 96), 7),
+    ("c7 64->64 @2x32^3", 2, 64, 64, (32, 32, 32), 7), ("c7 64->64 @4x24^3", 4, 64, 64, (24, 24, 24), 7), ("c7 64->64 @32x48x48", 1, 64, 64, (32, 48, 48), 7),
+]
+
+
 def timeit(fn, iters=5):
     fn()
     torch.cuda.synchronize()
@@ -41,6 +54,7 @@ def main():
     ap.add_argument("what", nargs="?", default="all")
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--filter", default="")
+    ap.add_argument("--widths", action="store_true", help="the W = 96 / 192 shape families next to their 128-wide twins (SHAPES_W)")
     ap.add_argument("--zeros", action="store_true", help="all-zero operands: the clock the chip holds without data toggling (DVFS diagnostic)")
     a = ap.parse_args()
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
@@ -48,15 +62,19 @@ def main():
         import dose_prediction_amd
         dose_prediction_amd.set_compute_dtype("fp32x3")
     dev = torch.device("cuda:0")
-    for name, N, ci, co, S, k in SHAPES:
+    for name, N, ci, co, S, k in (SHAPES_W if a.widths else SHAPES):
         if a.filter and a.filter not in name:
             continue
-        x = torch.randn((N, S, S, S, ci), device=dev).to(dt)
-        gy = torch.randn((N, S, S, S, co), device=dev).to(dt)
+        if isinstance(S, tuple):
+            D_, H_, W_ = S
+        else:
+            D_ = H_ = W_ = S
+        x = torch.randn((N, D_, H_, W_, ci), device=dev).to(dt)
+        gy = torch.randn((N, D_, H_, W_, co), device=dev).to(dt)
         w = (torch.randn((co, ci, k, k, k), device=dev) * (ci * k ** 3) ** -0.5).requires_grad_(True)
         if a.zeros:
             x.zero_(); gy.zero_(); w.data.zero_()
-        fl = 2.0 * N * S ** 3 * ci * co * k ** 3
+        fl = 2.0 * N * D_ * H_ * W_ * ci * co * k ** 3
         line = f"{name:28s}"
         if a.what in ("fwd", "all"):
             with torch.no_grad():
@@ -66,9 +84,9 @@ def main():
             def wg():
                 gw = torch.zeros(w.shape, dtype=torch.float32, device=dev)
                 taps = k ** 3
-                wse = _lib.lib().dp_conv3d_wgrad_tiled_ws_elems(ci, co, k, 1, k // 2, 1, 1, S)
+                wse = _lib.lib().dp_conv3d_wgrad_tiled_ws_elems(ci, co, k, 1, k // 2, 1, 1, W_)
                 ws = ops._zero_scratch(dev, wse)          # zero-in / zero-out scratch contract (dp_scratch_contract)
-                _lib.call("dp_conv3d_wgrad_tiled", x.data_ptr(), ci, gy.data_ptr(), co, gw.data_ptr(), ws.data_ptr(), N, S, S, S,
+                _lib.call("dp_conv3d_wgrad_tiled", x.data_ptr(), ci, gy.data_ptr(), co, gw.data_ptr(), ws.data_ptr(), N, D_, H_, W_,
                           ci, co, k, ci * taps, taps, 1, 1 if dt == torch.bfloat16 else 0, torch.cuda.current_stream().cuda_stream)
             ms = timeit(wg)
             line += f"  wgrad {ms:7.3f} ms {fl / ms / 1e9:7.1f} TF"
