@@ -374,7 +374,314 @@ __global__ void __launch_bounds__(256, OCC) k_conv_cc16(const T* __restrict__ x,
   }
 }
 
-int cc16_stat_blocks(int D, int H, int W) { return D * cdiv(H, 8) * cdiv(W, 128); }
+
+// ================================================================================================ row lengths other than 128 (round 5)
+// The kernel above gives each of its four waves 32 positions of a 128-position tile: at W = 96 (the segmentation network's own crop,
+// OARSegmentation/config.py:24, and the cascade's sliding-window roi, train_light_linked_model.py:152-154) one wave in four multiplies
+// padding, at W = 192 (BASELINE configs[4]) half of every second tile does: 15-20 % of the 7x7x7 rate (tools/bench_conv.py --widths).
+// k_conv_cc16w tiles W in units of 2 x NMT M tiles (NMT = 3: 96 positions) and splits the block's 8 output rows instead: wave = (column half
+// wcol, row half wrow) owns 4 rows x NMT M tiles of BOTH depth slices (2 x 4 x NMT x 4 accumulator registers: 96 for NMT = 3).  Every wave
+// works on every staged slab, whichever of the two depth slices the slab serves (no idle waves at the ends of the kd range), and an A
+// fragment now feeds the MFMAs of both depth slices (their kd differ by one: same slab, other weights): 1 ds_read_b128 per <= 4 MFMAs
+// with a 4-row window where the 8-row window above needs one per <= 4 for ONE slice.  Same slab layout / swizzle / staging / packed
+// weights / transposing epilogue / statistics as k_conv_cc16.
+template <typename T, int KS, int NMT, int OCC, typename TO>
+__global__ void __launch_bounds__(256, OCC) k_conv_cc16w(const T* __restrict__ x, const T* __restrict__ wq, const float* __restrict__ bias,
+                                                    TO* __restrict__ y, Cc16Geom g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* slab = (T*)smem_raw;
+  constexpr int PAD = KS / 2, KWP = (KS + 1) / 2, RWO = 8, RW = 4, ROWS = RWO + KS - 1, WROWS = RW + KS - 1, CK = 16, WPW = NMT * 16, TW = 2 * WPW, DT = 2;
+  constexpr int LP = (TW + KS - 1 + 7) & ~7, LR = ROWS;
+  constexpr bool SWZ = sizeof(T) == 2;
+  constexpr int lp_par = SWZ ? ((LP >> 3) & 1) : 0;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 15, q = lane >> 4;
+  const int wcol = wv & 1, wrow = wv >> 1;
+  int b = blockIdx.x;
+  if ((gridDim.x & 7) == 0) b = (b & 7) * (gridDim.x >> 3) + (b >> 3);
+  const int tw = b % g.tiles_w; b /= g.tiles_w; const int th = b % g.tiles_h; b /= g.tiles_h; const int dt = b % g.dtiles; const int n = b / g.dtiles;
+  const int h0 = th * RWO, w0 = tw * TW, d0 = dt * DT;
+  v4f acc[DT][RW][NMT];
+#pragma unroll
+  for (int a = 0; a < DT; a++)
+#pragma unroll
+    for (int i = 0; i < RW; i++)
+#pragma unroll
+      for (int m = 0; m < NMT; m++) acc[a][i][m] = (v4f){0.f, 0.f, 0.f, 0.f};
+
+  constexpr int pieces = LR * LP * 2;
+  constexpr int SU = 8;
+  const int cin_in = g.x3 ? 32 * g.x3 : g.Cin;
+  const bool fast = SWZ && ((g.x3 ? 2 * g.x3 : g.NCH) * 16 <= (g.x2 ? g.csplit + g.ldx2 : g.ldx)) && (g.ldx % 8 == 0) && (((uintptr_t)x & 15) == 0) &&
+                    (!g.x2 || ((g.csplit % 16 == 0) && (g.ldx2 % 8 == 0) && (((uintptr_t)g.x2 & 15) == 0))) &&
+                    (int64_t)g.H * g.W * max(g.ldx, g.x2 ? g.ldx2 : 0) < (1ll << 30);
+  const int st_half = tid & 1, st_lp0 = (tid >> 1) % LP, st_lr0 = (tid >> 1) / LP;
+  const int hsel = q & 1;
+  const int lane_off = r * 32 + q * 8;
+  constexpr int WT = 512;
+  const int row0 = wrow * RW;                       // first slab row of the wave's window
+
+  for (int z = d0 - PAD; z < d0 + DT + PAD; z++) {
+    if (z < 0 || z >= g.D) continue;
+    const int nstage = g.x3 ? 2 * g.x3 : g.NCH;
+    const int kd0 = z - d0 + PAD, kd1 = kd0 - 1;
+    const bool has0 = kd0 >= 0 && kd0 < KS && d0 < g.D && !(g.dbg & 2), has1 = kd1 >= 0 && kd1 < KS && d0 + 1 < g.D && !(g.dbg & 2);
+    for (int ch = 0; ch < nstage; ch++) {
+      lds_barrier();
+      if (g.dbg & 1) {
+      } else if (fast) {
+        const bool second = g.x2 && ch * CK >= g.csplit;
+        const T* xsrc = second ? (const T*)g.x2 : x;
+        const int ldsrc = second ? g.ldx2 : g.ldx, c0 = ch * CK - (second ? g.csplit : 0);
+        const T* xplane = xsrc + (((int64_t)n * g.D + z) * g.H) * (int64_t)g.W * ldsrc + c0 + st_half * 8;
+        int lp = st_lp0, lr = st_lr0, v = tid >> 1;
+        for (int p0 = 0; p0 < pieces; p0 += 256 * SU) {
+          v4u buf[SU]; int vv[SU];
+#pragma unroll
+          for (int j = 0; j < SU; j++) {
+            const int ih = h0 - PAD + lr, iw = w0 - PAD + lp;
+            const bool ok = (p0 + j * 256 + tid < pieces) && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W;
+            v4u t = *(const v4u*)(xplane + (ok ? (ih * g.W + iw) * ldsrc : 0));
+            buf[j] = ok ? t : (v4u){0, 0, 0, 0};
+            vv[j] = (p0 + j * 256 + tid < pieces) ? v : -1;
+            v += 128; lp += 128;
+#pragma unroll
+            for (int c_ = 0; c_ < (128 + LP - 1) / LP; c_++) if (lp >= LP) { lp -= LP; lr++; }
+          }
+#pragma unroll
+          for (int j = 0; j < SU; j++)
+            if (vv[j] >= 0) *(v4u*)(slab + (int64_t)vv[j] * CK + (st_half ^ ((vv[j] >> 3) & 1)) * 8) = buf[j];
+        }
+      } else {
+        for (int p = tid; p < pieces; p += 256) {
+          int half = p & 1, v = p >> 1, lp = v % LP, lr = v / LP;
+          int ih = h0 - PAD + lr, iw = w0 - PAD + lp, c = ch * CK + half * 8;
+          int nv = cin_in - c; nv = nv > 8 ? 8 : nv;
+          bool ok = ih >= 0 && ih < g.H && iw >= 0 && iw < g.W && nv > 0;
+          const bool second = g.x2 && c >= g.csplit;
+          if (!second && g.x2 && c + nv > g.csplit) nv = g.csplit - c;
+          const T* xsrc = second ? (const T*)g.x2 : x;
+          const int ldsrc = second ? g.ldx2 : g.ldx, cc = c - (second ? g.csplit : 0);
+          Frag8<T> f = ok ? frag_load(xsrc + ((((int64_t)n * g.D + z) * g.H + ih) * g.W + iw) * ldsrc + cc, nv) : frag_zero<T>();
+          frag_st_lds(slab + (int64_t)v * CK + (half ^ (SWZ ? ((v >> 3) & 1) : 0)) * 8, f);
+        }
+      }
+      lds_barrier();
+      const int nrep = (g.x3 && ch < g.x3) ? 2 : 1;
+#pragma unroll 1
+      for (int rep = 0; rep < nrep; rep++) {
+        const int wch = rep ? ch + 2 * g.x3 : ch;
+        // one sweep of the staged slab for the depth slices it serves (H0 / H1: slice d0 / d0 + 1; block-uniform)
+        auto sweep = [&]<bool H0, bool H1>() {
+          if constexpr (KS == 7) {
+            const T* wb0 = wq + ((int64_t)(kd0 * g.NCH + wch) * 25) * WT + lane_off;
+            const T* wb1 = wq + ((int64_t)(kd1 * g.NCH + wch) * 25) * WT + lane_off;
+            Frag8<T> bE[2][4], bO[2][3];
+            auto load_bE = [&](int p) {
+#pragma unroll
+              for (int i = 0; i < 4; i++) { if constexpr (H0) bE[0][i] = frag_ld_lds(wb0 + (7 * i + p) * WT); if constexpr (H1) bE[1][i] = frag_ld_lds(wb1 + (7 * i + p) * WT); }
+            };
+            auto load_bO = [&](int p) {
+#pragma unroll
+              for (int i = 0; i < 3; i++) { if constexpr (H0) bO[0][i] = frag_ld_lds(wb0 + (7 * i + 4 + p) * WT); if constexpr (H1) bO[1][i] = frag_ld_lds(wb1 + (7 * i + 4 + p) * WT); }
+            };
+            const int v_base = wcol * WPW + r;
+            // steps k = (window row, M tile): even kh use window rows 0 .. WROWS - 1, odd kh rows 1 .. WROWS - 2
+            constexpr int NE = WROWS * NMT, NO = (WROWS - 2) * NMT, RING = (NMT % 2) ? 6 : 4;
+            static_assert(NE % RING == 0 && NO % RING == 0, "the fragment ring returns to slot 0 after every type");
+            Frag8<T> fa[RING];
+            auto a_ptr = [&](int odd, int p, int rw_, int mt) -> const T* {
+              int pos = v_base + 2 * p + odd + (q >> 1), row = row0 + rw_;
+              if (!odd && p == 3 && (q >> 1) && row + 1 < ROWS) { pos = v_base; row = row + 1; }     // straddling slot: right tap = start of the next slab row
+              const int hs = SWZ ? (hsel ^ ((pos >> 3) & 1) ^ ((row & 1) ? lp_par : 0)) : hsel;
+              return slab + (pos + row * LP + mt * 16) * CK + hs * 8;
+            };
+            auto a_step = [&](int odd, int p, int k) -> const T* { return odd ? a_ptr(1, p, 1 + k / NMT, k % NMT) : a_ptr(0, p, k / NMT, k % NMT); };
+            auto do_type = [&](int odd, int p, int nodd, int np, bool pre_next) {
+              const int S = odd ? NO : NE;
+#pragma unroll
+              for (int k = 0; k < NE; k++) {
+                if (k >= S) continue;
+                const int nx = k + 3;
+                if (nx < S) fa[nx % RING] = frag_ld_lds(a_step(odd, p, nx));
+                else if (pre_next) fa[nx % RING] = frag_ld_lds(a_step(nodd, np, nx - S));
+                __builtin_amdgcn_sched_barrier(0);
+                const int rw_ = odd ? 1 + k / NMT : k / NMT, mt = k % NMT;
+                if (odd) {
+#pragma unroll
+                  for (int i = 2; i >= 0; i--) {
+                    const int orow = rw_ - (2 * i + 1);
+                    if (orow < 0 || orow >= RW) continue;
+                    if constexpr (H0) acc[0][orow][mt] = mma16(fa[k % RING], bO[0][i], acc[0][orow][mt]);
+                    if constexpr (H1) acc[1][orow][mt] = mma16(fa[k % RING], bO[1][i], acc[1][orow][mt]);
+                  }
+                } else {
+#pragma unroll
+                  for (int i = 3; i >= 0; i--) {
+                    const int orow = rw_ - 2 * i;
+                    if (orow < 0 || orow >= RW) continue;
+                    if constexpr (H0) acc[0][orow][mt] = mma16(fa[k % RING], bE[0][i], acc[0][orow][mt]);
+                    if constexpr (H1) acc[1][orow][mt] = mma16(fa[k % RING], bE[1][i], acc[1][orow][mt]);
+                  }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+              }
+            };
+            load_bE(0);
+            fa[0] = frag_ld_lds(a_step(0, 0, 0)); fa[1] = frag_ld_lds(a_step(0, 0, 1)); fa[2] = frag_ld_lds(a_step(0, 0, 2));
+#pragma unroll 1
+            for (int p = 0; p < 3; p++) {
+              load_bO(p); __builtin_amdgcn_sched_barrier(0);
+              do_type(0, p, 1, p, true);
+              load_bE(p + 1); __builtin_amdgcn_sched_barrier(0);
+              do_type(1, p, 0, p + 1, true);
+            }
+            do_type(0, 3, 0, 0, false);
+          } else {
+            const T* wb0 = wq + ((int64_t)(kd0 * g.NCH + wch) * KWP) * KS * WT + lane_off;
+            const T* wb1 = wq + ((int64_t)(kd1 * g.NCH + wch) * KWP) * KS * WT + lane_off;
+            Frag8<T> b0[2][KS], b1[2][KS];
+            auto load_b = [&](int kwp, Frag8<T> (*bb)[KS]) {
+#pragma unroll
+              for (int kh = 0; kh < KS; kh++) { if constexpr (H0) bb[0][kh] = frag_ld_lds(wb0 + (kwp * KS + kh) * WT); if constexpr (H1) bb[1][kh] = frag_ld_lds(wb1 + (kwp * KS + kh) * WT); }
+            };
+            constexpr int S = WROWS * NMT;
+            static_assert(S % 3 == 0, "three fragment registers sets");
+            Frag8<T> fa[3];
+            const int v_lane = wcol * WPW + r + (q >> 1);
+            auto a_ptr = [&](int kwp, int s_) -> const T* {
+              const int rw_ = s_ / NMT, mt = s_ % NMT, row = row0 + rw_;
+              const int vk = v_lane + 2 * kwp;
+              const int hs = SWZ ? (hsel ^ ((vk >> 3) & 1) ^ ((row & 1) ? lp_par : 0)) : hsel;
+              return slab + (vk + row * LP + mt * 16) * CK + hs * 8;
+            };
+            auto do_pair = [&](int kwp, Frag8<T> (*bb)[KS], bool pre_next) {
+#pragma unroll
+              for (int s_ = 0; s_ < S; s_++) {
+                const int nx = s_ + 2;
+                if (nx < S) fa[nx % 3] = frag_ld_lds(a_ptr(kwp, nx));
+                else if (pre_next) fa[nx % 3] = frag_ld_lds(a_ptr(kwp + 1, nx - S));
+                __builtin_amdgcn_sched_barrier(0);
+                const int rw_ = s_ / NMT, mt = s_ % NMT;
+#pragma unroll
+                for (int kh = 0; kh < KS; kh++) {
+                  const int orow = rw_ - kh;
+                  if (orow < 0 || orow >= RW) continue;
+                  if constexpr (H0) acc[0][orow][mt] = mma16(fa[s_ % 3], bb[0][kh], acc[0][orow][mt]);
+                  if constexpr (H1) acc[1][orow][mt] = mma16(fa[s_ % 3], bb[1][kh], acc[1][orow][mt]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+              }
+            };
+            load_b(0, b0);
+            fa[0] = frag_ld_lds(a_ptr(0, 0)); fa[1] = frag_ld_lds(a_ptr(0, 1));
+            static_assert(KWP % 2 == 0, "tap pairs are swept two at a time");
+#pragma unroll 1
+            for (int kwp = 0; kwp < KWP; kwp += 2) {
+              load_b(kwp + 1, b1); __builtin_amdgcn_sched_barrier(0);
+              do_pair(kwp, b0, true);
+              if (kwp + 2 < KWP) { load_b(kwp + 2, b0); __builtin_amdgcn_sched_barrier(0); }
+              do_pair(kwp + 1, b1, kwp + 2 < KWP);
+            }
+          }
+        };
+        if (has0 && has1) sweep.template operator()<true, true>();
+        else if (has0) sweep.template operator()<true, false>();
+        else if (has1) sweep.template operator()<false, true>();
+      }
+    }
+  }
+
+  // epilogue: each wave transposes one of its output rows (WPW positions x 16 channels) through a private LDS patch, 16-byte stores
+  constexpr int NC = 16;
+  constexpr int EPC = 16 / (int)sizeof(TO), CPP = NC / EPC, ITEMS = WPW * CPP, PASSES = (ITEMS + 63) / 64;
+  if (g.dbg & 4) return;
+  __syncthreads();
+  TO* patch = (TO*)smem_raw + wv * (2 * WPW * NC);
+  const float bv = (bias && r < g.Cout) ? bias[r] : 0.f;
+  const int wbase_o = w0 + wcol * WPW;
+  TO* y2 = (TO*)g.y2;
+  if (!g.wide) {
+#pragma unroll
+    for (int od = 0; od < DT; od++)
+#pragma unroll
+      for (int t = 0; t < RW; t++)
+#pragma unroll
+        for (int mt = 0; mt < NMT; mt++)
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            const int d = d0 + od, oh = h0 + row0 + t, ow = wbase_o + mt * 16 + 4 * q + e;
+            if (d < g.D && oh < g.H && ow < g.W && r < g.Cout) {
+              const int64_t vox = (((int64_t)n * g.D + d) * g.H + oh) * g.W + ow;
+              TO* dst = (y2 && r >= g.osplit) ? y2 + vox * g.ldy2 + (r - g.osplit) : y + vox * g.ldy + r;
+              st_f(dst, acc[od][t][mt][e] + bv);
+            }
+          }
+    return;
+  }
+  float st1 = 0.f, st2 = 0.f;
+#pragma unroll
+  for (int od = 0; od < DT; od++) {
+    const int d = d0 + od;
+    if (d >= g.D) continue;
+    if (g.stat_part) { st1 = 0.f; st2 = 0.f; }
+#pragma unroll
+    for (int t = 0; t < RW; t++) {
+      TO* pp = patch + (t & 1) * (WPW * NC);
+      const int oh = h0 + row0 + t;
+#pragma unroll
+      for (int mt = 0; mt < NMT; mt++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const int m = mt * 16 + 4 * q + e;
+          const float v = acc[od][t][mt][e] + bv;
+          st_f(pp + m * NC + r, v);
+          const float vs = (oh < g.H && wbase_o + m < g.W) ? as_stored<TO>(v) : 0.f;
+          st1 += vs; st2 += vs * vs;
+        }
+      __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int ps = 0; ps < PASSES; ps++) {
+        const int qq = ps * 64 + lane, m = qq / CPP, cc = (qq % CPP) * EPC;
+        const int ow = wbase_o + m;
+        if (qq < ITEMS && oh < g.H && ow < g.W && cc < g.Cout) {
+          const int64_t vox = (((int64_t)n * g.D + d) * g.H + oh) * g.W + ow;
+          TO* dst = (y2 && cc >= g.osplit) ? y2 + vox * g.ldy2 + (cc - g.osplit) : y + vox * g.ldy + cc;
+          if (cc + EPC <= g.Cout) *(v4u*)dst = *(const v4u*)(pp + m * NC + cc);
+          else for (int k = 0; k < EPC; k++) if (cc + k < g.Cout) dst[k] = pp[m * NC + cc + k];
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (g.stat_part) {
+      float a1 = st1 + __shfl_xor(st1, 16, 64), a2 = st2 + __shfl_xor(st2, 16, 64);
+      a1 += __shfl_xor(a1, 32, 64); a2 += __shfl_xor(a2, 32, 64);
+      __syncthreads();
+      float* sred = (float*)(smem_raw + 4 * 2 * WPW * NC * sizeof(TO));
+      if (lane < 16) { sred[(wv * 2) * 16 + lane] = a1; sred[(wv * 2 + 1) * 16 + lane] = a2; }
+      __syncthreads();
+      if (tid < 32) {
+        const int which = tid >> 4, c = tid & 15;
+        if (c < g.Cout) {
+          const int blk = (d * g.tiles_h + th) * g.tiles_w + tw;
+          g.stat_part[(((int64_t)n * g.stat_nblk + blk) * 2 + which) * g.Cout + c] =
+              (sred[(0 + which) * 16 + c] + sred[(2 + which) * 16 + c]) + (sred[(4 + which) * 16 + c] + sred[(6 + which) * 16 + c]);
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// tile width of the launch: 96-position tiles (k_conv_cc16w) when they cover the row with less padding than 128-position tiles
+// (W = 96, 192, 160, 288 ...; ties go to the 128-position kernel).  A function of W alone: dp_conv3d_tiled_stat_blocks must agree.
+// 7x7x7 only: the 3x3x3 launches are latency-bound and keep the three-blocks-per-CU kernel (measured at 4 x 96^3, 16 -> 16: 0.087 ms
+// there, 0.109 ms on the 96-position tiles at two blocks per CU; 7x7x7 16 -> 16: 0.597 -> 0.508 ms, 32 -> 16: 1.014 -> 0.864).
+static inline int cc16_tw(int W, int k) {
+  static const int off = [] { const char* e = getenv("DP_NO_CC16W"); return (e && atoi(e)) ? 1 : 0; }();
+  if (off || k != 7) return 128;
+  return cdiv(W, 96) * 96 < cdiv(W, 128) * 128 ? 96 : 128;
+}
+int cc16_stat_blocks(int D, int H, int W, int k) { return D * cdiv(H, 8) * cdiv(W, cc16_tw(W, k)); }
 
 template <typename T, int KS, int DT, int OCC, typename TO>
 static int cc16_go_impl(const void* x, const void* wq, const float* bias, void* y, Cc16Geom g, hipStream_t s);
@@ -410,6 +717,24 @@ static int cc16_go_impl(const void* x, const void* wq, const float* bias, void* 
   return 0;
 }
 
+template <typename T, int KS, typename TO = T>
+static int cc16w_go(const void* x, const void* wq, const float* bias, void* y, Cc16Geom g, hipStream_t s) {
+  constexpr int NMT = 3, ROWS = 8 + KS - 1, LP = (2 * NMT * 16 + KS - 1 + 7) & ~7;
+  size_t smem = (size_t)ROWS * LP * 16 * sizeof(T);
+  const size_t need = 4 * 2 * (NMT * 16) * 16 * sizeof(TO) + 8 * 16 * sizeof(float);      // epilogue patches + statistics scratch
+  if (smem < need) smem = need;
+  auto kern = k_conv_cc16w<T, KS, NMT, 2, TO>;
+  if (smem > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) { dp_set_error("conv_cc16w: cannot raise dynamic LDS to %zu: %s", smem, hipGetErrorString(e)); return 1; }
+  }
+  g.dtiles = cdiv(g.D, 2);
+  const int64_t blocks = (int64_t)g.N * g.dtiles * g.tiles_h * g.tiles_w;
+  if (blocks > 2000000000LL) { dp_set_error("conv_cc16w: grid too large"); return 1; }
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), smem, s, (const T*)x, (const T*)wq, bias, (TO*)y, g);
+  return 0;
+}
+
 bool cc16_wide(const void* y, int ldy, const void* y2, int ldy2, int osplit, int dtype) {
   const int es = (dtype == DP_F32 || dtype == DP_X3 || dtype == DP_X1) ? 4 : 2, epc = 16 / es;      // element size of the OUTPUT
   return (ldy * es) % 16 == 0 && (((uintptr_t)y & 15) == 0) && (!y2 || ((ldy2 * es) % 16 == 0 && (((uintptr_t)y2 & 15) == 0) && osplit % epc == 0));
@@ -426,9 +751,18 @@ int cc16_launch(const void* x, int ldx, const void* x2, int ldx2, int csplit, co
   g.y2 = y2; g.ldy2 = ldy2; g.osplit = osplit; g.wide = cc16_wide(y, ldy, y2, ldy2, osplit, dtype) ? 1 : 0;
   if (stat_part && !g.wide) { dp_set_error("conv_cc16: statistics need 16-byte aligned output rows"); return 1; }
   g.N = N; g.D = D; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.ldx = ldx; g.ldy = ldy; g.NCH = (Cin + 15) / 16;
-  g.tiles_h = cdiv(H, 8); g.tiles_w = cdiv(W, 128); g.dtiles = 0;
-  g.x2 = x2; g.ldx2 = ldx2; g.csplit = csplit; g.stat_part = stat_part; g.stat_nblk = cc16_stat_blocks(D, H, W);
+  const int tile_w = cc16_tw(W, k);
+  g.tiles_h = cdiv(H, 8); g.tiles_w = cdiv(W, tile_w); g.dtiles = 0;
+  g.x2 = x2; g.ldx2 = ldx2; g.csplit = csplit; g.stat_part = stat_part; g.stat_nblk = cc16_stat_blocks(D, H, W, k);
   int rc = 0;
+  if (tile_w == 96 && dtype != DP_F32) {          // (exact fp32: the 128-position kernel; its fragments are twice as wide)
+    if (dtype == DP_BF16) rc = k == 7 ? cc16w_go<bf16_t, 7>(x, wq, bias, y, g, s) : cc16w_go<bf16_t, 3>(x, wq, bias, y, g, s);
+    else if (dtype == DP_F16) rc = k == 7 ? cc16w_go<f16_t, 7>(x, wq, bias, y, g, s) : cc16w_go<f16_t, 3>(x, wq, bias, y, g, s);
+    else if (dtype == DP_X3 || dtype == DP_X1) rc = k == 7 ? cc16w_go<bf16_t, 7, float>(x, wq, bias, y, g, s) : cc16w_go<bf16_t, 3, float>(x, wq, bias, y, g, s);
+    else { dp_set_error("conv_cc16: bad dtype"); return 1; }
+    if (rc) return rc;
+    DP_CHECK_LAUNCH("conv_cc16w"); return 0;
+  }
   if (dtype == DP_BF16) rc = k == 7 ? cc16_go<bf16_t, 7>(x, wq, bias, y, g, s) : cc16_go<bf16_t, 3>(x, wq, bias, y, g, s);
   else if (dtype == DP_F16) rc = k == 7 ? cc16_go<f16_t, 7>(x, wq, bias, y, g, s) : cc16_go<f16_t, 3>(x, wq, bias, y, g, s);
   else if (dtype == DP_F32) rc = k == 7 ? cc16_go<float, 7>(x, wq, bias, y, g, s) : cc16_go<float, 3>(x, wq, bias, y, g, s);

@@ -568,7 +568,19 @@ static void tiled_geometry(TiledGeom& g, int k, int np, int rw, int& nt, int* yg
   if (!*w16 && np == 1 && nt == 2 && g.W <= 32 && ntt % 2 == 0 && allow_wn && !no_wn && !no_wn32 &&
       !(k == 7 && ntt == 2 && g.Cin > 64) && (int64_t)g.N * g.D * cdiv(g.H, 16) * (ntt / 2) < 400) { wn = 2; nt = 1; }
   if (wn_out) *wn_out = wn;
-  if (*w16) { g.TWC = 1; g.TRG = 4 / wn; } else if (g.W > 64) { g.TWC = 4; g.TRG = 1; } else if (g.W > 32) { g.TWC = 2; g.TRG = 2; } else { g.TWC = 1; g.TRG = 4 / wn; }
+  if (*w16) { g.TWC = 1; g.TRG = 4 / wn; }
+  else if (g.W > 32) {
+    // 32-position wave columns: 4 x 1, 2 x 2 or 1 x 4 (columns x row groups) -- whichever covers the row with the least padding, ties
+    // to the wider tile (round 5: W = 96 took one 128-position tile and W = 192 two, a quarter of the MFMAs on padding; now three
+    // 32 x 32-row tiles and three 64 x 16-row tiles.  A/B on one box, 7^3: 16 -> 32 at 4 x 96^3 1.328 -> 0.954 ms, 64 -> 32 at 64 x 96 x 96
+    // 0.855 -> 0.777, 32 -> 32 0.412 -> 0.387)
+    static const bool fixed = getenv("DP_TILED_TWC_OLD") != nullptr;
+    const int p4 = cdiv(g.W, 128) * 128, p2 = cdiv(g.W, 64) * 64, p1 = cdiv(g.W, 32) * 32;
+    int twc = g.W > 64 ? 4 : 2;
+    // (7^3 only: the 3^3 launches are staging-bound and lose 5-13 % to the wider halo of narrower tiles)
+    if (!fixed && k == 7) { twc = 4; int best = p4; if (p2 < best) { twc = 2; best = p2; } if (p1 < best) twc = 1; if (g.W <= 64 && twc == 4) twc = 2; }
+    g.TWC = twc; g.TRG = 4 / twc;
+  } else { g.TWC = 1; g.TRG = 4 / wn; }
   int rpa = *w16 ? 2 : 1;
   g.LR = g.TRG * rwo * rpa + (np - 1) + (np == 2 ? 2 * (JH - 1) : k - 1);
   g.LP = ((*w16 ? 16 : g.TWC * 32) + k - 1 + 7) & ~7;   // multiple of 8: the LDS swizzle bit of a row differs from row 0 by (row * LP/8) & 1
@@ -604,7 +616,7 @@ static bool tiled_wide(const TiledGeom& g, const void* y, int dtype) {
 // launch cannot produce statistics (split-kd volumes, output rows that are not 16-byte aligned: the caller then runs dp_stats_partial).
 extern "C" int dp_conv3d_tiled_stat_blocks(int N, int D, int H, int W, int Cin, int Cout, int k, int ldy, int dtype) {
   if (!tiled_applicable(Cin, Cout, k, 1, k / 2, 1, W)) return 0;
-  if (cc16_applicable(Cin, Cout, k, W)) return cc16_wide(nullptr, ldy, nullptr, 0, 0, dtype) ? cc16_stat_blocks(D, H, W) : 0;
+  if (cc16_applicable(Cin, Cout, k, W)) return cc16_wide(nullptr, ldy, nullptr, 0, 0, dtype) ? cc16_stat_blocks(D, H, W, k) : 0;
   int rw, nt; int np = tiled_config(Cout, &rw, &nt);
   TiledGeom g; g.N = N; g.D = D; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.dbg = 0; g.x2 = nullptr; g.y2 = nullptr; g.ldy = ldy;
   int ygrid; bool w16; tiled_geometry(g, k, np, rw, nt, &ygrid, &w16);

@@ -208,6 +208,11 @@ SAMPLED = [
     # BASELINE.json configs[2] (OAR-TRANSEG 128^3 bf16 batch 2): the two launches no other configuration has
     (2, 128, 128, 128, 1, 0, 16, 3, torch.bfloat16, 16),   # encoder1's first 3^3 conv: ONE input channel in a 16-channel padded row (oar_transeg.py:92-100)
     (2, 128, 128, 128, 16, 0, 8, 1, torch.bfloat16),       # the 1x1x1 output head 16 -> 8 classes + bias (base_blocks.py:151-162)
+    # row lengths other than 128: the 96^3 crop (OARSegmentation/config.py:24; four sliding windows per launch) and the
+    # 192-wide volume of BASELINE configs[4], on the 96-position tiles of k_conv_cc16w
+    (4, 96, 96, 96, 16, 0, 16, 7, torch.bfloat16),
+    (1, 128, 192, 192, 32, 16, 16, 7, torch.bfloat16),
+    (4, 96, 96, 96, 16, 0, 16, 3, torch.bfloat16),
 ]
 
 

@@ -134,6 +134,15 @@ DTYPES = [torch.float32, torch.bfloat16, torch.float16]
     (2, 64, 64, 32, 30, 24, 3, 1, 1, 1, True),
     (2, 64, 128, 26, 32, 20, 3, 1, 1, 1, False),
     (4, 32, 64, 26, 12, 32, 7, 1, 3, 1, True),
+    # row lengths other than 128 (k_conv_cc16w: 96-position tiles, waves = column half x row half, both depth slices per wave): the
+    # 96^3 crop of the segmentation network and the 192-wide rows of BASELINE configs[4]; odd depth (a block with one live slice),
+    # ragged rows, a ragged second tile (W = 160), partial chunks, fewer than 16 output channels
+    (1, 16, 16, 3, 17, 96, 7, 1, 3, 1, True),
+    (1, 32, 16, 2, 9, 192, 7, 1, 3, 1, True),
+    (2, 9, 16, 3, 12, 160, 3, 1, 1, 1, True),
+    (1, 16, 8, 5, 8, 96, 7, 1, 3, 1, False),
+    (2, 16, 16, 1, 8, 192, 3, 1, 1, 1, True),
+    (1, 25, 16, 4, 11, 96, 3, 1, 1, 1, False),
 ])
 def test_conv3d(cfg, dtype):
     from dose_prediction_amd import ops
@@ -593,7 +602,8 @@ def test_fused_adam_matches_torch(amsgrad):
     (2, 32, 32, 32, 64, 30, 29, 24, 3),      # (one-column tiles, two channel-tile groups per block, no kd split)
     (1, 16, 16, 16, 16, 5, 11, 96, 3),       # (W >= 96, Cout <= 16: the wave-private 3^3 kernel k_conv_w3, odd depth, ragged rows, split in and out)
     (2, 16, 9, 16, 16, 2, 8, 128, 3),        # (... second operand padded to 16 channels)
-    (1, 16, 16, 16, 16, 2, 9, 96, 7)])       # (the 25-slot 7^3 sweep of k_conv_cc16 over a split input)
+    (1, 16, 16, 16, 16, 2, 9, 96, 7),        # (the 25-slot 7^3 sweep over a split input; W = 96: k_conv_cc16w)
+    (1, 16, 16, 16, 16, 3, 10, 192, 7), (2, 16, 9, 16, 16, 2, 8, 192, 3)])     # (two 96-position tiles, split in and out)
 def test_conv3d_virtual_concat(cfg, dtype):
     """conv3d((a, b)) == conv3d(cat(a, b)) of the oracle, forward and every gradient (dp_conv3d_tiled2 / dp_conv3d_wgrad_tiled2;
     the last config is too narrow for the tiled kernels and must take the materialised-cat fallback)."""
@@ -799,6 +809,8 @@ def test_fused_adam_capturable_replays_correct_steps():
     # (N, Cin, ca (virtual-concat split or 0), Cout, D, H, W, k)
     (2, 16, 0, 16, 5, 19, 70, 7),       # tap-paired epilogue, ragged H and W tiles
     (1, 32, 16, 16, 4, 9, 130, 3),      # virtual concat, TWC = 4
+    (2, 16, 0, 16, 5, 20, 96, 7),       # 96-position tiles (k_conv_cc16w): statistics per (d, 8-row tile, 96-position tile), odd depth
+    (1, 32, 16, 16, 4, 13, 192, 3),     # ... two tiles per row, virtual concat, ragged H
     (2, 16, 0, 32, 50, 61, 40, 3),      # NPAIR == 1, one N tile (>= 400 blocks: no split-kd), ragged H
     (1, 24, 0, 72, 20, 78, 33, 3),      # two N tiles per block + a second channel block (grid.y), ragged Cout / H
     (4, 32, 0, 64, 100, 16, 16, 3),     # W16 tiles (two image rows per MFMA tile)

@@ -34,6 +34,9 @@ SHAPES_W = [
     ("c7 64->32 @2x64^3", 2, 64, 32, (64, 64, 64), 7), ("c7 64->32 @4x48^3", 4, 64, 32, (48, 48, 48), 7), ("c7 64->32 @64x96x96", 1, 64, 32, (64, 96, 96), 7),
     ("c7 32->32 @2x64^3", 2, 32, 32, (64, 64, 64), 7), ("c7 32->32 @4x48^3", 4, 32, 32, (48, 48, 48), 7), ("c7 32->32 @64x96x96", 1, 32, 32, (64, 96, 96), 7),
     ("c7 64->64 @2x32^3", 2, 64, 64, (32, 32, 32), 7), ("c7 64->64 @4x24^3", 4, 64, 64, (24, 24, 24), 7), ("c7 64->64 @32x48x48", 1, 64, 64, (32, 48, 48), 7),
+    ("c3 32->16 @2x128^3", 2, 32, 16, (128, 128, 128), 3), ("c3 32->16 @4x96^3", 4, 32, 16, (96, 96, 96), 3), ("c3 32->16 @128x192x192", 1, 32, 16, (128, 192, 192), 3),
+    ("c3 16->32 @2x128^3", 2, 16, 32, (128, 128, 128), 3), ("c3 16->32 @4x96^3", 4, 16, 32, (96, 96, 96), 3), ("c3 16->32 @128x192x192", 1, 16, 32, (128, 192, 192), 3),
+    ("c3 64->32 @2x64^3", 2, 64, 32, (64, 64, 64), 3), ("c3 64->32 @64x96x96", 1, 64, 32, (64, 96, 96), 3),
 ]
 
 
