@@ -679,6 +679,8 @@ __global__ void __launch_bounds__(256, OCC) k_conv_cc16w(const T* __restrict__ x
 static inline int cc16_tw(int W, int k) {
   static const int off = [] { const char* e = getenv("DP_NO_CC16W"); return (e && atoi(e)) ? 1 : 0; }();
   if (off || k != 7) return 128;
+  static const int t64 = [] { const char* e = getenv("DP_CC16W_64"); return (e && atoi(e)) ? 1 : 0; }();      // (experiment: 64-position tiles of the same wave geometry for W % 64 == 0)
+  if (t64 && W % 64 == 0) return 64;
   return cdiv(W, 96) * 96 < cdiv(W, 128) * 128 ? 96 : 128;
 }
 int cc16_stat_blocks(int D, int H, int W, int k) { return D * cdiv(H, 8) * cdiv(W, cc16_tw(W, k)); }
@@ -717,9 +719,9 @@ static int cc16_go_impl(const void* x, const void* wq, const float* bias, void* 
   return 0;
 }
 
-template <typename T, int KS, typename TO = T>
+template <typename T, int KS, typename TO = T, int NMT = 3>
 static int cc16w_go(const void* x, const void* wq, const float* bias, void* y, Cc16Geom g, hipStream_t s) {
-  constexpr int NMT = 3, ROWS = 8 + KS - 1, LP = (2 * NMT * 16 + KS - 1 + 7) & ~7;
+  constexpr int ROWS = 8 + KS - 1, LP = (2 * NMT * 16 + KS - 1 + 7) & ~7;
   size_t smem = (size_t)ROWS * LP * 16 * sizeof(T);
   const size_t need = 4 * 2 * (NMT * 16) * 16 * sizeof(TO) + 8 * 16 * sizeof(float);      // epilogue patches + statistics scratch
   if (smem < need) smem = need;
@@ -755,6 +757,12 @@ int cc16_launch(const void* x, int ldx, const void* x2, int ldx2, int csplit, co
   g.tiles_h = cdiv(H, 8); g.tiles_w = cdiv(W, tile_w); g.dtiles = 0;
   g.x2 = x2; g.ldx2 = ldx2; g.csplit = csplit; g.stat_part = stat_part; g.stat_nblk = cc16_stat_blocks(D, H, W, k);
   int rc = 0;
+  if (tile_w == 64 && dtype == DP_BF16 && k == 7) {
+    rc = cc16w_go<bf16_t, 7, bf16_t, 2>(x, wq, bias, y, g, s);
+    if (rc) return rc;
+    DP_CHECK_LAUNCH("conv_cc16w"); return 0;
+  }
+  if (tile_w == 64) { dp_set_error("conv_cc16: DP_CC16W_64 is a bf16 7x7x7 experiment"); return 1; }
   if (tile_w == 96 && dtype != DP_F32) {          // (exact fp32: the 128-position kernel; its fragments are twice as wide)
     if (dtype == DP_BF16) rc = k == 7 ? cc16w_go<bf16_t, 7>(x, wq, bias, y, g, s) : cc16w_go<bf16_t, 3>(x, wq, bias, y, g, s);
     else if (dtype == DP_F16) rc = k == 7 ? cc16w_go<f16_t, 7>(x, wq, bias, y, g, s) : cc16w_go<f16_t, 3>(x, wq, bias, y, g, s);
