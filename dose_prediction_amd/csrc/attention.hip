@@ -231,6 +231,140 @@ __global__ __launch_bounds__(256) void k_attn_fwd(const T* __restrict__ Q, const
   combine_store<T, D, ROWS, true>(part, lw, O + (int64_t)b * N * ldo + (int64_t)h * D, ldo, q0, N, tid);
 }
 
+
+// ------------------------------------------------------------------------------------------------ forward, fp32x3 mode (DP_X3)
+// The same contraction on fp32 q / k / v with the split-bf16 arithmetic of the fp32x3 mode (csrc/x3.hip): every operand is split into
+// hi = bf16(v), lo = bf16(v - hi) IN REGISTERS and every product takes three MFMAs (hi hi + lo hi + hi lo), fp32 accumulation, fp32
+// output.  Replaces the exact-fp32 GEMM + row softmax + transpose + GEMM chain the mode used for its forward pass (4 launches and
+// ~0.11 ms per layer at B = 2, N = 512: `k_gemm_nt<float>` 39 launches, 0.85 ms of the fp32x3 DOSE-PYFER step).  One 16-row query tile
+// per block (the doubled fragments leave no room for a second), keys / values streamed in 32-row chunks per wave as above; the V chunk
+// is staged as two bf16 tiles (hi, lo) so that the k-major read stays ds_read_b64_tr_b16.
+__device__ __forceinline__ void split_frag(const v4f& a, const v4f& b, Frag8<bf16_t>& hi, Frag8<bf16_t>& lo) {
+  const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+#pragma unroll
+  for (int d = 0; d < 4; d++) {
+    const bf16_t ah = f2bf(v[2 * d]), bh = f2bf(v[2 * d + 1]);
+    hi.u[d] = (unsigned)ah | ((unsigned)bh << 16);
+    lo.u[d] = (unsigned)f2bf(v[2 * d] - bf2f(ah)) | ((unsigned)f2bf(v[2 * d + 1] - bf2f(bh)) << 16);
+  }
+}
+template <int D>
+__global__ __launch_bounds__(256) void k_attn_fwd_x3(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V, int64_t ld,
+                                                     float* __restrict__ O, int64_t ldo, int heads, int N, float c) {
+  using C = AttCfg<D>;
+  typedef bf16_t T;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 15, g = lane >> 4;
+  const int tiles = (N + 15) / 16, flat = xcd_order(blockIdx.x, gridDim.x);
+  const int bh = flat / tiles, b = bh / heads, h = bh % heads, q0 = (flat % tiles) * 16;
+  const int64_t boff = (int64_t)b * N * ld + (int64_t)h * D;
+  const float *Qb = Q + boff, *Kb = K + boff, *Vb = V + boff;
+  Frag8<T> qh[C::KK], ql[C::KK];
+#pragma unroll
+  for (int kk = 0; kk < C::KK; kk++) {
+    const float* p = Qb + (int64_t)min(q0 + r, N - 1) * ld + 32 * kk + 8 * g;
+    split_frag(*(const v4f*)p, *(const v4f*)(p + 4), qh[kk], ql[kk]);
+  }
+  v4f acc[C::DT];
+#pragma unroll
+  for (int dt = 0; dt < C::DT; dt++) acc[dt] = (v4f){0, 0, 0, 0};
+  float m = -INFINITY, ls = 0.f;
+  // wave-private staging: [2 (hi, lo)][32 rows][LDP]
+  T* vs = (T*)smem + wv * (2 * C::CH * C::LDP);
+  const T* vtr = vs + (4 * g + (r >> 2)) * C::LDP + 4 * (r & 3);
+  const int nch = (N + 31) >> 5;
+  constexpr int PER_ROW = D / 8;
+  for (int ch = wv; ch < nch; ch += C::NW) {
+    const int k0 = ch * 32;
+    // V chunk: 32 rows x D floats -> hi / lo tiles (each lane converts D / 16 pieces of 8)
+#pragma unroll
+    for (int i = 0; i < D / 16; i++) {
+      const int idx = lane + 64 * i, row = idx / PER_ROW, c8 = idx % PER_ROW;
+      const float* p = Vb + (int64_t)min(k0 + row, N - 1) * ld + 8 * c8;
+      Frag8<T> vh, vl;
+      split_frag(*(const v4f*)p, *(const v4f*)(p + 4), vh, vl);
+      *(v4u*)(vs + row * C::LDP + 8 * c8) = vh.u;
+      *(v4u*)(vs + (C::CH + row) * C::LDP + 8 * c8) = vl.u;
+    }
+    v4f s[2] = {(v4f){0, 0, 0, 0}, (v4f){0, 0, 0, 0}};
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+      for (int kk = 0; kk < C::KK; kk++) {
+        const float* p = Kb + (int64_t)min(k0 + 16 * t + r, N - 1) * ld + 32 * kk + 8 * g;
+        Frag8<T> kh, kl;
+        split_frag(*(const v4f*)p, *(const v4f*)(p + 4), kh, kl);
+        s[t] = mma16(kh, qh[kk], s[t]);
+        s[t] = mma16(kl, qh[kk], s[t]);
+        s[t] = mma16(kh, ql[kk], s[t]);
+      }
+    float tv[8];
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const float x = s[t][j] * c;
+        tv[4 * t + j] = (k0 + 16 * t + 4 * g + j < N) ? x : -INFINITY;
+      }
+    float ml = tv[0];
+#pragma unroll
+    for (int i = 1; i < 8; i++) ml = fmaxf(ml, tv[i]);
+    const float mn = fmaxf(m, group_max(ml)), alpha = exp2f(m - mn);
+    m = mn;
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { tv[i] = exp2f(tv[i] - mn); sum += tv[i]; }
+    ls = ls * alpha + sum;
+#pragma unroll
+    for (int dt = 0; dt < C::DT; dt++) acc[dt] *= alpha;
+    Frag8<T> ph, pl;
+    split_frag((v4f){tv[0], tv[1], tv[2], tv[3]}, (v4f){tv[4], tv[5], tv[6], tv[7]}, ph, pl);
+    __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier();          // the wave's own LDS writes are visible to its reads
+#pragma unroll
+    for (int dt = 0; dt < C::DT; dt++) {
+      const Frag8<T> vh = tr_pair<16 * C::LDP, T>(vtr + 16 * dt), vl = tr_pair<16 * C::LDP, T>(vtr + C::CH * C::LDP + 16 * dt);
+      acc[dt] = mma16(vh, ph, acc[dt]);
+      acc[dt] = mma16(vl, ph, acc[dt]);
+      acc[dt] = mma16(vh, pl, acc[dt]);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  // merge the four key ranges (as in k_attn_fwd), fp32 rows out
+  constexpr int ROWS = 16;
+  float* part = (float*)smem;
+  float* mw = (float*)(smem + (size_t)C::NW * 2 * C::CH * C::LDP * 2);
+  float* lw = mw + C::NW * ROWS;
+  __syncthreads();
+  {
+    const float l = group_sum(ls);
+    if (g == 0) { mw[wv * ROWS + r] = m; lw[wv * ROWS + r] = l; }
+#pragma unroll
+    for (int dt = 0; dt < C::DT; dt++) *(v4f*)(part + ((wv * ROWS + r) * C::CP + 16 * dt + 4 * g)) = acc[dt];
+  }
+  __syncthreads();
+  if (tid < ROWS) {
+    float M = mw[tid];
+#pragma unroll
+    for (int w = 1; w < C::NW; w++) M = fmaxf(M, mw[w * ROWS + tid]);
+    float e[C::NW], L = 0.f;
+#pragma unroll
+    for (int w = 0; w < C::NW; w++) { e[w] = exp2f(mw[w * ROWS + tid] - M); L += lw[w * ROWS + tid] * e[w]; }
+    const float inv = 1.f / L;
+#pragma unroll
+    for (int w = 0; w < C::NW; w++) lw[w * ROWS + tid] = e[w] * inv;
+  }
+  __syncthreads();
+  float* Ob = O + (int64_t)b * N * ldo + (int64_t)h * D;
+  for (int idx = tid; idx < ROWS * (D / 4); idx += 256) {
+    const int row = idx / (D / 4), c4 = idx % (D / 4);
+    if (q0 + row >= N) continue;
+    v4f o = (v4f){0, 0, 0, 0};
+#pragma unroll
+    for (int w = 0; w < C::NW; w++) o += *(const v4f*)(part + ((w * ROWS + row) * C::CP + 4 * c4)) * lw[w * ROWS + row];
+    *(v4f*)(Ob + (int64_t)(q0 + row) * ldo + 4 * c4) = o;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ backward
 // delta[bh][q] = sum_d dO[q][d] O[q][d]   (= rowsum(dP o P)); rows of lse / delta have pitch Np = N rounded up to 32
 template <typename T, int D>
@@ -501,10 +635,30 @@ int launch_bwd(BwdArgs a, const void* o, int B, hipStream_t st) {
 
 }  // namespace
 
+template <int D>
+int launch_fwd_x3(const void* q, const void* k, const void* v, int64_t ld, void* o, int64_t ldo, int B, int heads, int N, float scale, hipStream_t st) {
+  using C = AttCfg<D>;
+  auto kern = k_attn_fwd_x3<D>;
+  constexpr size_t stage = (size_t)C::NW * 2 * C::CH * C::LDP * 2, comb = (size_t)C::NW * 16 * C::CP * 4;
+  constexpr size_t smem = (stage > comb ? stage : comb) + (size_t)2 * C::NW * 16 * 4;
+  static_assert(stage >= comb, "the combine tiles reuse the staging space; the statistics sit behind the staging space");
+  if (raise_lds(kern, smem, "attention_fwd_x3")) return 1;
+  hipLaunchKernelGGL(kern, dim3(cdiv(N, 16) * B * heads), dim3(256), smem, st, (const float*)q, (const float*)k, (const float*)v, ld, (float*)o, ldo, heads, N,
+                     scale * LOG2E);
+  DP_CHECK_LAUNCH("attention_fwd_x3");
+  return 0;
+}
+
 extern "C" int dp_attention_fwd(const void* q, const void* k, const void* v, int64_t ld, void* o, int64_t ldo, float* lse, int B, int heads, int N,
                                 int d, float scale, int dtype, void* stream) {
-  if (check_args("attention_fwd", q, k, v, o, ld, ldo, B, heads, N, d, dtype)) return 1;
   hipStream_t st = (hipStream_t)stream;
+  if (dtype == DP_X3) {      // fp32 tensors, split-bf16 arithmetic (three products), fp32 output; lse is not written
+    if (d != 64 && d != 128) DP_FAIL("attention_fwd: head dim %d not in {64, 128}", d);
+    if (B <= 0 || heads <= 0 || N <= 0) DP_FAIL("attention_fwd: bad sizes B=%d heads=%d N=%d", B, heads, N);
+    if ((ld & 3) || (ldo & 3) || (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15)) DP_FAIL("attention_fwd (DP_X3): rows must be 16-byte aligned");
+    return d == 64 ? launch_fwd_x3<64>(q, k, v, ld, o, ldo, B, heads, N, scale, st) : launch_fwd_x3<128>(q, k, v, ld, o, ldo, B, heads, N, scale, st);
+  }
+  if (check_args("attention_fwd", q, k, v, o, ld, ldo, B, heads, N, d, dtype)) return 1;
   if (dtype == DP_BF16) return d == 64 ? launch_fwd<bf16_t, 64, 4>(q, k, v, ld, o, ldo, lse, B, heads, N, scale, st)
                                        : launch_fwd<bf16_t, 128, 2>(q, k, v, ld, o, ldo, lse, B, heads, N, scale, st);
   return d == 64 ? launch_fwd<f16_t, 64, 4>(q, k, v, ld, o, ldo, lse, B, heads, N, scale, st)

@@ -2076,6 +2076,18 @@ class Attention(torch.autograd.Function):
         scale = d ** -0.5
         base = qkv.data_ptr()
         qp, kp, vp = base, base + H * es, base + 2 * H * es
+        from . import config as _cfg
+        if (_cfg.x3() and _cfg.x3_dgrad_terms() == 1 and qkv.dtype == torch.float32 and d in (64, 128) and not os.environ.get("DP_NO_FUSED_ATTN")
+                and not os.environ.get("DP_NO_X3_ATTN_FWD")):
+            # fp32x3 (round 5): the fused kernel on the fp32 operands, split into bf16 halves in registers, three products per MFMA step,
+            # fp32 output (dp_attention_fwd with DP_X3) -- one launch instead of GEMM + softmax + transpose + GEMM in exact fp32.  The
+            # backward pass of this setting (one-product data gradients) needs qkv only.
+            O = torch.empty((B, N, H), dtype=torch.float32, device=dev)
+            _lib.call("dp_attention_fwd", qp, kp, vp, H3, _p(O), H, 0, B, heads, N, d, float(scale), DP_X3, _stream())
+            ctx.fused_bwd = True
+            ctx.save_for_backward(qkv)
+            ctx.heads = heads
+            return O
         S = torch.empty((B, heads, N, N), dtype=qkv.dtype, device=dev)
         bat, sq = (B, heads), (N * H3, d)
         _lib.call("dp_gemm_nt", qp, H3, sq[0], sq[1], kp, H3, sq[0], sq[1], _p(S), N, heads * N * N, N * N, 0, N, N, d, B, heads,

@@ -107,7 +107,9 @@ int dp_softmax_bwd(const void* p, const void* gp, void* gs, int64_t rows, int co
  * (for the packed qkv Linear output: ld = 3*heads*d, k = q + heads*d, v = q + 2*heads*d); head h starts h*d elements
  * further.  o, go: [B][N][ldo] with the heads merged; dq/dk/dv: [B][N][ldg] laid out like q/k/v.  lse: float
  * [B*heads*Np], Np = N rounded up to 32, base-2 log-sum-exp of the scaled scores, written by fwd and read by bwd; delta:
- * float [B*heads*Np] scratch of bwd (rowsum(dO o O)); both 16-byte aligned.  The N x N scores are never stored.  fp32 storage: use dp_gemm_nt + dp_softmax_*. */
+ * float [B*heads*Np] scratch of bwd (rowsum(dO o O)); both 16-byte aligned.  The N x N scores are never stored.  fp32 storage: use dp_gemm_nt + dp_softmax_*,
+ * or -- dp_attention_fwd only -- dtype DP_X3: q / k / v / o are FP32 tensors, every operand is split into bf16 halves in registers and every
+ * product takes three MFMAs (the fp32x3 mode's forward pass: ~1e-5 relative on the output); lse is not written (may be NULL). */
 int dp_attention_fwd(const void* q, const void* k, const void* v, int64_t ld, void* o, int64_t ldo, float* lse, int B, int heads, int N,
                      int d, float scale, int dtype, void* stream);
 int dp_attention_bwd(const void* q, const void* k, const void* v, int64_t ld, const void* o, const void* go, int64_t ldo,

@@ -325,11 +325,12 @@ def test_x3_row_kernel_conv_transpose_and_wide_pointwise(cfg):
             assert 1e-4 < e < 6e-3, e
 
 
-@pytest.mark.parametrize("cfg", [(2, 512, 6, 128), (1, 77, 12, 64)])
+@pytest.mark.parametrize("cfg", [(2, 512, 6, 128), (1, 77, 12, 64), (1, 1152, 6, 128), (2, 33, 12, 64), (1, 512, 12, 64)])
 def test_x3_attention_backward_three_vs_one_product(cfg):
-    """softmax(q k^T d^-1/2) v on fp32 qkv: the forward pass is the exact-fp32 GEMM + row-softmax path in both settings; with
-    three-product data gradients so is the backward pass (3e-5), with one product (the default) the backward pass runs the fused bf16
-    kernels on the rounded operands (bf16 operator tolerance, 5 launches instead of 10)."""
+    """softmax(q k^T d^-1/2) v on fp32 qkv.  Three-product data gradients: the exact-fp32 GEMM + row-softmax path forward and backward
+    (3e-5).  One product (the default): the forward pass is the fused kernel on split operands (dp_attention_fwd with DP_X3, round 5:
+    three MFMAs per product, fp32 output -- the same 3e-5 bar), the backward pass the fused bf16 kernels on the rounded operands (bf16
+    operator tolerance, 5 launches instead of 10)."""
     import dose_prediction_amd
     from dose_prediction_amd import ops
     dev = _dev()
