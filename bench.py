@@ -341,19 +341,23 @@ def cpu_baseline(args):
     x = synth.dose_input(1, shape)
     gt = synth.dose_target(1, shape)
     nstep = max(1, args.cpu_steps)
-    t0 = time.time()
+    per_step = []
     for _ in range(nstep):
+        t0 = time.time()
         for v in sd.values():
             v.grad = None
         out = oracle.dose_pyfer(sd, x, num_layers=8, num_heads=6, act="mish", training=True)
         loss = oracle.gen_loss(out, gt, 10, 1, casecade=True, freez=True)
         loss.backward()
-    dt = (time.time() - t0) / nstep
+        per_step.append(time.time() - t0)
+    dt = sum(per_step) / nstep
     scale = (S / 128.0) ** 3
     res = {"value": scale / dt, "unit": "128^3-equivalent volumes/s (fwd+bwd)", "cores": threads, "kind": "port",
            "sample": f"{nstep} step(s) (forward + GenLoss + backward, net_A frozen) of the fp32 CPU oracle on one {S}^3 volume: "
-                     f"{dt:.2f} s per step with {threads} torch threads on {cores} host cores; scaled by voxel count ({scale:.4f})",
-           "seconds": dt * nstep}
+                     f"{dt:.2f} s per step (individual steps {', '.join(f'{t:.2f}' for t in per_step)} s) with {threads} torch threads on {cores} host "
+                     f"cores; scaled by voxel count ({scale:.4f}).  A shared host: this leg has been measured between 4.7 and 10.7 s per step "
+                     "on identical code (rounds 4-5, a 2.3 x spread) -- forward_128 (one real 128^3 forward, 11-12 s) is the stable figure",
+           "seconds": dt * nstep, "seconds_per_step": per_step}
     if args.cpu_full_forward and tuple(args.size * 3 if len(args.size) == 1 else args.size) == (128, 128, 128):
         # ONE real forward of the same network at the benchmark's own size (no voxel-count scaling: the patch-embedding GEMM and the
         # attention do not scale like the convolutions), fp32, no gradients

@@ -385,12 +385,13 @@ __global__ void __launch_bounds__(256, OCC) k_conv_cc16(const T* __restrict__ x,
 // fragment now feeds the MFMAs of both depth slices (their kd differ by one: same slab, other weights): 1 ds_read_b128 per <= 4 MFMAs
 // with a 4-row window where the 8-row window above needs one per <= 4 for ONE slice.  Same slab layout / swizzle / staging / packed
 // weights / transposing epilogue / statistics as k_conv_cc16.
-template <typename T, int KS, int NMT, int OCC, typename TO>
+template <typename T, int KS, int NMT, int OCC, typename TO, int DT = 2>
 __global__ void __launch_bounds__(256, OCC) k_conv_cc16w(const T* __restrict__ x, const T* __restrict__ wq, const float* __restrict__ bias,
                                                     TO* __restrict__ y, Cc16Geom g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* slab = (T*)smem_raw;
-  constexpr int PAD = KS / 2, KWP = (KS + 1) / 2, RWO = 8, RW = 4, ROWS = RWO + KS - 1, WROWS = RW + KS - 1, CK = 16, WPW = NMT * 16, TW = 2 * WPW, DT = 2;
+  constexpr int PAD = KS / 2, KWP = (KS + 1) / 2, RWO = 8, RW = 4, ROWS = RWO + KS - 1, WROWS = RW + KS - 1, CK = 16, WPW = NMT * 16, TW = 2 * WPW;
+  static_assert(DT == 1 || DT == 2, "one or two depth slices per block");
   constexpr int LP = (TW + KS - 1 + 7) & ~7, LR = ROWS;
   constexpr bool SWZ = sizeof(T) == 2;
   constexpr int lp_par = SWZ ? ((LP >> 3) & 1) : 0;
@@ -424,7 +425,7 @@ __global__ void __launch_bounds__(256, OCC) k_conv_cc16w(const T* __restrict__ x
     if (z < 0 || z >= g.D) continue;
     const int nstage = g.x3 ? 2 * g.x3 : g.NCH;
     const int kd0 = z - d0 + PAD, kd1 = kd0 - 1;
-    const bool has0 = kd0 >= 0 && kd0 < KS && d0 < g.D && !(g.dbg & 2), has1 = kd1 >= 0 && kd1 < KS && d0 + 1 < g.D && !(g.dbg & 2);
+    const bool has0 = kd0 >= 0 && kd0 < KS && d0 < g.D && !(g.dbg & 2), has1 = DT == 2 && kd1 >= 0 && kd1 < KS && d0 + 1 < g.D && !(g.dbg & 2);
     for (int ch = 0; ch < nstage; ch++) {
       lds_barrier();
       if (g.dbg & 1) {
@@ -584,9 +585,13 @@ __global__ void __launch_bounds__(256, OCC) k_conv_cc16w(const T* __restrict__ x
             }
           }
         };
-        if (has0 && has1) sweep.template operator()<true, true>();
-        else if (has0) sweep.template operator()<true, false>();
-        else if (has1) sweep.template operator()<false, true>();
+        if constexpr (DT == 2) {
+          if (has0 && has1) sweep.template operator()<true, true>();
+          else if (has0) sweep.template operator()<true, false>();
+          else if (has1) sweep.template operator()<false, true>();
+        } else {
+          if (has0) sweep.template operator()<true, false>();
+        }
       }
     }
   }
@@ -678,6 +683,8 @@ __global__ void __launch_bounds__(256, OCC) k_conv_cc16w(const T* __restrict__ x
 // there, 0.109 ms on the 96-position tiles at two blocks per CU; 7x7x7 16 -> 16: 0.597 -> 0.508 ms, 32 -> 16: 1.014 -> 0.864).
 static inline int cc16_tw(int W, int k) {
   static const int off = [] { const char* e = getenv("DP_NO_CC16W"); return (e && atoi(e)) ? 1 : 0; }();
+  static const int t3 = [] { const char* e = getenv("DP_CC16W3"); return e ? atoi(e) : 0; }();      // (experiment: the half-size 3x3x3 tile, 64 positions x 8 rows x 1 depth slice per block)
+  if (!off && k == 3 && t3 && W % 64 == 0) return 64;
   if (off || k != 7) return 128;
   static const int t64 = [] { const char* e = getenv("DP_CC16W_64"); return (e && atoi(e)) ? 1 : 0; }();      // (experiment: 64-position tiles of the same wave geometry for W % 64 == 0)
   if (t64 && W % 64 == 0) return 64;
@@ -719,18 +726,18 @@ static int cc16_go_impl(const void* x, const void* wq, const float* bias, void* 
   return 0;
 }
 
-template <typename T, int KS, typename TO = T, int NMT = 3>
+template <typename T, int KS, typename TO = T, int NMT = 3, int DT = 2, int OCC = 2>
 static int cc16w_go(const void* x, const void* wq, const float* bias, void* y, Cc16Geom g, hipStream_t s) {
   constexpr int ROWS = 8 + KS - 1, LP = (2 * NMT * 16 + KS - 1 + 7) & ~7;
   size_t smem = (size_t)ROWS * LP * 16 * sizeof(T);
   const size_t need = 4 * 2 * (NMT * 16) * 16 * sizeof(TO) + 8 * 16 * sizeof(float);      // epilogue patches + statistics scratch
   if (smem < need) smem = need;
-  auto kern = k_conv_cc16w<T, KS, NMT, 2, TO>;
+  auto kern = k_conv_cc16w<T, KS, NMT, OCC, TO, DT>;
   if (smem > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) { dp_set_error("conv_cc16w: cannot raise dynamic LDS to %zu: %s", smem, hipGetErrorString(e)); return 1; }
   }
-  g.dtiles = cdiv(g.D, 2);
+  g.dtiles = cdiv(g.D, DT);
   const int64_t blocks = (int64_t)g.N * g.dtiles * g.tiles_h * g.tiles_w;
   if (blocks > 2000000000LL) { dp_set_error("conv_cc16w: grid too large"); return 1; }
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), smem, s, (const T*)x, (const T*)wq, bias, (TO*)y, g);
@@ -757,6 +764,13 @@ int cc16_launch(const void* x, int ldx, const void* x2, int ldx2, int csplit, co
   g.tiles_h = cdiv(H, 8); g.tiles_w = cdiv(W, tile_w); g.dtiles = 0;
   g.x2 = x2; g.ldx2 = ldx2; g.csplit = csplit; g.stat_part = stat_part; g.stat_nblk = cc16_stat_blocks(D, H, W, k);
   int rc = 0;
+  if (tile_w == 64 && dtype == DP_BF16 && k == 3) {
+    static const int occ = [] { const char* e = getenv("DP_CC16W3"); return e ? atoi(e) : 0; }();
+    rc = occ >= 5 ? cc16w_go<bf16_t, 3, bf16_t, 2, 1, 5>(x, wq, bias, y, g, s) : occ == 4 ? cc16w_go<bf16_t, 3, bf16_t, 2, 1, 4>(x, wq, bias, y, g, s)
+                  : occ == 3 ? cc16w_go<bf16_t, 3, bf16_t, 2, 1, 3>(x, wq, bias, y, g, s) : cc16w_go<bf16_t, 3, bf16_t, 2, 2, 2>(x, wq, bias, y, g, s);
+    if (rc) return rc;
+    DP_CHECK_LAUNCH("conv_cc16w"); return 0;
+  }
   if (tile_w == 64 && dtype == DP_BF16 && k == 7) {
     rc = cc16w_go<bf16_t, 7, bf16_t, 2>(x, wq, bias, y, g, s);
     if (rc) return rc;

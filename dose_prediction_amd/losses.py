@@ -39,23 +39,56 @@ def gen_loss(predictions, gt, delta1=10.0, delta2=1.0, casecade=True, freez=True
     """GenLoss.forward, loss.py:69-117 (mode='train': 69-107; any other mode: the validation branch on a single prediction)."""
     if mode != "train":
         return gen_loss_val(predictions, gt, huber)
-    dose, mask = gt[:, 0:1], gt[:, 1:2]
+    # (the two channel slices of gt as contiguous fp32 volumes ONCE: every masked mean and the resampling below read them -- round 4 let
+    # each of those eight uses make its own copy)
+    dose, mask = gt[:, 0:1].contiguous().float(), gt[:, 1:2].contiguous().float()
     pred_a = None
     if casecade:
         pred_a, predictions = predictions[0], predictions[1]
     size = dose.shape[2:]
-    l_ds = 0
     inter = predictions[1:]
+    terms, weights = [], []
     for i, pr in enumerate(inter, start=1):
         dims = tuple(s // (2 ** i) for s in size)
         g, m = _resample_gt(dose, mask, dims)
-        l_ds = l_ds + _masked_l1(pr, g, m)
-    l_ds = l_ds / max(1, len(inter))
-    full = _masked_huber(predictions[0], dose, mask) if huber else _masked_l1(predictions[0], dose, mask)
-    loss = delta1 * full + delta2 * l_ds
+        terms.append(_masked_l1(pr, g, m))
+        weights.append(float(delta2) / max(1, len(inter)))
+    terms.append(_masked_huber(predictions[0], dose, mask) if huber else _masked_l1(predictions[0], dose, mask))
+    weights.append(float(delta1))
     if casecade and not freez:
-        loss = loss + 0.5 * _masked_l1(pred_a, dose, mask)
-    return loss
+        terms.append(_masked_l1(pred_a, dose, mask))
+        weights.append(0.5)
+    # loss = delta1 * full + delta2 * mean(deep-supervision terms) (+ 0.5 * L1(pred_A)): one weighted sum instead of a chain of 0-dim
+    # adds / multiplies / divides (19 ATen launches per step, forward + backward)
+    return _weighted_sum(terms, weights)
+
+
+class _WeightedSum(torch.autograd.Function):
+    """sum_i w_i t_i of 0-dim fp32 tensors: forward stack + dot (3 launches), backward one scaled copy of the weights."""
+
+    @staticmethod
+    def forward(ctx, w, *ts):
+        ctx.save_for_backward(w)
+        return (torch.stack(ts) * w).sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        (w,) = ctx.saved_tensors
+        gw = g * w
+        return (None,) + tuple(gw.unbind(0))
+
+
+_WS_W = {}
+
+
+def _weighted_sum(terms, weights):
+    key = (terms[0].device, tuple(weights))
+    w = _WS_W.get(key)
+    if w is None:
+        if len(_WS_W) > 16:
+            _WS_W.clear()
+        w = _WS_W[key] = torch.tensor(weights, dtype=torch.float32, device=terms[0].device)
+    return _WeightedSum.apply(w, *terms)
 
 
 def l1_loss(pred, gt, freez=True, casecade=True):

@@ -658,6 +658,7 @@ class Conv3d(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride, pad, dil, want_stats=False, bias_grad_zero=False):
         _chk_dev(x, weight)
+        ctx.set_materialize_grads(False)      # (the statistics output never has a gradient: no zero tensor of its shape per backward node)
         x = as_rows(x)
         rows, cx, ldx = rows_ld(x)
         N, Di, Hi, Wi = x.shape[:4]
@@ -707,6 +708,8 @@ class Conv3d(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy, *unused):
+        if gy is None:
+            return (None,) * 8
         x, weight = ctx.saved_tensors
         stride, pad, dil, has_bias = ctx.cfg
         gy = as_rows(gy)
@@ -833,6 +836,7 @@ class Conv3dCat(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xa, xb, weight, bias, pad, want_stats=False, bias_grad_zero=False):
         _chk_dev(xa, xb, weight)
+        ctx.set_materialize_grads(False)      # (the statistics output never has a gradient: no zero tensor of its shape per backward node)
         xa, xb = as_rows(xa), as_rows(xb)
         _, ca, lda = rows_ld(xa)
         _, cbp, ldb = rows_ld(xb)
@@ -863,6 +867,8 @@ class Conv3dCat(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy, *unused):
+        if gy is None:
+            return (None,) * 7
         xa, xb, weight = ctx.saved_tensors
         pad, has_bias = ctx.cfg
         gy = as_rows(gy)
@@ -1131,6 +1137,7 @@ class Conv3dX3(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xa, xb, weight, bias, want_stats=False, bias_grad_zero=False, gy_split=False):
         _chk_dev(xa, xb, weight)
+        ctx.set_materialize_grads(False)      # (the statistics output never has a gradient: no zero tensor of its shape per backward node)
         xa = as_rows(xa)
         xb = None if xb is None else as_rows(xb)
         cout, cin, k = weight.shape[0], weight.shape[1], weight.shape[2]
@@ -1180,6 +1187,8 @@ class Conv3dX3(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy, *unused):
+        if gy is None:
+            return (None,) * 7
         xs, weight = ctx.saved_tensors
         N, D, H, W, cin, cout, k, cp, ca, cxa, cxb = ctx.geom
         if ctx.gy_split:
@@ -1942,6 +1951,7 @@ class AddLayerNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b, gamma, beta, eps):
         _chk_dev(a, b)
+        ctx.set_materialize_grads(False)      # (an unused output -- the last block's residual sum -- must not cost a zero tensor and a pass over it)
         a, b = a.contiguous(), b.contiguous()
         C = a.shape[-1]
         rows = a.numel() // C
@@ -1959,7 +1969,7 @@ class AddLayerNorm(torch.autograd.Function):
         C = s.shape[-1]
         rows = s.numel() // C
         if gz is None:
-            return gs, gs, None, None, None
+            return gs, gs, None, None, None           # (also gs is None: nothing flows back)
         gz = gz.contiguous()
         gs = None if gs is None else gs.contiguous()
         gx = torch.empty_like(s)
