@@ -26,6 +26,23 @@ def rnd(t, dt):
     return t.to(dt).to(t.dtype)
 
 
+def f8_block(t):
+    """e4m3 with one power-of-two scale per block of 32 elements along the contraction (channel) axis, dim 1 of activations [N, C, ...] and of
+    weights [Cout, Cin, ...] (matrices [rows, K]: the last axis): the block's largest magnitude is scaled into [128, 256) (e4m3 tops out at
+    448), smaller elements keep 4 significant bits down to 2^-6 of the scaled range and flush through the subnormals below."""
+    ax = 1 if t.dim() > 2 else t.dim() - 1
+    C = t.shape[ax]
+    out = torch.empty_like(t)
+    for c0 in range(0, C, 32):
+        sl = [slice(None)] * t.dim()
+        sl[ax] = slice(c0, min(C, c0 + 32))
+        blk = t[tuple(sl)]
+        amax = blk.abs().amax(dim=ax, keepdim=True).clamp_min(1e-300)
+        sc = torch.exp2(torch.floor(torch.log2(amax)) - 7.0)
+        out[tuple(sl)] = (blk / sc).float().to(torch.float8_e4m3fn).to(t.dtype) * sc
+    return out
+
+
 def make(scheme, which="all"):
     def split2(t, dt):
         hi = rnd(t, dt)
@@ -46,6 +63,16 @@ def make(scheme, which="all"):
             xh, xl = split2(x, torch.bfloat16)
             wh, wl = split2(w, torch.bfloat16)
             return f(xh, wh) + f(xl, wh) + f(xh, wl)
+        if scheme in ("h16f8", "hb16f8", "h16f8i"):
+            # hi x hi in fp16 (or bf16) + the two correction terms on the block-scaled fp8 matrix instruction
+            # (v_mfma_scale_f32_16x16x128_f8f6f4: e4m3 operands, one power-of-two scale per 32 contraction elements): 2 x the bf16 MFMA
+            # time instead of 3 x.  "i": the idealised variant (4 significant bits, unlimited exponent range) -- what a per-ELEMENT scale
+            # would give; the gap to it is the cost of sharing one scale among 32 channels.
+            hdt = torch.bfloat16 if scheme == "hb16f8" else torch.float16
+            xh, xl = split2(x, hdt)
+            wh, wl = split2(w, hdt)
+            q = (lambda t: oracle.round_bits(t, 4)) if scheme == "h16f8i" else f8_block
+            return f(xh, wh) + f(q(xl), q(wh)) + f(q(xh), q(wl))
         if scheme == "x16w22":      # x_hi(fp16) x (w_hi + w_lo) with fp16 halves: what the kernel would really compute
             wh, wl = split2(w, torch.float16)
             return f(rnd(x, torch.float16), wh + wl)
@@ -86,7 +113,12 @@ def main():
     mask = gt[:, 1:2] > 0
     orig = (R.conv3d, R.linear, R.conv_transpose3d_k2s2)
     res = {}
-    for scheme, which in (("exact", "all"), ("x16", "all"), ("x16", "conv"), ("w16", "all"), ("x16w22", "all"), ("x3", "all"), ("xb", "all")):
+    only = os.environ.get("PROBE_SCHEMES")
+    todo = (("exact", "all"), ("x16", "all"), ("x16", "conv"), ("w16", "all"), ("x16w22", "all"), ("x3", "all"), ("xb", "all"), ("h16f8", "conv"), ("h16f8i", "conv"),
+            ("hb16f8", "conv"))
+    if only:
+        todo = (("exact", "all"),) + tuple(t for t in todo if t[0] in only.split(","))
+    for scheme, which in todo:
         R.conv3d, R.linear, R.conv_transpose3d_k2s2 = make(scheme, which)
         t0 = time.time()
         with torch.no_grad():
