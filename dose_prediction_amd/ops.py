@@ -1064,9 +1064,16 @@ def split_rows(a, ca, b, cb, cp, parts, pattern):
     return out
 
 
-def _x3_conv_shape_ok(W, cin, cout, k, stride, pad, dil):
+def _x3_min_w(weight):
+    """Shortest row the x3 convolution path takes: 16 when a weight gradient will be asked for (the tiled weight-gradient kernels start
+    there), 8 for forward-only passes -- the 12^3 level of the cascade's no-grad OAR-TRANSEG windows (96^3 crop) fell to the exact-fp32
+    kernel at 2.4 ms per 7x7x7 launch, 24 ms of the 134-ms C5 step (round 5)."""
+    return 16 if (torch.is_grad_enabled() and weight.requires_grad) else 8
+
+
+def _x3_conv_shape_ok(W, cin, cout, k, stride, pad, dil, min_w=16):
     """Shape test of the x3 convolution path (ops.Conv3dX3) alone."""
-    if not (USE_TILED and k in (3, 7) and stride == 1 and dil == 1 and pad == k // 2 and W >= 16 and cout >= 8 and cin >= 1):
+    if not (USE_TILED and k in (3, 7) and stride == 1 and dil == 1 and pad == k // 2 and W >= min_w and cout >= 8 and cin >= 1):
         return False
     cp = (cin + 15) // 16 * 16
     return bool(_lib.lib().dp_conv3d_tiled_weight_elems(3 * cp, cout, k, 1, pad, 1, W))
@@ -1099,12 +1106,12 @@ def _x3_conv_ok(xa, xb, weight, stride, pad, dil):
     W = xa.shape[3]
     if xa.dtype == torch.bfloat16:
         # an operand that already is split (norm_act(..., x3_split_for=...) wrote [x_hi | x_lo]): the producer checked the shape
-        if xb is not None or xa.shape[-1] != 2 * cin or cin % 16 or not _x3_conv_shape_ok(W, cin, cout, k, stride, pad, dil):
+        if xb is not None or xa.shape[-1] != 2 * cin or cin % 16 or not _x3_conv_shape_ok(W, cin, cout, k, stride, pad, dil, _x3_min_w(weight)):
             raise _lib.DoseHipError("conv3d: a bf16 tensor in the fp32x3 mode must be the [x_hi | x_lo] operand of an x3 convolution")
         return True
     if xa.dtype != torch.float32:
         return False
-    if not (k in (3, 7) and stride == 1 and dil == 1 and pad == k // 2 and W >= 16 and cout >= 8):
+    if not (k in (3, 7) and stride == 1 and dil == 1 and pad == k // 2 and W >= _x3_min_w(weight) and cout >= 8):
         return False
     if xb is not None:
         ca = xa.shape[-1]
@@ -1886,7 +1893,7 @@ def norm_act(x, kind, gamma=None, beta=None, running_mean=None, running_var=None
         c = x3_split_for
         C = x.shape[-1]
         split_out = (config.x3() and C % 16 == 0 and c.weight.shape[1] == C and
-                     _x3_conv_shape_ok(x.shape[3], C, c.weight.shape[0], c.kernel_size[0], c.stride[0], c.padding[0], c.dilation[0]))
+                     _x3_conv_shape_ok(x.shape[3], C, c.weight.shape[0], c.kernel_size[0], c.stride[0], c.padding[0], c.dilation[0], _x3_min_w(c.weight)))
     if split_out or grad_split:
         return NormAct.apply(x, kind, gamma, beta, running_mean, running_var, training, res, act, eps, momentum, stats, split_out, grad_split)
     return NormAct.apply(x, kind, gamma, beta, running_mean, running_var, training, res, act, eps, momentum, stats)

@@ -112,6 +112,42 @@ def test_x3_conv3d(cfg):
         check("gb", bh.grad, br.grad)
 
 
+@pytest.mark.parametrize("cfg", [
+    # (N, Cin, split ca | 0, Cout, D, H, W, k): rows shorter than 16 (W16 tiles, two image rows per MFMA tile) -- the 12^3 / 6^3... levels of
+    # the 96^3 sliding-window crop, four windows per launch
+    (4, 128, 0, 128, 12, 12, 12, 7), (4, 256, 128, 128, 12, 12, 12, 7), (4, 128, 0, 128, 12, 12, 12, 3), (2, 64, 32, 32, 10, 9, 8, 3), (1, 128, 0, 64, 8, 8, 15, 7)])
+def test_x3_forward_only_convolutions_on_short_rows(cfg):
+    """No-grad passes (the cascade's OAR-TRANSEG forward, train_light_linked_model.py:152-154) take the x3 kernels down to W = 8: the
+    three-product accuracy (3e-5) on rows the weight-gradient kernels do not reach.  With gradients enabled such rows keep the
+    exact-fp32 path (checked: the autograd node is not Conv3dX3)."""
+    from dose_prediction_amd import ops
+    dev = _dev()
+    N, Cin, ca, Cout, D, H, W, k = cfg
+    x = rnd((N, Cin, D, H, W), 1) * 1.3 + 0.2
+    w = rnd((Cout, Cin, k, k, k), 2, (Cin * k ** 3) ** -0.5)
+    b = rnd((Cout,), 3, 0.1)
+    yr = oracle.conv3d(x.double(), w.double(), b.double(), 1, k // 2, 1)
+    wh, bh = torch.nn.Parameter(w.to(dev)), torch.nn.Parameter(b.to(dev))
+    arg = (ndhwc(x[:, :ca]).to(dev), ndhwc(x[:, ca:]).to(dev)) if ca else ndhwc(x).to(dev)
+    calls = []
+    orig = ops._lib.call
+
+    def spy(name, *a):
+        calls.append((name, a))
+        return orig(name, *a)
+    ops._lib.call = spy
+    try:
+        with torch.no_grad():
+            yh = ops.conv3d(arg, wh, bh, 1, k // 2, 1)
+    finally:
+        ops._lib.call = orig
+    check("y", ncdhw(yh), yr)
+    assert any(n.startswith("dp_conv3d_tiled") and a[-2] == ops.DP_X3 for n, a in calls), [n for n, _ in calls]
+    yg = ops.conv3d(arg, wh, bh, 1, k // 2, 1)
+    assert "Conv3dX3" not in type(yg.grad_fn).__name__
+    check("y (grad-enabled path)", ncdhw(yg), yr)
+
+
 @pytest.mark.parametrize("cfg", [(2, 32, 16, 16, 3, 33, 70, 7), (1, 16, 0, 16, 5, 32, 32, 3), (1, 64, 0, 40, 2, 33, 32, 7)])
 def test_x3_single_product_weight_gradients(cfg):
     """config.set_x3_wgrad_terms(1), the mode's default: forward and data gradient are the three-product ones (3e-5); the weight
