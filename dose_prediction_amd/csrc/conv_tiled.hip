@@ -53,6 +53,7 @@ struct TiledGeom {
   int dbg;             // experiments only (env DP_DBG): 1 = skip staging, 2 = skip the MFMA sweep, 3 = both, 4 = also skip the epilogue
   int splitkd;         // 1: blockIdx.z selects ONE kd (and one of `chsplit` shares of the input chunks); results are atomically accumulated into the fp32 scratch `ws`
   int chsplit;
+  int64_t det_slab;    // deterministic mode: every (kd, chunk share) = blockIdx.z accumulates into ITS OWN slab of the scratch (det_slab elements apart; one contributor per address) and k_conv_split_finish adds the slabs in order; 0 = one shared scratch
   // "virtual concat": input channels >= csplit come from x2 (pitch ldx2), output channels >= osplit go to y2 (pitch ldy2).
   // torch.cat((a, b), dim=1) feeding a convolution is never materialised -- and each 16-channel chunk pass then reads whole,
   // contiguous voxel rows of ONE tensor (a 32-channel row read 16 channels at a time touches every cache line twice and
@@ -498,7 +499,7 @@ __global__ void __launch_bounds__(256, (RW == 8 ? DP_TILED_MINB8 : DP_TILED_MINB
           const int ow = W16 ? (m & 15) : wbase_o + m;
           if (co < g.Cout && oh < g.H && ow < g.W) {
             const int64_t vox = (((int64_t)n * g.D + d) * g.H + oh) * g.W + ow;
-            if (g.splitkd) atomicAdd(ws + vox * g.Cout + co, acc[i][j][e]);
+            if (g.splitkd) atomicAdd(ws + (int64_t)blockIdx.z * g.det_slab + vox * g.Cout + co, acc[i][j][e]);
             else st_f(out_ptr(vox, co), acc[i][j][e] + bv);
           }
         }
@@ -510,13 +511,15 @@ __global__ void __launch_bounds__(256, (RW == 8 ? DP_TILED_MINB8 : DP_TILED_MINB
 // split-kd epilogue: y = T(ws + bias)
 template <typename T>
 __global__ void k_conv_split_finish(float* __restrict__ ws, const float* __restrict__ bias, T* __restrict__ y, int64_t rows, int C, int ldy,
-                                    T* __restrict__ y2, int ldy2, int osplit, int rezero) {
+                                    T* __restrict__ y2, int ldy2, int osplit, int rezero, int nslab, int64_t slab) {
   int64_t total = rows * C;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     int64_t rrow = i / C; int c = (int)(i - rrow * C);
     T* dst = (y2 && c >= osplit) ? y2 + rrow * ldy2 + (c - osplit) : y + rrow * ldy + c;
-    st_f(dst, ws[i] + (bias ? bias[c] : 0.f));
+    float v = ws[i];
     if (rezero) ws[i] = 0.f;
+    for (int sl = 1; sl < nslab; sl++) { v += ws[i + sl * slab]; if (rezero) ws[i + sl * slab] = 0.f; }     // (deterministic mode: the kd / chunk shares in order)
+    st_f(dst, v + (bias ? bias[c] : 0.f));
   }
 }
 
@@ -536,15 +539,16 @@ static int launch_tiled(const void* x, const void* wq, const float* bias, void* 
     fprintf(stderr, "[dp] conv_tiled KS=%d NPAIR=%d RW=%d NT=%d TWP=%d smem=%zu grid=%u x %u x %u occupancy(blocks/CU)=%d (%s)\n", KS, NPAIR, RW, NT, TWP, smem,
             grid.x, grid.y, grid.z, nb, hipGetErrorString(e));
   }
+  const int nslab = (g.splitkd && g.det_slab) ? KS * g.chsplit : 1;
   if (g.splitkd && !g_scratch_zeroed) {
-    hipError_t me = hipMemsetAsync(ws, 0, (size_t)g.N * g.D * g.H * g.W * g.Cout * sizeof(float), s);
+    hipError_t me = hipMemsetAsync(ws, 0, (size_t)g.N * g.D * g.H * g.W * g.Cout * sizeof(float) * nslab, s);
     if (me != hipSuccess) { dp_set_error("conv3d_tiled: memset failed"); return 1; }
   }
   hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, (const T*)x, (const T*)wq, bias, (TO*)y, ws, g);
   if (g.splitkd) {
     int64_t rows = (int64_t)g.N * g.D * g.H * g.W;
     int gb = (int)((rows * g.Cout + 255) / 256); if (gb > 4096) gb = 4096;
-    hipLaunchKernelGGL(k_conv_split_finish<TO>, dim3(gb), dim3(256), 0, s, ws, bias, (TO*)y, rows, g.Cout, g.ldy, (TO*)g.y2, g.ldy2, g.osplit, g_scratch_zeroed);
+    hipLaunchKernelGGL(k_conv_split_finish<TO>, dim3(gb), dim3(256), 0, s, ws, bias, (TO*)y, rows, g.Cout, g.ldy, (TO*)g.y2, g.ldy2, g.osplit, g_scratch_zeroed, nslab, g.det_slab);
   }
   return 0;
 }
@@ -589,7 +593,7 @@ static void tiled_geometry(TiledGeom& g, int k, int np, int rw, int& nt, int* yg
   *ygrid = cdiv(g.NTT, nt * wn);
   int64_t blocks = (int64_t)g.N * g.D * g.tiles_h * g.tiles_w * *ygrid;
   const int split_below = (!*w16 && wn == 2) ? 200 : 400;   // (the 8-row arrangement is there to AVOID the split: 256 blocks are enough)
-  g.splitkd = (np == 1 && blocks < split_below && !dp_det(DET_SPLITKD)) ? 1 : 0;    // small volumes: one block per kd, fp32 atomic accumulation (deterministic mode: unsplit)
+  g.splitkd = (np == 1 && blocks < split_below) ? 1 : 0;    // small volumes: one block per kd, fp32 atomic accumulation (deterministic mode: one scratch slab per share, added in order)
   // ... and, when even k blocks per tile leave the chip half empty, per share of the input chunks (>= 4 chunks per share)
   g.chsplit = 1;
   if (g.splitkd) { while (blocks * k * g.chsplit < 400 && g.NCH / (g.chsplit * 2) >= 4) g.chsplit *= 2; }
@@ -604,6 +608,7 @@ extern "C" int dp_conv3d_tiled_ws_elems(int N, int D, int H, int W, int Cin, int
   int ygrid; bool w16; tiled_geometry(g, k, np, rw, nt, &ygrid, &w16);
   if (!g.splitkd) return 0;
   int64_t e = (int64_t)N * D * H * W * Cout;
+  if (dp_det(DET_SPLITKD)) e *= k * g.chsplit;
   return e > 2000000000LL ? -1 : (int)e;
 }
 
@@ -659,6 +664,7 @@ static int conv3d_tiled_impl(const void* x, int ldx, const void* x2, int ldx2, i
   g.N = N; g.D = D; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.ldx = ldx; g.ldy = ldy;
   g.x2 = x2; g.ldx2 = ldx2; g.csplit = csplit; g.y2 = y2; g.ldy2 = ldy2; g.osplit = osplit;
   int ygrid; bool w16; int wn; tiled_geometry(g, k, np, rw, nt, &ygrid, &w16, &wn);
+  g.det_slab = (g.splitkd && dp_det(DET_SPLITKD)) ? (int64_t)N * D * H * W * Cout : 0;
   g.x3 = 0;
   if (dtype == DP_X3) {
     if (x2 || Cin % 48 || ldx < 2 * (Cin / 3)) DP_FAIL("conv3d_tiled: a DP_X3 launch takes ONE [x_hi | x_lo] tensor of 2/3 Cin channels (Cin = 3 x a multiple of 16)");

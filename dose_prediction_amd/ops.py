@@ -450,6 +450,20 @@ def gemm_nt(A, B, out, bias=None, alpha=1.0, M=None, N=None, K=None, batch=(1, 1
               M, N, K, batch[0], batch[1], float(alpha), out_f32, splitk, _dt(A), _stream())
 
 
+def _gemm_nt_splitk_det(A, B, bias, rows, nout, K, lda, ldb, splitk):
+    """Deterministic split-K (config.set_deterministic): the K shares as a BATCHED GEMM into their own [rows, nout] fp32 slabs, added in
+    order (torch.sum over the leading axis is order-fixed) -- instead of fp32 atomics into one matrix, and without giving up the
+    parallelism over K (unsplit, the patch embedding's K = 102 400 runs on 48 tiles).  Returns the fp32 [rows, nout] result or None when
+    the shares cannot be cut on 16-byte boundaries (the caller then lets the library run it unsplit)."""
+    ks = K // splitk
+    if splitk < 2 or ks * splitk != K or ks % 8 or lda != K or ldb < K:
+        return None
+    parts = torch.empty((splitk, rows, nout), dtype=torch.float32, device=A.device)
+    gemm_nt(A, B, parts, M=rows, N=nout, K=ks, batch=(splitk, 1), sa=(ks, 0), sb=(ks, 0), sc=(rows * nout, 0), lda=lda, ldb=ldb, ldc=nout)
+    acc = parts.sum(0)
+    return acc if bias is None else acc.add_(bias)
+
+
 def _x3_terms(forward):
     """Split products a contraction may use in the CURRENT mode: None outside fp32x3 (exact arithmetic of the storage type), 3 for a
     forward pass, config.x3_dgrad_terms() for a data gradient."""
@@ -1350,8 +1364,13 @@ class LinearX3(torch.autograd.Function):
             x = xs
         wp = _pack_mat_x3(weight, False, cp, _PAT_W)
         b32 = None if bias is None else bias.detach()
-        y = (torch.zeros if splitk > 1 else torch.empty)(xshape[:-1] + (nout,), dtype=torch.float32, device=xs.device)
-        gemm_nt(xs, wp, y, bias=b32, M=rows, N=nout, K=3 * cp, lda=3 * cp, ldb=3 * cp, ldc=nout, splitk=splitk)
+        from . import config as _cfg
+        y = _gemm_nt_splitk_det(xs, wp, b32, rows, nout, 3 * cp, 3 * cp, 3 * cp, splitk) if (splitk > 1 and _cfg.deterministic(2)) else None
+        if y is not None:
+            y = y.view(xshape[:-1] + (nout,))
+        else:
+            y = (torch.zeros if splitk > 1 else torch.empty)(xshape[:-1] + (nout,), dtype=torch.float32, device=xs.device)
+            gemm_nt(xs, wp, y, bias=b32, M=rows, N=nout, K=3 * cp, lda=3 * cp, ldb=3 * cp, ldc=nout, splitk=splitk)
         ctx.save_for_backward(xs, weight)
         ctx.geom = (xshape, rows, K, cp)
         ctx.has_bias = bias is not None
@@ -1552,8 +1571,11 @@ class Linear(torch.autograd.Function):
         y = torch.empty(tuple(x.shape[:-1]) + (nout,), dtype=x.dtype, device=x.device)
         b32 = None if bias is None else bias.detach()
         if splitk > 1:
-            acc = torch.zeros((rows, nout), dtype=torch.float32, device=x.device)
-            gemm_nt(x, wp, acc, bias=b32, M=rows, N=nout, K=K, lda=ldx, ldb=wp.shape[-1], ldc=nout, splitk=splitk)
+            from . import config as _cfg
+            acc = _gemm_nt_splitk_det(x, wp, b32, rows, nout, K, ldx, wp.shape[-1], splitk) if _cfg.deterministic(2) else None
+            if acc is None:
+                acc = torch.zeros((rows, nout), dtype=torch.float32, device=x.device)
+                gemm_nt(x, wp, acc, bias=b32, M=rows, N=nout, K=K, lda=ldx, ldb=wp.shape[-1], ldc=nout, splitk=splitk)
             if x.dtype == torch.float32:
                 y = acc.view(y.shape)
             else:

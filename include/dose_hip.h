@@ -46,11 +46,12 @@ enum { DP_ACT_NONE = 0, DP_ACT_RELU = 1, DP_ACT_LRELU = 2, DP_ACT_MISH = 3, DP_A
 const char* dp_last_error(void);
 int dp_version(void);
 /* Deterministic mode (process-wide, default off): 1 = every reduction that normally meets in fp32 atomics takes a fixed-order path, so two
- * runs on the same inputs are BIT-IDENTICAL, as the reference's CPU path is (the parity gates run under it): split-kd convolutions run
- * unsplit, split-K GEMMs unsplit, the tiled / K-along-H weight-gradient kernels accumulate one scratch slab per voxel share which the unpack
- * pass adds in share order (dp_conv3d_wgrad_tiled_ws_elems grows accordingly), the generic weight gradient runs one wave per result tile,
- * dp_trilinear_up2_bwd gathers instead of scattering; LayerNorm's dgamma / dbeta need dp_add_layernorm_bwd_det.  Queries made before a
- * switch (workspace sizes, statistics blocks) do not carry over: ask again. */
+ * runs on the same inputs are BIT-IDENTICAL, as the reference's CPU path is (the parity gates run under it): split-kd convolutions and the
+ * tiled / K-along-H weight-gradient kernels accumulate one scratch slab per (kd, chunk) share / voxel share, which the finish / unpack pass
+ * adds in share order (dp_conv3d_tiled_ws_elems and dp_conv3d_wgrad_tiled_ws_elems grow accordingly), dp_gemm_nt / dp_gemm_tn run unsplit
+ * (callers that want the parallelism over K pass the shares as a batch and add the slabs themselves), the generic weight gradient runs one
+ * wave per result tile, dp_trilinear_up2_bwd gathers instead of scattering; LayerNorm's dgamma / dbeta need dp_add_layernorm_bwd_det.
+ * Queries made before a switch (workspace sizes) do not carry over: ask again. */
 int dp_set_deterministic(int on);
 int dp_get_deterministic(void);
 
