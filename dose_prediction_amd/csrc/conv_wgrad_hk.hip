@@ -249,7 +249,8 @@ int launch_hk(const void* x, const void* gy, float* ws, WgHkGeom g, hipStream_t 
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount;
     if (ncu < 1) ncu = 256;
   }
-  int want = (ncu * occ) / (KS * g.MT * g.NTn); if (want < 1) want = 1;
+  static const int occ_env = [] { const char* e = getenv("DP_HK_OCC"); return e ? atoi(e) : 0; }();      // (experiment: blocks per CU of the persistent grid)
+  int want = (ncu * (occ_env > 0 ? occ_env : occ)) / (KS * g.MT * g.NTn); if (want < 1) want = 1;
   int ydim = units < want ? units : want;
   // Shares in multiples of 8 whenever there are at least 8: only then does the block decode give every XCD whole shares (all kd /
   // channel-tile blocks of a unit range behind ONE L2).  Round 2 rounded down only when that cost < 5 % of the blocks; the layers
