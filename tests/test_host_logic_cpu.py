@@ -44,3 +44,29 @@ def test_oracle_sliding_window_pads_small_volumes():
                                         (w[:, :, :3].abs().sum() + w[:, :, 13:].abs().sum() + w[..., :1].abs().sum() + w[..., 14:].abs().sum()),
                                         overlap=0.25)
     assert float(y.abs().max()) == 0.0
+
+
+def test_tools_and_package_sources_compile_and_losses_reject_unsupported_arguments():
+    """The measurement tools (tools/*.py) are not run by any test (they need a GPU and minutes): at least every one of them, bench.py and
+    the package must byte-compile; and the host-side argument checks of the round-5 additions work without a GPU."""
+    import glob
+    import os
+    import pytest
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "tools", "*.py"))) + [os.path.join(root, "bench.py"), os.path.join(root, "__graft_entry__.py")] + \
+        sorted(glob.glob(os.path.join(root, "dose_prediction_amd", "**", "*.py"), recursive=True))
+    assert len(files) > 40
+    for f in files:
+        compile(open(f).read(), f, "exec")          # (SyntaxError names the file; nothing is written)
+    from dose_prediction_amd.losses import DiceCELoss, _weighted_sum
+    DiceCELoss(to_onehot_y=True, softmax=True)
+    for kw in (dict(), dict(to_onehot_y=True, softmax=True, squared_pred=True), dict(to_onehot_y=True, softmax=True, reduction="sum")):
+        with pytest.raises(ValueError):
+            DiceCELoss(**kw)
+    ts = [torch.tensor(float(i + 1), requires_grad=True) for i in range(4)]
+    out = _weighted_sum(ts, [1 / 3, 1 / 3, 1 / 3, 10.0])
+    out.backward()
+    assert abs(float(out.detach()) - 42.0) < 1e-5 and abs(float(ts[3].grad) - 10.0) < 1e-6 and abs(float(ts[0].grad) - 1 / 3) < 1e-6
+    # the deterministic split-K helper declines shapes whose K shares would not start on 16-byte boundaries
+    from dose_prediction_amd import ops
+    assert ops._gemm_nt_splitk_det(torch.zeros(2, 30), torch.zeros(4, 30), None, 2, 4, 30, 30, 30, 3) is None
