@@ -143,6 +143,9 @@ DTYPES = [torch.float32, torch.bfloat16, torch.float16]
     (1, 16, 8, 5, 8, 96, 7, 1, 3, 1, False),
     (2, 16, 16, 1, 8, 192, 3, 1, 1, 1, True),
     (1, 25, 16, 4, 11, 96, 3, 1, 1, 1, False),
+    (1, 16, 16, 2, 9, 160, 7, 1, 3, 1, True),     # 96 + 64: a ragged second 96-position tile
+    (1, 32, 16, 3, 8, 130, 7, 1, 3, 1, False),    # 96 + 34 (two tiles of 96 beat two of 128)
+    (1, 16, 12, 1, 12, 288, 7, 1, 3, 1, True),    # three whole tiles, one depth slice (every block has one dead slice), 12 output channels
 ])
 def test_conv3d(cfg, dtype):
     from dose_prediction_amd import ops
