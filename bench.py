@@ -444,6 +444,8 @@ def pmc_traffic(kernel_prefix):
 
 def main():
     args = parse()
+    # (multi-process GPU work on this pool needs the dmabuf IPC mode: RCCL / cross-process tensor sharing fail with the legacy one)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if args.gpus > 1 and "RANK" not in os.environ:
         spawn_ranks(args)
     rank = int(os.environ.get("RANK", 0))
