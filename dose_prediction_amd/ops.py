@@ -1079,10 +1079,13 @@ def split_rows(a, ca, b, cb, cp, parts, pattern):
 
 
 def _x3_min_w(weight):
-    """Shortest row the x3 convolution path takes: 16 when a weight gradient will be asked for (the tiled weight-gradient kernels start
-    there), 8 for forward-only passes -- the 12^3 level of the cascade's no-grad OAR-TRANSEG windows (96^3 crop) fell to the exact-fp32
-    kernel at 2.4 ms per 7x7x7 launch, 24 ms of the 134-ms C5 step (round 5)."""
-    return 16 if (torch.is_grad_enabled() and weight.requires_grad) else 8
+    """Shortest row the x3 convolution path takes: 8 -- the 12^3 level of the 96^3 crop (the cascade's no-grad OAR-TRANSEG windows, training
+    at the reference's own crop size) fell to the exact-fp32 kernel at 2.4 ms per 7x7x7 launch, 24 ms of the 134-ms C5 step (round 5) --
+    except with THREE-product weight gradients, whose tiled kernels start at 16."""
+    if torch.is_grad_enabled() and weight.requires_grad:
+        from . import config
+        return 8 if config.x3_wgrad_terms() == 1 else 16        # (one-product weight gradients of short rows: the generic kernel on x_hi, gy_hi)
+    return 8
 
 
 def _x3_conv_shape_ok(W, cin, cout, k, stride, pad, dil, min_w=16):
@@ -1281,11 +1284,18 @@ class Conv3dX3(torch.autograd.Function):
             if need_w:
                 from . import config
                 wse = max(L.dp_conv3d_wgrad_tiled_ws_elems(2 * cp, cout, k, 1, pad, 1, 1, W), L.dp_conv3d_wgrad_tiled_ws_elems(cp, cout, k, 1, pad, 1, 1, W))
-                if not wse:
+                if not wse and config.x3_wgrad_terms() == 1:
+                    # rows shorter than the tiled weight-gradient kernels take (W < 16): x_hi gy_hi on the generic bf16 kernel (accumulates: zeroed dW)
+                    gw = _wgrad_buffer(weight, True)
+                    wgrad(xs, 2 * cp, gys, ldgs, gw, (N, D, H, W, D, H, W), cin, cout, k, 1, pad, 1, 1, 0, cin * taps, taps, 1, 1)
+                elif not wse:
                     raise _lib.DoseHipError("x3 convolution: weight gradient outside the tiled kernels")
-                ws = _zero_scratch(dev, wse)
-                gw = _wgrad_buffer(weight, False)
-                if config.x3_wgrad_terms() == 1:
+                else:
+                    ws = _zero_scratch(dev, wse)
+                    gw = _wgrad_buffer(weight, False)
+                if not wse:
+                    pass
+                elif config.x3_wgrad_terms() == 1:
                     # (config.set_x3_wgrad_terms(1)) x_hi x gy_hi only: one bf16 launch straight into dW
                     _lib.call("dp_conv3d_wgrad_tiled", _p(xs), 2 * cp, _p(gys), ldgs, _p(gw), _p(ws), N, D, H, W, cin, cout, k,
                               cin * taps, taps, 1, 1, _stream())

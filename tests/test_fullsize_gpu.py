@@ -13,7 +13,8 @@ All through the C ABI on the GPU; the oracle is not used here."""
 import pytest
 import torch
 
-from helpers import rel_l2
+from helpers import rel_l2, rel_err
+import oracle
 
 pytestmark = pytest.mark.gpu
 S = (128, 128, 128)
@@ -360,6 +361,52 @@ def _transeg(dev, shape, seed=8765):
     # hyper-parameters: OARSegmentation/train_light_transeg.py:110-124 (oar_transeg.py:20-35)
     return oar_transeg.Model(in_channels=1, out_channels=8, img_size=shape, feature_size=16, hidden_size=768, mlp_dim=3072, num_heads=12,
                              pos_embed="perceptron", norm_name="instance", res_block=True, conv_block=True).to(dev)
+
+
+@pytest.mark.parametrize("mode", [torch.bfloat16, "fp32x3"])
+def test_transeg_training_steps_at_the_reference_crop_96(mode):
+    """OAR-TRANSEG as the reference itself trains it (OARSegmentation/config.py:24: IMAGE_SIZE = 96; train_light_transeg.py:113, 148): 96^3
+    crops (a batch of 4, the sliding-window batch of config.py:31), DiceCE loss, backward, fused Adam -- the row lengths 96 / 48 / 24 / 12 / 6
+    through every kernel family (96-position 7^3 tiles, least-padding wave columns, W16 tiles, generic kernels at 6^3) in one network:
+    three steps, every gradient finite, the loss falls; in fp32x3 the first forward pass is also checked against the float64 oracle on one
+    crop (logits within 1e-3, arg-max exact off near-ties)."""
+    import dose_prediction_amd
+    from dose_prediction_amd import synth
+    from dose_prediction_amd.losses import DiceCELoss
+    from dose_prediction_amd.optim import FusedAdam
+    dev = _dev()
+    S96 = (96, 96, 96)
+    dose_prediction_amd.set_compute_dtype(mode)
+    try:
+        net = _transeg(dev, S96).train()
+        x = synth.ct_input(4, S96).to(dev)
+        if mode == "fp32x3":
+            sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+            with torch.no_grad():
+                ref = oracle.oar_transeg(sd, x[:1].cpu(), num_heads=12, training=True)
+                got = net(x[:1]).float().cpu()
+            assert rel_err(got, ref) < 1e-3
+            top2 = ref.topk(2, dim=1).values
+            safe = (top2[:, 0] - top2[:, 1]) > 1e-3 * ref.abs().max()
+            assert int(((got.argmax(1) != ref.argmax(1)) & safe).sum()) == 0
+            net.load_state_dict(sd)
+        opt = FusedAdam(net.parameters(), lr=1e-4, weight_decay=1e-5)
+        lab = torch.randint(0, 8, (4, 1) + S96, generator=torch.Generator().manual_seed(5678)).float().to(dev)
+        loss_fn = DiceCELoss(to_onehot_y=True, softmax=True)
+        hist = []
+        for it in range(3):
+            opt.zero_grad(set_to_none=True)
+            logits = net(x)
+            assert logits.shape == (4, 8) + S96 and logits.dtype == torch.float32
+            loss = loss_fn(logits, lab)
+            loss.backward()
+            assert all(torch.isfinite(p.grad).all() for p in net.parameters() if p.grad is not None)
+            opt.step()
+            hist.append(loss.item())
+        print(f"[transeg 96^3 {mode}] DiceCE {hist}")
+        assert all(h == h and h < 1e3 for h in hist) and hist[-1] < hist[0], hist
+    finally:
+        dose_prediction_amd.set_compute_dtype(torch.float32)
 
 
 def test_c3_transeg_training_steps_128_bf16():

@@ -144,8 +144,27 @@ def test_x3_forward_only_convolutions_on_short_rows(cfg):
     check("y", ncdhw(yh), yr)
     assert any(n.startswith("dp_conv3d_tiled") and a[-2] == ops.DP_X3 for n, a in calls), [n for n, _ in calls]
     yg = ops.conv3d(arg, wh, bh, 1, k // 2, 1)
-    assert "Conv3dX3" not in type(yg.grad_fn).__name__
+    assert "Conv3dX3" not in type(yg.grad_fn).__name__          # (this file's fixture asks for three-product weight gradients: tiled kernels, W >= 16)
     check("y (grad-enabled path)", ncdhw(yg), yr)
+    # the mode's default (one-product gradients): short rows train on the x3 kernels too -- forward three products, data gradient gy_hi w_hi,
+    # weight gradient x_hi gy_hi on the generic bf16 kernel
+    import dose_prediction_amd
+    cfg_ = dose_prediction_amd.config
+    cfg_.set_x3_wgrad_terms(1); cfg_.set_x3_dgrad_terms(1)
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    r = rnd(yr.shape, 4)
+    (oracle.conv3d(xr, wr, b.double(), 1, k // 2, 1) * r.double()).sum().backward()
+    if ca:
+        xa, xb = (t.clone().requires_grad_(True) for t in arg)
+        y1 = ops.conv3d((xa, xb), wh, bh, 1, k // 2, 1)
+    else:
+        xa = arg.clone().requires_grad_(True)
+        y1 = ops.conv3d(xa, wh, bh, 1, k // 2, 1)
+    assert "Conv3dX3" in type(y1.grad_fn).__name__
+    y1.backward(ndhwc(r).to(dev))
+    check("y (one-product mode)", ncdhw(y1), yr)
+    gx = torch.cat((xa.grad, xb.grad), -1) if ca else xa.grad
+    assert rel_l2(ncdhw(gx).cpu(), xr.grad) < 8e-3 and rel_l2(wh.grad.cpu(), wr.grad) < 8e-3 and rel_l2(bh.grad.cpu(), r.double().sum((0, 2, 3, 4))) < 1e-4
 
 
 @pytest.mark.parametrize("cfg", [(2, 32, 16, 16, 3, 33, 70, 7), (1, 16, 0, 16, 5, 32, 32, 3), (1, 64, 0, 40, 2, 33, 32, 7)])
