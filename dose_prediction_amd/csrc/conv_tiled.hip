@@ -1298,7 +1298,10 @@ __global__ void __launch_bounds__(256) k_wgrad_unpack(float* __restrict__ dwt, f
 
 static inline bool wgt_applicable(int Cin, int Cout, int k, int stride, int pad, int dil, int shift, int W) {
   if (k == 1) return stride == 1 && pad == 0 && W >= 16 && Cin >= 8 && Cout >= 8 && Cin <= 256 && Cout <= 256;   // pointwise: HBM-bound row stream
-  return shift && (k == 3 || k == 7) && stride == 1 && dil == 1 && pad == k / 2 && W >= 16 && Cin >= 1 && Cout >= 8;
+  // (W >= 8, round 5: the 12^3 level of the 96^3 crop fell to the generic kernel -- 2 ms per 7x7x7 128 -> 128 launch at 4 x 12^3, 8.2 of the
+  // 31 ms of an OAR-TRANSEG step at the reference's own crop size; a tile of 16 / 32 positions with 12 real ones still runs on the tiled kernel)
+  static const int minw = [] { const char* e = getenv("DP_WGRAD_MINW"); return e ? atoi(e) : 8; }();
+  return shift && (k == 3 || k == 7) && stride == 1 && dil == 1 && pad == k / 2 && W >= minw && Cin >= 1 && Cout >= 8;
 }
 // fp32 scratch elements needed by dp_conv3d_wgrad_tiled (0: shape not supported, use dp_conv3d_wgrad)
 extern "C" int dp_conv3d_wgrad_tiled_ws_elems(int Cin, int Cout, int k, int stride, int pad, int dil, int shift, int W) {

@@ -204,19 +204,38 @@ __global__ void __launch_bounds__(DCE_BLOCK) k_dice_ce_partial(const float* __re
   for (int j = threadIdx.x; j < 1 + 3 * CM; j += DCE_BLOCK) out[j] = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
 }
 template <int CM>
-__global__ void __launch_bounds__(64) k_dice_ce_finish(const float* __restrict__ part, int B, int C, int64_t V, int nblk, float snr, float sdr, float ld, float lc,
-                                                       float* __restrict__ stats) {
-  // one wave; lane j < 1 + 3 CM owns partial column j of sample b (fixed order over the blocks, fp64)
-  __shared__ double tot[1 + 3 * CM];
+__global__ void __launch_bounds__(1024) k_dice_ce_finish(const float* __restrict__ part, int B, int C, int64_t V, int nblk, float snr, float sdr, float ld, float lc,
+                                                         float* __restrict__ stats) {
+  // column j < 1 + 3 CM of sample b: 16 threads take every 16th block row each (eight loads in flight), then a fixed-order tree over the 16
+  // (round 5: one thread per column walked all the rows one dependent load at a time -- 0.18 ms for 216 rows x 4 samples)
+  constexpr int NCOL = 1 + 3 * CM, G = 16;
+  __shared__ double tot[NCOL];
+  __shared__ double red[NCOL][G];
   __shared__ double acc[2];
+  const int col = threadIdx.x / G, sub = threadIdx.x % G;
   if (threadIdx.x == 0) { acc[0] = 0.0; acc[1] = 0.0; }
   for (int b = 0; b < B; b++) {
     __syncthreads();
-    if (threadIdx.x < 1 + 3 * CM) {
+    if (col < NCOL) {
       double s = 0.0;
-      const float* p = part + (int64_t)b * nblk * (1 + 3 * CM) + threadIdx.x;
-      for (int k = 0; k < nblk; k++) s += p[(int64_t)k * (1 + 3 * CM)];
-      tot[threadIdx.x] = s;
+      const float* p = part + (int64_t)b * nblk * NCOL + col;
+      int k = sub;
+      for (; k + 7 * G < nblk; k += 8 * G) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = p[(int64_t)(k + u * G) * NCOL];
+#pragma unroll
+        for (int u = 0; u < 8; u++) s += v[u];
+      }
+      for (; k < nblk; k += G) s += p[(int64_t)k * NCOL];
+      red[col][sub] = s;
+    }
+    __syncthreads();
+    if (col < NCOL && sub == 0) {
+      double s = 0.0;
+#pragma unroll
+      for (int u = 0; u < G; u++) s += red[col][u];
+      tot[col] = s;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -275,10 +294,10 @@ extern "C" int dp_dice_ce_fwd(const float* logits, const void* labels, int label
   if (nblk > 2000000000LL || B > 65535) DP_FAIL("dice_ce: tensor too large");
   if (C <= 8) {
     hipLaunchKernelGGL(k_dice_ce_partial<8>, dim3((unsigned)nblk, B), dim3(DCE_BLOCK), 0, STREAM, logits, labels, label_kind, C, V, (int)nblk, ws);
-    hipLaunchKernelGGL(k_dice_ce_finish<8>, dim3(1), dim3(64), 0, STREAM, (const float*)ws, B, C, V, (int)nblk, smooth_nr, smooth_dr, lambda_dice, lambda_ce, stats);
+    hipLaunchKernelGGL(k_dice_ce_finish<8>, dim3(1), dim3(16 * 25), 0, STREAM, (const float*)ws, B, C, V, (int)nblk, smooth_nr, smooth_dr, lambda_dice, lambda_ce, stats);
   } else {
     hipLaunchKernelGGL(k_dice_ce_partial<16>, dim3((unsigned)nblk, B), dim3(DCE_BLOCK), 0, STREAM, logits, labels, label_kind, C, V, (int)nblk, ws);
-    hipLaunchKernelGGL(k_dice_ce_finish<16>, dim3(1), dim3(64), 0, STREAM, (const float*)ws, B, C, V, (int)nblk, smooth_nr, smooth_dr, lambda_dice, lambda_ce, stats);
+    hipLaunchKernelGGL(k_dice_ce_finish<16>, dim3(1), dim3(16 * 49), 0, STREAM, (const float*)ws, B, C, V, (int)nblk, smooth_nr, smooth_dr, lambda_dice, lambda_ce, stats);
   }
   DP_CHECK_LAUNCH("dice_ce_fwd"); return 0;
 }
