@@ -502,7 +502,10 @@ bool wgrad_hk_applicable(int Cout, int k, int H, int W, int dtype) {
   static const bool off = getenv("DP_NO_HK") != nullptr;
   static const bool off3 = getenv("DP_NO_HK3") != nullptr;
   (void)Cout;
-  return !off && dtype != DP_F32 && (k == 7 || (k == 3 && !off3)) && H >= 32 && W >= 32;
+  // 7^3 on planes down to 24 x 24 (one zero-padded 32 x 32 tile; round 5, the 24^3 level of the 96^3 crop): 64 -> 64 at 4 x 24^3 0.241 -> 0.201 ms,
+  // 128 -> 64 0.500 -> 0.396 (644 -> 771 / 621 -> 784 TFLOP/s); 16 x 16 and 12 x 12 planes lose on it (a quarter / a seventh of the tile is real)
+  static const int minp = [] { const char* e = getenv("DP_HK_MINPLANE"); return e ? atoi(e) : 24; }();
+  return !off && dtype != DP_F32 && (k == 7 || (k == 3 && !off3)) && H >= (k == 7 ? minp : 32) && W >= (k == 7 ? minp : 32);
 }
 
 int64_t wgrad_hk_ws_elems(int Cin, int Cout, int k) {

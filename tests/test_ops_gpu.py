@@ -146,6 +146,9 @@ DTYPES = [torch.float32, torch.bfloat16, torch.float16]
     (1, 16, 16, 2, 9, 160, 7, 1, 3, 1, True),     # 96 + 64: a ragged second 96-position tile
     (1, 32, 16, 3, 8, 130, 7, 1, 3, 1, False),    # 96 + 34 (two tiles of 96 beat two of 128)
     (1, 16, 12, 1, 12, 288, 7, 1, 3, 1, True),    # three whole tiles, one depth slice (every block has one dead slice), 12 output channels
+    (2, 64, 32, 3, 24, 24, 7, 1, 3, 1, True),     # K-along-H weight gradient on a 24 x 24 plane (one zero-padded 32 x 32 tile): the 24^3 level of the 96^3 crop
+    (1, 16, 16, 2, 24, 30, 7, 1, 3, 1, False),
+    (1, 40, 24, 4, 27, 25, 7, 1, 3, 1, True),
 ])
 def test_conv3d(cfg, dtype):
     from dose_prediction_amd import ops

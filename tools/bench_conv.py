@@ -37,6 +37,8 @@ SHAPES_W = [
     ("c3 32->16 @2x128^3", 2, 32, 16, (128, 128, 128), 3), ("c3 32->16 @4x96^3", 4, 32, 16, (96, 96, 96), 3), ("c3 32->16 @128x192x192", 1, 32, 16, (128, 192, 192), 3),
     ("c3 16->32 @2x128^3", 2, 16, 32, (128, 128, 128), 3), ("c3 16->32 @4x96^3", 4, 16, 32, (96, 96, 96), 3), ("c3 16->32 @128x192x192", 1, 16, 32, (128, 192, 192), 3),
     ("c3 64->32 @2x64^3", 2, 64, 32, (64, 64, 64), 3), ("c3 64->32 @64x96x96", 1, 64, 32, (64, 96, 96), 3),
+    ("c7 128->128 @2x16^3", 2, 128, 128, (16, 16, 16), 7), ("c7 128->128 @4x12^3", 4, 128, 128, (12, 12, 12), 7), ("c7 256->128 @4x12^3", 4, 256, 128, (12, 12, 12), 7),
+    ("c7 128->64 @4x24^3", 4, 128, 64, (24, 24, 24), 7), ("c7 256->128 @2x16^3", 2, 256, 128, (16, 16, 16), 7),
 ]
 
 
