@@ -94,6 +94,10 @@ __global__ void __launch_bounds__(256, OCC) k_conv_cc16(const T* __restrict__ x,
   if ((gridDim.x & 7) == 0) b = (b & 7) * (gridDim.x >> 3) + (b >> 3);
   const int tw = b % g.tiles_w; b /= g.tiles_w; const int th = b % g.tiles_h; b /= g.tiles_h; const int dt = b % g.dtiles; const int n = b / g.dtiles;
   const int h0 = th * RWO, w0 = tw * TW, d0 = dt * DT;
+  if (g.dbg & 8) {          // experiment (DP_DBG=8): stagger the blocks that start together on a CU so that their phases do not coincide
+    const int lag = blockIdx.x < 768 ? ((blockIdx.x >> 8) % 3) * (g.dbg >> 4) : 0;       // (only the blocks of the first resident round: the later ones start when a slot frees up)
+    for (int i = 0; i < lag; i++) __builtin_amdgcn_s_sleep(127);
+  }
   v4f acc[DT][RWO][2];
 #pragma unroll
   for (int a = 0; a < DT; a++)
