@@ -7,12 +7,13 @@
 
 #define STREAM ((hipStream_t)stream)
 #define NT 256
-// Voxel rows per block of the row-stream kernels: 2048 for big volumes, fewer for small ones so that even an 8^3 / 16^3
+// Voxel rows per block of the row-stream kernels: 2048 for big volumes (4096 is 2-4 % faster alone on the chip, nothing in the step), fewer for small ones so that even an 8^3 / 16^3
 // feature map spreads over a few hundred blocks (a 4-block launch over 768 channels took ~190 us).
 static inline int rows_per_block(int64_t V) {
+  static const int max_rpb = getenv("DP_NORM_RPB") ? atoi(getenv("DP_NORM_RPB")) : 2048;      // (experiment switch)
   int64_t r = V / 128;
   if (r < 32) r = 32;
-  if (r > 2048) r = 2048;
+  if (r > max_rpb) r = max_rpb;
   return (int)r;
 }
 
@@ -233,12 +234,13 @@ struct NormArgs {
   // fp32x3 (T = float, fast path only): split_cp > 0: y (forward) / gx (backward) is a bf16 [rows][2 * split_cp] tensor of hi | lo
   // halves instead of fp32 rows (split_cp2: the same for the second source's gx); the consumer is an x3 convolution
   int split_cp, split_cp2;
+  int rev;      // backward apply walks the blocks in reverse order (the rows the partial pass read last are the likeliest still cached)
 };
 
 template <typename T, int ACT>
 __global__ void __launch_bounds__(NT) k_norm_act_fwd(NormArgs a) {
   const T* res = (const T*)a.res; T* y = (T*)a.y;
-  const int b = blockIdx.x, n = blockIdx.y;
+  const int b = a.rev ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x, n = a.rev ? (int)gridDim.y - 1 - (int)blockIdx.y : (int)blockIdx.y;
   RowGeom g = row_geom(a.C);
   if (!g.active) return;
   const bool second = a.x2 != nullptr && g.cg * 8 >= a.csplit;      // this thread's 8-channel chunk comes from the second source
@@ -335,7 +337,7 @@ __global__ void __launch_bounds__(NT) k_norm_act_bwd_partial(NormArgs a) {
 template <typename T, int ACT>
 __global__ void __launch_bounds__(NT) k_norm_act_bwd_apply(NormArgs a) {
   const T* gy = (const T*)a.gy; const T* res = (const T*)a.res; T* gres = (T*)a.gres;
-  const int b = blockIdx.x, n = blockIdx.y;
+  const int b = a.rev ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x, n = a.rev ? (int)gridDim.y - 1 - (int)blockIdx.y : (int)blockIdx.y;
   RowGeom g = row_geom(a.C);
   if (!g.active) return;
   const bool second = a.x2 != nullptr && g.cg * 8 >= a.csplit;
@@ -403,6 +405,10 @@ __global__ void __launch_bounds__(NT) k_norm_act_bwd_apply(NormArgs a) {
   }
 }
 
+// bit 0: the backward apply pass, bit 1: the forward pass walk their blocks from the last row to the first -- the rows the pass before
+// (partial sums / the producing convolution) touched last are the likeliest still in L2 / MALL: 128^3 backward -7..-11 % alone on the
+// chip (tools/bench_norm.py), but 23.25 -> 23.3 ms in the training step (profiles/r05_k_norm_block_order.txt): off by default
+static inline int norm_rev() { static const int r = getenv("DP_NORM_REV") ? atoi(getenv("DP_NORM_REV")) : 0; return r; }
 #define NORM_LAUNCH(KERN, args, grid) do { \
     switch (act) { \
       case DP_ACT_NONE: DP_DISPATCH(dtype, hipLaunchKernelGGL((KERN<T, DP_ACT_NONE>), grid, dim3(NT), 0, STREAM, args)); break; \
@@ -427,6 +433,7 @@ extern "C" int dp_norm_act_fwd(const void* x, int ldx, const float* mean, const 
   NormArgs a = {}; a.x = x; a.ldx = ldx; a.mean = mean; a.rstd = rstd; a.ssn = ssn; a.gamma = gamma; a.beta = beta; a.res = res; a.ldr = ldr;
   a.y = y; a.ldy = ldy; a.V = V; a.C = C; a.rpb = rows_per_block(V); a.nblk = dp_stats_nblk(V);
   a.fast = norm_fast(C, ldx, x, 0, nullptr, ldr, res, ldy, y, 0, nullptr);
+  a.rev = (norm_rev() >> 1) & 1;
   NORM_LAUNCH(k_norm_act_fwd, a, dim3(a.nblk, N));
   DP_CHECK_LAUNCH("norm_act_fwd"); return 0;
 }
@@ -438,6 +445,7 @@ extern "C" int dp_norm_act_cat_fwd(const void* xa, int lda, const float* mean_a,
   NormArgs a = {}; a.x = xa; a.ldx = lda; a.mean = mean_a; a.rstd = rstd_a; a.ssn = Ca; a.x2 = xb; a.ldx2 = ldb; a.mean2 = mean_b; a.rstd2 = rstd_b;
   a.ssn2 = Cb; a.csplit = Ca; a.y = y; a.ldy = ldy; a.V = V; a.C = C; a.rpb = rows_per_block(V); a.nblk = dp_stats_nblk(V);
   a.fast = norm_fast(C, lda, xa, 0, nullptr, 0, nullptr, ldy, y, 0, nullptr) && norm_fast(C, ldb, xb, 0, nullptr, 0, nullptr, ldy, y, 0, nullptr);
+  a.rev = (norm_rev() >> 1) & 1;
   NORM_LAUNCH(k_norm_act_fwd, a, dim3(a.nblk, N));
   DP_CHECK_LAUNCH("norm_act_cat_fwd"); return 0;
 }
@@ -474,6 +482,7 @@ extern "C" int dp_norm_act_cat_bwd_apply(const void* xa, int lda, const float* m
   a.ssn2 = Cb; a.csplit = Ca; a.gy = gy; a.ldgy = ldgy; a.y = gxa; a.ldy = ldgxa; a.y2 = gxb; a.ldy2 = ldgxb; a.s1 = s1; a.s2 = s2;
   a.inv_count = inv_count; a.use_stats = 1; a.V = V; a.C = C; a.rpb = rows_per_block(V); a.nblk = dp_stats_nblk(V);
   a.fast = norm_fast(C, lda, xa, ldgy, gy, 0, nullptr, ldgxa, gxa, 0, nullptr) && norm_fast(C, ldb, xb, 0, nullptr, 0, nullptr, ldgxb, gxb, 0, nullptr);
+  a.rev = norm_rev() & 1;
   NORM_LAUNCH(k_norm_act_bwd_apply, a, dim3(a.nblk, N));
   DP_CHECK_LAUNCH("norm_act_cat_bwd_apply"); return 0;
 }
@@ -515,6 +524,7 @@ extern "C" int dp_norm_act_bwd_apply(const void* x, int ldx, const void* gy, int
   a.res = res; a.ldr = ldr; a.y = gx; a.ldy = ldgx; a.gres = gres; a.ldgres = ldgres; a.s1 = s1; a.s2 = s2; a.inv_count = inv_count;
   a.use_stats = use_stats; a.V = V; a.C = C; a.rpb = rows_per_block(V); a.nblk = dp_stats_nblk(V);
   a.fast = norm_fast(C, ldx, x, ldgy, gy, ldr, res, ldgx, gx, ldgres, gres);
+  a.rev = norm_rev() & 1;
   NORM_LAUNCH(k_norm_act_bwd_apply, a, dim3(a.nblk, N));
   DP_CHECK_LAUNCH("norm_act_bwd_apply"); return 0;
 }
@@ -528,6 +538,7 @@ extern "C" int dp_norm_act_fwd_x3(const void* x, int ldx, const float* mean, con
   NormArgs a = {}; a.x = x; a.ldx = ldx; a.mean = mean; a.rstd = rstd; a.ssn = ssn; a.gamma = gamma; a.beta = beta; a.res = res; a.ldr = ldr;
   a.y = ys; a.ldy = 2 * cp; a.split_cp = cp; a.V = V; a.C = C; a.rpb = rows_per_block(V); a.nblk = dp_stats_nblk(V);
   a.fast = norm_fast(C, ldx, x, 0, nullptr, ldr, res, 8, ys, 0, nullptr);
+  a.rev = (norm_rev() >> 1) & 1;
   NORM_LAUNCH(k_norm_act_fwd, a, dim3(a.nblk, N));
   DP_CHECK_LAUNCH("norm_act_fwd_x3"); return 0;
 }
@@ -540,6 +551,7 @@ extern "C" int dp_norm_act_bwd_apply_x3(const void* x, int ldx, const void* gy, 
   a.res = res; a.ldr = ldr; a.y = gxs; a.ldy = 2 * cp; a.split_cp = cp; a.gres = gres; a.ldgres = ldgres; a.s1 = s1; a.s2 = s2; a.inv_count = inv_count;
   a.use_stats = use_stats; a.V = V; a.C = C; a.rpb = rows_per_block(V); a.nblk = dp_stats_nblk(V);
   a.fast = norm_fast(C, ldx, x, ldgy, gy, ldr, res, 8, gxs, ldgres, gres);
+  a.rev = norm_rev() & 1;
   NORM_LAUNCH(k_norm_act_bwd_apply, a, dim3(a.nblk, N));
   DP_CHECK_LAUNCH("norm_act_bwd_apply_x3"); return 0;
 }
