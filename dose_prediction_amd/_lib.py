@@ -73,7 +73,7 @@ PROFILE_NAMES = ("dp_conv3d", "dp_conv3d_tiled", "dp_conv3d_tiled2", "dp_conv3d_
 
 
 # entry points that may answer 3 = "not this kernel's shape, nothing launched" (the caller then takes its general path)
-SOFT_DECLINE = ("dp_tconv2x_fwd",)
+SOFT_DECLINE = ("dp_tconv2x_fwd", "dp_stats_partial_finalize", "dp_norm_act_bwd_partial_finalize", "dp_norm_act_cat_bwd_partial_finalize")
 
 
 def call(name, *args):

@@ -86,20 +86,155 @@ __device__ __forceinline__ RowGeom row_geom(int C) {
 
 // Deterministic block reduction of per-thread 16 partials (acc[0..7], acc2[0..7]) over the threads that share a chunk.
 // red: LDS float [NT][16].  Result written by threads c < 2*C... to part[(2)][C].
-__device__ __forceinline__ void block_reduce_store(float* red, const float* a1, const float* a2, const RowGeom& g, int C, float* part) {
+// coh: the row goes out with device-scope (sc1, written through the XCD's L2) stores, for a reader in ANOTHER block of the same launch
+// (ticket_is_last below)
+__device__ __forceinline__ void st_coh(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_coh(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void block_reduce_store(float* red, const float* a1, const float* a2, const RowGeom& g, int C, float* part, bool coh = false) {
   for (int i = 0; i < 8; i++) { red[threadIdx.x * 16 + i] = g.active ? a1[i] : 0.f; red[threadIdx.x * 16 + 8 + i] = g.active ? a2[i] : 0.f; }
   __syncthreads();
   for (int o = threadIdx.x; o < 2 * C; o += NT) {
     int which = o / C, c = o - which * C, cg = c >> 3, j = c & 7;
     float s = 0.f;
     for (int r = 0; r < g.rpi; r++) s += red[(r * g.cg8 + cg) * 16 + which * 8 + j];
-    part[which * C + c] = s;
+    if (coh) st_coh(part + which * C + c, s); else part[which * C + c] = s;
   }
 }
 
+// Parallel fp64 combine of the per-block partials: one 256-thread block per (statistics group, 16/32-channel slice);
+// threads are arranged [rows][channels] so every partial row is read coalesced, then the rows are tree-reduced in LDS.
+// COH = 1: the rows were written by other blocks of the SAME launch (st_coh): device-scope loads that do not trust this XCD's L2.
+template <int COH>
+__device__ __forceinline__ void combine_partials(const float* __restrict__ part, int n0, int n1, int nblk, int C, int c0, int cpb,
+                                                 double& s1, double& s2, double* red) {
+  const int t = threadIdx.x, cc = t % cpb, r = t / cpb, rows = 256 / cpb, c = c0 + cc;
+  double a1 = 0, a2 = 0;
+  if (c < C) {
+    const int64_t total = (int64_t)(n1 - n0) * nblk;
+    const float* p0 = part + (int64_t)n0 * nblk * 2 * C + c;
+    int64_t b = r;
+    // 8 partial rows per trip with all 16 loads issued before the first add: one thread walks up to 64 rows, and a load -> add
+    // chain paid one L2 round trip per row (these 10-us launches were almost pure latency)
+    for (; b + 7 * (int64_t)rows < total; b += 8 * (int64_t)rows) {
+      float u[8], v[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const float* p = p0 + (b + k * (int64_t)rows) * 2 * C;
+        if constexpr (COH) { u[k] = ld_coh(p); v[k] = ld_coh(p + C); } else { u[k] = p[0]; v[k] = p[C]; }
+      }
+#pragma unroll
+      for (int k = 0; k < 8; k++) { a1 += u[k]; a2 += v[k]; }
+    }
+    for (; b < total; b += rows) {
+      const float* p = p0 + b * 2 * C;
+      if constexpr (COH) { a1 += ld_coh(p); a2 += ld_coh(p + C); } else { a1 += p[0]; a2 += p[C]; }
+    }
+  }
+  red[t * 2] = a1; red[t * 2 + 1] = a2;
+  __syncthreads();
+  for (int st = rows / 2; st > 0; st >>= 1) {
+    if (r < st) { red[t * 2] += red[(t + st * cpb) * 2]; red[t * 2 + 1] += red[(t + st * cpb) * 2 + 1]; }
+    __syncthreads();
+  }
+  s1 = red[cc * 2]; s2 = red[cc * 2 + 1];
+}
+
+// One unit of the statistics finalize: (sum, sum of squares) partial rows of statistics group gidx, channels [bx * cpb, +cpb) -> mean / rstd
+// (+ running statistics, + the folded scale / shift).  Called by a whole 256-thread block (block-uniform arguments).
+struct StatsFin {
+  const float* part; int N, nblk, C; int64_t V; int batch_mode; float eps; float* mean; float* rstd; float* rmean; float* rvar; float momentum;
+  int cpb; const float* gamma; const float* beta; float* sc; float* sh; int cpad;
+};
+template <int COH>
+__device__ __forceinline__ void stats_finalize_unit(const StatsFin& f, int bx, int gidx, double* red) {
+  const int c0 = bx * f.cpb;
+  const int n0 = f.batch_mode ? 0 : gidx, n1 = f.batch_mode ? f.N : gidx + 1;
+  double s1, s2;
+  combine_partials<COH>(f.part, n0, n1, f.nblk, f.C, c0, f.cpb, s1, s2, red);
+  const int c = c0 + threadIdx.x;
+  if (threadIdx.x >= f.cpb || c >= f.C) return;
+  double cnt = (double)f.V * (n1 - n0);
+  double m = s1 / cnt, var = s2 / cnt - m * m;
+  if (var < 0) var = 0;
+  f.mean[gidx * f.C + c] = (float)m; f.rstd[gidx * f.C + c] = (float)(1.0 / sqrt(var + (double)f.eps));
+  if (f.sc) {   // z = x * sc + sh, the form the fused normalise kernels and the convolution prologue evaluate (float arithmetic as in k_norm_act_fwd)
+    const float r_ = f.rstd[gidx * f.C + c], g_ = f.gamma ? f.gamma[c] : 1.f, b_ = f.beta ? f.beta[c] : 0.f, s_ = r_ * g_;
+    f.sc[gidx * f.cpad + c] = s_; f.sh[gidx * f.cpad + c] = b_ - f.mean[gidx * f.C + c] * s_;
+  }
+  if (f.rmean && f.batch_mode) {
+    double unb = cnt > 1 ? var * cnt / (cnt - 1) : var;
+    f.rmean[c] = (float)((1.0 - f.momentum) * f.rmean[c] + f.momentum * m);
+    f.rvar[c] = (float)((1.0 - f.momentum) * f.rvar[c] + f.momentum * unb);
+  }
+}
+__global__ void __launch_bounds__(256) k_stats_finalize(StatsFin f) {
+  __shared__ double red[512];
+  stats_finalize_unit<0>(f, blockIdx.x, blockIdx.y, red);
+}
+
+// ---------------------------------------------------------------------------- finalize folded into the partial pass ("last block" ticket)
+// The partial-sum kernels below are pure read streams that end in one small store per block.  Instead of a second launch that combines
+// the rows (5-7 us alone on the chip, 10-20 us of the dependent chain inside the step, where the launch queues behind the blocks of the
+// other streams), every block of a statistics group takes a ticket after its row is written (device-scope stores, acknowledged, then a
+// device-scope atomicAdd) and the block that draws the last one runs the finalize units of that group itself, reading the rows with
+// device-scope loads: same code, same order of additions, bit-identical results.  One counter per statistics group (instance mode: the samples finish independently) from
+// a ring of zeroed counters; the last block puts the zero back.  Off with DP_NO_TICKET=1 (the callers then launch the finalize).
+#define TICKET_RING 8192
+static unsigned* g_ticket_ring[32] = {};
+static unsigned g_ticket_next[32] = {};
+static unsigned* ticket_counters(int n) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32 || n > TICKET_RING) return nullptr;
+  if (!g_ticket_ring[dev]) {
+    unsigned* p = nullptr;
+    if (hipMalloc(&p, TICKET_RING * sizeof(unsigned)) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, TICKET_RING * sizeof(unsigned)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipFree(p); return nullptr; }
+    g_ticket_ring[dev] = p;
+  }
+  unsigned at = g_ticket_next[dev];
+  if (at + n > TICKET_RING) at = 0;
+  g_ticket_next[dev] = at + n;
+  return g_ticket_ring[dev] + at;
+}
+static inline bool ticket_enabled() { static const bool off = getenv("DP_NO_TICKET") != nullptr; return !off; }
+extern "C" int dp_ticket_enabled(void) { return ticket_enabled() ? 1 : 0; }
+// true in exactly one block per counter: the one whose ticket is the last of `total`.  Every thread of the block must call it, after the
+// block's own row stores (st_coh).  NO release / acquire fence: on this part a device-scope fence is `buffer_wbl2 sc1` + `buffer_inv sc1`
+// -- a write-back and an invalidate of the XCD's whole L2, i.e. of the convolutions running beside this kernel on the other streams
+// (measured with fences: the 23.4-ms step took 28.8 ms).  Instead the rows travel as device-scope stores / loads (written through and read
+// past the L2), the writers wait for their stores to be acknowledged (vmcnt(0)) before the block's ticket is drawn, and the reader's
+// loads are control-dependent on the ticket it drew.
+__device__ __forceinline__ bool ticket_is_last(unsigned* counter, unsigned total, int* flag) {
+  __builtin_amdgcn_s_waitcnt(0);           // this thread's row stores have been acknowledged ...
+  __syncthreads();                         // ... for every thread of the block, before the ticket is drawn
+  if (threadIdx.x == 0) {
+    const unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *flag = (t == total - 1) ? 1 : 0;
+    if (t == total - 1) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-arm: the next user is a later launch
+  }
+  __syncthreads();
+  return *flag != 0;
+}
+
+static inline int pick_cpb(int C) { return C >= 32 ? 32 : (C >= 16 ? 16 : 8); }
+static inline StatsFin stats_fin(const float* part, int N, int nblk, int C, int64_t V, int batch_mode, float eps, float* mean, float* rstd,
+                                 float* running_mean, float* running_var, float momentum) {
+  StatsFin f = {}; f.part = part; f.N = N; f.nblk = nblk; f.C = C; f.V = V; f.batch_mode = batch_mode; f.eps = eps; f.mean = mean; f.rstd = rstd;
+  f.rmean = running_mean; f.rvar = running_var; f.momentum = momentum; f.cpb = pick_cpb(C);
+  return f;
+}
+extern "C" int dp_stats_finalize(const float* part, int N, int nblk, int C, int64_t V, int batch_mode, float eps, float* mean, float* rstd,
+                                 float* running_mean, float* running_var, float momentum, void* stream) {
+  StatsFin f = stats_fin(part, N, nblk, C, V, batch_mode, eps, mean, rstd, running_mean, running_var, momentum);
+  hipLaunchKernelGGL(k_stats_finalize, dim3(cdiv(C, f.cpb), batch_mode ? 1 : N), dim3(256), 0, STREAM, f);
+  DP_CHECK_LAUNCH("stats_finalize"); return 0;
+}
+
 template <typename T>
-__global__ void __launch_bounds__(NT) k_stats_partial(const T* __restrict__ x, int ld, int64_t V, int C, float* __restrict__ part, int nblk, int ROWS_PER_BLOCK, int fast) {
-  __shared__ float red[NT * 16];
+__global__ void __launch_bounds__(NT) k_stats_partial(const T* __restrict__ x, int ld, int64_t V, int C, float* __restrict__ part, int nblk, int ROWS_PER_BLOCK, int fast,
+                                                      unsigned* ticket, StatsFin f) {
+  __shared__ __align__(16) float red[NT * 16];
+  __shared__ int last_flag;
   if (C > 8 * NT) return;
   int b = blockIdx.x, n = blockIdx.y;
   RowGeom g = row_geom(C);
@@ -123,80 +258,36 @@ __global__ void __launch_bounds__(NT) k_stats_partial(const T* __restrict__ x, i
     float t[8]; unpack8<T>(x + ((int64_t)n * V + v) * ld + g.cg * 8, g.nv, t);
     for (int i = 0; i < 8; i++) { s1[i] += t[i]; s2[i] += t[i] * t[i]; }
   }
-  block_reduce_store(red, s1, s2, g, C, part + ((int64_t)n * nblk + b) * 2 * C);
+  block_reduce_store(red, s1, s2, g, C, part + ((int64_t)n * nblk + b) * 2 * C, ticket != nullptr);
+  if (!ticket) return;
+  // folded finalize: batch mode = one group over the whole grid, instance mode = one group per sample (blockIdx.y)
+  if (!ticket_is_last(ticket + (f.batch_mode ? 0 : n), f.batch_mode ? gridDim.x * gridDim.y : gridDim.x, &last_flag)) return;
+  for (int bx = 0; bx * f.cpb < C; bx++) { stats_finalize_unit<1>(f, bx, f.batch_mode ? 0 : n, (double*)red); __syncthreads(); }
 }
 extern "C" int dp_stats_partial(const void* x, int ld, int N, int64_t V, int C, float* part, int dtype, void* stream) {
   if (C > 8 * NT) DP_FAIL("stats: C too large");
   int nblk = dp_stats_nblk(V);
   int fast = (C % 8 == 0) && (ld % 8 == 0) && aligned16(x);
-  DP_DISPATCH(dtype, hipLaunchKernelGGL(k_stats_partial<T>, dim3(nblk, N), dim3(NT), 0, STREAM, (const T*)x, ld, V, C, part, nblk, rows_per_block(V), fast));
+  DP_DISPATCH(dtype, hipLaunchKernelGGL(k_stats_partial<T>, dim3(nblk, N), dim3(NT), 0, STREAM, (const T*)x, ld, V, C, part, nblk, rows_per_block(V), fast,
+                                        (unsigned*)nullptr, StatsFin{}));
   DP_CHECK_LAUNCH("stats_partial"); return 0;
 }
-
-// Parallel fp64 combine of the per-block partials: one 256-thread block per (statistics group, 16/32-channel slice);
-// threads are arranged [rows][channels] so every partial row is read coalesced, then the rows are tree-reduced in LDS.
-template <int DUMMY>
-__device__ __forceinline__ void combine_partials(const float* __restrict__ part, int n0, int n1, int nblk, int C, int c0, int cpb,
-                                                 double& s1, double& s2, double* red) {
-  const int t = threadIdx.x, cc = t % cpb, r = t / cpb, rows = 256 / cpb, c = c0 + cc;
-  double a1 = 0, a2 = 0;
-  if (c < C) {
-    const int64_t total = (int64_t)(n1 - n0) * nblk;
-    const float* p0 = part + (int64_t)n0 * nblk * 2 * C + c;
-    int64_t b = r;
-    // 8 partial rows per trip with all 16 loads issued before the first add: one thread walks up to 64 rows, and a load -> add
-    // chain paid one L2 round trip per row (these 10-us launches were almost pure latency)
-    for (; b + 7 * (int64_t)rows < total; b += 8 * (int64_t)rows) {
-      float u[8], v[8];
-#pragma unroll
-      for (int k = 0; k < 8; k++) { const float* p = p0 + (b + k * (int64_t)rows) * 2 * C; u[k] = p[0]; v[k] = p[C]; }
-#pragma unroll
-      for (int k = 0; k < 8; k++) { a1 += u[k]; a2 += v[k]; }
-    }
-    for (; b < total; b += rows) { const float* p = p0 + b * 2 * C; a1 += p[0]; a2 += p[C]; }
-  }
-  red[t * 2] = a1; red[t * 2 + 1] = a2;
-  __syncthreads();
-  for (int st = rows / 2; st > 0; st >>= 1) {
-    if (r < st) { red[t * 2] += red[(t + st * cpb) * 2]; red[t * 2 + 1] += red[(t + st * cpb) * 2 + 1]; }
-    __syncthreads();
-  }
-  s1 = red[cc * 2]; s2 = red[cc * 2 + 1];
+// dp_stats_partial + dp_stats_finalize in ONE launch (the last block of every statistics group finalizes it, see ticket_is_last).
+// Returns 3 (nothing launched) when the folded form is switched off or unavailable: the caller then makes the two calls.
+extern "C" int dp_stats_partial_finalize(const void* x, int ld, int N, int64_t V, int C, float* part, int batch_mode, float eps, float* mean,
+                                         float* rstd, float* running_mean, float* running_var, float momentum, int dtype, void* stream) {
+  if (C > 8 * NT) DP_FAIL("stats: C too large");
+  if (!ticket_enabled()) return 3;
+  unsigned* ticket = ticket_counters(batch_mode ? 1 : N);
+  if (!ticket) return 3;
+  int nblk = dp_stats_nblk(V);
+  int fast = (C % 8 == 0) && (ld % 8 == 0) && aligned16(x);
+  StatsFin f = stats_fin(part, N, nblk, C, V, batch_mode, eps, mean, rstd, running_mean, running_var, momentum);
+  DP_DISPATCH(dtype, hipLaunchKernelGGL(k_stats_partial<T>, dim3(nblk, N), dim3(NT), 0, STREAM, (const T*)x, ld, V, C, part, nblk, rows_per_block(V), fast,
+                                        ticket, f));
+  DP_CHECK_LAUNCH("stats_partial_finalize"); return 0;
 }
 
-__global__ void __launch_bounds__(256) k_stats_finalize(const float* __restrict__ part, int N, int nblk, int C, int64_t V, int batch_mode, float eps,
-                                                        float* mean, float* rstd, float* rmean, float* rvar, float momentum, int cpb,
-                                                        const float* __restrict__ gamma = nullptr, const float* __restrict__ beta = nullptr,
-                                                        float* sc = nullptr, float* sh = nullptr, int cpad = 0) {
-  __shared__ double red[512];
-  const int gidx = blockIdx.y, c0 = blockIdx.x * cpb;
-  const int n0 = batch_mode ? 0 : gidx, n1 = batch_mode ? N : gidx + 1;
-  double s1, s2;
-  combine_partials<0>(part, n0, n1, nblk, C, c0, cpb, s1, s2, red);
-  const int c = c0 + threadIdx.x;
-  if (threadIdx.x >= cpb || c >= C) return;
-  double cnt = (double)V * (n1 - n0);
-  double m = s1 / cnt, var = s2 / cnt - m * m;
-  if (var < 0) var = 0;
-  mean[gidx * C + c] = (float)m; rstd[gidx * C + c] = (float)(1.0 / sqrt(var + (double)eps));
-  if (sc) {   // z = x * sc + sh, the form the fused normalise kernels and the convolution prologue evaluate (float arithmetic as in k_norm_act_fwd)
-    const float r_ = rstd[gidx * C + c], g_ = gamma ? gamma[c] : 1.f, b_ = beta ? beta[c] : 0.f, s_ = r_ * g_;
-    sc[gidx * cpad + c] = s_; sh[gidx * cpad + c] = b_ - mean[gidx * C + c] * s_;
-  }
-  if (rmean && batch_mode) {
-    double unb = cnt > 1 ? var * cnt / (cnt - 1) : var;
-    rmean[c] = (float)((1.0 - momentum) * rmean[c] + momentum * m);
-    rvar[c] = (float)((1.0 - momentum) * rvar[c] + momentum * unb);
-  }
-}
-static inline int pick_cpb(int C) { return C >= 32 ? 32 : (C >= 16 ? 16 : 8); }
-extern "C" int dp_stats_finalize(const float* part, int N, int nblk, int C, int64_t V, int batch_mode, float eps, float* mean, float* rstd,
-                                 float* running_mean, float* running_var, float momentum, void* stream) {
-  int cpb = pick_cpb(C);
-  hipLaunchKernelGGL(k_stats_finalize, dim3(cdiv(C, cpb), batch_mode ? 1 : N), dim3(256), 0, STREAM, part, N, nblk, C, V, batch_mode, eps, mean, rstd,
-                     running_mean, running_var, momentum, cpb);
-  DP_CHECK_LAUNCH("stats_finalize"); return 0;
-}
 
 // ---------------------------------------------------------------------------- fused normalise + affine + residual + act
 struct NormConst { float m[8], r[8], ga[8], be[8]; };
@@ -222,6 +313,36 @@ __device__ __forceinline__ void st8_split(bf16_t* p, int cp, const float* o) {
   *(v4u*)p = hi; *(v4u*)(p + cp) = lo;
 }
 
+struct NormBwdFin { const float* part; int N, nblk, C, batch_mode; float* s1o; float* s2o; float* dgamma; float* dbeta; int cpb; };
+// One unit of the backward finalize (statistics group gidx, channels [bx * cpb, +cpb)); called by a whole 256-thread block.
+template <int COH>
+__device__ __forceinline__ void norm_bwd_finalize_unit(const NormBwdFin& f, int bx, int gidx, double* red) {
+  const int c0 = bx * f.cpb;
+  const int n0 = f.batch_mode ? 0 : gidx, n1 = f.batch_mode ? f.N : gidx + 1;
+  double s1, s2;
+  combine_partials<COH>(f.part, n0, n1, f.nblk, f.C, c0, f.cpb, s1, s2, red);
+  // dgamma / dbeta are sums over ALL samples.  Batch mode has ONE statistics group: its sums ARE dgamma / dbeta.  Instance mode: the
+  // block of sample 0 combines the partial rows of every sample once more, in the same fixed order (round 5: one fp32 atomic per sample
+  // used to meet here -- order-dependent for N > 2).  Either way a plain store: the caller need not zero them.
+  double t1 = s1, t2 = s2;
+  const bool owner = f.batch_mode || gidx == 0;
+  if (!f.batch_mode && gidx == 0 && f.N > 1 && (f.dgamma || f.dbeta)) {          // (block-uniform)
+    __syncthreads();
+    combine_partials<COH>(f.part, 0, f.N, f.nblk, f.C, c0, f.cpb, t1, t2, red);
+  }
+  const int c = c0 + threadIdx.x;
+  if (threadIdx.x >= f.cpb || c >= f.C) return;
+  f.s1o[gidx * f.C + c] = (float)s1; f.s2o[gidx * f.C + c] = (float)s2;
+  if (f.dgamma && owner) f.dgamma[c] = (float)t2;
+  if (f.dbeta && owner) f.dbeta[c] = (float)t1;
+}
+
+static inline NormBwdFin norm_bwd_fin(const float* part, int N, int nblk, int C, int batch_mode, float* s1, float* s2, float* dgamma, float* dbeta) {
+  NormBwdFin f = {}; f.part = part; f.N = N; f.nblk = nblk; f.C = C; f.batch_mode = batch_mode; f.s1o = s1; f.s2o = s2; f.dgamma = dgamma; f.dbeta = dbeta;
+  f.cpb = pick_cpb(C);
+  return f;
+}
+
 // The three row-stream kernels are templated on the activation (no per-element switch) and have a fast path (C % 8 == 0,
 // pitches % 8 == 0, aligned bases: unguarded 16-byte accesses, RU rows in flight per thread) next to the generic guarded loop.
 struct NormArgs {
@@ -234,6 +355,7 @@ struct NormArgs {
   // fp32x3 (T = float, fast path only): split_cp > 0: y (forward) / gx (backward) is a bf16 [rows][2 * split_cp] tensor of hi | lo
   // halves instead of fp32 rows (split_cp2: the same for the second source's gx); the consumer is an x3 convolution
   int split_cp, split_cp2;
+  unsigned* ticket; NormBwdFin fin;      // backward partial pass with the finalize folded in (ticket_is_last); ticket == nullptr: rows only
   int rev;      // backward apply walks the blocks in reverse order (the rows the partial pass read last are the likeliest still cached)
 };
 
@@ -289,7 +411,8 @@ __global__ void __launch_bounds__(NT) k_norm_act_fwd(NormArgs a) {
 
 template <typename T, int ACT>
 __global__ void __launch_bounds__(NT) k_norm_act_bwd_partial(NormArgs a) {
-  __shared__ float red[NT * 16];
+  __shared__ __align__(16) float red[NT * 16];
+  __shared__ int last_flag;
   const T* gy = (const T*)a.gy; const T* res = (const T*)a.res;
   const int b = blockIdx.x, n = blockIdx.y;
   RowGeom g = row_geom(a.C);
@@ -331,7 +454,11 @@ __global__ void __launch_bounds__(NT) k_norm_act_bwd_partial(NormArgs a) {
     if (res) unpack8<T>(res + row * a.ldr + g.cg * 8, g.nv, rr);
     body(t, d, rr);
   }
-  block_reduce_store(red, s1, s2, g, a.C, a.part + ((int64_t)n * a.nblk + b) * 2 * a.C);
+  block_reduce_store(red, s1, s2, g, a.C, a.part + ((int64_t)n * a.nblk + b) * 2 * a.C, a.ticket != nullptr);
+  if (!a.ticket) return;
+  const bool bm = a.fin.batch_mode != 0;
+  if (!ticket_is_last(a.ticket + (bm ? 0 : n), bm ? gridDim.x * gridDim.y : gridDim.x, &last_flag)) return;
+  for (int bx = 0; bx * a.fin.cpb < a.C; bx++) { norm_bwd_finalize_unit<1>(a.fin, bx, bm ? 0 : n, (double*)red); __syncthreads(); }
 }
 
 template <typename T, int ACT>
@@ -449,27 +576,64 @@ extern "C" int dp_norm_act_cat_fwd(const void* xa, int lda, const float* mean_a,
   NORM_LAUNCH(k_norm_act_fwd, a, dim3(a.nblk, N));
   DP_CHECK_LAUNCH("norm_act_cat_fwd"); return 0;
 }
-extern "C" int dp_norm_act_bwd_partial(const void* x, int ldx, const void* gy, int ldgy, const float* mean, const float* rstd, int ssn,
-                                       const float* gamma, const float* beta, const void* res, int ldr, int act, int N, int64_t V, int C,
-                                       float* part, int dtype, void* stream) {
+// Whether the folded finalize can serve this backward: every statistics group finalizes on its own, so the all-sample dgamma / dbeta
+// of an affine INSTANCE normalisation over several samples (which needs every group's rows) keeps the separate launch.
+static unsigned* bwd_ticket(int N, int batch_mode, const float* dgamma, const float* dbeta) {
+  if (!ticket_enabled() || (!batch_mode && N > 1 && (dgamma || dbeta))) return nullptr;
+  return ticket_counters(batch_mode ? 1 : N);
+}
+static int norm_act_bwd_partial_impl(const void* x, int ldx, const void* gy, int ldgy, const float* mean, const float* rstd, int ssn,
+                                     const float* gamma, const float* beta, const void* res, int ldr, int act, int N, int64_t V, int C,
+                                     float* part, unsigned* ticket, NormBwdFin fin, int dtype, void* stream) {
   if (C > 8 * NT) DP_FAIL("norm_act_bwd_partial: C too large");
   NormArgs a = {}; a.x = x; a.ldx = ldx; a.gy = gy; a.ldgy = ldgy; a.mean = mean; a.rstd = rstd; a.ssn = ssn; a.gamma = gamma; a.beta = beta;
   a.res = res; a.ldr = ldr; a.V = V; a.C = C; a.rpb = rows_per_block(V); a.nblk = dp_stats_nblk(V); a.part = part;
   a.fast = norm_fast(C, ldx, x, ldgy, gy, ldr, res, 0, nullptr, 0, nullptr);
+  a.ticket = ticket; a.fin = fin;
   NORM_LAUNCH(k_norm_act_bwd_partial, a, dim3(a.nblk, N));
   DP_CHECK_LAUNCH("norm_act_bwd_partial"); return 0;
 }
+extern "C" int dp_norm_act_bwd_partial(const void* x, int ldx, const void* gy, int ldgy, const float* mean, const float* rstd, int ssn,
+                                       const float* gamma, const float* beta, const void* res, int ldr, int act, int N, int64_t V, int C,
+                                       float* part, int dtype, void* stream) {
+  return norm_act_bwd_partial_impl(x, ldx, gy, ldgy, mean, rstd, ssn, gamma, beta, res, ldr, act, N, V, C, part, nullptr, NormBwdFin{}, dtype, stream);
+}
+// dp_norm_act_bwd_partial + dp_norm_bwd_finalize in ONE launch (the last block of every statistics group finalizes it).  Returns 3
+// (nothing launched) when the folded form is off or cannot serve the case (bwd_ticket): the caller then makes the two calls.
+extern "C" int dp_norm_act_bwd_partial_finalize(const void* x, int ldx, const void* gy, int ldgy, const float* mean, const float* rstd, int ssn,
+                                                const float* gamma, const float* beta, const void* res, int ldr, int act, int N, int64_t V, int C,
+                                                float* part, int batch_mode, float* s1, float* s2, float* dgamma, float* dbeta, int dtype, void* stream) {
+  unsigned* ticket = bwd_ticket(N, batch_mode, dgamma, dbeta);
+  if (!ticket) return 3;
+  return norm_act_bwd_partial_impl(x, ldx, gy, ldgy, mean, rstd, ssn, gamma, beta, res, ldr, act, N, V, C, part, ticket,
+                                   norm_bwd_fin(part, N, dp_stats_nblk(V), C, batch_mode, s1, s2, dgamma, dbeta), dtype, stream);
+}
 
-extern "C" int dp_norm_act_cat_bwd_partial(const void* xa, int lda, const float* mean_a, const float* rstd_a, int Ca, const void* xb, int ldb,
-                                           const float* mean_b, const float* rstd_b, int Cb, const void* gy, int ldgy, int act, int N, int64_t V,
-                                           float* part, int dtype, void* stream) {
+static int norm_act_cat_bwd_partial_impl(const void* xa, int lda, const float* mean_a, const float* rstd_a, int Ca, const void* xb, int ldb,
+                                         const float* mean_b, const float* rstd_b, int Cb, const void* gy, int ldgy, int act, int N, int64_t V,
+                                         float* part, unsigned* ticket, float* s1, float* s2, int dtype, void* stream) {
   const int C = Ca + Cb;
   if (C > 8 * NT || (Ca & 7) || (Cb & 7) || Ca <= 0 || Cb <= 0) DP_FAIL("norm_act_cat_bwd_partial: channel counts must be positive multiples of 8");
   NormArgs a = {}; a.x = xa; a.ldx = lda; a.mean = mean_a; a.rstd = rstd_a; a.ssn = Ca; a.x2 = xb; a.ldx2 = ldb; a.mean2 = mean_b; a.rstd2 = rstd_b;
   a.ssn2 = Cb; a.csplit = Ca; a.gy = gy; a.ldgy = ldgy; a.V = V; a.C = C; a.rpb = rows_per_block(V); a.nblk = dp_stats_nblk(V); a.part = part;
   a.fast = norm_fast(C, lda, xa, ldgy, gy, 0, nullptr, 0, nullptr, 0, nullptr) && norm_fast(C, ldb, xb, 0, nullptr, 0, nullptr, 0, nullptr, 0, nullptr);
+  a.ticket = ticket;
+  if (ticket) a.fin = norm_bwd_fin(part, N, a.nblk, C, 0, s1, s2, nullptr, nullptr);
   NORM_LAUNCH(k_norm_act_bwd_partial, a, dim3(a.nblk, N));
   DP_CHECK_LAUNCH("norm_act_cat_bwd_partial"); return 0;
+}
+extern "C" int dp_norm_act_cat_bwd_partial(const void* xa, int lda, const float* mean_a, const float* rstd_a, int Ca, const void* xb, int ldb,
+                                           const float* mean_b, const float* rstd_b, int Cb, const void* gy, int ldgy, int act, int N, int64_t V,
+                                           float* part, int dtype, void* stream) {
+  return norm_act_cat_bwd_partial_impl(xa, lda, mean_a, rstd_a, Ca, xb, ldb, mean_b, rstd_b, Cb, gy, ldgy, act, N, V, part, nullptr, nullptr, nullptr, dtype, stream);
+}
+// ... with the instance-mode finalize (s1 / s2 [N][Ca + Cb]) folded in; 3 = not launched (folded form off), make the two calls
+extern "C" int dp_norm_act_cat_bwd_partial_finalize(const void* xa, int lda, const float* mean_a, const float* rstd_a, int Ca, const void* xb, int ldb,
+                                                    const float* mean_b, const float* rstd_b, int Cb, const void* gy, int ldgy, int act, int N,
+                                                    int64_t V, float* part, float* s1, float* s2, int dtype, void* stream) {
+  unsigned* ticket = bwd_ticket(N, 0, nullptr, nullptr);
+  if (!ticket) return 3;
+  return norm_act_cat_bwd_partial_impl(xa, lda, mean_a, rstd_a, Ca, xb, ldb, mean_b, rstd_b, Cb, gy, ldgy, act, N, V, part, ticket, s1, s2, dtype, stream);
 }
 extern "C" int dp_norm_act_cat_bwd_apply(const void* xa, int lda, const float* mean_a, const float* rstd_a, int Ca, const void* xb, int ldb,
                                          const float* mean_b, const float* rstd_b, int Cb, const void* gy, int ldgy, int act, const float* s1,
@@ -487,31 +651,13 @@ extern "C" int dp_norm_act_cat_bwd_apply(const void* xa, int lda, const float* m
   DP_CHECK_LAUNCH("norm_act_cat_bwd_apply"); return 0;
 }
 
-__global__ void __launch_bounds__(256) k_norm_bwd_finalize(const float* __restrict__ part, int N, int nblk, int C, int batch_mode, float* s1o, float* s2o,
-                                                           float* dgamma, float* dbeta, int cpb) {
+__global__ void __launch_bounds__(256) k_norm_bwd_finalize(NormBwdFin f) {
   __shared__ double red[512];
-  const int gidx = blockIdx.y, c0 = blockIdx.x * cpb;
-  const int n0 = batch_mode ? 0 : gidx, n1 = batch_mode ? N : gidx + 1;
-  double s1, s2;
-  combine_partials<0>(part, n0, n1, nblk, C, c0, cpb, s1, s2, red);
-  // dgamma / dbeta are sums over ALL samples.  Batch mode has ONE statistics group: its sums ARE dgamma / dbeta.  Instance mode: the
-  // block of sample 0 combines the partial rows of every sample once more, in the same fixed order (round 5: one fp32 atomic per sample
-  // used to meet here -- order-dependent for N > 2).  Either way a plain store: the caller need not zero them.
-  double t1 = s1, t2 = s2;
-  const bool owner = batch_mode || gidx == 0;
-  if (!batch_mode && gidx == 0 && N > 1 && (dgamma || dbeta)) {          // (block-uniform)
-    __syncthreads();
-    combine_partials<0>(part, 0, N, nblk, C, c0, cpb, t1, t2, red);
-  }
-  const int c = c0 + threadIdx.x;
-  if (threadIdx.x >= cpb || c >= C) return;
-  s1o[gidx * C + c] = (float)s1; s2o[gidx * C + c] = (float)s2;
-  if (dgamma && owner) dgamma[c] = (float)t2;
-  if (dbeta && owner) dbeta[c] = (float)t1;
+  norm_bwd_finalize_unit<0>(f, blockIdx.x, blockIdx.y, red);
 }
 extern "C" int dp_norm_bwd_finalize(const float* part, int N, int nblk, int C, int batch_mode, float* s1, float* s2, float* dgamma, float* dbeta, void* stream) {
-  int cpb = pick_cpb(C);
-  hipLaunchKernelGGL(k_norm_bwd_finalize, dim3(cdiv(C, cpb), batch_mode ? 1 : N), dim3(256), 0, STREAM, part, N, nblk, C, batch_mode, s1, s2, dgamma, dbeta, cpb);
+  NormBwdFin f = norm_bwd_fin(part, N, nblk, C, batch_mode, s1, s2, dgamma, dbeta);
+  hipLaunchKernelGGL(k_norm_bwd_finalize, dim3(cdiv(C, f.cpb), batch_mode ? 1 : N), dim3(256), 0, STREAM, f);
   DP_CHECK_LAUNCH("norm_bwd_finalize"); return 0;
 }
 

@@ -1720,6 +1720,7 @@ def _norm_forward(x, kind, gamma, beta, running_mean, running_var, training, res
     dtc = _dt(x)
     dev = x.device
     use_batch_stats = kind == "instance" or training
+    own_rows = False
     if use_batch_stats:
         if part is not None:
             if tuple(part.shape[::2]) != (N, 2) or part.shape[3] != C:
@@ -1728,13 +1729,18 @@ def _norm_forward(x, kind, gamma, beta, running_mean, running_var, training, res
         else:
             nblk = L.dp_stats_nblk(V)
             part = torch.empty((N, nblk, 2, C), dtype=torch.float32, device=dev)
-            _lib.call("dp_stats_partial", _p(x), ldx, N, V, C, _p(part), dtc, _stream())
+            own_rows = True
         groups = N if kind == "instance" else 1
         mean = torch.empty((groups, C), dtype=torch.float32, device=dev)
         rstd = torch.empty((groups, C), dtype=torch.float32, device=dev)
         upd = kind == "batch" and training and running_mean is not None
-        _lib.call("dp_stats_finalize", _p(part), N, nblk, C, V, 1 if kind == "batch" else 0, float(eps), _p(mean), _p(rstd),
-                  _p(running_mean) if upd else 0, _p(running_var) if upd else 0, float(momentum), _stream())
+        fin = (1 if kind == "batch" else 0, float(eps), _p(mean), _p(rstd), _p(running_mean) if upd else 0, _p(running_var) if upd else 0,
+               float(momentum))
+        # rows of our own: ONE launch, the last block of every statistics group finalizes it (3 = folded form off: the two calls)
+        if not own_rows or _lib.call("dp_stats_partial_finalize", _p(x), ldx, N, V, C, _p(part), *fin, dtc, _stream()) == 3:
+            if own_rows:
+                _lib.call("dp_stats_partial", _p(x), ldx, N, V, C, _p(part), dtc, _stream())
+            _lib.call("dp_stats_finalize", _p(part), N, nblk, C, V, *fin, _stream())
     else:   # eval-mode batch norm: running statistics
         mean = running_mean.detach().reshape(1, C).float()
         rstd = torch.empty((1, C), dtype=torch.float32, device=dev)
@@ -1778,10 +1784,11 @@ def _norm_backward(x, mean, rstd, gamma, beta, res, kind, act, use_stats, ssn, g
     dgamma = torch.empty((C,), dtype=torch.float32, device=dev) if need_gb else None
     dbeta = torch.empty((C,), dtype=torch.float32, device=dev) if need_gb else None
     if use_stats or need_gb:
-        _lib.call("dp_norm_act_bwd_partial", _p(x), ldx, gy_ptr, ldg, _p(mean), _p(rstd), ssn, _p(g32), _p(b32), _p(res), ldr,
-                  _act_code(act, x.dtype), N, V, C, _p(part), dtc, _stream())
-        _lib.call("dp_norm_bwd_finalize", _p(part), N, nblk, C, 0 if kind == "instance" else 1, _p(s1), _p(s2),
-                  _p(dgamma), _p(dbeta), _stream())
+        src = (_p(x), ldx, gy_ptr, ldg, _p(mean), _p(rstd), ssn, _p(g32), _p(b32), _p(res), ldr, _act_code(act, x.dtype), N, V, C, _p(part))
+        fin = (0 if kind == "instance" else 1, _p(s1), _p(s2), _p(dgamma), _p(dbeta))
+        if _lib.call("dp_norm_act_bwd_partial_finalize", *src, *fin, dtc, _stream()) == 3:      # (3: folded form off / not applicable)
+            _lib.call("dp_norm_act_bwd_partial", *src, dtc, _stream())
+            _lib.call("dp_norm_bwd_finalize", _p(part), N, nblk, C, *fin, _stream())
     gx = gres = None
     if need_x or need_res:
         gres = torch.empty(x.shape, dtype=x.dtype, device=dev) if need_res else None
@@ -1894,8 +1901,9 @@ class NormActCat(torch.autograd.Function):
             ga = torch.empty(xa.shape, dtype=xa.dtype, device=dev)
             gb = torch.empty(xb.shape, dtype=xb.dtype, device=dev)
             src = (_p(xa), rows_ld(xa)[2], _p(ma), _p(ra), ca, _p(xb), rows_ld(xb)[2], _p(mb), _p(rb), cb, _p(gy), ldg, _act_code(act, xa.dtype))
-            _lib.call("dp_norm_act_cat_bwd_partial", *src, N, V, _p(part), dtc, _stream())
-            _lib.call("dp_norm_bwd_finalize", _p(part), N, nblk, ca + cb, 0, _p(s12[0]), _p(s12[1]), 0, 0, _stream())
+            if _lib.call("dp_norm_act_cat_bwd_partial_finalize", *src, N, V, _p(part), _p(s12[0]), _p(s12[1]), dtc, _stream()) == 3:
+                _lib.call("dp_norm_act_cat_bwd_partial", *src, N, V, _p(part), dtc, _stream())
+                _lib.call("dp_norm_bwd_finalize", _p(part), N, nblk, ca + cb, 0, _p(s12[0]), _p(s12[1]), 0, 0, _stream())
             _lib.call("dp_norm_act_cat_bwd_apply", *src, _p(s12[0]), _p(s12[1]), 1.0 / V, _p(ga), ca, _p(gb), cb, N, V, dtc, _stream())
             return ga, gb, None, None, None, None
         if ctx.needs_input_grad[0]:

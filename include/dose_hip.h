@@ -156,6 +156,23 @@ int dp_norm_act_bwd_partial(const void* x, int ldx, const void* gy, int ldgy, co
  * OVERWRITTEN in both modes (fixed-order fp64 combination of the partial rows: no atomics, no zero-fill needed). */
 int dp_norm_bwd_finalize(const float* part, int N, int nblk, int C, int batch_mode, float* s1, float* s2,
                          float* dgamma, float* dbeta, void* stream);
+/* The partial pass with its finalize folded in: ONE launch instead of two.  Every block stores its partial row, issues a device-scope
+ * release fence and draws a ticket of its statistics group (atomicAdd on a zeroed counter from an internal ring); the block that draws
+ * the group's last ticket runs that group's finalize itself -- the same code in the same order of additions, so the results are
+ * bit-identical to the two-call form (and deterministic).  Return value 3 = nothing was launched, make the two calls: the folded form
+ * is switched off (env DP_NO_TICKET=1, dp_ticket_enabled() == 0) or cannot serve the case (dgamma / dbeta of an affine INSTANCE
+ * normalisation over N > 1 samples need every group's rows).  Arguments as in the calls they replace; `part` is still the scratch.
+ * replaces: the same reference lines as dp_stats_partial / dp_stats_finalize / dp_norm_act_bwd_partial / dp_norm_bwd_finalize. */
+int dp_ticket_enabled(void);
+int dp_stats_partial_finalize(const void* x, int ld, int N, int64_t V, int C, float* part, int batch_mode, float eps, float* mean,
+                              float* rstd, float* running_mean, float* running_var, float momentum, int dtype, void* stream);
+int dp_norm_act_bwd_partial_finalize(const void* x, int ldx, const void* gy, int ldgy, const float* mean, const float* rstd,
+                                     int stat_stride_n, const float* gamma, const float* beta, const void* res, int ldr, int act,
+                                     int N, int64_t V, int C, float* part, int batch_mode, float* s1, float* s2, float* dgamma,
+                                     float* dbeta, int dtype, void* stream);
+int dp_norm_act_cat_bwd_partial_finalize(const void* xa, int lda, const float* mean_a, const float* rstd_a, int Ca, const void* xb, int ldb,
+                                         const float* mean_b, const float* rstd_b, int Cb, const void* gy, int ldgy, int act, int N,
+                                         int64_t V, float* part, float* s1, float* s2, int dtype, void* stream);
 /* backward pass 2: gx = gamma*rstd*(g - s1/M - xhat*s2/M) (use_stats) or gamma*rstd*g (eval BN);
  * gres = g (if non-NULL). M = count per statistics group. */
 int dp_norm_act_bwd_apply(const void* x, int ldx, const void* gy, int ldgy, const float* mean, const float* rstd,

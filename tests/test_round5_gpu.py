@@ -266,3 +266,80 @@ def test_pyfer_training_step_is_bit_identical_under_the_switch_64(det):
     a, b = run(), run()
     bad = [i for i, (u, v) in enumerate(zip(a, b)) if not torch.equal(u, v)]
     assert not bad, f"{len(bad)} of {len(a)} tensors differ between two deterministic steps (first: {bad[:8]})"
+
+
+# ------------------------------------------------------------------------------------------------ finalize folded into the partial pass
+@pytest.mark.parametrize("shape,batch_mode,dtype", [
+    ((2, 64, 64, 64, 16), 0, torch.bfloat16), ((2, 64, 64, 64, 16), 1, torch.float32), ((4, 24, 24, 24, 64), 0, torch.float32),
+    ((1, 16, 16, 16, 256), 1, torch.bfloat16), ((3, 9, 10, 11, 24), 0, torch.float16), ((2, 128, 128, 128, 16), 0, torch.bfloat16)])
+def test_folded_finalize_is_bit_identical_to_the_two_launch_form(shape, batch_mode, dtype):
+    """dp_stats_partial_finalize / dp_norm_act_bwd_partial_finalize (the last block of every statistics group runs the finalize: one
+    launch) against dp_stats_partial + dp_stats_finalize / dp_norm_act_bwd_partial + dp_norm_bwd_finalize, 100 repetitions each on two
+    streams at once (a stale read of another block's row, or two launches sharing a counter, would show as a differing bit)."""
+    from dose_prediction_amd import _lib, ops
+    L = _lib.lib()
+    if not L.dp_ticket_enabled():
+        pytest.skip("DP_NO_TICKET is set")
+    dev = torch.device("cuda:0")
+    N, C = shape[0], shape[-1]
+    V = shape[1] * shape[2] * shape[3]
+    g = torch.Generator().manual_seed(11)
+    x = (torch.randn(shape, generator=g) * 2 + 0.5).to(dev).to(dtype)
+    gy = torch.randn(shape, generator=g).to(dev).to(dtype)
+    gamma, beta = torch.rand(C, generator=g).to(dev) + 0.5, torch.randn(C, generator=g).to(dev)
+    dtc, nblk, groups = ops._dt(x), L.dp_stats_nblk(V), (1 if batch_mode else N)
+    P = lambda t: 0 if t is None else t.data_ptr()
+    need_gb = bool(batch_mode) or N == 1      # (affine instance normalisation over several samples keeps the two-launch form)
+
+    def forward(folded, stream):
+        part = torch.empty((N, nblk, 2, C), dtype=torch.float32, device=dev)
+        mean, rstd = torch.empty((groups, C), device=dev), torch.empty((groups, C), device=dev)
+        rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+        fin = (batch_mode, 1e-5, P(mean), P(rstd), P(rm) if batch_mode else 0, P(rv) if batch_mode else 0, 0.1)
+        if folded:
+            assert _lib.call("dp_stats_partial_finalize", P(x), C, N, V, C, P(part), *fin, dtc, stream) == 0
+        else:
+            _lib.call("dp_stats_partial", P(x), C, N, V, C, P(part), dtc, stream)
+            _lib.call("dp_stats_finalize", P(part), N, nblk, C, V, *fin, stream)
+        return mean, rstd, rm, rv
+
+    def backward(folded, stream, mean, rstd):
+        part = torch.empty((N, nblk, 2, C), dtype=torch.float32, device=dev)
+        s1, s2 = torch.empty((groups, C), device=dev), torch.empty((groups, C), device=dev)
+        dg, db = (torch.empty(C, device=dev), torch.empty(C, device=dev)) if need_gb else (None, None)
+        src = (P(x), C, P(gy), C, P(mean), P(rstd), 0 if batch_mode else C, P(gamma), P(beta), 0, 0, 1, N, V, C, P(part))
+        fin = (batch_mode, P(s1), P(s2), P(dg), P(db))
+        if folded:
+            assert _lib.call("dp_norm_act_bwd_partial_finalize", *src, *fin, dtc, stream) == 0
+        else:
+            _lib.call("dp_norm_act_bwd_partial", *src, dtc, stream)
+            _lib.call("dp_norm_bwd_finalize", P(part), N, nblk, C, *fin, stream)
+        return [t for t in (s1, s2, dg, db) if t is not None]
+
+    main = torch.cuda.current_stream()
+    ref_f = forward(False, main.cuda_stream)
+    ref_b = backward(False, main.cuda_stream, ref_f[0], ref_f[1])
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(t).all() for t in ref_f + tuple(ref_b))
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for s in streams:
+        s.wait_stream(main)
+    reps = 100 if V * C <= (1 << 24) else 20
+    got = []
+    for i in range(reps):
+        s = streams[i & 1]
+        with torch.cuda.stream(s):
+            f = forward(True, s.cuda_stream)
+            got.append((f, backward(True, s.cuda_stream, ref_f[0], ref_f[1])))
+    torch.cuda.synchronize()
+    for f, b in got:
+        for a, r in zip(f, ref_f):
+            assert torch.equal(a, r)
+        for a, r in zip(b, ref_b):
+            assert torch.equal(a, r)
+    # an affine instance normalisation over several samples is declined (3), not served wrongly
+    if not batch_mode and N > 1:
+        part = torch.empty((N, nblk, 2, C), dtype=torch.float32, device=dev)
+        t = [torch.empty((N, C), device=dev) for _ in range(2)] + [torch.empty(C, device=dev) for _ in range(2)]
+        src = (P(x), C, P(gy), C, P(ref_f[0]), P(ref_f[1]), C, P(gamma), P(beta), 0, 0, 1, N, V, C, P(part))
+        assert _lib.call("dp_norm_act_bwd_partial_finalize", *src, 0, *[P(v) for v in t], dtc, main.cuda_stream) == 3
