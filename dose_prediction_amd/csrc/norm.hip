@@ -4,6 +4,7 @@
 // keeps its per-channel constants in registers and walks the block's voxel range.
 #include "common.h"
 #include <stdlib.h>
+#include <mutex>
 
 #define STREAM ((hipStream_t)stream)
 #define NT 256
@@ -182,13 +183,17 @@ __global__ void __launch_bounds__(256) k_stats_finalize(StatsFin f) {
 #define TICKET_RING 8192
 static unsigned* g_ticket_ring[32] = {};
 static unsigned g_ticket_next[32] = {};
+static std::mutex g_ticket_mutex;          // (forward and backward may be driven from different host threads)
 static unsigned* ticket_counters(int n) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32 || n > TICKET_RING) return nullptr;
+  std::lock_guard<std::mutex> lock(g_ticket_mutex);
   if (!g_ticket_ring[dev]) {
     unsigned* p = nullptr;
-    if (hipMalloc(&p, TICKET_RING * sizeof(unsigned)) != hipSuccess) return nullptr;
-    if (hipMemset(p, 0, TICKET_RING * sizeof(unsigned)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipFree(p); return nullptr; }
+    if (hipMalloc(&p, TICKET_RING * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (hipMemset(p, 0, TICKET_RING * sizeof(unsigned)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+      (void)hipGetLastError(); (void)hipFree(p); return nullptr;
+    }
     g_ticket_ring[dev] = p;
   }
   unsigned at = g_ticket_next[dev];
