@@ -212,7 +212,7 @@ int wgrad_hk_launch(const void* x, const void* gy, float* ws, const WgHkGeom& g,
 bool cc16_applicable(int Cin, int Cout, int k, int W);
 int cc16_weight_elems(int Cin, int Cout, int k);
 int cc16_pack(const float* w, void* dst, int Cout, int Cin, int k, int tf, int dtype, hipStream_t s);
-int cc16_stat_blocks(int D, int H, int W, int k);
+int cc16_stat_blocks(int D, int H, int W, int k, int dtype);
 bool cc16_wide(const void* y, int ldy, const void* y2, int ldy2, int osplit, int dtype);
 int cc16_launch(const void* x, int ldx, const void* x2, int ldx2, int csplit, const void* wq, const float* bias, void* y, int ldy,
                 void* y2, int ldy2, int osplit, float* stat_part, int N, int D, int H, int W, int Cin, int Cout, int k, int dtype, hipStream_t s);

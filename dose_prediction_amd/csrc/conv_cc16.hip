@@ -694,7 +694,275 @@ static inline int cc16_tw(int W, int k) {
   if (t64 && W % 64 == 0) return 64;
   return cdiv(W, 96) * 96 < cdiv(W, 128) * 128 ? 96 : 128;
 }
-int cc16_stat_blocks(int D, int H, int W, int k) { return D * cdiv(H, 8) * cdiv(W, cc16_tw(W, k)); }
+
+// ================================================================================================ 3x3x3 marching along depth (round 5)
+// EXPERIMENT, off by default (env DP_CC16M=1): parity-green (every 3x3x3 case of tests/test_ops_gpu.py incl. statistics, virtual concat,
+// fp32x3), but 0.138 ms against 0.098 ms for 16 -> 16 at 2 x 128^3 (0.29 against 0.195 for 32 -> 16).
+// The 3x3x3 launches of the kernels above are bound by re-staging: a block owns one or two depth slices and stages every input slab it
+// needs (3 per slice with DT = 1, 2 with DT = 2), so every input voxel travels L2 -> LDS 2-3 times (x 1.25 for the row halo).
+// k_conv_cc16m turns the loop around: a block owns 8 rows x 64 positions and MARCHES over a segment of ML depth slices.  Every input slab
+// is staged ONCE per block (ML + 2 slabs for ML slices: 1.4 voxel loads per output voxel instead of 3.8) and is swept input-stationary:
+// an A fragment (16 positions of slab row rho, tap pair kwp) feeds the MFMAs of every (kd, kh) it contributes to -- up to nine, into
+// the accumulators of the three output slices z - 1, z, z + 1 that are live at any time (3 x 8 rows x 4 registers = 96 per wave: one
+// 16-position M tile per wave).  With one input chunk all 18 weight fragments of the 3x3x3 kernel stay in registers for the whole march.
+// A slice is finished when the slab behind it has been swept; the wave then transposes it through its private LDS patch (no block
+// barrier) and clears the accumulator slot for the slice three further on.  Statistics: one partial row per BLOCK.
+// Why it loses: 96 accumulator + 72 weight + 12 fragment-ring + 24 prefetch registers and the addressing come to 304 per lane, i.e. ONE
+// block of four waves per CU (at two blocks the compiler spills the weights into the sweep: 0.30 ms).  With one wave per SIMD nothing
+// overlaps: the step time is the SUM of its phases -- knock-outs at 2 x 128^3, 34 steps per block: sweep 1.6 us (1.0 of MFMA issue),
+// epilogue of the finished slice 1.6 us, exposed staging 0.6 us with the next slab prefetched into registers during the sweep (1.9
+// without) -- where k_conv_cc16 overlaps the phases of three resident blocks.  A 4-row variant (48 accumulator registers, two blocks per
+// CU, 1.6 voxel loads per output) would be MFMA-bound near 45 us + epilogues, at best ~10 % under the kernel it replaces: not built.
+#define CC16M_TW 64
+static inline bool cc16m_use(int k, int dtype) {
+  static const bool on = [] { const char* e = getenv("DP_CC16M"); return e && atoi(e); }();      // measured slower than k_conv_cc16 (below): opt-in
+  return on && k == 3 && (dtype == DP_BF16 || dtype == DP_F16 || dtype == DP_X3 || dtype == DP_X1);
+}
+static inline int cc16m_ml(int D) {
+  static const int e = [] { const char* v = getenv("DP_CC16M_ML"); return v ? atoi(v) : 16; }();
+  const int ml = e < 1 ? 1 : e;
+  return ml > D ? D : ml;
+}
+
+// ALL: every tap kd of this slab feeds a live output slice (the steady state of the march): straight-line code.  The first two and the
+// last two steps of a segment take the guarded form (block-uniform branches around the MFMA groups).
+template <int J, bool ALL, typename T>
+__device__ __forceinline__ void cc16m_sweep(v4f (&acc)[3][8], const Frag8<T> (&B)[3][2][3], const T* __restrict__ slab, int v_lane, int hsel,
+                                            bool m0, bool m1, bool m2) {
+  constexpr int LP = 72, CK = 16, ROWS = 10, RWO = 8, S = 2 * ROWS;
+  Frag8<T> fa[3];
+  // four lane addresses (tap pair x row parity: LP / 8 = 9 is odd, so the swizzle bit flips with the row); the row is an immediate offset
+  const T* abase[2][2];
+#pragma unroll
+  for (int kwp = 0; kwp < 2; kwp++)
+#pragma unroll
+    for (int par = 0; par < 2; par++) {
+      const int vk = v_lane + 2 * kwp;
+      abase[kwp][par] = slab + vk * CK + (hsel ^ ((vk >> 3) & 1) ^ par) * 8;
+    }
+  auto a_ptr = [&](int s) -> const T* { const int rho = s >> 1, kwp = s & 1; return abase[kwp][rho & 1] + rho * LP * CK; };
+  fa[0] = frag_ld_lds(a_ptr(0)); fa[1] = frag_ld_lds(a_ptr(1));
+#pragma unroll
+  for (int s = 0; s < S; s++) {
+    if (s + 2 < S) fa[(s + 2) % 3] = frag_ld_lds(a_ptr(s + 2));
+    __builtin_amdgcn_sched_barrier(0);
+    const int rho = s >> 1, kwp = s & 1;
+    // input slab z, tap kd -> output slice z + 1 - kd, accumulator slot (J - kd) mod 3  (J = step index mod 3)
+    if (ALL || m0) {
+#pragma unroll
+      for (int kh = 0; kh < 3; kh++) { const int orow = rho - kh; if (orow < 0 || orow >= RWO) continue; acc[J][orow] = mma16(fa[s % 3], B[0][kwp][kh], acc[J][orow]); }
+    }
+    if (ALL || m1) {
+#pragma unroll
+      for (int kh = 0; kh < 3; kh++) { const int orow = rho - kh; if (orow < 0 || orow >= RWO) continue; acc[(J + 2) % 3][orow] = mma16(fa[s % 3], B[1][kwp][kh], acc[(J + 2) % 3][orow]); }
+    }
+    if (ALL || m2) {
+#pragma unroll
+      for (int kh = 0; kh < 3; kh++) { const int orow = rho - kh; if (orow < 0 || orow >= RWO) continue; acc[(J + 1) % 3][orow] = mma16(fa[s % 3], B[2][kwp][kh], acc[(J + 1) % 3][orow]); }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// RES: one input chunk (and no DP_X3 operand split): the 18 weight fragments are loaded once and stay in registers for the whole march
+template <typename T, typename TO, bool RES>
+__global__ void __launch_bounds__(256, 1) k_conv_cc16m(const T* __restrict__ x, const T* __restrict__ wq, const float* __restrict__ bias,
+                                                       TO* __restrict__ y, Cc16Geom g, int ML) {
+  static_assert(sizeof(T) == 2, "16-bit operands");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr int KS = 3, PAD = 1, KWP = 2, RWO = 8, ROWS = RWO + KS - 1, CK = 16, TW = CC16M_TW, LP = 72, LR = ROWS, NC = 16, WT = 512;
+  static_assert(LP == ((TW + KS - 1 + 7) & ~7), "slab pitch");
+  constexpr int SLAB_BYTES = LR * LP * CK * (int)sizeof(T);
+  T* slab = (T*)smem_raw;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 15, q = lane >> 4;
+  TO* patch = (TO*)(smem_raw + SLAB_BYTES) + wv * (32 * NC);
+  float* sred = (float*)(smem_raw + SLAB_BYTES + 4 * 32 * NC * sizeof(TO));
+  int b = blockIdx.x;
+  if ((gridDim.x & 7) == 0) b = (b & 7) * (gridDim.x >> 3) + (b >> 3);          // XCD-aware order (see k_conv_cc16)
+  const int tw = b % g.tiles_w; b /= g.tiles_w; const int th = b % g.tiles_h; b /= g.tiles_h; const int seg = b % g.dtiles; const int n = b / g.dtiles;
+  const int h0 = th * RWO, w0 = tw * TW, d0 = seg * ML, MLe = min(ML, g.D - d0);
+  v4f acc[3][8];
+#pragma unroll
+  for (int a = 0; a < 3; a++)
+#pragma unroll
+    for (int i = 0; i < RWO; i++) acc[a][i] = (v4f){0.f, 0.f, 0.f, 0.f};
+
+  constexpr int pieces = LR * LP * 2;
+  const int cin_in = g.x3 ? 32 * g.x3 : g.Cin;
+  const int nstage = g.x3 ? 2 * g.x3 : g.NCH;
+  const bool fast = (nstage * 16 <= (g.x2 ? g.csplit + g.ldx2 : g.ldx)) && (g.ldx % 8 == 0) && (((uintptr_t)x & 15) == 0) &&
+                    (!g.x2 || ((g.csplit % 16 == 0) && (g.ldx2 % 8 == 0) && (((uintptr_t)g.x2 & 15) == 0))) &&
+                    (int64_t)g.H * g.W * max(g.ldx, g.x2 ? g.ldx2 : 0) < (1ll << 30);
+  const int st_half = tid & 1, st_lp0 = (tid >> 1) % LP, st_lr0 = (tid >> 1) / LP;
+  const int v_lane = wv * 16 + r + (q >> 1), hsel = q & 1;
+  const int lane_off = r * 32 + q * 8;
+  Frag8<T> B[3][2][3];
+  auto load_B = [&](int wch) {
+#pragma unroll
+    for (int kd = 0; kd < 3; kd++) {
+      const T* wbase = wq + ((int64_t)(kd * g.NCH + wch) * KWP) * KS * WT + lane_off;
+#pragma unroll
+      for (int kwp = 0; kwp < 2; kwp++)
+#pragma unroll
+        for (int kh = 0; kh < 3; kh++) B[kd][kwp][kh] = frag_ld_lds(wbase + (kwp * KS + kh) * WT);
+    }
+  };
+  constexpr bool resident = RES;
+  if (resident) {          // (complete BEFORE the march: a pending weight load would make every sweep wait for vmcnt(0), i.e. for the prefetch too)
+    load_B(0);
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  const float bv = (bias && r < g.Cout) ? bias[r] : 0.f;
+  const int wbase_o = w0 + wv * 16;
+  TO* y2 = (TO*)g.y2;
+  constexpr int EPC = 16 / (int)sizeof(TO), CPP = NC / EPC, PASSES = 32 * CPP / 64;
+  float st1 = 0.f, st2 = 0.f;
+
+  // finished slice in accumulator slot SL -> memory (two output rows per trip through the wave's patch), then the slot is cleared
+  auto finish = [&](auto slot_c, int d) {
+    constexpr int SL = decltype(slot_c)::value;
+#pragma unroll
+    for (int t = 0; t < RWO; t += 2) {
+#pragma unroll
+      for (int tt = 0; tt < 2; tt++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const int m = tt * 16 + 4 * q + e;
+          const float v = acc[SL][t + tt][e] + bv;
+          st_f(patch + m * NC + r, v);
+          const float vs = (h0 + t + tt < g.H && wbase_o + 4 * q + e < g.W) ? as_stored<TO>(v) : 0.f;
+          st1 += vs; st2 += vs * vs;
+        }
+      __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int ps = 0; ps < PASSES; ps++) {
+        const int qq = ps * 64 + lane, m = qq / CPP, cc = (qq % CPP) * EPC;
+        const int oh = h0 + t + (m >> 4), ow = wbase_o + (m & 15);
+        if (oh < g.H && ow < g.W && cc < g.Cout) {
+          const int64_t vox = (((int64_t)n * g.D + d) * g.H + oh) * g.W + ow;
+          TO* dst = (y2 && cc >= g.osplit) ? y2 + vox * g.ldy2 + (cc - g.osplit) : y + vox * g.ldy + cc;
+          if (cc + EPC <= g.Cout) *(v4u*)dst = *(const v4u*)(patch + m * NC + cc);
+          else for (int k = 0; k < EPC; k++) if (cc + k < g.Cout) dst[k] = patch[m * NC + cc + k];
+        }
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int i = 0; i < RWO; i++) acc[SL][i] = (v4f){0.f, 0.f, 0.f, 0.f};
+  };
+
+  // Staging in two halves with the sweep in between: the global loads of the NEXT slab are issued (into registers) right after the
+  // barrier that publishes the current one, travel while the current slab is swept, and are written to LDS after the next barrier --
+  // with one block of four waves per CU (304 registers per lane) nothing else hides that latency.
+  constexpr int SUP = (pieces + 255) / 256;          // 16-byte pieces per thread
+  v4u pbuf[SUP];
+  auto stage_load = [&](int z, int ch) {
+    if (!fast) return;                               // (guarded shapes: staged directly in stage_store)
+    const bool second = g.x2 && ch * CK >= g.csplit;
+    const T* xsrc = second ? (const T*)g.x2 : x;
+    const int ldsrc = second ? g.ldx2 : g.ldx, c0 = ch * CK - (second ? g.csplit : 0);
+    const T* xplane = xsrc + (((int64_t)n * g.D + z) * g.H) * (int64_t)g.W * ldsrc + c0 + st_half * 8;
+    int lp = st_lp0, lr = st_lr0;
+#pragma unroll
+    for (int j = 0; j < SUP; j++) {
+      const int ih = h0 - PAD + lr, iw = w0 - PAD + lp;
+      const bool ok = (j * 256 + tid < pieces) && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W;
+      v4u t = *(const v4u*)(xplane + (ok ? (ih * g.W + iw) * ldsrc : 0));
+      pbuf[j] = ok ? t : (v4u){0, 0, 0, 0};
+      lp += 128;
+#pragma unroll
+      for (int c_ = 0; c_ < (128 + LP - 1) / LP; c_++) if (lp >= LP) { lp -= LP; lr++; }
+    }
+  };
+  auto stage_store = [&](int z, int ch) {
+    if (fast) {
+#pragma unroll
+      for (int j = 0; j < SUP; j++) {
+        const int v = (tid >> 1) + 128 * j;
+        if (j * 256 + tid < pieces) *(v4u*)(slab + (int64_t)v * CK + (st_half ^ ((v >> 3) & 1)) * 8) = pbuf[j];
+      }
+    } else {
+      for (int p = tid; p < pieces; p += 256) {
+        int half = p & 1, v = p >> 1, lp = v % LP, lr = v / LP;
+        int ih = h0 - PAD + lr, iw = w0 - PAD + lp, c = ch * CK + half * 8;
+        int nv = cin_in - c; nv = nv > 8 ? 8 : nv;
+        bool ok = ih >= 0 && ih < g.H && iw >= 0 && iw < g.W && nv > 0;
+        const bool second = g.x2 && c >= g.csplit;
+        if (!second && g.x2 && c + nv > g.csplit) nv = g.csplit - c;
+        const T* xsrc = second ? (const T*)g.x2 : x;
+        const int ldsrc = second ? g.ldx2 : g.ldx, cc = c - (second ? g.csplit : 0);
+        Frag8<T> f = ok ? frag_load(xsrc + ((((int64_t)n * g.D + z) * g.H + ih) * g.W + iw) * ldsrc + cc, nv) : frag_zero<T>();
+        frag_st_lds(slab + (int64_t)v * CK + (half ^ ((v >> 3) & 1)) * 8, f);
+      }
+    }
+  };
+
+  auto step = [&](auto j_c, int zi) {
+    constexpr int J = decltype(j_c)::value;
+    const int z = d0 - 1 + zi;
+    // tap kd of slab z feeds output slice oi = zi - kd of the segment
+    const bool m0 = zi < MLe, m1 = zi >= 1 && zi - 1 < MLe, m2 = zi >= 2 && zi - 2 < MLe;
+    if (z >= 0 && z < g.D) {
+      for (int ch = 0; ch < nstage; ch++) {
+        lds_barrier();                                 // every wave is done with the previous slab
+        stage_store(z, ch);
+        lds_barrier();
+        const int nrep = (g.x3 && ch < g.x3) ? 2 : 1;  // an x_hi slab meets w_hi (chunk ch) and w_lo (chunk 2 x3 + ch)
+#pragma unroll 1
+        for (int rep = 0; rep < nrep; rep++) {
+          if (!resident) { load_B(rep ? ch + 2 * g.x3 : ch); __builtin_amdgcn_sched_barrier(0); }
+          if (rep == 0) {                              // (after the weight loads: waiting for those must not wait for the prefetch)
+            if (ch + 1 < nstage) stage_load(z, ch + 1);
+            else if (zi + 1 < MLe + 2 && z + 1 < g.D) stage_load(z + 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          if (m0 && m1 && m2) cc16m_sweep<J, true>(acc, B, slab, v_lane, hsel, true, true, true);
+          else cc16m_sweep<J, false>(acc, B, slab, v_lane, hsel, m0, m1, m2);
+        }
+      }
+    }
+    if (m2) finish(std::integral_constant<int, (J + 1) % 3>{}, d0 + zi - 2);
+  };
+  stage_load(d0 == 0 ? 0 : d0 - 1, 0);               // the first slab inside the volume (slab -1 of the first segment is padding)
+  for (int zi = 0; zi < MLe + 2; zi += 3) {
+    step(std::integral_constant<int, 0>{}, zi);
+    if (zi + 1 < MLe + 2) step(std::integral_constant<int, 1>{}, zi + 1);
+    if (zi + 2 < MLe + 2) step(std::integral_constant<int, 2>{}, zi + 2);
+  }
+
+  if (g.stat_part) {          // block-uniform: per-channel (sum, sum of squares) over the voxels of ALL slices of this block
+    float a1 = st1 + __shfl_xor(st1, 16, 64), a2 = st2 + __shfl_xor(st2, 16, 64);
+    a1 += __shfl_xor(a1, 32, 64); a2 += __shfl_xor(a2, 32, 64);
+    if (lane < 16) { sred[(wv * 2) * 16 + lane] = a1; sred[(wv * 2 + 1) * 16 + lane] = a2; }
+    __syncthreads();
+    if (tid < 32) {
+      const int which = tid >> 4, c = tid & 15;
+      if (c < g.Cout) {
+        const int blk = (seg * g.tiles_h + th) * g.tiles_w + tw;
+        g.stat_part[(((int64_t)n * g.stat_nblk + blk) * 2 + which) * g.Cout + c] =
+            (sred[(0 + which) * 16 + c] + sred[(2 + which) * 16 + c]) + (sred[(4 + which) * 16 + c] + sred[(6 + which) * 16 + c]);
+      }
+    }
+  }
+}
+
+template <typename T, typename TO>
+static int cc16m_go(const void* x, const void* wq, const float* bias, void* y, Cc16Geom g, hipStream_t s) {
+  const int ML = cc16m_ml(g.D);
+  const size_t smem = (size_t)10 * 72 * 16 * sizeof(T) + 4 * 32 * 16 * sizeof(TO) + 8 * 16 * sizeof(float);
+  g.tiles_w = cdiv(g.W, CC16M_TW); g.dtiles = cdiv(g.D, ML);
+  const int64_t blocks = (int64_t)g.N * g.dtiles * g.tiles_h * g.tiles_w;
+  if (blocks > 2000000000LL) { dp_set_error("conv_cc16m: grid too large"); return 1; }
+  if (g.NCH == 1 && !g.x3) hipLaunchKernelGGL((k_conv_cc16m<T, TO, true>), dim3((unsigned)blocks), dim3(256), smem, s, (const T*)x, (const T*)wq, bias, (TO*)y, g, ML);
+  else hipLaunchKernelGGL((k_conv_cc16m<T, TO, false>), dim3((unsigned)blocks), dim3(256), smem, s, (const T*)x, (const T*)wq, bias, (TO*)y, g, ML);
+  return 0;
+}
+
+int cc16_stat_blocks(int D, int H, int W, int k, int dtype) {
+  if (cc16m_use(k, dtype)) return cdiv(D, cc16m_ml(D)) * cdiv(H, 8) * cdiv(W, CC16M_TW);      // k_conv_cc16m: one partial row per block
+  return D * cdiv(H, 8) * cdiv(W, cc16_tw(W, k));
+}
 
 template <typename T, int KS, int DT, int OCC, typename TO>
 static int cc16_go_impl(const void* x, const void* wq, const float* bias, void* y, Cc16Geom g, hipStream_t s);
@@ -766,8 +1034,15 @@ int cc16_launch(const void* x, int ldx, const void* x2, int ldx2, int csplit, co
   g.N = N; g.D = D; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.ldx = ldx; g.ldy = ldy; g.NCH = (Cin + 15) / 16;
   const int tile_w = cc16_tw(W, k);
   g.tiles_h = cdiv(H, 8); g.tiles_w = cdiv(W, tile_w); g.dtiles = 0;
-  g.x2 = x2; g.ldx2 = ldx2; g.csplit = csplit; g.stat_part = stat_part; g.stat_nblk = cc16_stat_blocks(D, H, W, k);
+  g.x2 = x2; g.ldx2 = ldx2; g.csplit = csplit; g.stat_part = stat_part; g.stat_nblk = cc16_stat_blocks(D, H, W, k, dtype);
   int rc = 0;
+  if (cc16m_use(k, dtype) && g.wide) {                 // 3x3x3, 16-bit operands: marching along depth
+    if (dtype == DP_BF16) rc = cc16m_go<bf16_t, bf16_t>(x, wq, bias, y, g, s);
+    else if (dtype == DP_F16) rc = cc16m_go<f16_t, f16_t>(x, wq, bias, y, g, s);
+    else rc = cc16m_go<bf16_t, float>(x, wq, bias, y, g, s);
+    if (rc) return rc;
+    DP_CHECK_LAUNCH("conv_cc16m"); return 0;
+  }
   if (tile_w == 64 && dtype == DP_BF16 && k == 3) {
     static const int occ = [] { const char* e = getenv("DP_CC16W3"); return e ? atoi(e) : 0; }();
     rc = occ >= 5 ? cc16w_go<bf16_t, 3, bf16_t, 2, 1, 5>(x, wq, bias, y, g, s) : occ == 4 ? cc16w_go<bf16_t, 3, bf16_t, 2, 1, 4>(x, wq, bias, y, g, s)

@@ -621,7 +621,7 @@ static bool tiled_wide(const TiledGeom& g, const void* y, int dtype) {
 // launch cannot produce statistics (split-kd volumes, output rows that are not 16-byte aligned: the caller then runs dp_stats_partial).
 extern "C" int dp_conv3d_tiled_stat_blocks(int N, int D, int H, int W, int Cin, int Cout, int k, int ldy, int dtype) {
   if (!tiled_applicable(Cin, Cout, k, 1, k / 2, 1, W)) return 0;
-  if (cc16_applicable(Cin, Cout, k, W)) return cc16_wide(nullptr, ldy, nullptr, 0, 0, dtype) ? cc16_stat_blocks(D, H, W, k) : 0;
+  if (cc16_applicable(Cin, Cout, k, W)) return cc16_wide(nullptr, ldy, nullptr, 0, 0, dtype) ? cc16_stat_blocks(D, H, W, k, dtype) : 0;
   int rw, nt; int np = tiled_config(Cout, &rw, &nt);
   TiledGeom g; g.N = N; g.D = D; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.dbg = 0; g.x2 = nullptr; g.y2 = nullptr; g.ldy = ldy;
   int ygrid; bool w16; tiled_geometry(g, k, np, rw, nt, &ygrid, &w16);

@@ -343,3 +343,20 @@ def test_folded_finalize_is_bit_identical_to_the_two_launch_form(shape, batch_mo
         t = [torch.empty((N, C), device=dev) for _ in range(2)] + [torch.empty(C, device=dev) for _ in range(2)]
         src = (P(x), C, P(gy), C, P(ref_f[0]), P(ref_f[1]), C, P(gamma), P(beta), 0, 0, 1, N, V, C, P(part))
         assert _lib.call("dp_norm_act_bwd_partial_finalize", *src, 0, *[P(v) for v in t], dtc, main.cuda_stream) == 3
+
+
+def test_marching_3x3x3_experiment_kernel_passes_the_conv_parity_cases():
+    """k_conv_cc16m (csrc/conv_cc16.hip: input-stationary 3^3 marching along depth; measured slower, hence opt-in through DP_CC16M=1,
+    which the library reads once): the 3^3 long-row cases of test_conv3d, the epilogue-statistics and the virtual-concat tests run
+    in a child process with the switch on, in all storage types and in the fp32x3 convolution test."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DP_CC16M="1", DOSE_TEST_CC16_3_ONLY="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider", os.path.join(root, "tests", "test_ops_gpu.py"),
+                        "-k", "test_conv3d or conv_epilogue_statistics or conv3d_virtual_concat"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=1200)
+    tail = (r.stdout or "")[-1500:] + (r.stderr or "")[-500:]
+    assert r.returncode == 0, tail
+    assert " passed" in r.stdout and "failed" not in r.stdout, tail
