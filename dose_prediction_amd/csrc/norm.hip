@@ -184,11 +184,15 @@ __global__ void __launch_bounds__(256) k_stats_finalize(StatsFin f) {
 static unsigned* g_ticket_ring[32] = {};
 static unsigned g_ticket_next[32] = {};
 static std::mutex g_ticket_mutex;          // (forward and backward may be driven from different host threads)
-static unsigned* ticket_counters(int n) {
+static unsigned* ticket_counters(int n, hipStream_t stream) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32 || n > TICKET_RING) return nullptr;
   std::lock_guard<std::mutex> lock(g_ticket_mutex);
   if (!g_ticket_ring[dev]) {
+    // (first use inside a stream capture: no allocation / memset / device synchronisation there -- the caller takes the two-launch form)
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (cs != hipStreamCaptureStatusNone) return nullptr;
     unsigned* p = nullptr;
     if (hipMalloc(&p, TICKET_RING * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     if (hipMemset(p, 0, TICKET_RING * sizeof(unsigned)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
@@ -283,7 +287,7 @@ extern "C" int dp_stats_partial_finalize(const void* x, int ld, int N, int64_t V
                                          float* rstd, float* running_mean, float* running_var, float momentum, int dtype, void* stream) {
   if (C > 8 * NT) DP_FAIL("stats: C too large");
   if (!ticket_enabled()) return 3;
-  unsigned* ticket = ticket_counters(batch_mode ? 1 : N);
+  unsigned* ticket = ticket_counters(batch_mode ? 1 : N, STREAM);
   if (!ticket) return 3;
   int nblk = dp_stats_nblk(V);
   int fast = (C % 8 == 0) && (ld % 8 == 0) && aligned16(x);
@@ -583,9 +587,9 @@ extern "C" int dp_norm_act_cat_fwd(const void* xa, int lda, const float* mean_a,
 }
 // Whether the folded finalize can serve this backward: every statistics group finalizes on its own, so the all-sample dgamma / dbeta
 // of an affine INSTANCE normalisation over several samples (which needs every group's rows) keeps the separate launch.
-static unsigned* bwd_ticket(int N, int batch_mode, const float* dgamma, const float* dbeta) {
+static unsigned* bwd_ticket(int N, int batch_mode, const float* dgamma, const float* dbeta, void* stream) {
   if (!ticket_enabled() || (!batch_mode && N > 1 && (dgamma || dbeta))) return nullptr;
-  return ticket_counters(batch_mode ? 1 : N);
+  return ticket_counters(batch_mode ? 1 : N, STREAM);
 }
 static int norm_act_bwd_partial_impl(const void* x, int ldx, const void* gy, int ldgy, const float* mean, const float* rstd, int ssn,
                                      const float* gamma, const float* beta, const void* res, int ldr, int act, int N, int64_t V, int C,
@@ -608,7 +612,7 @@ extern "C" int dp_norm_act_bwd_partial(const void* x, int ldx, const void* gy, i
 extern "C" int dp_norm_act_bwd_partial_finalize(const void* x, int ldx, const void* gy, int ldgy, const float* mean, const float* rstd, int ssn,
                                                 const float* gamma, const float* beta, const void* res, int ldr, int act, int N, int64_t V, int C,
                                                 float* part, int batch_mode, float* s1, float* s2, float* dgamma, float* dbeta, int dtype, void* stream) {
-  unsigned* ticket = bwd_ticket(N, batch_mode, dgamma, dbeta);
+  unsigned* ticket = bwd_ticket(N, batch_mode, dgamma, dbeta, stream);
   if (!ticket) return 3;
   return norm_act_bwd_partial_impl(x, ldx, gy, ldgy, mean, rstd, ssn, gamma, beta, res, ldr, act, N, V, C, part, ticket,
                                    norm_bwd_fin(part, N, dp_stats_nblk(V), C, batch_mode, s1, s2, dgamma, dbeta), dtype, stream);
@@ -636,7 +640,7 @@ extern "C" int dp_norm_act_cat_bwd_partial(const void* xa, int lda, const float*
 extern "C" int dp_norm_act_cat_bwd_partial_finalize(const void* xa, int lda, const float* mean_a, const float* rstd_a, int Ca, const void* xb, int ldb,
                                                     const float* mean_b, const float* rstd_b, int Cb, const void* gy, int ldgy, int act, int N,
                                                     int64_t V, float* part, float* s1, float* s2, int dtype, void* stream) {
-  unsigned* ticket = bwd_ticket(N, 0, nullptr, nullptr);
+  unsigned* ticket = bwd_ticket(N, 0, nullptr, nullptr, stream);
   if (!ticket) return 3;
   return norm_act_cat_bwd_partial_impl(xa, lda, mean_a, rstd_a, Ca, xb, ldb, mean_b, rstd_b, Cb, gy, ldgy, act, N, V, part, ticket, s1, s2, dtype, stream);
 }
