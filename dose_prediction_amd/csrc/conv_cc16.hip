@@ -718,6 +718,10 @@ static inline bool cc16m_use(int k, int dtype) {
   static const bool on = [] { const char* e = getenv("DP_CC16M"); return e && atoi(e); }();      // measured slower than k_conv_cc16 (below): opt-in
   return on && k == 3 && (dtype == DP_BF16 || dtype == DP_F16 || dtype == DP_X3 || dtype == DP_X1);
 }
+static inline int cc16m_rows() {          // output rows per block: 8 (one block per CU), or 4 (48 accumulator registers: two blocks per CU)
+  static const int e = [] { const char* v = getenv("DP_CC16M_ROWS"); return (v && atoi(v) == 4) ? 4 : 8; }();
+  return e;
+}
 static inline int cc16m_ml(int D) {
   static const int e = [] { const char* v = getenv("DP_CC16M_ML"); return v ? atoi(v) : 16; }();
   const int ml = e < 1 ? 1 : e;
@@ -726,10 +730,10 @@ static inline int cc16m_ml(int D) {
 
 // ALL: every tap kd of this slab feeds a live output slice (the steady state of the march): straight-line code.  The first two and the
 // last two steps of a segment take the guarded form (block-uniform branches around the MFMA groups).
-template <int J, bool ALL, typename T>
-__device__ __forceinline__ void cc16m_sweep(v4f (&acc)[3][8], const Frag8<T> (&B)[3][2][3], const T* __restrict__ slab, int v_lane, int hsel,
+template <int J, bool ALL, int RWO, typename T>
+__device__ __forceinline__ void cc16m_sweep(v4f (&acc)[3][RWO], const Frag8<T> (&B)[3][2][3], const T* __restrict__ slab, int v_lane, int hsel,
                                             bool m0, bool m1, bool m2) {
-  constexpr int LP = 72, CK = 16, ROWS = 10, RWO = 8, S = 2 * ROWS;
+  constexpr int LP = 72, CK = 16, ROWS = RWO + 2, S = 2 * ROWS;
   Frag8<T> fa[3];
   // four lane addresses (tap pair x row parity: LP / 8 = 9 is odd, so the swizzle bit flips with the row); the row is an immediate offset
   const T* abase[2][2];
@@ -765,12 +769,12 @@ __device__ __forceinline__ void cc16m_sweep(v4f (&acc)[3][8], const Frag8<T> (&B
 }
 
 // RES: one input chunk (and no DP_X3 operand split): the 18 weight fragments are loaded once and stay in registers for the whole march
-template <typename T, typename TO, bool RES>
-__global__ void __launch_bounds__(256, 1) k_conv_cc16m(const T* __restrict__ x, const T* __restrict__ wq, const float* __restrict__ bias,
+template <typename T, typename TO, bool RES, int RWO = 8, int OCC = 1>
+__global__ void __launch_bounds__(256, OCC) k_conv_cc16m(const T* __restrict__ x, const T* __restrict__ wq, const float* __restrict__ bias,
                                                        TO* __restrict__ y, Cc16Geom g, int ML) {
   static_assert(sizeof(T) == 2, "16-bit operands");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  constexpr int KS = 3, PAD = 1, KWP = 2, RWO = 8, ROWS = RWO + KS - 1, CK = 16, TW = CC16M_TW, LP = 72, LR = ROWS, NC = 16, WT = 512;
+  constexpr int KS = 3, PAD = 1, KWP = 2, ROWS = RWO + KS - 1, CK = 16, TW = CC16M_TW, LP = 72, LR = ROWS, NC = 16, WT = 512;
   static_assert(LP == ((TW + KS - 1 + 7) & ~7), "slab pitch");
   constexpr int SLAB_BYTES = LR * LP * CK * (int)sizeof(T);
   T* slab = (T*)smem_raw;
@@ -781,7 +785,7 @@ __global__ void __launch_bounds__(256, 1) k_conv_cc16m(const T* __restrict__ x, 
   if ((gridDim.x & 7) == 0) b = (b & 7) * (gridDim.x >> 3) + (b >> 3);          // XCD-aware order (see k_conv_cc16)
   const int tw = b % g.tiles_w; b /= g.tiles_w; const int th = b % g.tiles_h; b /= g.tiles_h; const int seg = b % g.dtiles; const int n = b / g.dtiles;
   const int h0 = th * RWO, w0 = tw * TW, d0 = seg * ML, MLe = min(ML, g.D - d0);
-  v4f acc[3][8];
+  v4f acc[3][RWO];
 #pragma unroll
   for (int a = 0; a < 3; a++)
 #pragma unroll
@@ -917,8 +921,8 @@ __global__ void __launch_bounds__(256, 1) k_conv_cc16m(const T* __restrict__ x, 
             else if (zi + 1 < MLe + 2 && z + 1 < g.D) stage_load(z + 1, 0);
             __builtin_amdgcn_sched_barrier(0);
           }
-          if (m0 && m1 && m2) cc16m_sweep<J, true>(acc, B, slab, v_lane, hsel, true, true, true);
-          else cc16m_sweep<J, false>(acc, B, slab, v_lane, hsel, m0, m1, m2);
+          if (m0 && m1 && m2) cc16m_sweep<J, true, RWO>(acc, B, slab, v_lane, hsel, true, true, true);
+          else cc16m_sweep<J, false, RWO>(acc, B, slab, v_lane, hsel, m0, m1, m2);
         }
       }
     }
@@ -947,20 +951,24 @@ __global__ void __launch_bounds__(256, 1) k_conv_cc16m(const T* __restrict__ x, 
   }
 }
 
-template <typename T, typename TO>
-static int cc16m_go(const void* x, const void* wq, const float* bias, void* y, Cc16Geom g, hipStream_t s) {
+template <typename T, typename TO, int RWO, int OCC>
+static int cc16m_go_rows(const void* x, const void* wq, const float* bias, void* y, Cc16Geom g, hipStream_t s) {
   const int ML = cc16m_ml(g.D);
-  const size_t smem = (size_t)10 * 72 * 16 * sizeof(T) + 4 * 32 * 16 * sizeof(TO) + 8 * 16 * sizeof(float);
-  g.tiles_w = cdiv(g.W, CC16M_TW); g.dtiles = cdiv(g.D, ML);
+  const size_t smem = (size_t)(RWO + 2) * 72 * 16 * sizeof(T) + 4 * 32 * 16 * sizeof(TO) + 8 * 16 * sizeof(float);
+  g.tiles_h = cdiv(g.H, RWO); g.tiles_w = cdiv(g.W, CC16M_TW); g.dtiles = cdiv(g.D, ML);
   const int64_t blocks = (int64_t)g.N * g.dtiles * g.tiles_h * g.tiles_w;
   if (blocks > 2000000000LL) { dp_set_error("conv_cc16m: grid too large"); return 1; }
-  if (g.NCH == 1 && !g.x3) hipLaunchKernelGGL((k_conv_cc16m<T, TO, true>), dim3((unsigned)blocks), dim3(256), smem, s, (const T*)x, (const T*)wq, bias, (TO*)y, g, ML);
-  else hipLaunchKernelGGL((k_conv_cc16m<T, TO, false>), dim3((unsigned)blocks), dim3(256), smem, s, (const T*)x, (const T*)wq, bias, (TO*)y, g, ML);
+  if (g.NCH == 1 && !g.x3) hipLaunchKernelGGL((k_conv_cc16m<T, TO, true, RWO, OCC>), dim3((unsigned)blocks), dim3(256), smem, s, (const T*)x, (const T*)wq, bias, (TO*)y, g, ML);
+  else hipLaunchKernelGGL((k_conv_cc16m<T, TO, false, RWO, OCC>), dim3((unsigned)blocks), dim3(256), smem, s, (const T*)x, (const T*)wq, bias, (TO*)y, g, ML);
   return 0;
+}
+template <typename T, typename TO>
+static int cc16m_go(const void* x, const void* wq, const float* bias, void* y, Cc16Geom g, hipStream_t s) {
+  return cc16m_rows() == 4 ? cc16m_go_rows<T, TO, 4, 2>(x, wq, bias, y, g, s) : cc16m_go_rows<T, TO, 8, 1>(x, wq, bias, y, g, s);
 }
 
 int cc16_stat_blocks(int D, int H, int W, int k, int dtype) {
-  if (cc16m_use(k, dtype)) return cdiv(D, cc16m_ml(D)) * cdiv(H, 8) * cdiv(W, CC16M_TW);      // k_conv_cc16m: one partial row per block
+  if (cc16m_use(k, dtype)) return cdiv(D, cc16m_ml(D)) * cdiv(H, cc16m_rows()) * cdiv(W, CC16M_TW);      // k_conv_cc16m: one partial row per block
   return D * cdiv(H, 8) * cdiv(W, cc16_tw(W, k));
 }
 
