@@ -711,8 +711,9 @@ static inline int cc16_tw(int W, int k) {
 // block of four waves per CU (at two blocks the compiler spills the weights into the sweep: 0.30 ms).  With one wave per SIMD nothing
 // overlaps: the step time is the SUM of its phases -- knock-outs at 2 x 128^3, 34 steps per block: sweep 1.6 us (1.0 of MFMA issue),
 // epilogue of the finished slice 1.6 us, exposed staging 0.6 us with the next slab prefetched into registers during the sweep (1.9
-// without) -- where k_conv_cc16 overlaps the phases of three resident blocks.  A 4-row variant (48 accumulator registers, two blocks per
-// CU, 1.6 voxel loads per output) would be MFMA-bound near 45 us + epilogues, at best ~10 % under the kernel it replaces: not built.
+// without) -- where k_conv_cc16 overlaps the phases of three resident blocks.  The 4-row variant (DP_CC16M_ROWS=4: 48 accumulator
+// registers, 255 in all, two blocks per CU, 1.6 voxel loads per output) closes most of the gap and no more: 0.116 ms (32 -> 16, whose two
+// chunks reload the 18 weight fragments per slab: 0.30).
 #define CC16M_TW 64
 static inline bool cc16m_use(int k, int dtype) {
   static const bool on = [] { const char* e = getenv("DP_CC16M"); return e && atoi(e); }();      // measured slower than k_conv_cc16 (below): opt-in
