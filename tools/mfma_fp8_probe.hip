@@ -1,0 +1,151 @@
+// Hardware probe for the block-scaled fp8 matrix instruction of gfx950, v_mfma_scale_f32_16x16x128_f8f6f4 (test tooling, not product
+// code): the groundwork of the fp8-corrected fp32x3 forward pass queued in DESIGN section 8.
+//   1. lane <-> element map of the A / B operands (e4m3, 32 bytes per lane), checked with exact small values;
+//   2. the E8M0 scale operands (per lane, selected byte), incl. the constant scales 2^-11 / 2^-15 the scheme needs;
+//   3. issue rate against v_mfma_f32_16x16x32_bf16 (one wave per SIMD, independent accumulators).
+// Build: hipcc --offload-arch=gfx950 -O2 tools/mfma_fp8_probe.hip -o /tmp/mfma_fp8_probe
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+// e4m3 (OCP FP8 E4M3, bias 7, no infinities): encode a few exact values
+static unsigned char e4m3(float v) {
+  if (v == 0.f) return 0;
+  unsigned char s = v < 0 ? 0x80 : 0; v = fabsf(v);
+  int e; float m = frexpf(v, &e);          // v = m 2^e, m in [0.5, 1)
+  int E = e - 1 + 7;                        // exponent of 1.xxx form
+  float frac = m * 2.f - 1.f;               // in [0, 1)
+  int M = (int)lrintf(frac * 8.f);
+  if (M == 8) { M = 0; E++; }
+  if (E <= 0) { M = (int)lrintf(v / ldexpf(1.f, -9)); return s | (unsigned char)M; }      // subnormal: multiples of 2^-9
+  return s | (unsigned char)((E << 3) | M);
+}
+static float e4m3_val(unsigned char b) {
+  int s = b >> 7, E = (b >> 3) & 15, M = b & 7;
+  float v = E == 0 ? ldexpf((float)M, -9) : ldexpf(1.f + M / 8.f, E - 7);
+  return s ? -v : v;
+}
+
+// hypothesis H: lane l = (r = l & 15, g = l >> 4) holds, for row r of A / column r of B, the 32 K values kmap(g, j), j = 0..31, byte j of
+// its 8 dwords.  map 0: k = 32 g + j.  map 1: k = 16 g + (j & 15) + 64 (j >> 4)  (two 64-wide halves, as the 16x16x32 pair would stack).
+__global__ void k_fp8(const unsigned char* A, const unsigned char* B, float* C, int map, int sa, int sb, int opsel) {
+  int l = threadIdx.x, r = l & 15, g = l >> 4;
+  unsigned char ab[32], bb[32];
+  for (int j = 0; j < 32; j++) {
+    int k = map == 0 ? 32 * g + j : 16 * g + (j & 15) + 64 * (j >> 4);
+    ab[j] = A[r * 128 + k]; bb[j] = B[k * 16 + r];
+  }
+  v8i a, b;
+  for (int d = 0; d < 8; d++) {
+    a[d] = (int)((unsigned)ab[4 * d] | ((unsigned)ab[4 * d + 1] << 8) | ((unsigned)ab[4 * d + 2] << 16) | ((unsigned)ab[4 * d + 3] << 24));
+    b[d] = (int)((unsigned)bb[4 * d] | ((unsigned)bb[4 * d + 1] << 8) | ((unsigned)bb[4 * d + 2] << 16) | ((unsigned)bb[4 * d + 3] << 24));
+  }
+  v4f c = {0, 0, 0, 0};
+  // cbsz / blgp = 0: both operands e4m3.  scale registers: byte `opsel` of sa / sb is the E8M0 exponent of this lane's K block.
+  if (opsel == 2) c = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, sa - g, 0, sb);                // per-lane A scales (by K group)
+  else if (opsel == 3) c = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, sa, 0, sb - (r & 1));      // per-lane B scales (by column)
+  else if (opsel == 4) c = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, sa - (r & 1), 0, sb);      // per-lane A scales (by row)
+  else if (opsel == 0) c = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, sa, 0, sb);
+  else c = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 1, sa, 1, sb);
+  for (int i = 0; i < 4; i++) C[(g * 4 + i) * 16 + r] = c[i];
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(256) k_rate(float* out, int iters) {
+  v4f c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
+  if (MODE == 0) {
+    v8bf a, b;
+    for (int j = 0; j < 8; j++) { a[j] = (__bf16)(float)(threadIdx.x & 3); b[j] = (__bf16)1.0f; }
+    for (int i = 0; i < iters; i++) {
+      c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c0, 0, 0, 0); c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c1, 0, 0, 0);
+      c2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c2, 0, 0, 0); c3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c3, 0, 0, 0);
+    }
+  } else {
+    v8i a, b;
+    for (int d = 0; d < 8; d++) { a[d] = 0x38383838 + (threadIdx.x & 1); b[d] = 0x38383838; }
+    for (int i = 0; i < iters; i++) {
+      c0 = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c0, 0, 0, 0, 127, 0, 127); c1 = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c1, 0, 0, 0, 127, 0, 127);
+      c2 = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c2, 0, 0, 0, 127, 0, 127); c3 = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c3, 0, 0, 0, 127, 0, 127);
+    }
+  }
+  out[blockIdx.x * 256 + threadIdx.x] = c0[0] + c1[1] + c2[2] + c3[3];
+}
+
+int main() {
+  std::vector<unsigned char> A(16 * 128), B(128 * 16);
+  const float vals[] = {0.f, 1.f, -1.f, 2.f, 0.5f, -0.5f, 1.5f, 3.f, -2.f, 0.25f, 1.25f, -3.f};
+  srand(7);
+  for (auto& v : A) v = e4m3(vals[rand() % 12]);
+  for (auto& v : B) v = e4m3(vals[rand() % 12]);
+  std::vector<double> ref(256, 0.0);
+  for (int m = 0; m < 16; m++) for (int n = 0; n < 16; n++) { double s = 0; for (int k = 0; k < 128; k++) s += (double)e4m3_val(A[m * 128 + k]) * e4m3_val(B[k * 16 + n]); ref[m * 16 + n] = s; }
+  unsigned char *dA, *dB; float* dC;
+  CK(hipMalloc(&dA, A.size())); CK(hipMalloc(&dB, B.size())); CK(hipMalloc(&dC, 256 * 4));
+  CK(hipMemcpy(dA, A.data(), A.size(), hipMemcpyHostToDevice)); CK(hipMemcpy(dB, B.data(), B.size(), hipMemcpyHostToDevice));
+  std::vector<float> C(256);
+  auto run = [&](int map, int sa, int sb, int opsel, double scale, const char* what) {
+    hipLaunchKernelGGL(k_fp8, dim3(1), dim3(64), 0, 0, dA, dB, dC, map, sa, sb, opsel);
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(C.data(), dC, 256 * 4, hipMemcpyDeviceToHost));
+    double worst = 0;
+    for (int i = 0; i < 256; i++) worst = fmax(worst, fabs(C[i] - ref[i] * scale));
+    printf("%-78s max |C - ref| = %.3e  %s\n", what, worst, worst == 0 ? "EXACT" : "mismatch");
+    return worst == 0;
+  };
+  printf("1. operand layout (e4m3 x e4m3, scales 2^0):\n");
+  bool m0 = run(0, 127, 127, 0, 1.0, "   lane (r, g) holds K = 32 g + j in byte j");
+  bool m1 = run(1, 127, 127, 0, 1.0, "   lane (r, g) holds K = 16 g + (j & 15) + 64 (j >> 4) in byte j");
+  const int map = m0 ? 0 : (m1 ? 1 : 0);
+  printf("2. E8M0 scale operands (byte 0 of the scale register = exponent + 127):\n");
+  run(map, 127 - 11, 127, 0, ldexp(1.0, -11), "   scale_a = 2^-11, scale_b = 1");
+  run(map, 127, 127 - 15, 0, ldexp(1.0, -15), "   scale_a = 1, scale_b = 2^-15");
+  run(map, 127 - 11, 127 - 4, 0, ldexp(1.0, -15), "   scale_a = 2^-11, scale_b = 2^-4");
+  run(map, (127 - 3) << 8 | 127, (127 + 2) << 8 | 127, 1, ldexp(1.0, -1), "   opsel = 1: byte 1 of the registers (2^-3, 2^2), byte 0 ignored");
+  // per-lane scales: which lanes' scale bytes apply to which (row, K block)?
+  auto run_lane = [&](int map, int mode, const char* what, auto&& expo) {
+    hipLaunchKernelGGL(k_fp8, dim3(1), dim3(64), 0, 0, dA, dB, dC, map, 127, 127, mode);
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(C.data(), dC, 256 * 4, hipMemcpyDeviceToHost));
+    double worst = 0;
+    for (int m = 0; m < 16; m++) for (int n = 0; n < 16; n++) {
+      double s2 = 0;
+      for (int k = 0; k < 128; k++) s2 += ldexp((double)e4m3_val(A[m * 128 + k]) * e4m3_val(B[k * 16 + n]), -expo(m, n, k));
+      worst = fmax(worst, fabs(C[m * 16 + n] - s2));
+    }
+    printf("%-78s max |C - ref| = %.3e  %s\n", what, worst, worst == 0 ? "EXACT" : "mismatch");
+  };
+  run_lane(0, 3, "   B scale 2^-(n & 1) from the lanes of column n: whole column scaled", [](int, int n, int) { return n & 1; });
+  run_lane(0, 4, "   A scale 2^-(m & 1) from the lanes of row m: whole row scaled", [](int m, int, int) { return m & 1; });
+  run_lane(0, 2, "   A scale 2^-g from lane group g, operands K = 32 g + j: block k / 32 = g", [](int, int, int k) { return k / 32; });
+  run_lane(1, 2, "   A scale 2^-g from lane group g, operands K = 16 g + (j&15) + 64 (j>>4): blocks", [](int, int, int k) { return (k & 63) / 16; });
+  run_lane(0, 2, "   A scale 2^-g ... if ONLY lane group 0's scale byte counted (no scaling)", [](int, int, int) { return 0; });
+  printf("3. issue rate (1024 blocks x 4 waves, 4 independent accumulators per wave):\n");
+  float* dO; CK(hipMalloc(&dO, 1024 * 256 * 4));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  const int iters = 20000;
+  double tf[2];
+  for (int mode = 0; mode < 2; mode++) {
+    for (int rep = 0; rep < 2; rep++) {
+      CK(hipEventRecord(e0));
+      if (mode == 0) hipLaunchKernelGGL(k_rate<0>, dim3(1024), dim3(256), 0, 0, dO, iters);
+      else hipLaunchKernelGGL(k_rate<1>, dim3(1024), dim3(256), 0, 0, dO, iters);
+      CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    }
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    const double K = mode == 0 ? 32 : 128, flop = 1024.0 * 4 * iters * 4 * 2 * 16 * 16 * K;
+    tf[mode] = flop / (ms * 1e-3) * 1e-12;
+    printf("   %-34s %8.3f ms  %8.1f TFLOP/s (constant operands: the clock the chip holds without data toggling)\n",
+           mode == 0 ? "v_mfma_f32_16x16x32_bf16" : "v_mfma_scale_f32_16x16x128_f8f6f4", ms, tf[mode]);
+  }
+  printf("   fp8 / bf16 rate: %.2f x  (a K = 128 fp8 instruction = %.2f bf16 K = 32 issue slots)\n", tf[1] / tf[0], 4.0 / (tf[1] / tf[0]));
+  return 0;
+}
