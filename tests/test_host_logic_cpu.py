@@ -70,3 +70,41 @@ def test_tools_and_package_sources_compile_and_losses_reject_unsupported_argumen
     # the deterministic split-K helper declines shapes whose K shares would not start on 16-byte boundaries
     from dose_prediction_amd import ops
     assert ops._gemm_nt_splitk_det(torch.zeros(2, 30), torch.zeros(4, 30), None, 2, 4, 30, 30, 30, 3) is None
+
+
+def test_folded_finalize_falls_back_to_the_two_launch_form_when_declined(monkeypatch):
+    """ops._norm_forward / _norm_backward ask for the one-launch form first (dp_*_partial_finalize); on return value 3 (switched off, or an
+    affine instance normalisation over several samples) they must make the two calls of the old form, in order, with the same scratch;
+    on 0 nothing else may be launched.  Checked on the call sequence with the library mocked (no GPU)."""
+    from dose_prediction_amd import _lib, ops
+
+    class FakeLib:
+        def dp_stats_nblk(self, V):
+            return 3
+
+    for decline in (True, False):
+        calls = []
+
+        def fake_call(name, *a, _d=decline):
+            calls.append(name)
+            return 3 if (_d and name.endswith("_partial_finalize")) else 0
+
+        monkeypatch.setattr(_lib, "lib", lambda: FakeLib())
+        monkeypatch.setattr(_lib, "call", fake_call)
+        monkeypatch.setattr(ops, "_stream", lambda: 0)
+        x = torch.zeros((2, 4, 4, 4, 16))
+        y = torch.empty_like(x)
+        mean, rstd, use_stats, ssn = ops._norm_forward(x, "instance", None, None, None, None, True, None, "relu", 1e-5, 0.1, y.data_ptr(), 16)
+        assert tuple(mean.shape) == (2, 16) and use_stats and ssn == 16
+        want = ["dp_stats_partial_finalize"] + (["dp_stats_partial", "dp_stats_finalize"] if decline else []) + ["dp_norm_act_fwd"]
+        assert calls == want, calls
+        # rows that came out of a convolution epilogue: only the finalize, never the folded form
+        calls.clear()
+        part = torch.zeros((2, 5, 2, 16))
+        ops._norm_forward(x, "batch", None, None, None, None, True, None, "relu", 1e-5, 0.1, y.data_ptr(), 16, part=part)
+        assert calls == ["dp_stats_finalize", "dp_norm_act_fwd"], calls
+        calls.clear()
+        gy = torch.zeros_like(x)
+        ops._norm_backward(x, mean, rstd, None, None, None, "instance", "relu", True, ssn, gy.data_ptr(), 16, True, False, False)
+        want = ["dp_norm_act_bwd_partial_finalize"] + (["dp_norm_act_bwd_partial", "dp_norm_bwd_finalize"] if decline else []) + ["dp_norm_act_bwd_apply"]
+        assert calls == want, calls
