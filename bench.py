@@ -24,6 +24,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md chip table
 PEAK_F32_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0       # HBM3E, same table (about 6.3 TB/s is what a copy kernel reaches)
 
 
 def parse():
@@ -156,6 +157,12 @@ def summarize_profile(records, steps):
         elif name == "dp_gemm_tn":
             # (A, lda, B, ldb, C, ldc, M, N, K, splitk, dtype, stream)
             fl, key = 2.0 * a[6] * a[7] * a[8], "gemm_tn"
+        elif name == "dp_attention_fwd":
+            # (q, k, v, ld, o, ldo, lse, B, heads, N, d, scale, dtype, stream): QK^T + PV = 4 B h N^2 d
+            fl, key = 4.0 * a[7] * a[8] * a[9] * a[9] * a[10], "attention_fwd"
+        elif name == "dp_attention_bwd":
+            # (q, k, v, ld, o, go, ldo, lse, delta, dq, dk, dv, ldg, B, heads, N, d, scale, dtype, stream): S, dP, dV, dQ, dK = 10 B h N^2 d
+            fl, key = 10.0 * a[13] * a[14] * a[15] * a[15] * a[16], "attention_bwd"
         else:
             M, N, K, nb0, nb1 = a[13], a[14], a[15], a[16], a[17]
             fl, key = 2.0 * M * N * K * nb0 * nb1, "gemm_nt"
@@ -167,6 +174,125 @@ def summarize_profile(records, steps):
     for key, (fl, ms, n) in groups.items():
         out[key] = {"launches_per_step": n / steps, "avg_launch_ms": ms / n, "ms_per_step": ms / steps,
                     "tflops": fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0}
+    return out
+
+
+def _tiled_geom(name, a):
+    """(N, D, H, W, Cin, Cout, k, dtype code) of a tiled-convolution launch record, or None."""
+    if name == "dp_conv3d_tiled":
+        return tuple(a[7:14]) + (a[14],)
+    if name == "dp_conv3d_tiled2":
+        return tuple(a[13:20]) + (a[20],)
+    if name == "dp_conv3d_tiled_stats":
+        return tuple(a[11:18]) + (a[18],)
+    return None
+
+
+def hbm_roofline(records, records_serial, full_voxels):
+    """north_star's HBM target (>= 0.60 of the roofline on the 3x3x3 conv stages): the 3x3x3 launches of the FULL-RESOLUTION level with
+    <= 32 channels a side (SURVEY 8d classifies exactly these as HBM-bound: 9->16, 16->16, 25->16, 32->16 and their data gradients),
+    forward + data-gradient launches of one step.  achieved = ALGORITHMIC bytes per launch -- (Cin + Cout) x N x D x H x W x element size:
+    every activation read once and written once, weights (< 30 KB) ignored -- / HIP-event time on the launch stream; peak 8 TB/s."""
+    def collect(recs):
+        per, tot_b, tot_ms, n = {}, 0.0, 0.0, 0
+        for name, a, e0, e1 in recs or ():
+            g = _tiled_geom(name, a)
+            if g is None:
+                continue
+            N, D, H, W, cin, cout, k, dtc = g
+            if k != 3 or D * H * W != full_voxels or max(cin, cout) > 48:
+                continue
+            if dtc in (3, 4):          # DP_X3 / DP_X1: bf16 [hi | lo] (or hi) rows in, fp32 rows out; `cin` counts the packed contraction axis
+                es_in, es_out, cin_r = 2, 4, (cin * 2 // 3 if dtc == 3 else cin)
+            else:
+                es_in = es_out = 4 if dtc == 0 else 2
+                cin_r = cin
+            by = float(N) * D * H * W * (cin_r * es_in + cout * es_out)
+            ms = e0.elapsed_time(e1)
+            ent = per.setdefault(f"{cin}->{cout}", [0.0, 0.0, 0])
+            ent[0] += by; ent[1] += ms; ent[2] += 1
+            tot_b += by; tot_ms += ms; n += 1
+        return per, tot_b, tot_ms, n
+    per, tb, tms, n = collect(records)
+    if not n:
+        return None
+    pers, tbs, tmss, ns = collect(records_serial)
+    traffic, src = pmc_traffic("k_conv_cc16<unsigned short, 3,")
+    out = {"bound": "hbm", "kernel": "conv3d 3x3x3 at the full-resolution level, <= 32 channels (k_conv_cc16<3>: forward + data-gradient launches)",
+           "achieved": tb / (tms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": tb / (tms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+           "target_frac": 0.60, "bytes_per_launch": tb / n, "avg_launch_us": 1e3 * tms / n, "launches_per_step": n,
+           "traffic": traffic, "traffic_unit": "bytes/launch (fabric reads x2-corrected + writes, PMC; all k_conv_cc16<3> launches of the step)",
+           "traffic_source": src,
+           "per_shape": {k: {"launches": v[2], "avg_launch_us": 1e3 * v[1] / v[2], "GBps": v[0] / (v[1] * 1e-3) / 1e9} for k, v in per.items()},
+           "note": "achieved / frac: as co-scheduled in the shipped configuration (these launches run on the branch stream beside the 7x7x7 kernels); "
+                   "*_serial: every kernel alone on the chip.  Diagnosis of the gap to 0.60: profiles/r06_a_3x3x3_phase_counters.md, DESIGN section 5"}
+    if ns:
+        out.update({"achieved_serial": tbs / (tmss * 1e-3) / 1e9, "frac_serial": tbs / (tmss * 1e-3) / 1e9 / PEAK_HBM_GBS, "avg_launch_us_serial": 1e3 * tmss / ns,
+                    "per_shape_serial": {k: {"launches": v[2], "avg_launch_us": 1e3 * v[1] / v[2], "GBps": v[0] / (v[1] * 1e-3) / 1e9} for k, v in pers.items()}})
+    return out
+
+
+def mfma_busy(kernel_prefix):
+    """MFMA utilisation of a kernel from the committed PMC pass (profiles/*_mfma_busy.json: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x
+    1024 SIMDs), tools/pmc_mfma.py) -- counters cannot be read inside the timed run."""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_mfma_busy.json")))
+    for f in reversed(files):
+        try:
+            for k in json.load(open(f))["kernels"]:
+                if kernel_prefix in k["kernel"]:
+                    return k["mfma_util"], os.path.basename(f)
+        except Exception:
+            continue
+    return None, None
+
+
+def attention_line(records, records_serial, dev):
+    """north_star's MFMA target (>= 40 % MFMA utilisation on the attention block): live HIP-event time of the fused attention launches of
+    one step, their FLOPs, and the MFMA-busy fraction of the committed PMC pass; next to it the LAUNCH FLOOR measured here (a 64-element
+    fill between two events on the same stream): what a launch costs before it computes anything."""
+    def collect(recs, key):
+        ms = [e0.elapsed_time(e1) for name, a, e0, e1 in (recs or ()) if name == key]
+        ar = [a for name, a, e0, e1 in (recs or ()) if name == key]
+        return ms, ar
+    if not any(name == "dp_attention_fwd" for name, *_ in records or ()):
+        return None
+    # the launches of the LARGEST token count of the step (a cascade step also holds the segmentation network's 216-token windows)
+    N = max(a[9] for name, a, e0, e1 in records if name == "dp_attention_fwd")
+    pick = lambda recs: [r for r in (recs or ()) if (r[0] == "dp_attention_fwd" and r[1][9] == N) or (r[0] == "dp_attention_bwd" and r[1][15] == N)]   # noqa: E731
+    records, records_serial = pick(records), pick(records_serial)
+    f_ms, f_a = collect(records, "dp_attention_fwd")
+    b_ms, b_a = collect(records, "dp_attention_bwd")
+    fs_ms, _ = collect(records_serial, "dp_attention_fwd")
+    bs_ms, _ = collect(records_serial, "dp_attention_bwd")
+    Bn, heads, N, d = f_a[0][7:11]
+    from dose_prediction_amd import _lib
+    buf = torch.zeros(64, device=dev)
+    s = torch.cuda.current_stream().cuda_stream
+    floor = []
+    for _ in range(20):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _lib.call("dp_fill_f32", buf.data_ptr(), 0.0, 64, s)
+        e1.record()
+        torch.cuda.synchronize()
+        floor.append(e0.elapsed_time(e1) * 1e3)
+    floor.sort()
+    gf, gb = 4.0 * Bn * heads * N * N * d / 1e9, 10.0 * Bn * heads * N * N * d / 1e9
+    uf, src = mfma_busy("k_attn_fwd<")
+    ub, _ = mfma_busy("k_attn_bwd<")
+    med = lambda v: sorted(v)[len(v) // 2] if v else None      # noqa: E731
+    out = {"kernel": "fused multi-head self-attention (k_attn_fwd / k_attn_delta + k_attn_bwd)", "tokens": N, "heads": heads, "head_dim": d, "batch": Bn,
+           "launches_per_step": {"fwd": len(f_ms), "bwd": len(b_ms)}, "gflop_per_launch": {"fwd": gf, "bwd": gb},
+           "us_per_launch": {"fwd": 1e3 * med(f_ms), "bwd": 1e3 * med(b_ms) if b_ms else None},
+           "us_per_launch_serial": {"fwd": 1e3 * med(fs_ms) if fs_ms else None, "bwd": 1e3 * med(bs_ms) if bs_ms else None},
+           "tflops": {"fwd": gf / med(f_ms), "bwd": gb / med(b_ms) if b_ms else None},
+           "mfma_busy": {"fwd": uf, "bwd": ub, "source": src}, "target_mfma_busy": 0.40,
+           "launch_floor_us": floor[len(floor) // 2],
+           "mfma_time_at_peak_us": {"fwd": gf / PEAK_BF16_TFLOPS * 1e3, "bwd": gb / PEAK_BF16_TFLOPS * 1e3},
+           "note": "at this problem size one launch holds %.2f GFLOP = %.2f us of matrix-core time at the dense bf16 peak, against a launch floor of a few us: "
+                   "the 40 %% target is out of reach for ANY kernel at N = %d (DESIGN section 6); the bwd figure covers dp_attention_bwd's two launches"
+                   % (gf, gf / PEAK_BF16_TFLOPS * 1e3, N)}
     return out
 
 
@@ -478,6 +604,14 @@ def main():
                 dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+    ranks_seen = None
+    if ddp_on:
+        # every rank contributes 1 + its rank: the sum proves that `world` distinct ranks took part in a collective on this backend
+        t = torch.tensor([1.0, float(rank)], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(t)
+        ranks_seen = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks_counted": int(t[0].item()),
+                      "rank_sum": int(t[1].item()), "rank_sum_expected": world * (world - 1) // 2,
+                      "gpus_visible": ndev, "one_gpu_per_rank": ndev >= world}
     shape = tuple(args.size * 3) if len(args.size) == 1 else tuple(args.size)
     from dose_prediction_amd import synth, losses, _lib
     from dose_prediction_amd.ddp import attach_gradient_allreduce
@@ -740,6 +874,15 @@ def main():
             "kernels": prof,
             "kernels_serial": prof_serial,
         }
+        full_voxels = dose_shape[0] * dose_shape[1] * dose_shape[2]
+        try:
+            res["roofline_hbm"] = hbm_roofline(records, records_serial, full_voxels)
+            res["attention"] = attention_line(records, records_serial, dev)
+        except Exception as e:          # (secondary objects must never cost the line)
+            res["roofline_hbm"] = {"error": repr(e)}
+        if ddp_on:
+            res["rccl_ranks_seen"] = ranks_seen
+            res["grad_exchange_algo"] = os.environ.get("DOSE_DDP_ALGO", "allreduce")
         if fp32_leg is not None:
             res["fp32_mode"] = fp32_leg
         if not args.no_cpu_baseline and world == 1:      # (the host-side baseline is reported by the 1-GPU run only)

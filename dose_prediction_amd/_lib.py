@@ -69,7 +69,7 @@ def lib():
 # (name, args, start_event, end_event).
 PROFILE = None
 PROFILE_NAMES = ("dp_conv3d", "dp_conv3d_tiled", "dp_conv3d_tiled2", "dp_conv3d_tiled_stats", "dp_conv3d_wgrad", "dp_conv3d_wgrad_tiled", "dp_conv3d_wgrad_tiled2",
-                 "dp_gemm_nt", "dp_gemm_tn")
+                 "dp_gemm_nt", "dp_gemm_tn", "dp_attention_fwd", "dp_attention_bwd")
 
 
 # entry points that may answer 3 = "not this kernel's shape, nothing launched" (the caller then takes its general path)

@@ -682,14 +682,16 @@ __global__ void __launch_bounds__(256, OCC) k_conv_cc16w(const T* __restrict__ x
 }
 
 // tile width of the launch: 96-position tiles (k_conv_cc16w) when they cover the row with less padding than 128-position tiles
-// (W = 96, 192, 160, 288 ...; ties go to the 128-position kernel).  A function of W alone: dp_conv3d_tiled_stat_blocks must agree.
+// (W = 96, 192, 160, 288 ...; ties go to the 128-position kernel).  A function of (W, k, dtype) alone: dp_conv3d_tiled_stat_blocks must
+// agree.  Exact fp32 always runs the 128-position kernel (its fragments are twice as wide): its grid and statistics rows are those of
+// 128-position tiles too, not 96-position ones with every third tile empty.
 // 7x7x7 only: the 3x3x3 launches are latency-bound and keep the three-blocks-per-CU kernel (measured at 4 x 96^3, 16 -> 16: 0.087 ms
 // there, 0.109 ms on the 96-position tiles at two blocks per CU; 7x7x7 16 -> 16: 0.597 -> 0.508 ms, 32 -> 16: 1.014 -> 0.864).
-static inline int cc16_tw(int W, int k) {
+static inline int cc16_tw(int W, int k, int dtype) {
   static const int off = [] { const char* e = getenv("DP_NO_CC16W"); return (e && atoi(e)) ? 1 : 0; }();
   static const int t3 = [] { const char* e = getenv("DP_CC16W3"); return e ? atoi(e) : 0; }();      // (experiment: the half-size 3x3x3 tile, 64 positions x 8 rows x 1 depth slice per block)
   if (!off && k == 3 && t3 && W % 64 == 0) return 64;
-  if (off || k != 7) return 128;
+  if (off || k != 7 || dtype == DP_F32) return 128;
   static const int t64 = [] { const char* e = getenv("DP_CC16W_64"); return (e && atoi(e)) ? 1 : 0; }();      // (experiment: 64-position tiles of the same wave geometry for W % 64 == 0)
   if (t64 && W % 64 == 0) return 64;
   return cdiv(W, 96) * 96 < cdiv(W, 128) * 128 ? 96 : 128;
@@ -970,7 +972,7 @@ static int cc16m_go(const void* x, const void* wq, const float* bias, void* y, C
 
 int cc16_stat_blocks(int D, int H, int W, int k, int dtype) {
   if (cc16m_use(k, dtype)) return cdiv(D, cc16m_ml(D)) * cdiv(H, cc16m_rows()) * cdiv(W, CC16M_TW);      // k_conv_cc16m: one partial row per block
-  return D * cdiv(H, 8) * cdiv(W, cc16_tw(W, k));
+  return D * cdiv(H, 8) * cdiv(W, cc16_tw(W, k, dtype));
 }
 
 template <typename T, int KS, int DT, int OCC, typename TO>
@@ -1041,7 +1043,7 @@ int cc16_launch(const void* x, int ldx, const void* x2, int ldx2, int csplit, co
   g.y2 = y2; g.ldy2 = ldy2; g.osplit = osplit; g.wide = cc16_wide(y, ldy, y2, ldy2, osplit, dtype) ? 1 : 0;
   if (stat_part && !g.wide) { dp_set_error("conv_cc16: statistics need 16-byte aligned output rows"); return 1; }
   g.N = N; g.D = D; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.ldx = ldx; g.ldy = ldy; g.NCH = (Cin + 15) / 16;
-  const int tile_w = cc16_tw(W, k);
+  const int tile_w = cc16_tw(W, k, dtype);
   g.tiles_h = cdiv(H, 8); g.tiles_w = cdiv(W, tile_w); g.dtiles = 0;
   g.x2 = x2; g.ldx2 = ldx2; g.csplit = csplit; g.stat_part = stat_part; g.stat_nblk = cc16_stat_blocks(D, H, W, k, dtype);
   int rc = 0;
@@ -1065,7 +1067,7 @@ int cc16_launch(const void* x, int ldx, const void* x2, int ldx2, int csplit, co
     DP_CHECK_LAUNCH("conv_cc16w"); return 0;
   }
   if (tile_w == 64) { dp_set_error("conv_cc16: DP_CC16W_64 is a bf16 7x7x7 experiment"); return 1; }
-  if (tile_w == 96 && dtype != DP_F32) {          // (exact fp32: the 128-position kernel; its fragments are twice as wide)
+  if (tile_w == 96) {          // (never exact fp32: cc16_tw)
     if (dtype == DP_BF16) rc = k == 7 ? cc16w_go<bf16_t, 7>(x, wq, bias, y, g, s) : cc16w_go<bf16_t, 3>(x, wq, bias, y, g, s);
     else if (dtype == DP_F16) rc = k == 7 ? cc16w_go<f16_t, 7>(x, wq, bias, y, g, s) : cc16w_go<f16_t, 3>(x, wq, bias, y, g, s);
     else if (dtype == DP_X3 || dtype == DP_X1) rc = k == 7 ? cc16w_go<bf16_t, 7, float>(x, wq, bias, y, g, s) : cc16w_go<bf16_t, 3, float>(x, wq, bias, y, g, s);

@@ -273,12 +273,15 @@ __global__ void __launch_bounds__(256) k_dice_ce_bwd(const float* __restrict__ z
     for (int c = 0; c < CM; c++) { l[c] = c < C ? expf(l[c] - m) : 0.f; S += l[c]; }
     const float rS = 1.f / S;
     const int t = dce_label(lab, lkind, (int64_t)b * V + v);
+    // a label outside [0, C) contributes no cross-entropy term in k_dice_ce_partial (torch / MONAI raise on such labels; here the voxel is
+    // ignored by the CE half and matches no class in the Dice half): its CE gradient is zero as well, so backward == d(forward)
+    const float csv = (t >= 0 && t < C) ? cs : 0.f;
     float s = 0.f;
 #pragma unroll
     for (int c = 0; c < CM; c++) { l[c] *= rS; s += (u[c] - (c == t ? w[c] : 0.f)) * l[c]; }
 #pragma unroll
     for (int c = 0; c < CM; c++)
-      if (c < C) gb[(int64_t)c * V + v] = g0 * (l[c] * ((u[c] - (c == t ? w[c] : 0.f)) - s) + cs * (l[c] - (c == t ? 1.f : 0.f)));
+      if (c < C) gb[(int64_t)c * V + v] = g0 * (l[c] * ((u[c] - (c == t ? w[c] : 0.f)) - s) + csv * (l[c] - (c == t ? 1.f : 0.f)));
   }
 }
 extern "C" int64_t dp_dice_ce_ws_elems(int B, int C, int64_t V) {

@@ -181,24 +181,38 @@ __global__ void __launch_bounds__(256) k_stats_finalize(StatsFin f) {
 // device-scope loads: same code, same order of additions, bit-identical results.  One counter per statistics group (instance mode: the samples finish independently) from
 // a ring of zeroed counters; the last block puts the zero back.  Off with DP_NO_TICKET=1 (the callers then launch the finalize).
 #define TICKET_RING 8192
+#define TICKET_CAPTURE 4096     // counters handed to launches that are being CAPTURED into a HIP graph: never recycled (see ticket_counters)
 static unsigned* g_ticket_ring[32] = {};
 static unsigned g_ticket_next[32] = {};
+static unsigned g_ticket_cap_next[32] = {};
 static std::mutex g_ticket_mutex;          // (forward and backward may be driven from different host threads)
+// Counters for one launch.  Eager launches rotate through a ring of TICKET_RING zeroed counters (a slot comes back after ~8 000 later
+// hand-outs, i.e. dozens of steps: its launch has long retired and re-armed it).  A launch that is being CAPTURED keeps its slot for as
+// long as the graph lives and runs it again on every replay, so it must never share a slot with a later eager launch (two launches
+// drawing tickets from one counter at the same time would both miscount: ADVICE r5): captured launches get counters from a separate
+// region that is only ever bumped, and the two-launch form (nullptr) when that region is used up.
 static unsigned* ticket_counters(int n, hipStream_t stream) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32 || n > TICKET_RING) return nullptr;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &cs) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  const bool capturing = cs != hipStreamCaptureStatusNone;
   std::lock_guard<std::mutex> lock(g_ticket_mutex);
   if (!g_ticket_ring[dev]) {
     // (first use inside a stream capture: no allocation / memset / device synchronisation there -- the caller takes the two-launch form)
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(stream, &cs) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    if (cs != hipStreamCaptureStatusNone) return nullptr;
+    if (capturing) return nullptr;
     unsigned* p = nullptr;
-    if (hipMalloc(&p, TICKET_RING * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    if (hipMemset(p, 0, TICKET_RING * sizeof(unsigned)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+    if (hipMalloc(&p, (TICKET_RING + TICKET_CAPTURE) * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (hipMemset(p, 0, (TICKET_RING + TICKET_CAPTURE) * sizeof(unsigned)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
       (void)hipGetLastError(); (void)hipFree(p); return nullptr;
     }
     g_ticket_ring[dev] = p;
+  }
+  if (capturing) {
+    unsigned at = g_ticket_cap_next[dev];
+    if (at + n > TICKET_CAPTURE) return nullptr;
+    g_ticket_cap_next[dev] = at + n;
+    return g_ticket_ring[dev] + TICKET_RING + at;
   }
   unsigned at = g_ticket_next[dev];
   if (at + n > TICKET_RING) at = 0;
@@ -208,13 +222,20 @@ static unsigned* ticket_counters(int n, hipStream_t stream) {
 static inline bool ticket_enabled() { static const bool off = getenv("DP_NO_TICKET") != nullptr; return !off; }
 extern "C" int dp_ticket_enabled(void) { return ticket_enabled() ? 1 : 0; }
 // true in exactly one block per counter: the one whose ticket is the last of `total`.  Every thread of the block must call it, after the
-// block's own row stores (st_coh).  NO release / acquire fence: on this part a device-scope fence is `buffer_wbl2 sc1` + `buffer_inv sc1`
+// block's own row stores (st_coh).  NO agent-scope release / acquire fence: on this part that is `buffer_wbl2 sc1` + `buffer_inv sc1`
 // -- a write-back and an invalidate of the XCD's whole L2, i.e. of the convolutions running beside this kernel on the other streams
-// (measured with fences: the 23.4-ms step took 28.8 ms).  Instead the rows travel as device-scope stores / loads (written through and read
-// past the L2), the writers wait for their stores to be acknowledged (vmcnt(0)) before the block's ticket is drawn, and the reader's
-// loads are control-dependent on the ticket it drew.
+// (measured with fences: the 23.4-ms step took 28.8 ms).  Instead the rows travel as agent-scope atomic stores / loads (sc1: written
+// through and read past the L2), and the ORDER row stores -> ticket -> row loads is made explicit at both levels:
+//   * compiler: a workgroup-scope release fence after the row stores and a workgroup-scope acquire fence after the ticket is known
+//     (atomic accesses may not be moved across them; on gfx950 they lower to s_waitcnt only -- no L2 maintenance -- which is checked
+//     in the ISA by tests/test_cabi_cpu.py::test_ticket_fences_do_not_touch_the_l2);
+//   * hardware: s_waitcnt vmcnt(0) -- every row store of this thread has been ACKNOWLEDGED by the memory system (sc1 stores are
+//     acknowledged at device coherence) -- then the block barrier, then thread 0's agent-scope fetch_add; the reader's loads are issued
+//     after its own fetch_add returned the last ticket, which every writer's fetch_add (and hence its acknowledged stores) precedes.
 __device__ __forceinline__ bool ticket_is_last(unsigned* counter, unsigned total, int* flag) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_s_waitcnt(0);           // this thread's row stores have been acknowledged ...
+  asm volatile("" ::: "memory");           // (... and nothing that touches memory is scheduled across this point)
   __syncthreads();                         // ... for every thread of the block, before the ticket is drawn
   if (threadIdx.x == 0) {
     const unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -222,7 +243,10 @@ __device__ __forceinline__ bool ticket_is_last(unsigned* counter, unsigned total
     if (t == total - 1) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-arm: the next user is a later launch
   }
   __syncthreads();
-  return *flag != 0;
+  const bool last = *flag != 0;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  asm volatile("" ::: "memory");
+  return last;
 }
 
 static inline int pick_cpb(int C) { return C >= 32 ? 32 : (C >= 16 ? 16 : 8); }

@@ -17,6 +17,12 @@ when Cin == Cout) are taken out of the buckets' arrival counts from the second p
 in-order launches; should one of them receive a gradient later, or an expected gradient stay away, the end-of-backward
 callback still reduces everything (correct, just without overlap for that bucket).
 
+Exchange algorithm (``algo=`` / env ``DOSE_DDP_ALGO``): ``"allreduce"`` (default) hands every bucket chunk to RCCL as ONE all-reduce and
+leaves the algorithm to the library; ``"rs_ag"`` issues it as reduce-scatter + all-gather (``reduce_scatter_tensor`` of the chunk into
+this rank's 1/world share, ``all_gather_into_tensor`` of the shares back into the chunk: the two halves of a ring all-reduce as separate
+collectives, the form SURVEY 8e asks to A/B over the seven xGMI links of a node).  Same bytes, same averaged result (tests/test_ddp_cpu.py
+compares the two on two gloo ranks); behind the switch until an 8-GPU node can measure which one the xGMI mesh prefers.
+
 ``grad_dtype=torch.bfloat16`` exchanges bf16 copies of the gradients (half the xGMI bytes: 325 MB instead of 650 MB per step for
 DOSE-PYFER); the fp32 ``.grad`` tensors are overwritten with the averaged values afterwards.
 """
@@ -48,12 +54,20 @@ def _timed(name):
     return deco
 
 
+ALGOS = ("allreduce", "rs_ag")
+
+
 class GradAllReducer:
-    def __init__(self, module, bucket_mb=32.0, process_group=None, broadcast=True, grad_dtype=torch.float32):
+    def __init__(self, module, bucket_mb=32.0, process_group=None, broadcast=True, grad_dtype=torch.float32, algo=None):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         if grad_dtype not in (torch.float32, torch.bfloat16, torch.float16):
             raise ValueError("grad_dtype must be float32, bfloat16 or float16")
+        algo = algo or os.environ.get("DOSE_DDP_ALGO", "allreduce")
+        if algo not in ALGOS:
+            raise ValueError(f"gradient exchange algorithm {algo!r}: expected one of {ALGOS}")
+        self.algo = algo
+        self._shard = {}             # rs_ag: this rank's share of a chunk, one persistent buffer per (share size, dtype, device)
         self.pg = process_group
         self.world = dist.get_world_size(process_group)
         self.params = [p for p in module.parameters() if p.requires_grad]
@@ -216,10 +230,38 @@ class GradAllReducer:
     def _collectives(self, flat, n):
         for c0 in range(0, n, self.chunk):
             piece = flat[c0:min(n, c0 + self.chunk)]
+            if self.algo == "rs_ag":
+                piece = self._reduce_scatter_all_gather(piece)       # (returns the < world elements it could not split, or None)
+                if piece is None:
+                    continue
             if self.backend == "nccl":
                 self.work.append(dist.all_reduce(piece, op=dist.ReduceOp.AVG, group=self.pg, async_op=True))
             else:
                 self.work.append((dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.pg, async_op=True), piece))
+
+    def _reduce_scatter_all_gather(self, piece):
+        """One chunk as reduce-scatter + all-gather: the first world * s elements (s = numel // world) are reduced into this rank's
+        share [rank * s, (rank + 1) * s) -- a persistent side buffer, so no collective ever reads and writes overlapping memory -- and
+        the averaged shares are gathered back into the chunk.  RCCL: both collectives are enqueued asynchronously; they execute in
+        issue order on the process group's stream.  gloo (CPU tests): its worker threads may run asynchronous operations out of order,
+        so the two halves run synchronously (SUM, then the share is divided: gloo has no AVG)."""
+        w = self.world
+        s_ = piece.numel() // w
+        if s_ == 0:
+            return piece
+        body = piece[: w * s_]
+        key = (s_, piece.dtype, piece.device)
+        shard = self._shard.get(key)
+        if shard is None:
+            shard = self._shard[key] = torch.empty(s_, dtype=piece.dtype, device=piece.device)
+        if self.backend == "nccl":
+            self.work.append(dist.reduce_scatter_tensor(shard, body, op=dist.ReduceOp.AVG, group=self.pg, async_op=True))
+            self.work.append(dist.all_gather_into_tensor(body, shard, group=self.pg, async_op=True))
+        else:
+            dist.reduce_scatter_tensor(shard, body, op=dist.ReduceOp.SUM, group=self.pg)
+            shard.div_(w)
+            dist.all_gather_into_tensor(body, shard, group=self.pg)
+        return piece[w * s_:] if piece.numel() > w * s_ else None
 
     @_timed("flush")
     def _flush(self, ops):
@@ -311,6 +353,7 @@ class GradAllReducer:
         self._reset()
 
 
-def attach_gradient_allreduce(module, bucket_mb=32.0, process_group=None, broadcast=True, grad_dtype=torch.float32):
-    """Install the bucketed RCCL gradient exchange on ``module`` in place and return the reducer."""
-    return GradAllReducer(module, bucket_mb, process_group, broadcast, grad_dtype)
+def attach_gradient_allreduce(module, bucket_mb=32.0, process_group=None, broadcast=True, grad_dtype=torch.float32, algo=None):
+    """Install the bucketed RCCL gradient exchange on ``module`` in place and return the reducer.  algo: "allreduce" (default) or
+    "rs_ag" (reduce-scatter + all-gather per bucket chunk); None reads env DOSE_DDP_ALGO."""
+    return GradAllReducer(module, bucket_mb, process_group, broadcast, grad_dtype, algo)

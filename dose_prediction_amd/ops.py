@@ -274,12 +274,12 @@ def _zero_bias_grad(bias):
         off = pool["slots"][key] = pool["used"]
         pool["used"] += (n + 63) // 64 * 64
     task = _graph_task_id()
-    if not pool.get("armed") or pool.get("task") != task:
+    if not pool.get("armed") or _pass_is_stale(pool, task):
         # first hand-out of this backward pass: wipe the pool (one 256 KB fill), so that whatever was written into a previous step's
         # .grad in place (a regulariser's grad.add_, a NaN from clip_grad_norm_) cannot survive into this step; a pass
-        # that raised before its end-of-backward callback leaves "armed" behind -- the pass id tells
+        # that raised before its end-of-backward callback leaves "armed" behind -- _pass_is_stale tells
         pool["buf"].zero_()
-        pool["armed"], pool["task"] = True, task
+        pool["armed"], pool["task"], pool["epoch"] = True, task, _FWD_EPOCH[0]
         torch.autograd.Variable._execution_engine.queue_callback(lambda: pool.__setitem__("armed", False))
     # a FRESH view object every time: autograd adopts it as .grad without a copy only if nobody else holds the tensor object
     return pool["buf"][off:off + n].view(bias.shape)
@@ -289,6 +289,16 @@ _PASS_ARENA = {}
 _PASS_ARENA_ON = os.environ.get("DOSE_HIP_PASS_ARENA", "1") != "0"      # (A/B switch)
 _PASS_ARENA_MAX_ELEMS = 1 << 20
 _graph_task_id = getattr(torch._C, "_current_graph_task_id", lambda: -1)      # id of the running backward pass (-1 outside one)
+_FWD_EPOCH = [0]        # bumped by the network-entry conversion (ToNDHWC.forward) whenever it runs OUTSIDE any backward pass
+
+
+def _pass_is_stale(state, task):
+    """state was armed by backward pass state["task"] and never disarmed; the request comes from pass `task`.  A different id alone does
+    not make the armed pass dead: a NESTED backward (reentrant activation checkpointing, torch.autograd.grad inside a backward node) has
+    an id of its own while the outer pass is suspended, and resetting there re-allocates / re-fills once per segment.  The
+    armed pass is known to be dead when a network forward has started outside every backward pass since it armed (its end-of-backward
+    callback would have run first had it ended normally)."""
+    return state.get("task") != task and state.get("epoch") != _FWD_EPOCH[0]
 
 
 def _pass_zeros(shape, dev):
@@ -310,12 +320,13 @@ def _pass_zeros(shape, dev):
     if a is None:
         a = _PASS_ARENA[dev] = {"buf": None, "used": 0, "need": 0, "now": 0, "armed": False, "ev": None, "stream": None, "task": None}
     task = _graph_task_id()
-    if a["armed"] and a["task"] != task:
-        # the pass that armed the arena never reached its end-of-backward callback (it raised): start over
+    if a["armed"] and _pass_is_stale(a, task):
+        # the pass that armed the arena never reached its end-of-backward callback (it raised): start over.  A nested pass
+        # keeps drawing from the outer pass's arena: slices that were never handed out are still zero whoever asks.
         a["armed"], a["buf"] = False, None
     if not a["armed"]:
         a["buf"] = torch.zeros((max(a["need"], 1 << 16),), dtype=torch.float32, device=dev)
-        a["used"], a["now"], a["armed"], a["task"] = 0, 0, True, task
+        a["used"], a["now"], a["armed"], a["task"], a["epoch"] = 0, 0, True, task, _FWD_EPOCH[0]
         a["stream"] = torch.cuda.current_stream(dev)
         a["ev"] = torch.cuda.Event()
         a["ev"].record(a["stream"])
@@ -500,6 +511,8 @@ class ToNDHWC(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, cpad, dtype):
         _chk_dev(x)
+        if _graph_task_id() == -1:
+            _FWD_EPOCH[0] += 1          # a network forward outside any backward pass: whatever pass state is still armed is dead (_pass_is_stale)
         x = x.contiguous().float()
         N, C = x.shape[:2]
         sp = tuple(x.shape[2:])
@@ -1284,18 +1297,13 @@ class Conv3dX3(torch.autograd.Function):
             if need_w:
                 from . import config
                 wse = max(L.dp_conv3d_wgrad_tiled_ws_elems(2 * cp, cout, k, 1, pad, 1, 1, W), L.dp_conv3d_wgrad_tiled_ws_elems(cp, cout, k, 1, pad, 1, 1, W))
-                if not wse and config.x3_wgrad_terms() == 1:
-                    # rows shorter than the tiled weight-gradient kernels take (W < 16): x_hi gy_hi on the generic bf16 kernel (accumulates: zeroed dW)
-                    gw = _wgrad_buffer(weight, True)
-                    wgrad(xs, 2 * cp, gys, ldgs, gw, (N, D, H, W, D, H, W), cin, cout, k, 1, pad, 1, 1, 0, cin * taps, taps, 1, 1)
-                elif not wse:
-                    raise _lib.DoseHipError("x3 convolution: weight gradient outside the tiled kernels")
-                else:
-                    ws = _zero_scratch(dev, wse)
-                    gw = _wgrad_buffer(weight, False)
                 if not wse:
-                    pass
-                elif config.x3_wgrad_terms() == 1:
+                    # (cannot happen for a shape _x3_conv_ok admitted: the tiled weight-gradient kernels take every row of >= 8 voxels and
+                    # _x3_min_w is 8; the generic-kernel fallback that used to sit here was unreachable and untested -- ADVICE r5)
+                    raise _lib.DoseHipError("x3 convolution: weight gradient outside the tiled kernels")
+                ws = _zero_scratch(dev, wse)
+                gw = _wgrad_buffer(weight, False)
+                if config.x3_wgrad_terms() == 1:
                     # (config.set_x3_wgrad_terms(1)) x_hi x gy_hi only: one bf16 launch straight into dW
                     _lib.call("dp_conv3d_wgrad_tiled", _p(xs), 2 * cp, _p(gys), ldgs, _p(gw), _p(ws), N, D, H, W, cin, cout, k,
                               cin * taps, taps, 1, 1, _stream())
@@ -1961,7 +1969,7 @@ class LayerNorm(torch.autograd.Function):
         C = x.shape[-1]
         rows = x.numel() // C
         gx = torch.empty_like(x)
-        if _deterministic():
+        if _layernorm_det(C):
             dgb = _layernorm_bwd_det(x, gy, None, gamma, mean, rstd, gx, rows, C)
             return gx, dgb[0], dgb[1], None
         dgb = _pass_zeros((2, C), x.device)      # (accumulated by atomics)
@@ -1978,6 +1986,27 @@ def layer_norm(x, gamma, beta, eps=1e-5):
 def _deterministic():
     from . import config
     return config.deterministic(32)
+
+
+_LN_DET_MAXC = 1024
+_LN_DET_WARNED = [False]
+
+
+def _layernorm_det(C):
+    """True when the LayerNorm backward takes the fixed-order (deterministic) kernel: config.set_deterministic is on AND the row fits it
+    (dp_add_layernorm_bwd_det keeps a row in registers: C <= 1024; the reference's hidden size is 768).  Wider rows keep the atomic
+    dgamma / dbeta accumulation of dp_layernorm_bwd -- a working model must not turn into an exception because the switch is on
+     -- and say so once."""
+    if not _deterministic():
+        return False
+    if C <= _LN_DET_MAXC:
+        return True
+    if not _LN_DET_WARNED[0]:
+        _LN_DET_WARNED[0] = True
+        import warnings
+        warnings.warn(f"set_deterministic: LayerNorm rows of {C} > {_LN_DET_MAXC} channels accumulate dgamma / dbeta with fp32 atomics "
+                      "(run-to-run differences in their last bits); everything else stays deterministic")
+    return False
 
 
 def _layernorm_bwd_det(x, gy, gsum, gamma, mean, rstd, gx, rows, C):
@@ -2020,7 +2049,7 @@ class AddLayerNorm(torch.autograd.Function):
         gz = gz.contiguous()
         gs = None if gs is None else gs.contiguous()
         gx = torch.empty_like(s)
-        if _deterministic():
+        if _layernorm_det(C):
             dgb = _layernorm_bwd_det(s, gz, gs, gamma, mean, rstd, gx, rows, C)
             return gx, gx, dgb[0], dgb[1], None
         dgb = _pass_zeros((2, C), s.device)

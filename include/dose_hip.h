@@ -156,12 +156,16 @@ int dp_norm_act_bwd_partial(const void* x, int ldx, const void* gy, int ldgy, co
  * OVERWRITTEN in both modes (fixed-order fp64 combination of the partial rows: no atomics, no zero-fill needed). */
 int dp_norm_bwd_finalize(const float* part, int N, int nblk, int C, int batch_mode, float* s1, float* s2,
                          float* dgamma, float* dbeta, void* stream);
-/* The partial pass with its finalize folded in: ONE launch instead of two.  Every block stores its partial row, issues a device-scope
- * release fence and draws a ticket of its statistics group (atomicAdd on a zeroed counter from an internal ring); the block that draws
- * the group's last ticket runs that group's finalize itself -- the same code in the same order of additions, so the results are
- * bit-identical to the two-call form (and deterministic).  Return value 3 = nothing was launched, make the two calls: the folded form
- * is switched off (env DP_NO_TICKET=1, dp_ticket_enabled() == 0) or cannot serve the case (dgamma / dbeta of an affine INSTANCE
- * normalisation over N > 1 samples need every group's rows).  Arguments as in the calls they replace; `part` is still the scratch.
+/* The partial pass with its finalize folded in: ONE launch instead of two.  Every block writes its partial row with device-scope
+ * (write-through) stores, waits until they are acknowledged (workgroup-scope release fence + s_waitcnt vmcnt(0): NO L2 write-back /
+ * invalidate is issued -- see csrc/norm.hip ticket_is_last) and draws a ticket of its statistics group (device-scope atomicAdd on a
+ * zeroed counter); the block that draws the group's last ticket runs that group's finalize itself, reading the rows with device-scope
+ * loads -- the same code in the same order of additions, so the results are bit-identical to the two-call form (and deterministic).
+ * Counters: eager launches rotate through an internal ring; launches recorded by a stream capture get counters of their own that are
+ * never handed out again (a graph replays them).  Return value 3 = nothing was launched, make the two calls: the folded form
+ * is switched off (env DP_NO_TICKET=1, dp_ticket_enabled() == 0), cannot serve the case (dgamma / dbeta of an affine INSTANCE
+ * normalisation over N > 1 samples need every group's rows), or has no counter to give (first use inside a capture, capture pool
+ * exhausted).  Arguments as in the calls they replace; `part` is still the scratch.
  * replaces: the same reference lines as dp_stats_partial / dp_stats_finalize / dp_norm_act_bwd_partial / dp_norm_bwd_finalize. */
 int dp_ticket_enabled(void);
 int dp_stats_partial_finalize(const void* x, int ld, int N, int64_t V, int C, float* part, int batch_mode, float eps, float* mean,

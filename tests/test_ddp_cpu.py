@@ -32,14 +32,15 @@ class Net(nn.Module):
         return self.b(torch.relu(self.bn(self.a(self.frozen(x))))).sum()
 
 
-def _worker(rank, world, port, out, grad_dtype=torch.float32):
+def _worker(rank, world, port, out, grad_dtype=torch.float32, algo=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from dose_prediction_amd.ddp import attach_gradient_allreduce
     torch.manual_seed(100 + rank)          # different initial weights per rank: the broadcast must fix that
     net = Net()
     keys_before = list(net.state_dict().keys())
-    red = attach_gradient_allreduce(net, bucket_mb=0.002, grad_dtype=grad_dtype)
+    red = attach_gradient_allreduce(net, bucket_mb=0.002, grad_dtype=grad_dtype, algo=algo)
+    assert red.algo == (algo or "allreduce")
     assert list(net.state_dict().keys()) == keys_before
     w0 = net.a.weight.detach().clone()
     res = {"w0": w0}
@@ -186,3 +187,39 @@ def test_bf16_gradient_buckets_gloo():
             assert g16.dtype == torch.float32
             assert torch.equal(g16, out16[1][f"g{step}"][k])
             assert (g16 - g32).abs().max() <= 2 ** -7 * g32.abs().max() + 1e-12, (step, k)
+
+
+def test_reduce_scatter_all_gather_exchange_equals_the_allreduce():
+    """DOSE_DDP_ALGO=rs_ag ("direct reduce-scatter + all-gather across the 7 xGMI links"): every bucket chunk
+    as reduce_scatter_tensor + all_gather_into_tensor instead of one all_reduce.  Two gloo ranks, the chunked bucket (b.weight, larger than
+    a bucket) and odd-sized buckets included (a share that does not divide by the world size leaves a tail that is all-reduced): the
+    averaged gradients are identical on both ranks and equal to the all-reduce path's (fp32: the same two addends in either form, so
+    bit-identical; bf16 buckets: identical too -- one rounding of each rank's contribution, one sum), over two steps and the
+    gradient-less-parameter step; the overlap bookkeeping (every bucket exchanged inside backward from the second pass) is unchanged."""
+    world = 2
+    mgr = mp.Manager()
+    for dt in (torch.float32, torch.bfloat16):
+        out_ar, out_rs = mgr.dict(), mgr.dict()
+        mp.spawn(_worker, args=(world, _free_port(), out_ar, dt, "allreduce"), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, _free_port(), out_rs, dt, "rs_ag"), nprocs=world, join=True)
+        for step in range(2):
+            assert set(out_rs[0][f"g{step}"]) == set(out_ar[0][f"g{step}"])
+            for k, g_ar in out_ar[0][f"g{step}"].items():
+                g_rs = out_rs[0][f"g{step}"][k]
+                assert torch.equal(g_rs, out_rs[1][f"g{step}"][k]), (dt, step, k)
+                assert torch.equal(g_rs, g_ar), (dt, step, k, float((g_rs - g_ar).abs().max()))
+        assert out_rs[0]["launched1"] == out_ar[0]["launched1"]
+
+
+def test_unknown_exchange_algorithm_is_rejected():
+    import pytest
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        from dose_prediction_amd.ddp import attach_gradient_allreduce
+        with pytest.raises(ValueError):
+            attach_gradient_allreduce(nn.Linear(2, 2), algo="ring")
+        red = attach_gradient_allreduce(nn.Linear(2, 2), algo="rs_ag")          # world size 1: share == chunk
+        assert red.algo == "rs_ag"
+    finally:
+        dist.destroy_process_group()

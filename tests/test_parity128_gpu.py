@@ -147,3 +147,76 @@ def test_transeg_128_argmax_exact_off_near_ties(transeg_case, mode):
     assert e < 1e-3
     assert int((mism & safe).sum()) == 0
     assert int(mism.sum()) <= int((~safe).sum())
+
+
+# ------------------------------------------------------------------------------------------------ backward at the benchmark size (round 6)
+BWD_KEYS = [
+    "net_B.dose_convertors.0.0.weight",                                         # the full-resolution head (1x1x1, 16 -> 1)
+    "net_B.decoder.decoder1.conv_block.cov_.conv_7.0.conv.0.weight",           # 7^3 32 -> 16 at 128^3 on the virtual concat: k_wgrad_hk<7>
+    "net_B.decoder.decoder1.conv_block.cov_.conv_7.0.conv.3.weight",           # 7^3 16 -> 16 at 128^3
+    "net_B.decoder.decoder1.conv_block.cov_.conv_3.0.conv.0.weight",           # 3^3 32 -> 16 at 128^3: k_wgrad_hk3
+    "net_B.decoder.decoder1.conv_block.cov_.conv.0.weight",                    # the 1x1x1 mixer: k_wgrad_rows
+    "net_B.decoder.decoder1.transp_conv.conv.weight",                          # ConvTranspose 32 -> 16, 64^3 -> 128^3
+    "net_B.decoder.decoder2.conv_block.cov_.conv_7.0.conv.0.weight",           # 7^3 64 -> 32 at 64^3
+    "net_B.encoder.skip1.layer.conv1.conv.weight",                             # 3^3 25 -> 16 at 128^3 (the first layer of the 128^3 skip block)
+    "net_B.encoder.vit.blocks.0.attn.qkv.weight",                              # the first transformer layer: grouped TN GEMM
+    "net_B.encoder.vit.patch_embedding.patch_embeddings.1.weight",             # K = 102 400 split-K weight gradient, the LAST gradient of the pass
+]
+
+
+def oracle_backward_128(sd, x, gt, keys):
+    """ONE fp32 oracle forward + GenLoss + backward of DOSE-PYFER on a 128^3 volume on the host (net_A frozen as in
+    train_light_pyfer.py:85-88; only `keys` require gradients, so the CPU skips every other weight gradient): loss, gradients."""
+    sdg = {k: v.clone() for k, v in sd.items()}
+    for k in keys:
+        sdg[k].requires_grad_(True)
+    out = oracle.dose_pyfer(sdg, x, num_layers=8, num_heads=6, act="mish", training=True)
+    loss = oracle.gen_loss(out, gt, 10, 1, casecade=True, freez=True)
+    loss.backward()
+    return float(loss.detach()), {k: sdg[k].grad.detach() for k in keys}
+
+
+def test_pyfer_128_fp32x3_backward_matches_oracle(pyfer_case):
+    """Backward parity AT THE BENCHMARK SIZE: one training step's gradients (GenLoss, network_trainer.py:200-213) of
+    B = 1 x 128^3 in fp32x3 against ONE oracle backward() on the host, for ten weight-gradient tensors that together cover the
+    production-only backward branches no 64^3 test reaches end to end: k_wgrad_hk<7> / k_wgrad_hk3 at the full plane count, the XCD
+    renumbering of the 128^3 data-gradient launches that every one of these gradients has passed through, the K = 102 400 split-K
+    patch-embedding gradient (the last gradient of the pass: everything upstream of it is in it), the grouped transformer launch.
+    Tolerance 4e-2 relative L2 per tensor: the default fp32x3 backward is ONE bf16 product per contraction (the
+    whole gradient vector sits at 1.07e-2 of float64 at 64^3, single Linear tensors at 1.6-1.85e-2, and the exact-fp32 mode itself at
+    4.2e-3 -- ReLU / LeakyReLU gates of pre-activations within round-off of zero); a wrong tile decode, a dropped halo or a lost split-K
+    share is an O(1) error.  The loss value is compared too (1e-4)."""
+    import dose_prediction_amd
+    from dose_prediction_amd import losses
+    from dose_prediction_amd.models.dose_pyfer import Model
+    import time
+    sd, x, gt, _, _ = pyfer_case
+    dev = _dev()
+    t0 = time.time()
+    ref_loss, ref = oracle_backward_128(sd, x, gt, BWD_KEYS)
+    t_or = time.time() - t0
+    dose_prediction_amd.set_compute_dtype("fp32x3")
+    net = Model(in_ch=9, out_ch=1, list_ch_A=[-1, 16, 32, 64, 128, 256], feature_size=16, img_size=FULL, num_layers=8, num_heads=6,
+                act="mish", mode_multi_dec=True, multiS_conv=True)
+    net.load_state_dict(sd)
+    for n, p in net.named_parameters():
+        if "net_A" in n or "conv_out_A" in n:
+            p.requires_grad = False
+    net = net.to(dev).train()
+    out = net(x.to(dev))
+    loss = losses.gen_loss(out, gt.to(dev), 10.0, 1.0, casecade=True, freez=True)
+    loss.backward()
+    torch.cuda.synchronize()
+    named = dict(net.named_parameters())
+    errs = {}
+    for k in BWD_KEYS:
+        g, r = named[k].grad.detach().double().cpu().reshape(-1), ref[k].double().reshape(-1)
+        errs[k] = float((g - r).norm() / r.norm())
+    print(f"[parity128] backward fp32x3 vs oracle ({t_or:.0f} s on the host): loss {float(loss):.6f} vs {ref_loss:.6f}; "
+          + ", ".join(f"{k.split('net_B.')[-1]} {e:.2e}" for k, e in errs.items()))
+    got_loss = float(loss.detach())
+    del net, out, loss
+    torch.cuda.empty_cache()
+    assert abs(got_loss - ref_loss) < 1e-4 * abs(ref_loss), (got_loss, ref_loss)
+    worst = max(errs.items(), key=lambda kv: kv[1])
+    assert worst[1] < 4e-2, worst

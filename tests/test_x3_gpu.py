@@ -439,31 +439,68 @@ def test_x3_packs_follow_fused_adam():
     check("linear after two Adam steps", ops.linear(t, lw), torch.nn.functional.linear(t.cpu().double(), lw.detach().cpu().double()))
 
 
-@pytest.mark.parametrize("name,args", [
+X3_GOLDEN_CASES = [
     ("test_g1_base_unet", ()), ("test_g2_conv_3_1", ("relu",)), ("test_g2_conv_3_1", ("mish",)), ("test_g2_conv_3_1_old_and_dual", ()),
     ("test_g4_c3d_cascade", ()), ("test_g7_subset", ("multi", dict(mode_multi_dec=True, multiS_conv=True))),
     ("test_g7_subset", ("plain", dict(mode_multi_dec=False))), ("test_g7_pyfer_model", ()), ("test_g7_transeg", ("new",)),
-    ("test_g7_transeg", ("old",))])
-def test_reference_goldens_in_x3_mode(name, args, monkeypatch):
+    ("test_g7_transeg", ("old",))]
+
+
+def x3_case_id(name, args):
+    return name[5:] + ("/" + str(args[0]) if args else "")
+
+
+def _x3_atomic_tolerances(cid):
+    """Gradient tolerances of one golden gate in the fp32x3 mode with the DEFAULT (atomic) reductions: max(1e-2, 1.5 x the largest value
+    MEASURED over 200 passes on an MI355X) for the input gradient and for the worst parameter gradient
+    (tests/golden/x3_atomic_spread.json, written by tools/golden_spread.py), next to the band the float64 oracle predicts for the same
+    arithmetic (tests/golden/grad_bands.json, mode "x3", written by tests/golden/make_grad_bands.py).  No retry: a pass outside
+    1.5 x the widest of 200 measured passes fails."""
+    import json
+    import os
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    with open(os.path.join(gdir, "x3_atomic_spread.json")) as f:
+        m = json.load(f).get(cid, {}).get("fp32x3")
+    with open(os.path.join(gdir, "grad_bands.json")) as f:
+        bands = json.load(f)
+    nc = cid.replace("/", "_")
+    band = max((v["x3"]["gx"] for k, v in bands.items()
+                if not k.startswith("_") and (k.replace("/", "_") == nc or nc.startswith(k.replace("/", "_")))), default=None)
+    if m is None:
+        return 1e-2, 1e-2, band
+    return max(1e-2, 1.5 * m["gx_max"]), max(1e-2, 1.5 * m["param_max"]), band
+
+
+@pytest.mark.parametrize("det", [True, False], ids=["det", "atomic"])
+@pytest.mark.parametrize("name,args", X3_GOLDEN_CASES, ids=[x3_case_id(n, a) for n, a in X3_GOLDEN_CASES])
+def test_reference_goldens_in_x3_mode(name, args, det, monkeypatch):
     """Every golden-vector network test of test_models_gpu.py (reference-generated G1, G2, G4; reference wiring G7), re-run with the
     parity mode replaced by fp32x3: the same 1e-3 tolerance on every output and the same arg-max exactness off near-ties.
     Gradients: 1e-2 instead of 2e-3 relative L2.  A forward perturbation of 4e-6 per layer (x3) instead of 3e-7 (exact fp32) flips the
     ReLU gate of the few pre-activations that lie that close to zero; every flipped gate changes the gradient field around it by
     O(1), so on these tiny networks (32 x 16 x 16 voxels, 4-16 channels) the gradient error is sqrt(#flips / #elements) ~ 2e-3
     (measured on G1: output 1.9e-5, input gradient 2.1e-3; tools/x3_error_probe.py) although every single operator is accurate
-    to 4.4e-6.  The production-width check is test_x3_pyfer_full_width_64_meets_the_north_star_tolerance."""
+    to 4.4e-6.  The production-width check is test_x3_pyfer_full_width_64_meets_the_north_star_tolerance.
+
+    Both reduction modes, no retry.  "det": config.set_deterministic(True), every reduction in a fixed
+    order, two passes bit-identical (tests/test_round5_gpu.py: 1000 of 1000 on the G7 subset network), gate 1e-2.  "atomic": the default
+    the benchmark runs -- every pass of a bf16-operand backward is a different, equally valid rounding (about one pass in a hundred of the
+    G7 subset network lands 1e-2 away from the others: two fp32 atomic additions near the output retiring in the other order, amplified
+    1e5 x by the batch-statistics BatchNorm backward of its 4-8-channel 16 x 8 x 8 level: tools/x3_event_bisect.py,
+    tools/determinism_probe.py), so its gate is the measured width of that distribution (_x3_atomic_tolerances)."""
     import dose_prediction_amd
     import test_models_gpu as M
     monkeypatch.setattr(M, "_set", lambda dtype: dose_prediction_amd.set_compute_dtype("fp32x3" if dtype == torch.float32 else dtype))
     orig = M._check_grads
-    monkeypatch.setattr(M, "_check_grads", lambda mod, gold, tol=1e-2: orig(mod, gold, max(tol, 1e-2)))
-    monkeypatch.setattr(M, "GRAD_TOL", 1e-2)
-    # No retry (VERDICT r4 item 2): the pass runs under config.set_deterministic(True), where every reduction has a fixed order and two
-    # passes are bit-identical (tests/test_round5_gpu.py: 1000 of 1000 on the G7 subset network).  Rounds 3-4 wrapped this call in a
-    # three-attempt loop because about one backward pass in a hundred of that network landed on a second result (two fp32 atomic
-    # additions near the output retiring in the other order, amplified 1e5 x by the batch-statistics BatchNorm backward of its
-    # 4-8-channel 16 x 8 x 8 level: tools/x3_event_bisect.py, tools/determinism_probe.py).
-    with dose_prediction_amd.config.deterministic_as(True):
+    if det:
+        gx_tol = p_tol = 1e-2
+    else:
+        gx_tol, p_tol, band = _x3_atomic_tolerances(x3_case_id(name, args))
+        print(f"[x3 atomic] {x3_case_id(name, args)}: input-gradient gate {gx_tol:.2e}, parameter gate {p_tol:.2e}"
+              + (f"; the oracle's predicted input-gradient band {band:.2e}" if band is not None else ""))
+    monkeypatch.setattr(M, "_check_grads", lambda mod, gold, tol=p_tol: orig(mod, gold, max(tol, p_tol)))
+    monkeypatch.setattr(M, "GRAD_TOL", gx_tol)
+    with dose_prediction_amd.config.deterministic_as(det):
         getattr(M, name)(*args)
     assert dose_prediction_amd.compute_mode() == "fp32x3"
 
