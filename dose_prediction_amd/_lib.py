@@ -49,8 +49,16 @@ class DoseHipError(RuntimeError):
     pass
 
 
+_FN = {}            # entry point name -> the callable call() uses (fast binding when built, else the ctypes function)
+BINDING = None      # "fastcall" | "ctypes" once lib() has run
+
+
 def lib():
-    global _lib
+    """The loaded library as an object with one attribute per entry point of include/dose_hip.h.  The symbols are always resolved
+    through ctypes first (a declared but missing symbol raises AttributeError); calls then go through the generated METH_FASTCALL
+    module (dose_prediction_amd/_fastgen.py: ~0.3 us per call instead of 4-6 us of ctypes argument conversion -- the launch thread
+    makes ~1 300 calls per training step) when it has been built, unless DOSE_HIP_CTYPES=1."""
+    global _lib, BINDING
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise DoseHipError(
@@ -60,7 +68,27 @@ def lib():
         for name, (restype, argtypes, _) in PROTOS.items():
             fn = getattr(L, name)          # AttributeError if the .so does not export a declared symbol
             fn.restype, fn.argtypes = restype, argtypes
-        _lib = L
+        fast = None
+        if not os.environ.get("DOSE_HIP_CTYPES"):
+            try:
+                from . import _dose_fastcall as fast
+                fast.bind(LIB_PATH)
+                if any(not hasattr(fast, name) for name in PROTOS):
+                    raise ImportError("built from another version of include/dose_hip.h")
+            except ImportError as e:
+                import warnings
+                warnings.warn(f"dose_prediction_amd: fast C binding unavailable ({e}); calling the library through ctypes "
+                              "(same results, ~5 ms more host time per training step) -- run __graft_entry__.build()")
+                fast = None
+        if fast is not None:
+            import types
+            ns = types.SimpleNamespace(**{name: getattr(fast, name) for name in PROTOS})
+            ns._cdll = L
+            _FN.update({name: getattr(fast, name) for name in PROTOS})
+            _lib, BINDING = ns, "fastcall"
+        else:
+            _FN.update({name: getattr(L, name) for name in PROTOS})
+            _lib, BINDING = L, "ctypes"
     return _lib
 
 
@@ -78,16 +106,19 @@ SOFT_DECLINE = ("dp_tconv2x_fwd", "dp_stats_partial_finalize", "dp_norm_act_bwd_
 
 def call(name, *args):
     """Call an int-returning entry point; raise DoseHipError(dp_last_error()) on a non-zero status (3 is returned for SOFT_DECLINE names)."""
-    L = lib()
+    fn = _FN.get(name)
+    if fn is None:
+        lib()
+        fn = _FN[name]
     if PROFILE is not None and name in PROFILE_NAMES:
         import torch
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        rc = getattr(L, name)(*args)
+        rc = fn(*args)
         e1.record()
         PROFILE.append((name, args, e0, e1))
     else:
-        rc = getattr(L, name)(*args)
+        rc = fn(*args)
     if rc != 0 and not (rc == 3 and name in SOFT_DECLINE):
-        raise DoseHipError(f"{name} failed (rc={rc}): {L.dp_last_error().decode()}")
+        raise DoseHipError(f"{name} failed (rc={rc}): {_FN['dp_last_error']().decode()}")
     return rc

@@ -281,9 +281,13 @@ def side_streams_allowed():
     return _capture_side_streams or not torch.cuda.is_current_stream_capturing()
 
 
+_capture_branch = os.environ.get("DOSE_HIP_CAPTURE_BRANCH", "0") == "1"      # (experiment: keep the branch stream inside a capture)
+
+
 def branch_stream_allowed():
-    """The 3x3x3 branch / small-block stream: never inside a capture (see set_capture_side_streams)."""
-    return not torch.cuda.is_current_stream_capturing()
+    """The 3x3x3 branch / small-block stream: never inside a capture (see set_capture_side_streams), unless DOSE_HIP_CAPTURE_BRANCH=1
+    asks for the experiment (tools/r06_graph_repro.sh)."""
+    return _capture_branch or not torch.cuda.is_current_stream_capturing()
 
 
 _deterministic = 0

@@ -59,7 +59,17 @@ template <typename R> constexpr bool role_row_live(int r, int cc, int KS, int CW
   return false;
 }
 
-template <typename T, int KS>
+// BUF (round 6): the tile prefetch as BUFFER loads woven into the sweep.  Wave-cycle counters of the round-2 form (profiles/r06_a_wgrad_hk_stalls.md):
+// the prefetch of a tile is ~20 VALU + ~10 SALU per 16-byte piece (a division by 38 for the piece's halo coordinates, four bounds
+// compares, a 64-bit address, four v_cndmask to zero an out-of-volume piece) -- 4.2e7 VALU per launch next to 4.3e7 MFMAs -- issued as ONE
+// block between two barriers, where the matrix pipe has nothing to do: without staging the kernel is 20 % faster (MFMA-busy 55 -> 69 %).
+// Now (a) a thread owns a COLUMN of the halo tile (piece, column lc, row group r of 3) and walks rows r, r + 3, ...: every piece is the
+// previous offset + 3 rows, every LDS write an immediate offset; (b) the loads go through a buffer descriptor of the PLANE
+// (num_records = H * W * ld bytes), so rows above / below the volume are out of range by unsigned wrap-around and come back as zeros
+// from the hardware -- no compare, no select; a column outside the volume (or a channel piece beyond the tensor) parks the thread's
+// base offset at 2^31; (c) with 1-2 VALU per piece the 21 pieces of the NEXT tile are issued one per column step inside the sweep.
+// Needs a block-uniform source tensor: virtual concats split on a multiple of 16 channels (else BUF = false, the round-2 form).
+template <typename T, int KS, bool BUF>
 __global__ void __launch_bounds__(256, 2) k_wgrad_hk(const T* __restrict__ x, const T* __restrict__ gy, float* __restrict__ dwt, WgHkGeom g) {
   static_assert(sizeof(T) == 2, "16-bit storage types only");
   using C = HkCfg<T, KS>;
@@ -146,13 +156,69 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_hk(const T* __restrict__ x, co
 #pragma unroll
     for (int j = 0; j < PG; j++) *(v4u*)(gs + ((4 * j + g_r) * C::GP + g_c) * C::GC + piece * 8) = rg[j];
   };
+  // ---- BUF staging (see the kernel's header comment)
+  constexpr int RG3 = 3, PXB = (C::LR + RG3 - 1) / RG3;                    // 13 x pieces per thread (the last one only for row groups 0, 1)
+  static_assert(!BUF || (2 * C::LC * RG3 <= 256 && PG * 4 == C::TH), "thread map of the buffer-load staging");
+  v4u bx[PXB], bg[PG];
+  const int b_t2 = tid >> 1, b_rg = b_t2 / C::LC, b_lc = b_t2 - b_rg * C::LC;
+  const bool b_xsecond = g.x2 && mt * C::XC >= g.csplit;                   // block-uniform (csplit % 16 == 0)
+  const T* const b_xsrc = b_xsecond ? (const T*)g.x2 : x;
+  const int b_ldx = b_xsecond ? g.ldx2 : g.ldx, b_c0 = mt * C::XC - (b_xsecond ? g.csplit : 0) + piece * 8;
+  const bool b_xthr = b_rg < RG3 && b_c0 + 8 <= b_ldx;
+  const unsigned b_cx = (unsigned)(((b_rg * g.W + b_lc) * b_ldx + b_c0) * 2), b_xrow3 = (unsigned)(RG3 * g.W * b_ldx * 2);
+  const unsigned b_cg = (unsigned)(((g_r * g.W + g_c) * g.ldgy + nt * C::GC + piece * 8) * 2), b_grow4 = (unsigned)(4 * g.W * g.ldgy * 2);
+  const unsigned b_xbytes = (unsigned)(g.H * g.W * b_ldx * 2), b_gbytes = (unsigned)(g.H * g.W * g.ldgy * 2);
+  // LDS home of the thread's x pieces: + k * RG3 * LP * XC (immediate).  The 28 threads without a column (row group 3) write their
+  // zeros into the PAD column (lc = LC, never read: the row pitch is LC | 1) of rows 0, 3, ...: no branch in the commit -- a skipped
+  // commit is a path on which the loads are never waited for, and the waitcnt pass then stalls the sweep on them
+  static_assert(C::LP > C::LC, "the pad column takes the idle threads' writes");
+  T* const b_xl = xs + ((b_rg < RG3 ? b_rg : 0) * C::LP + (b_rg < RG3 ? b_lc : C::LC)) * C::XC + piece * 8;
+  T* const b_xl_last = (b_rg * 1 + (PXB - 1) * RG3 < C::LR || b_rg >= RG3) ? b_xl + (PXB - 1) * RG3 * C::LP * C::XC
+                                                                          : xs + C::LC * C::XC + piece * 8;      // (row 38 does not exist: pad column of row 0)
+  T* const b_gl = gs + (g_r * C::GP + g_c) * C::GC + piece * 8;            // + j * 4 * GP * GC
+  auto rsrc_of = [](const T* base, unsigned bytes) {
+    // (descriptor inputs made provably wave-uniform: a descriptor the compiler believes divergent is wrapped in a waterfall loop per load)
+    const uint64_t a = (uint64_t)(uintptr_t)base;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)(((uint64_t)hi << 32) | lo), 0, (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+  };
+  struct BufTile { __amdgpu_buffer_rsrc_t rx, rg; unsigned vx, vg; };
+  auto buf_tile = [&](const Tile& t, bool live) {
+    BufTile b;
+    b.rx = rsrc_of(b_xsrc + (((int64_t)t.n * g.D + t.id) * g.H) * (int64_t)g.W * b_ldx, b_xbytes);
+    b.rg = rsrc_of(gy + (((int64_t)t.n * g.D + t.d) * g.H) * (int64_t)g.W * g.ldgy, b_gbytes);
+    const int ihb = t.h0 - C::PAD, iwb = t.w0 - C::PAD;
+    const unsigned sx = (unsigned)((ihb * g.W + iwb) * b_ldx * 2), sg = (unsigned)((t.h0 * g.W + t.w0) * g.ldgy * 2);
+    const bool xok = live && b_xthr && (unsigned)(iwb + b_lc) < (unsigned)g.W, gok = live && g_exists && t.w0 + g_c < g.W;
+    b.vx = xok ? b_cx + sx : 0x80000000u;       // rows above the volume: negative -> wraps beyond num_records -> zeros from the hardware
+    b.vg = gok ? b_cg + sg : 0x80000000u;
+    return b;
+  };
+  auto buf_issue_x = [&](const BufTile& b, auto k_) {
+    constexpr int k = decltype(k_)::value;
+    unsigned v = b.vx + (unsigned)k * b_xrow3;
+    if constexpr (k * RG3 + RG3 > C::LR) { if (k * RG3 + b_rg >= C::LR) v = 0x80000000u; }      // (row 38 of row group 2 does not exist)
+    bx[k] = __builtin_bit_cast(v4u, __builtin_amdgcn_raw_buffer_load_b128(b.rx, v, 0, 0));
+  };
+  auto buf_issue_g = [&](const BufTile& b, auto j_) {
+    constexpr int j = decltype(j_)::value;
+    bg[j] = __builtin_bit_cast(v4u, __builtin_amdgcn_raw_buffer_load_b128(b.rg, b.vg + (unsigned)j * b_grow4, 0, 0));
+  };
+  auto buf_commit = [&]() {
+    static_for<0, PXB>([&](auto k_) {
+      constexpr int k = decltype(k_)::value;
+      if constexpr (k == PXB - 1) *(v4u*)b_xl_last = bx[k];
+      else *(v4u*)(b_xl + k * RG3 * C::LP * C::XC) = bx[k];
+    });
+    static_for<0, PG>([&](auto j_) { constexpr int j = decltype(j_)::value; *(v4u*)(b_gl + j * 4 * C::GP * C::GC) = bg[j]; });
+  };
   // one tile: the wave walks over the STEPS x columns of the tile's CW gy columns; everything below is static after unrolling.
   // Software pipeline with (almost) no second buffers -- the kernel sits at the 256-VGPR limit of two waves per SIMD, and a
   // spilled register costs an s_waitcnt vmcnt(0) in front of the tile prefetch: the gy fragment of column cc+1 is requested at
   // the start of step cc (ring of KS+1), an x row requests its next column right after its own last MFMA of the step, i.e. the
   // other rows' 6-9 MFMAs (100-150 cycles) before its first use; only RoleLast's 7-tap row, which has just three MFMAs of other
   // rows behind it, keeps two buffers (that role has three accumulators fewer).
-  auto sweep = [&]<typename R>(R) {
+  auto sweep = [&]<typename R, typename H>(R, H&& hook) {
     Frag8<T> X[R::NR], Xd[2], G[KS + 1];
     auto ldx = [&](auto r_, auto cc_) {
       constexpr int r = decltype(r_)::value, cc = decltype(cc_)::value;
@@ -172,6 +238,7 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_hk(const T* __restrict__ x, co
       constexpr std::integral_constant<int, cc + 1> nx{};
       ldg(nx);
       static_for<0, R::NR>([&](auto r_) { if constexpr (R::dbuf(decltype(r_)::value)) ldx(r_, nx); });
+      hook(cc_);                           // (BUF: one piece of the next tile's prefetch per column step)
       __builtin_amdgcn_sched_barrier(0);
       static_for<0, R::NR>([&](auto r_) {
         constexpr int r = decltype(r_)::value;
@@ -194,15 +261,51 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_hk(const T* __restrict__ x, co
   int cu = u0;
   while (cu < u1 && !tile_ok(cu)) cu++;
   const bool nostage = g.dbg & 1, nosweep = g.dbg & 2;               // experiments only (env DP_DBG)
-  if (cu < u1 && !nostage) issue(tile_of(cu));
-  while (cu < u1) {
-    lds_barrier();
-    if (!nostage) commit();
-    const int nu = next_ok(cu);
-    if (nu < u1 && !nostage) issue(tile_of(nu));
-    lds_barrier();
-    if (!nosweep) { if (last_role) sweep(RoleLast{}); else sweep(RolePair{}); }
-    cu = nu;
+  auto nohook = [](auto) {};
+  if constexpr (BUF) {
+    // (DP_DBG bit 0, "no staging", parks the offsets out of range instead of skipping code: every load is still issued and every
+    // commit still runs, so the compiler sees ONE path on which each load is waited for exactly once -- with the commit under a runtime
+    // condition its waitcnt pass had to assume loads still in flight at the top of the sweep and stalled the column walk on vmcnt)
+    if (cu < u1) {
+      const BufTile b = buf_tile(tile_of(cu), !nostage);
+      static_for<0, PXB>([&](auto k_) { buf_issue_x(b, k_); });
+      static_for<0, PG>([&](auto j_) { buf_issue_g(b, j_); });
+    }
+    while (cu < u1) {
+      lds_barrier();
+      buf_commit();
+      const int nu = next_ok(cu);
+      // (no next tile: every offset parked out of range -- the loads come back as zeros without touching memory)
+      const BufTile b = buf_tile(tile_of(nu < u1 ? nu : cu), nu < u1 && !nostage);
+      // two pieces per column step from step 0 (x 0..12, then gy 0..7): the last request leaves at step 10 of 38, ~350 MFMAs (2.7 us)
+      // before the commit asks for it -- with one piece per step up to step 25 the commit still waited on the tail (MFMA-busy 59.9 %)
+      auto piece_at = [&](auto p_) {
+        constexpr int pc = decltype(p_)::value;
+        if constexpr (pc < PXB) buf_issue_x(b, std::integral_constant<int, pc>{});
+        else if constexpr (pc < PXB + PG) buf_issue_g(b, std::integral_constant<int, pc - PXB>{});
+      };
+      auto hook = [&](auto cc_) {
+        constexpr int cc = decltype(cc_)::value;
+        piece_at(std::integral_constant<int, 2 * cc>{});
+        piece_at(std::integral_constant<int, 2 * cc + 1>{});
+      };
+      lds_barrier();
+      // (DP_DBG bit 1, "no sweep": nothing is issued either -- a second code path with 21 loads in flight falls through, in the CFG, into
+      // the sweep and makes the waitcnt pass stall the column walk on loads that are never pending there)
+      if (!nosweep) { if (last_role) sweep(RoleLast{}, hook); else sweep(RolePair{}, hook); }
+      cu = nu;
+    }
+  } else {
+    if (cu < u1 && !nostage) issue(tile_of(cu));
+    while (cu < u1) {
+      lds_barrier();
+      if (!nostage) commit();
+      const int nu = next_ok(cu);
+      if (nu < u1 && !nostage) issue(tile_of(nu));
+      lds_barrier();
+      if (!nosweep) { if (last_role) sweep(RoleLast{}, nohook); else sweep(RolePair{}, nohook); }
+      cu = nu;
+    }
   }
   if (g.dbg & 4) return;
   // C/D of the 16x16 MFMA: col (co) = lane&15, row (ci) = 4*(lane>>4) + e
@@ -229,10 +332,20 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_hk(const T* __restrict__ x, co
   if (last_role) flush(RoleLast{}); else flush(RolePair{});
 }
 
+template <typename T, int KS, bool BUF>
+int launch_hk_impl(const void* x, const void* gy, float* ws, WgHkGeom g, hipStream_t s);
 template <typename T, int KS>
 int launch_hk(const void* x, const void* gy, float* ws, WgHkGeom g, hipStream_t s) {
+  // buffer-load staging (BUF) needs a block-uniform source tensor, 32-bit plane offsets and 16-byte aligned rows; DP_HK_BUF=0: the round-2 form
+  static const int buf_env = [] { const char* e = getenv("DP_HK_BUF"); return e ? atoi(e) : 1; }();
+  const int64_t xplane = (int64_t)g.H * g.W * (g.ldx > g.ldx2 ? g.ldx : g.ldx2) * 2, gplane = (int64_t)g.H * g.W * g.ldgy * 2;
+  const bool buf = buf_env && (!g.x2 || g.csplit % 16 == 0) && xplane < (1LL << 30) && gplane < (1LL << 30);
+  return buf ? launch_hk_impl<T, KS, true>(x, gy, ws, g, s) : launch_hk_impl<T, KS, false>(x, gy, ws, g, s);
+}
+template <typename T, int KS, bool BUF>
+int launch_hk_impl(const void* x, const void* gy, float* ws, WgHkGeom g, hipStream_t s) {
   using C = HkCfg<T, KS>;
-  auto kern = k_wgrad_hk<T, KS>;
+  auto kern = k_wgrad_hk<T, KS, BUF>;
   static bool raised = false;
   if (!raised) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::SMEM);

@@ -2490,3 +2490,24 @@ def dose_postprocess(pred, mask, scale=70.0):
     out = torch.empty_like(pred)
     _lib.call("dp_dose_postprocess", _p(pred), _p(mask), _p(out), pred.numel(), float(scale), _stream())
     return out
+
+
+# ------------------------------------------------------------------------------------------------ launch-thread economy
+def _direct_apply():
+    """torch.autograd.Function.apply is a PYTHON classmethod: it binds default arguments for setup_context-style Functions, asks functorch
+    whether a transform is active and walks every argument through _functorch.utils.unwrap_dead_wrappers before it reaches the C++
+    THPFunction_apply (3-4 us per call; ~380 applications per training step, tools/host_profile.py).  None of that applies here (no
+    setup_context, no functorch transforms over raw-pointer kernels), so every Function of this module calls the C++ entry point directly:
+    same autograd graph, same results.  DOSE_HIP_PY_APPLY=1 keeps the Python classmethod (A/B)."""
+    if os.environ.get("DOSE_HIP_PY_APPLY"):
+        return
+    base = torch.autograd.Function
+    for obj in list(globals().values()):
+        if isinstance(obj, type) and issubclass(obj, base) and obj is not base and "apply" not in obj.__dict__:
+            try:
+                obj.apply = super(base, obj).apply
+            except Exception:      # (a torch build without the C classmethod: keep the stock path)
+                return
+
+
+_direct_apply()

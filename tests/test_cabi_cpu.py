@@ -77,3 +77,30 @@ def test_state_dict_contract():
     # frozen-net_A filtering by substring works as in train_light_pyfer.py:85-88
     frozen = [k for k, _ in m.named_parameters() if "net_A" in k or "conv_out_A" in k]
     assert len(frozen) == 86      # 84 net_A tensors + conv_out_A.{weight,bias}
+
+
+def test_ticket_fences_do_not_touch_the_l2(tmp_path):
+    """The folded statistics finalize (csrc/norm.hip ticket_is_last) orders row stores -> ticket -> row loads with WORKGROUP-scope
+    release / acquire fences (compiler-level ordering) around device-scope atomic accesses.  On gfx950 those fences must
+    lower to s_waitcnt only: an agent-scope fence is `buffer_wbl2 sc1` / `buffer_inv sc1`, a write-back / invalidate of the XCD's whole L2
+    under the convolutions running beside these kernels (measured: 23.4 -> 28.8 ms per step).  Checked in the ISA of the shipped library:
+    the code object that holds the statistics kernels contains the tickets' atomic adds and no L2 maintenance instruction."""
+    import glob
+    import shutil
+    import subprocess
+    from dose_prediction_amd import _lib
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not available")
+    so = shutil.copy(_lib.LIB_PATH, tmp_path / "lib.so")
+    subprocess.run([objdump, "--offloading", str(so)], check=True, capture_output=True, cwd=tmp_path)
+    found = False
+    for co in sorted(glob.glob(str(tmp_path / "lib.so.*gfx950"))):
+        syms = subprocess.run([objdump, "-t", co], capture_output=True, text=True).stdout
+        if "k_stats_partial" not in syms:
+            continue
+        found = True
+        isa = subprocess.run([objdump, "-d", co], capture_output=True, text=True, check=True).stdout
+        assert isa.count("global_atomic_add") >= 5, "the ticket draws (three storage types of k_stats_partial + the backward partial kernels)"
+        assert "buffer_wbl2" not in isa and "buffer_inv" not in isa, "an L2 write-back / invalidate crept into the normalisation kernels"
+    assert found, "no gfx950 code object with k_stats_partial in the library"

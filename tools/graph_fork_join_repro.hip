@@ -1,0 +1,75 @@
+// Stand-alone reproduction attempt of the hipStreamEndCapture crash seen when the training step is captured WITH the 3x3x3 branch stream
+// (dose_prediction_amd/config.py set_capture_side_streams).  No torch: plain HIP runtime, one trivial kernel.
+//
+// The step's stream graph during a capture on stream A (what the package and the autograd engine do):
+//   * branch stream B: forked from A (event on A, B waits), a few kernels on B beside kernels on A, joined (event on B, A waits) -- once per
+//     multi-scale block in the forward pass and again (by the autograd engine) in the backward pass: ~30 fork / join pairs per step;
+//   * weight-gradient stream W: forked from WHICHEVER stream runs the convolution's backward node -- A or B -- with a fresh event per fork
+//     (~80 per step), never joined to its origin but only to A, ONCE, at the end of the backward pass ("cross join": W's work forked from B
+//     is joined into A directly, B itself is joined into A separately);
+//   * transformer stream V: one long fork from A, joined near the end.
+// usage: graph_fork_join_repro <pattern> <pairs> <mode> [reuse_events]
+//   pattern 0: A <-> B fork / join pairs only
+//   pattern 1: + W forked from A each pair, joined to A once at the end
+//   pattern 2: + W forked from B (inside the pair), joined to A once at the end           (the shipped configuration's shape)
+//   pattern 3: pattern 2, but W is ALSO joined to B before B joins A (every fork joins its origin)
+//   pattern 4: pattern 2 with the join of B into A BEFORE W's work is enqueued on W from B's event (B's join does not cover W)
+//   mode 0 global, 1 thread-local, 2 relaxed;  reuse_events 1: one event object per edge kind re-recorded every pair (default: fresh events)
+// Prints one line: "<pattern> <pairs> <mode> <reuse>: nodes=<n> OK" or the failing call; a crash shows as the shell's exit status.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s -> %s\n", #x, hipGetErrorString(e_)); fflush(stdout); return 2; } } while (0)
+
+__global__ void k_touch(float* p, int n) { int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] += 1.0f; }
+
+int main(int argc, char** argv) {
+  const int pattern = argc > 1 ? atoi(argv[1]) : 2, pairs = argc > 2 ? atoi(argv[2]) : 30, mode = argc > 3 ? atoi(argv[3]) : 0;
+  const int reuse = argc > 4 ? atoi(argv[4]) : 0;
+  hipStream_t A, B, W;
+  CK(hipStreamCreateWithFlags(&A, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&B, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&W, hipStreamNonBlocking));
+  float* buf; const int n = 1 << 16;
+  CK(hipMalloc(&buf, 4 * n * sizeof(float))); CK(hipMemset(buf, 0, 4 * n * sizeof(float)));
+  std::vector<hipEvent_t> evs;
+  hipEvent_t shared[4];
+  for (auto& e : shared) CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  auto ev = [&](int kind) -> hipEvent_t {
+    if (reuse) return shared[kind];
+    hipEvent_t e; if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) exit(3);
+    evs.push_back(e); return e;
+  };
+  auto launch = [&](hipStream_t s, int slot) { hipLaunchKernelGGL(k_touch, dim3(n / 256), dim3(256), 0, s, buf + slot * n, n); };
+  const hipStreamCaptureMode cm = mode == 0 ? hipStreamCaptureModeGlobal : mode == 1 ? hipStreamCaptureModeThreadLocal : hipStreamCaptureModeRelaxed;
+  CK(hipStreamBeginCapture(A, cm));
+  bool w_used = false;
+  for (int i = 0; i < pairs; i++) {
+    hipEvent_t f = ev(0);
+    CK(hipEventRecord(f, A)); CK(hipStreamWaitEvent(B, f, 0));                 // fork A -> B
+    launch(B, 1);
+    if (pattern == 1) { hipEvent_t g = ev(1); CK(hipEventRecord(g, A)); CK(hipStreamWaitEvent(W, g, 0)); launch(W, 2); w_used = true; }
+    if (pattern == 2 || pattern == 3) { hipEvent_t g = ev(1); CK(hipEventRecord(g, B)); CK(hipStreamWaitEvent(W, g, 0)); launch(W, 2); w_used = true; }
+    hipEvent_t g4 = nullptr;
+    if (pattern == 4) { g4 = ev(1); CK(hipEventRecord(g4, B)); }
+    launch(A, 0);
+    launch(B, 1);
+    if (pattern == 3) { hipEvent_t h = ev(2); CK(hipEventRecord(h, W)); CK(hipStreamWaitEvent(B, h, 0)); }
+    hipEvent_t j = ev(3);
+    CK(hipEventRecord(j, B)); CK(hipStreamWaitEvent(A, j, 0));                 // join B -> A
+    if (pattern == 4) { CK(hipStreamWaitEvent(W, g4, 0)); launch(W, 2); w_used = true; }
+    launch(A, 0);
+  }
+  if (w_used) { hipEvent_t j = ev(2); CK(hipEventRecord(j, W)); CK(hipStreamWaitEvent(A, j, 0)); }      // the one join of W, into A
+  hipGraph_t graph;
+  CK(hipStreamEndCapture(A, &graph));
+  size_t nodes = 0; CK(hipGraphGetNodes(graph, nullptr, &nodes));
+  hipGraphExec_t exec;
+  CK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+  CK(hipGraphLaunch(exec, A)); CK(hipGraphLaunch(exec, A));
+  CK(hipStreamSynchronize(A));
+  float h[4];
+  for (int s = 0; s < 3; s++) CK(hipMemcpy(&h[s], buf + s * n, sizeof(float), hipMemcpyDeviceToHost));
+  printf("pattern %d pairs %d mode %d reuse %d: nodes=%zu OK (counts %.0f %.0f %.0f)\n", pattern, pairs, mode, reuse, nodes, h[0], h[1], h[2]);
+  return 0;
+}

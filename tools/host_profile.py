@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """Host-side cost of one DOSE-PYFER training step (the launch thread must stay ahead of the GPU): cProfile over 10 steps, top functions
-by own time, with and without the data-parallel reducer (1-rank RCCL).  usage: tools/host_profile.py [ddp]"""
+by own time, with and without the data-parallel reducer (1-rank RCCL).  The autograd engine walks a CUDA graph on a worker thread of
+its own, which cProfile does not see (the whole backward pass shows up as run_backward's own time): the second table profiles the same steps
+with torch.autograd.set_multithreading_enabled(False), i.e. the backward functions on the calling thread.
+usage: tools/host_profile.py [ddp]"""
 import cProfile
 import os
 import pstats
@@ -81,3 +84,27 @@ pr.disable()
 torch.cuda.synchronize()
 st = pstats.Stats(pr)
 st.sort_stats("tottime").print_stats(45)
+print("\n==== the same with the backward pass on the calling thread (torch.autograd.set_multithreading_enabled(False)) ====")
+from dose_prediction_amd import _lib
+print("binding:", _lib.BINDING)
+with torch.autograd.set_multithreading_enabled(False):
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(6):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        step()
+        ts.append(1e3 * (time.perf_counter() - t0))
+    torch.cuda.synchronize()
+    print("host enqueue time per step, single-threaded backward: " + " ".join(f"{t:.1f}" for t in ts) + " ms")
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(10):
+        step()
+    pr.disable()
+    torch.cuda.synchronize()
+st = pstats.Stats(pr)
+st.sort_stats("tottime").print_stats(60)
+st.sort_stats("cumtime").print_stats(60)
