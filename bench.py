@@ -59,6 +59,7 @@ def parse():
     ap.add_argument("--fp32-steps", type=int, default=3)
     ap.add_argument("--no-branch-stream", action="store_true", help="3x3x3 branches / small skip blocks on the main stream (A/B)")
     ap.add_argument("--no-wgrad-stream", action="store_true", help="convolution weight gradients on the caller's stream (A/B)")
+    ap.add_argument("--engine-thread", action="store_true", help="leave the backward pass on the autograd engine's worker thread (A/B; default: calling thread)")
     ap.add_argument("--seg-mode", default=None, choices=["fp32x3", "fp32", "same"],
                     help="cascade: mode of the no-grad OAR-TRANSEG forward (default fp32x3: the reference's masks; 'same' = the dose network's storage type)")
     return ap.parse_args()
@@ -613,6 +614,8 @@ def main():
                       "rank_sum": int(t[1].item()), "rank_sum_expected": world * (world - 1) // 2,
                       "gpus_visible": ndev, "one_gpu_per_rank": ndev >= world}
     shape = tuple(args.size * 3) if len(args.size) == 1 else tuple(args.size)
+    import dose_prediction_amd as _dpa0
+    _dpa0.config.set_backward_on_calling_thread(not args.engine_thread)      # (launch-thread economy: config.set_backward_on_calling_thread)
     from dose_prediction_amd import synth, losses, _lib
     from dose_prediction_amd.ddp import attach_gradient_allreduce
     # cascade: `shape` is the CT volume in the segmentation loader's axis order; the dose network sees it reversed (W, H, D),
@@ -855,6 +858,8 @@ def main():
                        "optimizer": (type(opt).__name__ + "(amsgrad)") if opt is not None else None,
                        "launch": "hipGraph replay" if graph is not None else "eager",
                        "activation_checkpointing": bool(args.checkpoint), "loss_scale": args.loss_scale,
+                       "backward_on_calling_thread": __import__("dose_prediction_amd").config.backward_on_calling_thread(),
+                       "c_binding": _lib.BINDING,
                        "vit_side_stream": not args.no_side_stream, "branch_stream": __import__("dose_prediction_amd").config.branch_stream(),
                        "peak_memory_gib": peak_mem,
                        "grad_exchange_dtype": args.grad_dtype if ddp_on else None,

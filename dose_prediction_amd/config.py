@@ -334,3 +334,17 @@ class deterministic_as:
 
 if os.environ.get("DOSE_HIP_DETERMINISTIC", "0") == "1":
     set_deterministic(True)
+
+
+def set_backward_on_calling_thread(on=True):
+    """Run the backward pass on the thread that calls loss.backward() (torch.autograd.set_multithreading_enabled(not on)) instead of the
+    autograd engine's per-device worker thread.  One process drives one GPU here and every backward node is a launch, so the worker
+    thread buys nothing, and the hand-over costs the launch thread 1.2 ms of a 14-ms step (tools/host_profile.py, round 6: 14.0 -> 12.8 ms)
+    -- host time that matters as soon as the data-parallel reducer's hooks share that thread.  A process-wide torch setting, so it is NOT
+    switched at import: bench.py switches it on (config.backward_on_calling_thread in its line); a trainer does it once at start-up
+    (INTEGRATION.md).  Same graph, same kernels, same results."""
+    torch.autograd.set_multithreading_enabled(not on)
+
+
+def backward_on_calling_thread():
+    return not torch.autograd.is_multithreading_enabled()

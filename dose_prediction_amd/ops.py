@@ -60,7 +60,10 @@ def _chk_dev(*ts):
 
 def rows_ld(t):
     """(rows, C, ld) of an activation / matrix whose rows are uniformly pitched."""
-    shape, st = t.shape, t.stride()          # (one call each: this runs ~900 times per training step)
+    if t.is_contiguous() and t.dim() > 0:    # (the common case in ~0.3 us: this runs ~720 times per training step, tools/host_profile.py)
+        C = t.shape[-1]
+        return (t.numel() // C if C else 0), C, C
+    shape, st = t.shape, t.stride()
     C, nd = shape[-1], len(shape)
     if st[-1] != 1 and C > 1:
         raise ValueError("last dim must be contiguous")
@@ -1784,19 +1787,22 @@ def _norm_backward(x, mean, rstd, gamma, beta, res, kind, act, use_stats, ssn, g
     g32 = None if gamma is None else gamma.detach()
     b32 = None if beta is None else beta.detach()
     nblk = L.dp_stats_nblk(V)
-    part = torch.empty((N, nblk, 2, C), dtype=torch.float32, device=dev)
     groups = N if kind == "instance" else 1
-    s1 = torch.empty((groups, C), dtype=torch.float32, device=dev)
-    s2 = torch.empty((groups, C), dtype=torch.float32, device=dev)
+    # ONE allocation for the pass's scratch -- [s1 | s2 | partial rows], handed to the kernels as pointers: three torch.empty calls cost the
+    # launch thread ~8 us per normalisation (tools/host_profile.py: torch.empty is the largest single item of the host step)
+    gc = groups * C
+    scr = torch.empty((2 * gc + N * nblk * 2 * C,), dtype=torch.float32, device=dev)
+    s1p = scr.data_ptr()
+    s2p, partp = s1p + 4 * gc, s1p + 8 * gc
     # (dp_norm_bwd_finalize overwrites both in either mode: the sample-0 block of an instance normalisation combines every sample's rows)
     dgamma = torch.empty((C,), dtype=torch.float32, device=dev) if need_gb else None
     dbeta = torch.empty((C,), dtype=torch.float32, device=dev) if need_gb else None
     if use_stats or need_gb:
-        src = (_p(x), ldx, gy_ptr, ldg, _p(mean), _p(rstd), ssn, _p(g32), _p(b32), _p(res), ldr, _act_code(act, x.dtype), N, V, C, _p(part))
-        fin = (0 if kind == "instance" else 1, _p(s1), _p(s2), _p(dgamma), _p(dbeta))
+        src = (_p(x), ldx, gy_ptr, ldg, _p(mean), _p(rstd), ssn, _p(g32), _p(b32), _p(res), ldr, _act_code(act, x.dtype), N, V, C, partp)
+        fin = (0 if kind == "instance" else 1, s1p, s2p, _p(dgamma), _p(dbeta))
         if _lib.call("dp_norm_act_bwd_partial_finalize", *src, *fin, dtc, _stream()) == 3:      # (3: folded form off / not applicable)
             _lib.call("dp_norm_act_bwd_partial", *src, dtc, _stream())
-            _lib.call("dp_norm_bwd_finalize", _p(part), N, nblk, C, *fin, _stream())
+            _lib.call("dp_norm_bwd_finalize", partp, N, nblk, C, *fin, _stream())
     gx = gres = None
     if need_x or need_res:
         gres = torch.empty(x.shape, dtype=x.dtype, device=dev) if need_res else None
@@ -1804,11 +1810,11 @@ def _norm_backward(x, mean, rstd, gamma, beta, res, kind, act, use_stats, ssn, g
         if split_cp and need_x:
             gx = torch.empty(tuple(x.shape[:-1]) + (2 * split_cp,), dtype=torch.bfloat16, device=dev)      # [gx_hi | gx_lo]
             _lib.call("dp_norm_act_bwd_apply_x3", _p(x), ldx, gy_ptr, ldg, _p(mean), _p(rstd), ssn, _p(g32), _p(b32), _p(res), ldr,
-                      _act_code(act, x.dtype), _p(s1), _p(s2), 1.0 / cnt, 1 if use_stats else 0, _p(gx), split_cp, _p(gres), C, N, V, C, _stream())
+                      _act_code(act, x.dtype), s1p, s2p, 1.0 / cnt, 1 if use_stats else 0, _p(gx), split_cp, _p(gres), C, N, V, C, _stream())
             return gx, dgamma, dbeta, gres
         gx = torch.empty(x.shape, dtype=x.dtype, device=dev) if need_x else None
         _lib.call("dp_norm_act_bwd_apply", _p(x), ldx, gy_ptr, ldg, _p(mean), _p(rstd), ssn, _p(g32), _p(b32), _p(res), ldr,
-                  _act_code(act, x.dtype), _p(s1), _p(s2), 1.0 / cnt, 1 if use_stats else 0, _p(gx), C, _p(gres), C, N, V, C, dtc, _stream())
+                  _act_code(act, x.dtype), s1p, s2p, 1.0 / cnt, 1 if use_stats else 0, _p(gx), C, _p(gres), C, N, V, C, dtc, _stream())
     return gx, dgamma, dbeta, gres
 
 

@@ -44,7 +44,7 @@ int main(int argc, char** argv) {
   const hipStreamCaptureMode cm = mode == 0 ? hipStreamCaptureModeGlobal : mode == 1 ? hipStreamCaptureModeThreadLocal : hipStreamCaptureModeRelaxed;
   CK(hipStreamBeginCapture(A, cm));
   bool w_used = false;
-  for (int i = 0; i < pairs; i++) {
+  for (int i = 0; i < (pattern <= 4 ? pairs : 0); i++) {
     hipEvent_t f = ev(0);
     CK(hipEventRecord(f, A)); CK(hipStreamWaitEvent(B, f, 0));                 // fork A -> B
     launch(B, 1);
@@ -61,6 +61,33 @@ int main(int argc, char** argv) {
     launch(A, 0);
   }
   if (w_used) { hipEvent_t j = ev(2); CK(hipEventRecord(j, W)); CK(hipStreamWaitEvent(A, j, 0)); }      // the one join of W, into A
+  // patterns 5-9 (round 6, after tools/graph_capture_bisect.py: the crash needs the backward pass AND the transformer stream V AND the branch
+  // stream B): two streams forked from A with CROSS edges between them, each joined into A on its own; `pairs` cross edges
+  if (pattern >= 5 && pattern <= 9) {
+    hipStream_t V = W;
+    hipEvent_t f = ev(0); CK(hipEventRecord(f, A)); CK(hipStreamWaitEvent(V, f, 0));                     // fork A -> V (long branch)
+    launch(V, 2);
+    hipEvent_t f2 = ev(0); CK(hipEventRecord(f2, A)); CK(hipStreamWaitEvent(B, f2, 0));                  // fork A -> B
+    launch(B, 1); launch(A, 0);
+    for (int i = 0; i < pairs; i++) {
+      if (pattern == 5 || pattern == 6) { hipEvent_t e = ev(1); CK(hipEventRecord(e, V)); CK(hipStreamWaitEvent(B, e, 0)); launch(B, 1); launch(V, 2); }   // V -> B
+      if (pattern == 6 || pattern == 7) { hipEvent_t e = ev(2); CK(hipEventRecord(e, B)); CK(hipStreamWaitEvent(V, e, 0)); launch(V, 2); launch(B, 1); }   // B -> V
+      if (pattern == 8) {      // B joins A and is forked again every round while V keeps waiting on B's events (the engine's per-node syncs)
+        hipEvent_t e = ev(2); CK(hipEventRecord(e, B)); CK(hipStreamWaitEvent(V, e, 0)); launch(V, 2);
+        hipEvent_t j = ev(3); CK(hipEventRecord(j, B)); CK(hipStreamWaitEvent(A, j, 0)); launch(A, 0);
+        hipEvent_t g = ev(0); CK(hipEventRecord(g, A)); CK(hipStreamWaitEvent(B, g, 0)); launch(B, 1);
+      }
+      if (pattern == 9) {      // V waits on an event of B that was recorded BEFORE B's join into A, AFTER that join
+        hipEvent_t e = ev(2); CK(hipEventRecord(e, B));
+        hipEvent_t j = ev(3); CK(hipEventRecord(j, B)); CK(hipStreamWaitEvent(A, j, 0)); launch(A, 0);
+        CK(hipStreamWaitEvent(V, e, 0)); launch(V, 2);
+        hipEvent_t g = ev(0); CK(hipEventRecord(g, A)); CK(hipStreamWaitEvent(B, g, 0)); launch(B, 1);
+      }
+    }
+    hipEvent_t jb = ev(3); CK(hipEventRecord(jb, B)); CK(hipStreamWaitEvent(A, jb, 0));
+    hipEvent_t jv = ev(3); CK(hipEventRecord(jv, V)); CK(hipStreamWaitEvent(A, jv, 0));
+    launch(A, 0);
+  }
   hipGraph_t graph;
   CK(hipStreamEndCapture(A, &graph));
   size_t nodes = 0; CK(hipGraphGetNodes(graph, nullptr, &nodes));

@@ -30,7 +30,13 @@ def errs(named, gold):
 
 def run(case, det, mode):
     dose_prediction_amd.set_compute_dtype(mode)
-    with dose_prediction_amd.config.deterministic_as(det):
+    import contextlib
+    if isinstance(det, bool):
+        cm = dose_prediction_amd.config.deterministic_as(det)
+    else:
+        dose_prediction_amd.config.set_deterministic(det)
+        cm = contextlib.nullcontext()
+    with cm:
         if case == "subset":
             g = load_golden("g7_subset_multi")
             net = MainSubsetModel(in_ch=5, out_ch=1, img_size=(32, 16, 16), feature_size=4, hidden_size=48, mlp_dim=96, num_heads=6, num_layers=8, act="mish",
@@ -57,11 +63,17 @@ MODES = [{"fp32x3": "fp32x3", "fp32": torch.float32}[m] for m in os.environ.get(
 for case in CASES:
     for mode in MODES:
         res = {}
-        for det in (True, False):
+        dets = (True, False)
+        if os.environ.get("PROBE_MASK"):          # a mask of deterministic SITES instead of the full switch, atomic everywhere else (config.set_deterministic)
+            dets = (int(os.environ["PROBE_MASK"]),)
+        if os.environ.get("PROBE_ATOMIC_ONLY"):
+            dets = (False,)
+        for det in dets:
             e, grads = run(case, det, mode)
             res[det] = grads
             top = sorted(e.items(), key=lambda kv: -kv[1][0])[:5]
-            print(f"{case} {mode} {'det' if det else 'atomic'}: " + "; ".join(f"{k} {v[0]:.2e} (|g| {v[1]:.2e}, floor {v[2]:.2e}, {v[3]})" for k, v in top))
-        d = sorted(((float((res[True][k].double() - res[False][k].double()).norm() / max(float(res[True][k].double().norm()), 1e-30)), k) for k in res[True]), reverse=True)[:5]
-        print(f"   det vs atomic, relative: " + "; ".join(f"{k} {v:.2e}" for v, k in d))
+            print(f"{case} {mode} {('det' if det else 'atomic') if isinstance(det, bool) else 'mask %d' % det}: " + "; ".join(f"{k} {v[0]:.2e} (|g| {v[1]:.2e}, floor {v[2]:.2e}, {v[3]})" for k, v in top))
+        if True in res and False in res:
+            d = sorted(((float((res[True][k].double() - res[False][k].double()).norm() / max(float(res[True][k].double().norm()), 1e-30)), k) for k in res[True]), reverse=True)[:5]
+            print(f"   det vs atomic, relative: " + "; ".join(f"{k} {v:.2e}" for v, k in d))
 dose_prediction_amd.set_compute_dtype(torch.float32)
