@@ -399,7 +399,11 @@ struct Hk3Cfg {
   static constexpr size_t SMEM = ((size_t)3 * XPLANE + (size_t)TH * GP * GC) * sizeof(T);
 };
 
-template <typename T>
+// BUF (round 6): the plane prefetch as buffer loads, as in k_wgrad_hk<7, BUF> -- a block owns ONE column of tiles for its whole life, so a thread's
+// byte offsets are kernel constants (thread = (piece, column lc, row group of 3), rows walked 3 at a time); only the plane's buffer descriptor
+// changes per step, and a plane outside the volume is a descriptor of zero bytes.  With one wave per SIMD (148 KB of LDS per block) the
+// ~20 VALU per piece of the old form were time the matrix pipe simply waited.
+template <typename T, bool BUF>
 __global__ void __launch_bounds__(256, 1) k_wgrad_hk3(const T* __restrict__ x, const T* __restrict__ gy, float* __restrict__ dwt, WgHkGeom g) {
   static_assert(sizeof(T) == 2, "16-bit storage types only");
   using C = Hk3Cfg<T>;
@@ -422,7 +426,9 @@ __global__ void __launch_bounds__(256, 1) k_wgrad_hk3(const T* __restrict__ x, c
 #pragma unroll
   for (int a = 0; a < 27; a++) acc[a] = (v4f){0.f, 0.f, 0.f, 0.f};
 
-  constexpr int PX = (C::LR * C::LC * 2 + 255) / 256, PG = C::TH * C::TW * 2 / 256;
+  constexpr int RG3 = 3, PXB = (C::LR + RG3 - 1) / RG3;
+  constexpr int PX = BUF ? PXB : (C::LR * C::LC * 2 + 255) / 256, PG = C::TH * C::TW * 2 / 256;
+  static_assert(!BUF || (2 * C::LC * RG3 <= 256 && C::LP > C::LC), "thread map of the buffer-load staging");
   v4u rxs[2][PX], rgs[2][PG];          // two register sets: the loads of plane d+3 / gy d+2 are issued while plane d is swept
   const int piece = tid & 1, cpiece = mt * C::XC + piece * 8;
   const bool xsecond = g.x2 && cpiece >= g.csplit;
@@ -433,7 +439,35 @@ __global__ void __launch_bounds__(256, 1) k_wgrad_hk3(const T* __restrict__ x, c
   auto opaque = [](int v) { asm volatile("" : "+v"(v)); return v; };
   auto xvox = [&](int t2, int j, int& lr, int& lc) { const int v = j * 128 + t2; lr = v / C::LC; lc = v - lr * C::LC; return v < C::LR * C::LC; };
   const int g_r = tid >> 6, g_c = (tid >> 1) & 31;
-  auto issue_x = [&](int p, v4u* rx) {                   // x plane p (zeros outside the volume) -> rx
+  // ---- BUF staging: kernel-constant per-thread offsets
+  const int b_t2 = tid >> 1, b_rg = b_t2 / C::LC, b_lc = b_t2 - b_rg * C::LC;
+  const bool b_xsecond = g.x2 && mt * C::XC >= g.csplit;                   // block-uniform (csplit % 16 == 0)
+  const T* const b_xsrc = b_xsecond ? (const T*)g.x2 : x;
+  const int b_ldx = b_xsecond ? g.ldx2 : g.ldx, b_c0 = mt * C::XC - (b_xsecond ? g.csplit : 0) + piece * 8;
+  const bool b_xok = b_rg < RG3 && b_c0 + 8 <= b_ldx && (unsigned)(w0 - C::PAD + b_lc) < (unsigned)g.W;
+  const unsigned b_xrow3 = (unsigned)(RG3 * g.W * b_ldx * 2), b_grow4 = (unsigned)(4 * g.W * g.ldgy * 2);
+  const unsigned b_vx = b_xok ? (unsigned)((((h0 - C::PAD + b_rg) * g.W + (w0 - C::PAD + b_lc)) * b_ldx + b_c0) * 2) : 0x80000000u;   // (rows above the volume wrap out of range)
+  const unsigned b_vg = (g_exists && w0 + g_c < g.W) ? (unsigned)((((h0 + g_r) * g.W + w0 + g_c) * g.ldgy + nt * C::GC + piece * 8) * 2) : 0x80000000u;
+  const unsigned b_xbytes = (unsigned)(g.H * g.W * b_ldx * 2), b_gbytes = (unsigned)(g.H * g.W * g.ldgy * 2);
+  const int b_xl0 = ((b_rg < RG3 ? b_rg : 0) * C::LP + (b_rg < RG3 ? b_lc : C::LC)) * C::XC + piece * 8;       // (idle threads: the pad column)
+  const int b_xl_last = (b_rg + (PXB - 1) * RG3 < C::LR || b_rg >= RG3) ? b_xl0 + (PXB - 1) * RG3 * C::LP * C::XC : C::LC * C::XC + piece * 8;
+  auto rsrc_of = [](const T* base, unsigned bytes) {
+    const uint64_t a = (uint64_t)(uintptr_t)base;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)(((uint64_t)hi << 32) | lo), 0, (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+  };
+  auto issue_x = [&](int p, v4u* rx, bool live = true) {                   // x plane p (zeros outside the volume) -> rx
+    if constexpr (BUF) {
+      const bool pin = live && p >= 0 && p < g.D;
+      const auto rs = rsrc_of(b_xsrc + (((int64_t)n * g.D + (pin ? p : 0)) * g.H) * (int64_t)g.W * b_ldx, pin ? b_xbytes : 0u);
+      static_for<0, PXB>([&](auto k_) {
+        constexpr int k = decltype(k_)::value;
+        unsigned v = b_vx + (unsigned)k * b_xrow3;
+        if constexpr (k * RG3 + RG3 > C::LR) { if (k * RG3 + b_rg >= C::LR) v = 0x80000000u; }
+        rx[k] = __builtin_bit_cast(v4u, __builtin_amdgcn_raw_buffer_load_b128(rs, v, 0, 0));
+      });
+      return;
+    }
     const bool pin = p >= 0 && p < g.D;
     const T* xplane = xsrc + (((int64_t)n * g.D + (pin ? p : 0)) * g.H) * (int64_t)g.W * ldsrc;
     const int ihb = h0 - C::PAD, iwb = w0 - C::PAD, t2 = opaque(tid >> 1);
@@ -446,7 +480,13 @@ __global__ void __launch_bounds__(256, 1) k_wgrad_hk3(const T* __restrict__ x, c
       rx[j] = ok ? v : (v4u){0, 0, 0, 0};
     }
   };
-  auto issue_g = [&](int d, v4u* rg) {
+  auto issue_g = [&](int d, v4u* rg, bool live = true) {
+    if constexpr (BUF) {
+      const bool pin = live && d >= 0 && d < g.D;
+      const auto rs = rsrc_of(gy + (((int64_t)n * g.D + (pin ? d : 0)) * g.H) * (int64_t)g.W * g.ldgy, pin ? b_gbytes : 0u);
+      static_for<0, PG>([&](auto j_) { constexpr int j = decltype(j_)::value; rg[j] = __builtin_bit_cast(v4u, __builtin_amdgcn_raw_buffer_load_b128(rs, b_vg + (unsigned)j * b_grow4, 0, 0)); });
+      return;
+    }
     const T* gplane = gsrc + (((int64_t)n * g.D + d) * g.H) * (int64_t)g.W * g.ldgy;
 #pragma unroll
     for (int j = 0; j < PG; j++) {
@@ -457,6 +497,15 @@ __global__ void __launch_bounds__(256, 1) k_wgrad_hk3(const T* __restrict__ x, c
     }
   };
   auto commit_x = [&](int slot, const v4u* rx) {
+    if constexpr (BUF) {
+      T* dst = xs + slot * C::XPLANE;
+      static_for<0, PXB>([&](auto k_) {
+        constexpr int k = decltype(k_)::value;
+        if constexpr (k == PXB - 1) *(v4u*)(dst + b_xl_last) = rx[k];
+        else *(v4u*)(dst + b_xl0 + k * RG3 * C::LP * C::XC) = rx[k];
+      });
+      return;
+    }
     const int t2 = opaque(tid >> 1);
     T* dst = xs + slot * C::XPLANE;
 #pragma unroll
@@ -518,12 +567,21 @@ __global__ void __launch_bounds__(256, 1) k_wgrad_hk3(const T* __restrict__ x, c
     issue_x(z0 - 1, rxs[0]); commit_x(slot_of(z0 - 1), rxs[0]);
     issue_x(z0, rxs[0]); commit_x(slot_of(z0), rxs[0]);
     issue_x(z0 + 1, rxs[0]); issue_g(z0, rgs[0]);
-    if (z0 + 1 < z1) { issue_x(z0 + 2, rxs[1]); issue_g(z0 + 1, rgs[1]); }
+    if constexpr (BUF) { issue_x(z0 + 2, rxs[1], z0 + 1 < z1); issue_g(z0 + 1, rgs[1], z0 + 1 < z1); }
+    else if (z0 + 1 < z1) { issue_x(z0 + 2, rxs[1]); issue_g(z0 + 1, rgs[1]); }
   }
   auto step = [&](int d, v4u* rx, v4u* rg) {
     lds_barrier();                                                  // sweep d-1 is over: slot of plane d-2 and the gy tile are free
-    if (!nostage) { commit_x(slot_of(d + 1), rx); commit_g(rg); }
-    if (d + 2 < z1 && !nostage) { issue_x(d + 3, rx); issue_g(d + 2, rg); }
+    if constexpr (BUF) {
+      // every step commits and issues UNCONDITIONALLY (a prefetch beyond the segment, or DP_DBG's "no staging", is a descriptor of zero bytes):
+      // with the refill under a runtime condition the compiler must assume that the OTHER register set's 20 loads may not be in flight and
+      // waits for the newest load at every commit -- one plane of prefetch distance instead of two
+      commit_x(slot_of(d + 1), rx); commit_g(rg);
+      issue_x(d + 3, rx, d + 2 < z1 && !nostage); issue_g(d + 2, rg, d + 2 < z1 && !nostage);
+    } else {
+      if (!nostage) { commit_x(slot_of(d + 1), rx); commit_g(rg); }
+      if (d + 2 < z1 && !nostage) { issue_x(d + 3, rx); issue_g(d + 2, rg); }
+    }
     lds_barrier();
     if (!nosweep) sweep(d);
   };
@@ -579,10 +637,19 @@ __global__ void __launch_bounds__(256) k_wgrad_hk3_finish(float* __restrict__ sl
   }
 }
 
+template <typename T, bool BUF>
+int launch_hk3_impl(const void* x, const void* gy, float* ws, WgHkGeom g, hipStream_t s);
 template <typename T>
 int launch_hk3(const void* x, const void* gy, float* ws, WgHkGeom g, hipStream_t s) {
+  static const int buf_env = [] { const char* e = getenv("DP_HK_BUF"); return e ? atoi(e) : 1; }();
+  const int64_t xplane = (int64_t)g.H * g.W * (g.ldx > g.ldx2 ? g.ldx : g.ldx2) * 2, gplane = (int64_t)g.H * g.W * g.ldgy * 2;
+  const bool buf = buf_env && (!g.x2 || g.csplit % 16 == 0) && xplane < (1LL << 30) && gplane < (1LL << 30);
+  return buf ? launch_hk3_impl<T, true>(x, gy, ws, g, s) : launch_hk3_impl<T, false>(x, gy, ws, g, s);
+}
+template <typename T, bool BUF>
+int launch_hk3_impl(const void* x, const void* gy, float* ws, WgHkGeom g, hipStream_t s) {
   using C = Hk3Cfg<T>;
-  auto kern = k_wgrad_hk3<T>;
+  auto kern = k_wgrad_hk3<T, BUF>;
   static bool raised = false;
   if (!raised) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::SMEM);

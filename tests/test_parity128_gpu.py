@@ -182,10 +182,11 @@ def test_pyfer_128_fp32x3_backward_matches_oracle(pyfer_case):
     production-only backward branches no 64^3 test reaches end to end: k_wgrad_hk<7> / k_wgrad_hk3 at the full plane count, the XCD
     renumbering of the 128^3 data-gradient launches that every one of these gradients has passed through, the K = 102 400 split-K
     patch-embedding gradient (the last gradient of the pass: everything upstream of it is in it), the grouped transformer launch.
-    Tolerance 4e-2 relative L2 per tensor: the default fp32x3 backward is ONE bf16 product per contraction (the
+    Tolerance 2.5e-2 relative L2 per tensor: the default fp32x3 backward is ONE bf16 product per contraction (the
     whole gradient vector sits at 1.07e-2 of float64 at 64^3, single Linear tensors at 1.6-1.85e-2, and the exact-fp32 mode itself at
-    4.2e-3 -- ReLU / LeakyReLU gates of pre-activations within round-off of zero); a wrong tile decode, a dropped halo or a lost split-K
-    share is an O(1) error.  The loss value is compared too (1e-4)."""
+    4.2e-3 -- ReLU / LeakyReLU gates of pre-activations within round-off of zero); measured here (round 6, two boxes): 2.5e-5 (the head)
+    .. 1.0e-2 (the patch embedding, the last gradient of the pass), loss within 7e-7.  A wrong tile decode, a dropped halo or a lost
+    split-K share is an O(1) error.  The loss value is compared too (1e-4)."""
     import dose_prediction_amd
     from dose_prediction_amd import losses
     from dose_prediction_amd.models.dose_pyfer import Model
@@ -212,11 +213,11 @@ def test_pyfer_128_fp32x3_backward_matches_oracle(pyfer_case):
     for k in BWD_KEYS:
         g, r = named[k].grad.detach().double().cpu().reshape(-1), ref[k].double().reshape(-1)
         errs[k] = float((g - r).norm() / r.norm())
-    print(f"[parity128] backward fp32x3 vs oracle ({t_or:.0f} s on the host): loss {float(loss):.6f} vs {ref_loss:.6f}; "
-          + ", ".join(f"{k.split('net_B.')[-1]} {e:.2e}" for k, e in errs.items()))
     got_loss = float(loss.detach())
+    print(f"[parity128] backward fp32x3 vs oracle ({t_or:.0f} s on the host): loss {got_loss:.6f} vs {ref_loss:.6f}; "
+          + ", ".join(f"{k.split('net_B.')[-1]} {e:.2e}" for k, e in errs.items()))
     del net, out, loss
     torch.cuda.empty_cache()
     assert abs(got_loss - ref_loss) < 1e-4 * abs(ref_loss), (got_loss, ref_loss)
     worst = max(errs.items(), key=lambda kv: kv[1])
-    assert worst[1] < 4e-2, worst
+    assert worst[1] < 2.5e-2, worst

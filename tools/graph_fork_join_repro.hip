@@ -15,6 +15,9 @@
 //   pattern 3: pattern 2, but W is ALSO joined to B before B joins A (every fork joins its origin)
 //   pattern 4: pattern 2 with the join of B into A BEFORE W's work is enqueued on W from B's event (B's join does not cover W)
 //   mode 0 global, 1 thread-local, 2 relaxed;  reuse_events 1: one event object per edge kind re-recorded every pair (default: fresh events)
+//   pattern 98: an explicit edge list (argv[5], e.g. "01 12 02 21"); pattern 99: a random event graph over four streams (argv[4] = seed).
+// RESULT (round 6): patterns 0-9 all capture fine; **pattern 98 with "01 12 02 21" dies in hipStreamEndCapture** -- unbounded recursion of
+// hip::Stream::EndCapture() over a cycle in the runtime's parallel-capture-stream lists (docs/experiments/r06_graph_capture_branch_stream.md).
 // Prints one line: "<pattern> <pairs> <mode> <reuse>: nodes=<n> OK" or the failing call; a crash shows as the shell's exit status.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -40,7 +43,7 @@ int main(int argc, char** argv) {
     hipEvent_t e; if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) exit(3);
     evs.push_back(e); return e;
   };
-  auto launch = [&](hipStream_t s, int slot) { hipLaunchKernelGGL(k_touch, dim3(n / 256), dim3(256), 0, s, buf + slot * n, n); };
+  auto launch = [&](auto s_, int slot) { hipStream_t s = (hipStream_t)s_; hipLaunchKernelGGL(k_touch, dim3(n / 256), dim3(256), 0, s, buf + slot * n, n); };
   const hipStreamCaptureMode cm = mode == 0 ? hipStreamCaptureModeGlobal : mode == 1 ? hipStreamCaptureModeThreadLocal : hipStreamCaptureModeRelaxed;
   CK(hipStreamBeginCapture(A, cm));
   bool w_used = false;
@@ -86,6 +89,47 @@ int main(int argc, char** argv) {
     }
     hipEvent_t jb = ev(3); CK(hipEventRecord(jb, B)); CK(hipStreamWaitEvent(A, jb, 0));
     hipEvent_t jv = ev(3); CK(hipEventRecord(jv, V)); CK(hipStreamWaitEvent(A, jv, 0));
+    launch(A, 0);
+  }
+  // pattern 99 (round 6, after rocgdb showed the crash to be UNBOUNDED RECURSION inside hip::Stream::EndCapture -- a cycle in the runtime's
+  // "parallel capture streams" lists): a random event graph over four streams; `pairs` = number of record/wait edges, argv[4] (reuse) = seed.
+  // Prints the edge list first, so that a crashing seed documents itself.
+  if (pattern == 99) {
+    hipStream_t X; CK(hipStreamCreateWithFlags(&X, hipStreamNonBlocking));
+    hipStream_t S[4] = {A, B, W, X}; bool cap[4] = {true, false, false, false};
+    unsigned rng = 12345u + 7919u * (unsigned)reuse;
+    auto rnd = [&](int n) { rng = rng * 1664525u + 1013904223u; return (int)((rng >> 16) % (unsigned)n); };
+    printf("edges:");
+    for (int i = 0; i < pairs; i++) {
+      int src; do { src = rnd(4); } while (!cap[src]);
+      int dst; do { dst = rnd(4); } while (dst == src);
+      hipEvent_t e; CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      launch(S[src], src & 3);
+      CK(hipEventRecord(e, S[src])); CK(hipStreamWaitEvent(S[dst], e, 0));
+      cap[dst] = true;
+      launch(S[dst], dst & 3);
+      printf(" %d>%d", src, dst);
+    }
+    for (int k = 3; k >= 1; k--) if (cap[k]) { hipEvent_t e; CK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); CK(hipEventRecord(e, S[k])); CK(hipStreamWaitEvent(A, e, 0)); printf(" %d>0", k); }
+    launch(A, 0);
+    printf("\n"); fflush(stdout);
+  }
+  // pattern 98: an explicit edge list in argv[5] ("01 12 21": record on the first stream, wait on the second), then every capturing stream joins 0
+  if (pattern == 98 && argc > 5) {
+    hipStream_t X; CK(hipStreamCreateWithFlags(&X, hipStreamNonBlocking));
+    hipStream_t S[4] = {A, B, W, X}; bool cap[4] = {true, false, false, false};
+    for (const char* p = argv[5]; *p; p++) {
+      if (*p < '0' || *p > '3' || p[1] < '0' || p[1] > '3') continue;
+      const int src = *p - '0', dst = p[1] - '0'; p++;
+      if (!cap[src] || src == dst) { printf("invalid edge %d>%d\n", src, dst); return 4; }
+      hipEvent_t e; CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      launch(S[src], src & 3);
+      CK(hipEventRecord(e, S[src])); CK(hipStreamWaitEvent(S[dst], e, 0));
+      cap[dst] = true;
+      launch(S[dst], dst & 3);
+    }
+    const bool nojoin = argc > 6;
+    for (int k = 3; k >= 1; k--) if (cap[k] && !nojoin) { hipEvent_t e; CK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); CK(hipEventRecord(e, S[k])); CK(hipStreamWaitEvent(A, e, 0)); }
     launch(A, 0);
   }
   hipGraph_t graph;
