@@ -175,7 +175,7 @@ def set_x3_wgrad_terms(n):
     (10.5 ms per DOSE-PYFER step more).  Why 1 is the default: a weight-gradient element is a sum over millions of voxels, the
     operand rounding is unbiased, and what it adds (~1.6e-3 relative per element) is below what separates the EXACT fp32 mode from
     float64 on the same gradients (4.2e-3, ReLU gates of pre-activations within round-off of zero).  Measured at production width
-    (tools/x3_grad_probe.py, tools/x3_trajectory_probe.py): gradient vector vs float64 1.05e-2 (1 product) / 1.03e-2 (3 products);
+    (tools/probes/x3_grad_probe.py, tools/probes/x3_trajectory_probe.py): gradient vector vs float64 1.05e-2 (1 product) / 1.03e-2 (3 products);
     parameters after six Adam steps 7.6 % of the update away from an exact-fp32 run in BOTH cases (two exact-fp32 runs: 4.6 %,
     bf16: 44 %); the reference trainer's G6 sequence passes in both (tests/test_trainer_sequence.py)."""
     global _x3_wgrad_terms
@@ -192,11 +192,11 @@ def set_x3_dgrad_terms(n):
     """fp32x3 mode: number of split products in the DATA gradients of the convolutions and Linear layers.  1 (default since round 4):
     gy_hi w_hi only (a DP_X1 launch: the bf16 kernels on the hi halves, fp32 result); 3: like the forward pass (+7 ms per DOSE-PYFER
     step).  The forward pass -- every output, loss and validation metric, i.e. what the north-star's 1e-3 / arg-max bar is stated on --
-    always uses three products.  Why 1 is the default: measured at production width (tools/x3_grad_probe.py, 64^3, all 148 trainable
+    always uses three products.  Why 1 is the default: measured at production width (tools/probes/x3_grad_probe.py, 64^3, all 148 trainable
     tensors against the float64 oracle) the gradient vector is 1.09e-2 away with one product and 1.04e-2 with three -- the floor is set
     by activation gates of pre-activations within round-off of zero, not by the backward arithmetic -- against 2.6e-1 in the bf16 mode,
     whose error comes from its FORWARD activations; six fused-Adam steps end 8.0 % of the update away from an exact-fp32 run with one
-    product, 8.1 % with three (two exact-fp32 runs: 5.4 %; bf16: 40 %) (tools/x3_trajectory_probe.py).  bench.py reports the
+    product, 8.1 % with three (two exact-fp32 runs: 5.4 %; bf16: 40 %) (tools/probes/x3_trajectory_probe.py).  bench.py reports the
     three-product variants beside the default (fp32_mode.dgrad_three_products, .all_three_products)."""
     global _x3_dgrad_terms
     if n not in (1, 3):
@@ -212,7 +212,7 @@ def set_x3_linear_wgrad_terms(n):
     """fp32x3 mode: split products in the weight gradients of the LINEAR layers (transformer, patch embedding): 1 = x_hi gy_hi (default
     since round 4), 3 = all three.  Their contraction runs over 1-2 k token rows, not over millions of voxels, so the averaging argument
     of set_x3_wgrad_terms does not carry over -- round 3 therefore defaulted to 3 until there was per-layer evidence.  That
-    evidence (tools/x3_grad_probe.py, the 33 Linear weight tensors of DOSE-PYFER at production width, each against the float64 oracle):
+    evidence (tools/probes/x3_grad_probe.py, the 33 Linear weight tensors of DOSE-PYFER at production width, each against the float64 oracle):
     relative L2 error per tensor median 1.56e-2 / max 1.82e-2 with three products, 1.60e-2 / 1.85e-2 with one; all 33 together 1.81e-2
     vs 1.84e-2; six Adam steps end 8.1 % of the update away from the exact-fp32 run in both cases.  The gradient error of these layers is
     set upstream (activation gates flipping within round-off of zero), not by the operand rounding of their own contraction."""
@@ -307,7 +307,7 @@ def set_deterministic(on):
     Process-wide (the flag lives in libdose_hip.so); off by default, env DOSE_HIP_DETERMINISTIC=1 switches it on at import."""
     global _deterministic
     from . import _lib
-    # (an int other than 0 / 1 is a mask of single sites, for experiments -- tools/determinism_probe.py: 1 split-kd convolutions, 2 split-K
+    # (an int other than 0 / 1 is a mask of single sites, for experiments -- tools/probes/determinism_probe.py: 1 split-kd convolutions, 2 split-K
     # GEMMs, 4 tiled weight gradients, 8 generic weight gradient, 16 trilinear backward, 32 LayerNorm dgamma / dbeta)
     mask = 0x7fffffff if on is True or on == 1 else int(on or 0)
     _lib.lib().dp_set_deterministic(mask)

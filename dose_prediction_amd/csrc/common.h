@@ -96,7 +96,7 @@ __device__ __forceinline__ Frag8<f16_t> frag_ld_lds(const f16_t* p) { Frag8<f16_
 
 // One K=32 MFMA step on 16x16 tiles: acc += A(16x32) * B(32x16).  Lane l holds, for row/col (l&15), the 8
 // k-values 8*(l>>4)+j.  bf16: one v_mfma_f32_16x16x32_bf16.  f32: 8 x v_mfma_f32_16x16x4_f32 (step j uses
-// element j of every lane's fragment => k = 8q+j for q=0..3; exact fp32 FMA chain).  Verified by tools/mfma_probe.hip.
+// element j of every lane's fragment => k = 8q+j for q=0..3; exact fp32 FMA chain).  Verified by tools/probes/mfma_probe.hip.
 __device__ __forceinline__ v4f mma16(const Frag8<bf16_t>& a, const Frag8<bf16_t>& b, v4f c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, a.u), __builtin_bit_cast(v8bf, b.u), c, 0, 0, 0);
 }
@@ -222,7 +222,7 @@ static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 // dp_set_deterministic (elementwise.hip): 1 = every reduction that normally meets in fp32 atomics takes a fixed-order path instead, so that
 // two runs on the same inputs are bit-identical (split-kd convolutions run unsplit, split-K GEMMs unsplit, the weight-gradient kernels write one
 // scratch slab per voxel share and the unpack pass adds the slabs in order, LayerNorm's dgamma / dbeta go through per-block partial rows).
-int dp_det(int site = 0x7fffffff);        // site: DET_* bit(s); experiments (tools/determinism_probe.py) switch single sites on through dp_set_deterministic(mask)
+int dp_det(int site = 0x7fffffff);        // site: DET_* bit(s); experiments (tools/probes/determinism_probe.py) switch single sites on through dp_set_deterministic(mask)
 enum { DET_SPLITKD = 1, DET_SPLITK = 2, DET_WGRAD = 4, DET_WGRAD_GENERIC = 8, DET_TRILINEAR = 16 };
 // slabs of `base` fp32 elements the tap-major weight-gradient scratch holds in deterministic mode (<= 32 Mi elements in total)
 static inline int det_slabs(int64_t base) { int64_t n = (32ll << 20) / (base > 0 ? base : 1); return n < 1 ? 1 : (n > 512 ? 512 : (int)n); }

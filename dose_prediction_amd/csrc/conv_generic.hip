@@ -130,7 +130,7 @@ extern "C" int dp_conv3d(const void* x, int ldx, const void* wp, const float* bi
 // dw[co][ci][tap] += sum_v gy[v][co (+ tap*choff)] * x[in(v,tap)][ci].  GEMM view: M = co, N = ci, K = voxels.
 // Both operands are k-STRIDED in memory (channels are the contiguous axis), so each wave stages its 32-voxel K-step
 // of gy and (gathered) x into a private LDS tile [voxel][channel] and reads k-major fragments with
-// ds_read_b64_tr_b16 (bf16; map verified by tools/mfma_probe.hip) or plain ds_read_b32 (f32).
+// ds_read_b64_tr_b16 (bf16; map verified by tools/probes/mfma_probe.hip) or plain ds_read_b32 (f32).
 // Block = 4 waves that split the block's voxel range; each wave accumulates up to 4x4 (co x ci) tiles and
 // atomically adds them to the fp32 gradient at the end.
 #define WG_VOX 4096        // voxels per block

@@ -10,7 +10,7 @@
 // BK: k-depth of one LDS stage (32 or 64).  LDP = padded LDS row (elements): keeps 16-B alignment, breaks the power-of-two stride.
 
 #ifdef DP_GEMM_PROBE
-__device__ unsigned long long dp_gemm_probe[40];      // tools/gemm_probe.hip: s_memtime at block start, every K step, phases of step 2, loop end, block end
+__device__ unsigned long long dp_gemm_probe[40];      // tools/probes/gemm_probe.hip: s_memtime at block start, every K step, phases of step 2, loop end, block end
 #define PROBE(i) do { if (probe) dp_gemm_probe[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define PROBE(i) do { } while (0)

@@ -55,7 +55,7 @@ class _Store(torch.autograd.Function):
         return g.to(ctx.dt).to(g.dtype), None
 
 
-# Round-off sensitivity of the BACKWARD pass (tools/determinism_probe.py): `with grad_noise(eps, seed):` multiplies the gradient arriving
+# Round-off sensitivity of the BACKWARD pass (tools/probes/determinism_probe.py): `with grad_noise(eps, seed):` multiplies the gradient arriving
 # at every stored tensor by (1 + eps u), u uniform in [-1, 1] per element -- one fp32 rounding (eps = 2^-24) at each point where the
 # HIP path writes a gradient.  Run in float64, the spread of the results over a few seeds is the band inside which ANY correct fp32
 # evaluation order of this network's backward pass must be expected to land; the forward values are untouched.

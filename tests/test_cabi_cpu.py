@@ -104,3 +104,41 @@ def test_ticket_fences_do_not_touch_the_l2(tmp_path):
         assert isa.count("global_atomic_add") >= 5, "the ticket draws (three storage types of k_stats_partial + the backward partial kernels)"
         assert "buffer_wbl2" not in isa and "buffer_inv" not in isa, "an L2 write-back / invalidate crept into the normalisation kernels"
     assert found, "no gfx950 code object with k_stats_partial in the library"
+
+
+def test_fast_binding_is_generated_from_the_header_and_agrees_with_ctypes():
+    """The METH_FASTCALL module (dose_prediction_amd/_fastgen.py, round 6) is generated from include/dose_hip.h: one wrapper per declared
+    prototype, same results as the ctypes binding on the entry points that need no GPU, argument-count and type errors raised as TypeError
+    (not a crash), NULL for None, and `bind` refusing a library that lacks a declared symbol."""
+    import __graft_entry__ as g
+    g.build()
+    from dose_prediction_amd import _lib, _fastgen
+    L = _lib.lib()
+    assert _lib.BINDING == "fastcall" and os.path.exists(_fastgen.SO_PATH)
+    from dose_prediction_amd import _dose_fastcall as F
+    protos = _fastgen.parse(_lib.HEADER)
+    assert {n for n, _, _ in protos} == set(_lib.PROTOS)
+    for name, rk, args in protos:
+        assert hasattr(F, name), name
+        assert len(args) == len(_lib.PROTOS[name][1]), name
+    C = L._cdll
+    for args in ((32, 16, 7, 1, 3, 1, 128), (16, 16, 3, 1, 1, 1, 128), (64, 32, 7, 1, 3, 1, 64), (3, 8, 3, 2, 1, 1, 32)):
+        assert L.dp_conv3d_tiled_weight_elems(*args) == C.dp_conv3d_tiled_weight_elems(*args)
+    for v in (1, 5000, 128 ** 3, 192 * 192 * 128):
+        assert L.dp_stats_nblk(v) == C.dp_stats_nblk(v)
+    assert L.dp_conv3d_tiled_ws_elems(2, 16, 8, 8, 128, 64, 7) == C.dp_conv3d_tiled_ws_elems(2, 16, 8, 8, 128, 64, 7)
+    assert L.dp_version() == C.dp_version() and isinstance(L.dp_last_error(), bytes)
+    with pytest.raises(TypeError):
+        L.dp_stats_nblk()
+    with pytest.raises(TypeError):
+        L.dp_stats_nblk(1.5)
+    with pytest.raises(TypeError):
+        L.dp_stats_nblk("7")
+    with pytest.raises(OverflowError):
+        L.dp_conv3d_tiled_weight_elems(1 << 40, 16, 7, 1, 3, 1, 128)
+    # a launch entry point with a NULL pointer argument and no GPU: the library reports an error status, the binding does not crash
+    with pytest.raises(_lib.DoseHipError):
+        _lib.call("dp_stats_partial", None, 8, 1, 64, 5000, None, 0, None)       # C > 8 * NT: rejected before any launch
+    with pytest.raises(AttributeError):
+        F.bind("/usr/lib/x86_64-linux-gnu/libm.so.6")
+    F.bind(_lib.LIB_PATH)       # (restore the binding for the tests that follow)

@@ -479,7 +479,7 @@ def test_reference_goldens_in_x3_mode(name, args, det, monkeypatch):
     Gradients: 1e-2 instead of 2e-3 relative L2.  A forward perturbation of 4e-6 per layer (x3) instead of 3e-7 (exact fp32) flips the
     ReLU gate of the few pre-activations that lie that close to zero; every flipped gate changes the gradient field around it by
     O(1), so on these tiny networks (32 x 16 x 16 voxels, 4-16 channels) the gradient error is sqrt(#flips / #elements) ~ 2e-3
-    (measured on G1: output 1.9e-5, input gradient 2.1e-3; tools/x3_error_probe.py) although every single operator is accurate
+    (measured on G1: output 1.9e-5, input gradient 2.1e-3; tools/probes/x3_error_probe.py) although every single operator is accurate
     to 4.4e-6.  The production-width check is test_x3_pyfer_full_width_64_meets_the_north_star_tolerance.
 
     Both reduction modes, no retry.  "det": config.set_deterministic(True), every reduction in a fixed
@@ -487,7 +487,7 @@ def test_reference_goldens_in_x3_mode(name, args, det, monkeypatch):
     the benchmark runs -- every pass of a bf16-operand backward is a different, equally valid rounding (about one pass in a hundred of the
     G7 subset network lands 1e-2 away from the others: two fp32 atomic additions near the output retiring in the other order, amplified
     1e5 x by the batch-statistics BatchNorm backward of its 4-8-channel 16 x 8 x 8 level: tools/x3_event_bisect.py,
-    tools/determinism_probe.py), so its gate is the measured width of that distribution (_x3_atomic_tolerances)."""
+    tools/probes/determinism_probe.py), so its gate is the measured width of that distribution (_x3_atomic_tolerances)."""
     import dose_prediction_amd
     import test_models_gpu as M
     monkeypatch.setattr(M, "_set", lambda dtype: dose_prediction_amd.set_compute_dtype("fp32x3" if dtype == torch.float32 else dtype))
@@ -510,7 +510,7 @@ def test_x3_pyfer_full_width_64_meets_the_north_star_tolerance():
     fp32x3 against the float64 oracle: the four dose maps within 1e-3 relative (north_star; measured 0.7-1.3e-4), the dose-MAE in Gy,
     and the gradient vector of all 162 M trainable parameters within 2.5e-2 relative L2.  The gradient bound is what the metric
     allows, not what the arithmetic costs: for a random upstream gradient the EXACT-fp32 mode itself sits at 4.2e-3 from float64
-    (ReLU / LeakyReLU gates of pre-activations within round-off of zero flip; tools/x3_grad_probe.py: fp32 4.2e-3, fp32x3 1.0e-2,
+    (ReLU / LeakyReLU gates of pre-activations within round-off of zero flip; tools/probes/x3_grad_probe.py: fp32 4.2e-3, fp32x3 1.0e-2,
     bf16 2.5e-1)."""
     import dose_prediction_amd
     from dose_prediction_amd import synth

@@ -1,14 +1,14 @@
 #!/usr/bin/env python3
 """What would running the optimizer step beside the frozen net_A forward of the NEXT step give?  (net_A's weights are frozen in the
 benchmarked configuration, so its forward does not depend on the update.)  The Adam launch goes to its own stream; the caller's
-stream waits for it in a forward pre-hook of net_B.     python tools/adam_overlap_probe.py [dtype]"""
+stream waits for it in a forward pre-hook of net_B.     python tools/probes/adam_overlap_probe.py [dtype]"""
 import os
 import sys
 import time
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 from dose_prediction_amd import losses, synth  # noqa: E402

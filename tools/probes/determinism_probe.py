@@ -6,14 +6,14 @@ in a hundred runs) in the fp32x3 mode.
   (3) the bound: the float64 oracle's backward pass with ONE fp32 rounding (relative 2^-24, random sign) injected at every point where a
       gradient tensor is stored (oracle.grad_noise) -- the band inside which any correct fp32 evaluation order of this network's backward
       must be expected to land.  Both outcomes of (2) have to sit inside it (their mutual distance <= the band's width).
-    python tools/determinism_probe.py [passes]            (writes a table to stdout; profiles/r05_determinism_probe.txt is a run of it)"""
+    python tools/probes/determinism_probe.py [passes]            (writes a table to stdout; profiles/r05_determinism_probe.txt is a run of it)"""
 import hashlib
 import os
 import sys
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle  # noqa: E402

@@ -1,5 +1,5 @@
 // In-kernel timeline of dp_gemm_nt (s_memtime ticks of one block): where does a token GEMM spend its microseconds?
-// build: hipcc --offload-arch=gfx950 -O3 -std=c++20 -DDP_GEMM_PROBE -o gemm_probe tools/gemm_probe.hip ; run on the GPU box.
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++20 -DDP_GEMM_PROBE -o gemm_probe tools/probes/gemm_probe.hip ; run on the GPU box.
 #include "../dose_prediction_amd/csrc/gemm.hip"
 #include <stdarg.h>
 #include <vector>

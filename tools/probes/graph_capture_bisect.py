@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Which part of the step makes hipStreamEndCapture die when the 3x3x3 branch stream is kept inside a capture?
 One configuration per PROCESS (a segfault ends it): DOSE-PYFER at 64^3 (same stream structure as 128^3, seconds instead of minutes).
-    python tools/graph_capture_bisect.py <phase> [size]      phase: fwd | fwd_nograd | fwdbwd | step
+    python tools/probes/graph_capture_bisect.py <phase> [size]      phase: fwd | fwd_nograd | fwdbwd | step
 Stream switches through the environment: DOSE_HIP_CAPTURE_BRANCH=1 (keep the branch stream), DOSE_HIP_WGRAD_STREAM=0, DOSE_HIP_SIDE_STREAM=0
 (transformer stream), DOSE_HIP_BRANCH_STREAM=0.  Prints "CAPTURE OK <nodes?>" and replays twice, or dies."""
 import faulthandler
@@ -11,7 +11,7 @@ import sys
 import torch
 
 faulthandler.enable()
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import dose_prediction_amd  # noqa: E402
 from dose_prediction_amd import losses, synth  # noqa: E402

@@ -64,7 +64,7 @@ int main(int argc, char** argv) {
     launch(A, 0);
   }
   if (w_used) { hipEvent_t j = ev(2); CK(hipEventRecord(j, W)); CK(hipStreamWaitEvent(A, j, 0)); }      // the one join of W, into A
-  // patterns 5-9 (round 6, after tools/graph_capture_bisect.py: the crash needs the backward pass AND the transformer stream V AND the branch
+  // patterns 5-9 (round 6, after tools/probes/graph_capture_bisect.py: the crash needs the backward pass AND the transformer stream V AND the branch
   // stream B): two streams forked from A with CROSS edges between them, each joined into A on its own; `pairs` cross edges
   if (pattern >= 5 && pattern <= 9) {
     hipStream_t V = W;

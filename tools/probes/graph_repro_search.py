@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
-"""Exhaustive search for the SHORTEST event graph that sends hipStreamEndCapture into unbounded recursion (tools/graph_fork_join_repro.hip,
+"""Exhaustive search for the SHORTEST event graph that sends hipStreamEndCapture into unbounded recursion (tools/probes/graph_fork_join_repro.hip,
 pattern 98): all edge sequences over three streams up to the given length, each in its own process.  usage: graph_repro_search.py [maxlen=4]"""
 import itertools
 import os
 import subprocess
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-BIN = os.path.join(ROOT, "tools", "graph_fork_join_repro.bin")
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+BIN = os.path.join(ROOT, "tools", "probes", "graph_fork_join_repro.bin")
 maxlen = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 NS = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 edges = [(a, b) for a in range(NS) for b in range(NS) if a != b]

@@ -3,7 +3,7 @@
 //   1. lane <-> element map of the A / B operands (e4m3, 32 bytes per lane), checked with exact small values;
 //   2. the E8M0 scale operands (per lane, selected byte), incl. the constant scales 2^-11 / 2^-15 the scheme needs;
 //   3. issue rate against v_mfma_f32_16x16x32_bf16 (one wave per SIMD, independent accumulators).
-// Build: hipcc --offload-arch=gfx950 -O2 tools/mfma_fp8_probe.hip -o /tmp/mfma_fp8_probe
+// Build: hipcc --offload-arch=gfx950 -O2 tools/probes/mfma_fp8_probe.hip -o /tmp/mfma_fp8_probe
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>

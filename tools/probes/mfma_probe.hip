@@ -1,7 +1,7 @@
 // Hardware-layout probe for gfx950 (test tooling, not product code).
 // Verifies, with exact small-integer data, the lane<->element maps this repo's kernels
 // rely on: v_mfma_f32_16x16x32_bf16, v_mfma_f32_16x16x4_f32, v_mfma_f32_32x32x16_bf16
-// and ds_read_b64_tr_b16.  Build: hipcc --offload-arch=gfx950 -O2 tools/mfma_probe.hip -o mfma_probe
+// and ds_read_b64_tr_b16.  Build: hipcc --offload-arch=gfx950 -O2 tools/probes/mfma_probe.hip -o mfma_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

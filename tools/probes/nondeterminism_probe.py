@@ -1,11 +1,11 @@
 """Which module's output differs bit-wise between two forward passes on identical inputs?  (G7 subset network, fp32x3 by default.)
-python tools/nondeterminism_probe.py [mode] [repeats]"""
+python tools/probes/nondeterminism_probe.py [mode] [repeats]"""
 import os
 import sys
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import dose_prediction_amd  # noqa: E402

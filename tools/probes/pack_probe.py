@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Which packed-weight layouts does the per-step refresh (dp_pack_multi) rebuild, how many bytes, and how long does each kind take
-alone?  (DOSE-PYFER bench model, one training step to populate the pack cache.)  usage: python tools/pack_probe.py [bf16|fp32x3]"""
+alone?  (DOSE-PYFER bench model, one training step to populate the pack cache.)  usage: python tools/probes/pack_probe.py [bf16|fp32x3]"""
 import collections
 import os
 import sys

@@ -1,5 +1,5 @@
 // Prints what v_permlane16_swap_b32 does on gfx950 (used by the tap-pairing epilogue of conv_tiled.hip).
-// build: hipcc --offload-arch=gfx950 -O2 -o /tmp/permlane_probe tools/permlane_probe.hip
+// build: hipcc --offload-arch=gfx950 -O2 -o /tmp/permlane_probe tools/probes/permlane_probe.hip
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 typedef unsigned v2u __attribute__((ext_vector_type(2)));

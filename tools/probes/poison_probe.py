@@ -1,13 +1,13 @@
 """Uninitialised-memory hunt: before every pass the caching allocator's free blocks are filled with NaN (a big tensor is filled and
 released), a fresh model is built and run forward + backward; any kernel that reads memory nobody wrote turns its output into NaN.
 Reports the first leaf module whose output is not finite and every parameter / input gradient that is not.
-    python tools/poison_probe.py [mode] [passes] [multi|plain|pyfer]"""
+    python tools/probes/poison_probe.py [mode] [passes] [multi|plain|pyfer]"""
 import os
 import sys
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import dose_prediction_amd  # noqa: E402

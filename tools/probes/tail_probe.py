@@ -3,7 +3,7 @@
 Runs DOSE-PYFER bench steps and prints, per step, elapsed(main reached the join, ViT stream reached the join)."""
 import sys
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import dose_prediction_amd
 from dose_prediction_amd import ops, losses
 from dose_prediction_amd.models import dose_pyfer

@@ -3,14 +3,14 @@
  (1) duration of the ViT forward on its side stream, and how long the caller's stream then WAITS for it in _SideRun.final;
  (2) step time with an extra spin kernel of `ms` milliseconds put on the side stream in front of the ViT forward / the ViT backward:
      a branch that is hidden behind the main stream absorbs the delay, a branch on the critical path passes it on one to one.
-     python tools/vit_exposure_probe.py [dtype]"""
+     python tools/probes/vit_exposure_probe.py [dtype]"""
 import os
 import sys
 import time
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 from dose_prediction_amd import blocks, losses, synth  # noqa: E402

@@ -2,7 +2,7 @@
 oracle: DOSE-PYFER at production width on a 64^3 sample, forward, float64 everywhere EXCEPT the operand roundings of the scheme
 under test, applied where the HIP path would apply them (the k in {3, 7} stride-1 convolutions and the Linear layers).
 
-    python tools/x2_emulation_probe.py [size]        (test infrastructure: uses oracle/, nothing of the product)
+    python tools/probes/x2_emulation_probe.py [size]        (test infrastructure: uses oracle/, nothing of the product)
 
 schemes:  x16     x rounded to fp16 (x_hi only), weights exact   -> y = x_hi (w_hi + w_lo): TWO fp16 products
           w16     weights rounded to fp16, x exact               -> y = (x_hi + x_lo) w_hi:  TWO fp16 products
@@ -15,7 +15,7 @@ import time
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import oracle                                   # noqa: E402
 from oracle import ref_ops as R                  # noqa: E402

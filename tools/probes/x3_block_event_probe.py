@@ -1,12 +1,12 @@
 """Rare discrete events in the multi-scale block (blocks.conv_3_1: 3^3 || 7^3 branches -> normalise into the mixer's input -> 1^3
 conv -> IN -> act) in the fp32x3 mode: forward + backward repeated on fixed data; every gradient compared with the first repetition's.
-    python tools/x3_block_event_probe.py [repetitions]"""
+    python tools/probes/x3_block_event_probe.py [repetitions]"""
 import os
 import sys
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import dose_prediction_amd  # noqa: E402
 from dose_prediction_amd import blocks  # noqa: E402

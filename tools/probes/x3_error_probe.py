@@ -1,7 +1,7 @@
 """Error of the fp32x3 mode next to the exact-fp32 mode on the golden networks and on single convolutions (vs float64)."""
 import os, sys
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle
 from helpers import load_golden, sub, rel_err, rel_l2, cmp_prefix

@@ -1,7 +1,7 @@
 """Per-parameter gradient error of the fp32 / fp32x3 (/ bf16) modes against the float64 oracle, DOSE-PYFER full width at 64^3."""
 import os, sys
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle
 import dose_prediction_amd

@@ -1,12 +1,12 @@
 """Rare discrete events inside single fp32x3 convolutions: the same conv3d forward + backward repeated many times; a result further
 than 1e-5 (relative L2) from the first repetition's is an event (atomics reorder sums at the 1e-7 level only).
-    python tools/x3_rare_event_probe.py [repetitions]      (terms from the DOSE_HIP_X3_* variables; default here: three everywhere)"""
+    python tools/probes/x3_rare_event_probe.py [repetitions]      (terms from the DOSE_HIP_X3_* variables; default here: three everywhere)"""
 import os
 import sys
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import dose_prediction_amd  # noqa: E402
 from dose_prediction_amd import ops  # noqa: E402

@@ -7,7 +7,7 @@ import sys
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import dose_prediction_amd  # noqa: E402
 from dose_prediction_amd import ops  # noqa: E402

@@ -4,7 +4,7 @@ exact-fp32 run's as a fraction of the update that run made -- next to the distan
 mode itself non-reproducible: Adam turns round-off-level gradient differences into lr-sized steps)."""
 import os, sys
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import dose_prediction_amd
 from dose_prediction_amd import losses, synth

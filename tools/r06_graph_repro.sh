@@ -4,7 +4,7 @@ cd "$GRAFT_REPO_ROOT"
 o=gpurun_out/r06_graph_repro.txt
 : > $o
 for mode in 0 2; do for reuse in 0 1; do for pat in 0 1 2 3 4; do for pairs in 8 30 100 400; do
-  timeout 30 tools/graph_fork_join_repro.bin $pat $pairs $mode $reuse >> $o 2>&1; rc=$?
+  timeout 30 tools/probes/graph_fork_join_repro.bin $pat $pairs $mode $reuse >> $o 2>&1; rc=$?
   if [ $rc -ne 0 ]; then echo "pattern $pat pairs $pairs mode $mode reuse $reuse: EXIT $rc" >> $o; fi
 done; done; done; done
 # the real thing: the training step captured with the branch stream allowed (DOSE_HIP_CAPTURE_BRANCH=1), in a child process

@@ -7,7 +7,7 @@ for v in 0 1; do
   DP_HK_BUF=$v python tools/bench_conv.py wgrad --filter "dec" 2>&1 | grep -v amdgpu >> ${o}_wgrad_hk_ab.txt
 done
 timeout 1500 python -m pytest tests/test_ops_gpu.py tests/test_fullsize_gpu.py::test_conv_sampled_oracle_full_size tests/test_round6_gpu.py -m gpu -q -x --tb=short -p no:cacheprovider -k "conv or wgrad or grad or round6 or dice or nested or folded or deterministic" 2>&1 | grep -v "^$" | tail -30 > ${o}_tests.txt
-python tools/x3_atomic_vs_det_probe.py > ${o}_x3_atomic_vs_det.txt 2>&1
+python tools/probes/x3_atomic_vs_det_probe.py > ${o}_x3_atomic_vs_det.txt 2>&1
 python tools/host_profile.py > ${o}_host_profile.txt 2>&1
 DOSE_HIP_CTYPES=1 DOSE_HIP_PY_APPLY=1 python tools/host_profile.py 2>&1 | head -12 > ${o}_host_profile_ctypes.txt
 python tools/host_profile.py ddp 2>&1 | head -14 > ${o}_host_profile_ddp.txt

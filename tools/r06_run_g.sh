@@ -4,7 +4,7 @@ cd "$GRAFT_REPO_ROOT"
 o=gpurun_out/r06_g_x3_streams.txt
 : > $o
 export PROBE_CASES=subset PROBE_MODES=fp32x3 PROBE_ATOMIC_ONLY=1
-probe() { for i in 1 2 3 4; do ( env "$@" python tools/x3_atomic_vs_det_probe.py 2>&1 | grep "atomic\|mask" | cut -c1-330 >> $o ); done; }
+probe() { for i in 1 2 3 4; do ( env "$@" python tools/probes/x3_atomic_vs_det_probe.py 2>&1 | grep "atomic\|mask" | cut -c1-330 >> $o ); done; }
 echo "== default streams" >> $o; probe A=1
 echo "== every side stream off" >> $o; probe DOSE_HIP_SIDE_STREAM=0 DOSE_HIP_WGRAD_STREAM=0 DOSE_HIP_BRANCH_STREAM=0
 echo "== transformer stream off only" >> $o; probe DOSE_HIP_SIDE_STREAM=0
