@@ -142,7 +142,7 @@ class conv_3_1(nn.Module):
         first = x[0] if isinstance(x, (tuple, list)) else x
         if config.branch_stream() and first.is_cuda and config.branch_stream_allowed():
             # the latency- / fabric-bound 3x3x3 branch on a second stream beside the MFMA-bound 7x7x7 branch
-            main = torch.cuda.current_stream(first.device)
+            main = ops._current_stream_object(first.device)
             side = _branch_side_stream(first.device, main)
         else:
             main = side = None

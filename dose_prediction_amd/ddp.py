@@ -36,6 +36,12 @@ _REORDER = os.environ.get("DOSE_DDP_REORDER", "1") == "1"
 _TIMING = os.environ.get("DOSE_DDP_TIMING", "0") == "1"       # host seconds spent in the reducer's hooks (self.host_s), diagnosis
 
 
+def _cur_stream(dev=None):
+    """torch.cuda.current_stream(dev) without its ~9 us of Python (ops._current_stream_object: cached by raw handle)."""
+    from . import ops
+    return ops._current_stream_object(dev)
+
+
 def _timed(name):
     def deco(fn):
         if not _TIMING:
@@ -161,6 +167,8 @@ class GradAllReducer:
         self.launched = [False] * len(self.buckets)
         self._arrivals, self._last_arrival = 0, [0] * len(self.buckets)
         self.callback_queued = False
+        self._cursor = 0
+        self._index_order = list(range(len(self.buckets)))
         self.work = []
         self._taken = set()
         self._streams = []
@@ -175,7 +183,7 @@ class GradAllReducer:
             if ops.deferred_pending():
                 raise RuntimeError("gradient all-reduce: deferred weight gradients still pending after the flush")
             return self._launch_on_current(bi, at_end)
-        cur = torch.cuda.current_stream()
+        cur = ops._current_stream_object(flat.device)
         home = streams.side_stream(flat.device, cur, streams.ROLE_WGRAD) if config.wgrad_stream() else cur
         # The bucket is packed and handed to RCCL from the WEIGHT-GRADIENT stream (config.set_wgrad_stream): that stream already
         # carries most of the bucket's producers, it is off the critical path of the backward pass, and RCCL orders the collective
@@ -205,7 +213,7 @@ class GradAllReducer:
         if self.inplace[bi] and self.grad_ref[bi] is not None:
             flat = self.grad_ref[bi]
             if flat.is_cuda:
-                flat.record_stream(torch.cuda.current_stream())      # (the in-place exchange runs on the launch stream)
+                flat.record_stream(_cur_stream(flat.device))      # (the in-place exchange runs on the launch stream)
         else:
             # pack the whole bucket with one multi-tensor copy (a copy_ per parameter was ~230 launches and as many Python
             # round trips inside the backward pass: +3 ms per step before any byte moved); converts to grad_dtype on the way
@@ -216,7 +224,8 @@ class GradAllReducer:
                 if flat.is_cuda:
                     #  the gradients were allocated on the streams that produced them and are read here on the launch
                     # stream: the caching allocator must not hand their blocks out again before this copy has run
-                    cs = torch.cuda.current_stream()
+                    from . import ops as _ops
+                    cs = _ops._current_stream_object(flat.device)
                     for _, g_ in have:
                         g_.record_stream(cs)
         self.launched[bi] = True
@@ -276,7 +285,7 @@ class GradAllReducer:
         if self.inplace[bi] and p.grad.is_contiguous():
             self.grad_ref[bi] = p.grad.view(-1)
         if p.is_cuda:
-            s = torch.cuda.current_stream()
+            s = _cur_stream(p.device)
             if s not in self._streams:
                 self._streams.append(s)
         p._dp_has_grad = True
@@ -291,13 +300,16 @@ class GradAllReducer:
         # approximation of the backward order: the transformer's gradients arrive BEFORE those of skip1, which is registered after
         # it, so in index order every transformer bucket and the 314 MB patch-embedding exchange waited for the very last
         # gradients of the pass (kernel trace: 10 of 12 buckets launched after the backward pass had ended).
-        order = self.launch_order if self.launch_order is not None else range(len(self.buckets))
-        for i in order:
-            if self.launched[i]:
-                continue
-            if self.pending[i] > 0:
-                break
-            self._launch(i)
+        order = self.launch_order if self.launch_order is not None else self._index_order
+        c, n = self._cursor, len(order)      # (a cursor instead of a walk from the start: 182 hooks x 14 buckets per pass)
+        while c < n:
+            i = order[c]
+            if not self.launched[i]:
+                if self.pending[i] > 0:
+                    break
+                self._launch(i)
+            c += 1
+        self._cursor = c
 
     @_timed("finish")
     def _finish(self):
@@ -330,7 +342,7 @@ class GradAllReducer:
         home = getattr(self, "_home", None)
         if home is not None:
             # (the collectives were issued from the weight-gradient stream: everything it carries is complete for the caller too)
-            torch.cuda.current_stream().wait_stream(home)
+            _cur_stream(home.device).wait_stream(home)
         for w in self.work:
             if isinstance(w, tuple):
                 w[0].wait()

@@ -35,7 +35,7 @@ class _SideRun:
     def hidden(self, i):
         t = self.hid[i]
         if self.side is not None:
-            cur = torch.cuda.current_stream(t.device)
+            cur = ops._current_stream_object(t.device)
             cur.wait_event(self.events[i])
             t.record_stream(cur)
         return t
@@ -75,7 +75,7 @@ def run_vit_beside(vit, x_in, first=None, first_inputs=()):
         out = first() if first is not None else None
         z, hidden = vit(x_in)
         return _SideRun(z, hidden, None, None, None), out
-    main = torch.cuda.current_stream(x_in.device)
+    main = ops._current_stream_object(x_in.device)
     key = (x_in.device.index, main.cuda_stream)
     side = _SIDE_STREAMS.get(key)
     if side is None:
@@ -112,7 +112,7 @@ class small_blocks_beside:
             self.ctx.__enter__()
             return lambda *outs: None
         from ..blocks import _branch_side_stream
-        self.main = torch.cuda.current_stream(self.dev)
+        self.main = ops._current_stream_object(self.dev)
         self.side = _branch_side_stream(self.dev, self.main)
         self.side.wait_stream(self.main)
         self.ctx = torch.cuda.stream(self.side)

@@ -330,7 +330,7 @@ def _pass_zeros(shape, dev):
     if not a["armed"]:
         a["buf"] = torch.zeros((max(a["need"], 1 << 16),), dtype=torch.float32, device=dev)
         a["used"], a["now"], a["armed"], a["task"], a["epoch"] = 0, 0, True, task, _FWD_EPOCH[0]
-        a["stream"] = torch.cuda.current_stream(dev)
+        a["stream"] = _current_stream_object(dev)
         a["ev"] = torch.cuda.Event()
         a["ev"].record(a["stream"])
 
@@ -343,7 +343,7 @@ def _pass_zeros(shape, dev):
         return torch.zeros(shape, dtype=torch.float32, device=dev)
     t = a["buf"][a["used"]:a["used"] + n].view(shape)
     a["used"] += step
-    cur = torch.cuda.current_stream(dev)
+    cur = _current_stream_object(dev)
     if cur != a["stream"]:
         cur.wait_event(a["ev"])           # (the fill ran on the stream of the pass's first request)
         a["buf"].record_stream(cur)
@@ -607,12 +607,17 @@ _WG = {"dirty": {}, "queued": False}
 _STREAM_OBJ = {}
 
 
-def _current_stream_object(dev):
-    """torch.cuda.current_stream(dev), cached by raw handle (the Stream constructor costs 8 us, this runs ~100 times per step)."""
-    key = (dev.index, _stream())          # (the default stream has handle 0 on EVERY device: ADVICE r3)
+def _current_stream_object(dev=None):
+    """torch.cuda.current_stream(dev), cached by raw handle: the stock call goes through three Python layers (device-index resolution,
+    is_available, the Stream constructor: ~9 us), and the reducer's per-parameter hooks alone made it 220 times per step (round 6,
+    tools/host_profile.py ddp: 3.0 ms of host time per step).  dev=None: the current device."""
+    if _raw_stream is None:
+        return torch.cuda.current_stream(dev)
+    idx = _raw_device() if (dev is None or dev.index is None) else dev.index
+    key = (idx, _raw_stream(idx))          # (the default stream has handle 0 on EVERY device: ADVICE r3)
     s = _STREAM_OBJ.get(key)
     if s is None:
-        s = _STREAM_OBJ[key] = torch.cuda.current_stream(dev)
+        s = _STREAM_OBJ[key] = torch.cuda.current_stream(idx)
     return s
 
 
@@ -677,7 +682,7 @@ def join_wgrad_stream():
     _WG["queued"] = False
     if _WG["dirty"]:
         for idx, wg in list(_WG["dirty"].items()):
-            torch.cuda.current_stream(wg.device).wait_stream(wg)
+            _current_stream_object(wg.device).wait_stream(wg)
         _WG["dirty"].clear()
 
 
@@ -1504,7 +1509,7 @@ def _defer_wgrad(gy, ldg, x, ldx, gw, gb, nout, nin, rows):
     was waiting for the partner's .grad, and leaked entries for ever under torch.autograd.grad)."""
     ev = torch.cuda.Event()
     ev.record()                                            # on the stream that produced gy (the ViT branch runs on a side stream)
-    _DEFER["pending"].append((gy, ldg, x, ldx, _alias(gw), None if gb is None else _alias(gb), nout, nin, rows, ev, torch.cuda.current_stream()))
+    _DEFER["pending"].append((gy, ldg, x, ldx, _alias(gw), None if gb is None else _alias(gb), nout, nin, rows, ev, _current_stream_object()))
     if not _DEFER["queued"]:
         # (safety net: whatever is still pending at the end of the backward pass is flushed then)
         torch.autograd.Variable._execution_engine.queue_callback(flush_deferred)
@@ -1524,7 +1529,7 @@ def flush_deferred(*_unused):
     backward node)."""
     _DEFER["queued"] = False
     pend, _DEFER["pending"] = _DEFER["pending"], []
-    cur = torch.cuda.current_stream() if (pend or _DEFER.get("last_stream") is not None) else None
+    cur = _current_stream_object() if (pend or _DEFER.get("last_stream") is not None) else None
     by = {}
     for e in pend:
         by.setdefault((e[0].dtype, e[0].device, e[10]), []).append(e)
