@@ -215,9 +215,12 @@ def test_g7_transeg(tag):
     assert torch.equal(y.cpu().argmax(1)[safe], ref.argmax(1)[safe])
     assert safe.float().mean() > 0.98
     y.backward(g["r"].to(dev))
-    assert cmp_prefix(x.grad.cpu(), g["gx"]) < GRAD_TOL
     # OldModels variant: BatchNorm->ReLU chains make a few gradients ill-conditioned in fp32 -- the fp32 CPU oracle itself
-    # deviates from the fp64 golden by 6.1e-3 on decoder2...conv_7.conv.1.bias (measured) -- hence 1e-2 there.
+    # deviates from the fp64 golden by 6.1e-3 on decoder2...conv_7.conv.1.bias (measured) -- hence 1e-2 there.  The same gate event reaches
+    # the input gradient: 200 exact-fp32 passes with the default (atomic) reductions have a median of 9e-7 and a maximum of 1.4e-3
+    # (tests/golden/x3_atomic_spread.json, mode "fp32": one ReLU gate at a pre-activation within round-off of zero), so the input-gradient
+    # gate of the old variant is 1e-2 as well (the new variant: 2.2e-4 in every pass, gate 2e-3).
+    assert cmp_prefix(x.grad.cpu(), g["gx"]) < (GRAD_TOL if tag == "new" else 1e-2)
     _check_grads(net, sub(g, "grad"), tol=GRAD_TOL if tag == "new" else 1e-2)
 
 
