@@ -56,7 +56,7 @@ class UpConv(nn.Module):
 
     def forward(self, x):
         conv, norm = self.conv[0], self.conv[1]
-        y, st = ops.conv3d(ops.trilinear_up2(x), conv.weight, conv.bias, 1, 1, 1, stats=True, bias_grad_zero=True)
+        y, st = ops.conv3d(ops.trilinear_up2(x, x3_split_for=conv), conv.weight, conv.bias, 1, 1, 1, stats=True, bias_grad_zero=True)
         return ops.norm_act(y, "instance", norm.weight, norm.bias, act="relu", eps=norm.eps, stats=st)
 
 

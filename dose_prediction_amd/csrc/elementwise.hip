@@ -366,7 +366,9 @@ __device__ __forceinline__ void tri_coord(int o, int n_in, int& i0, int& i1, flo
   i1 = i0 + 1 < n_in ? i0 + 1 : n_in - 1;
   f = s - (float)i0;
 }
-template <typename T, typename I>
+// SPLIT (fp32x3 mode, round 6): fp32 input, the result written as the bf16 [hi | lo] operand of the x3 convolution that consumes it (hi at
+// channel c, lo at c + ldy / 2 of a 2 cp-channel row): the fp32 up-sampled tensor and the split pass over it never exist.
+template <typename T, typename I, bool SPLIT = false>
 __device__ __forceinline__ void trilinear_fwd_body(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, I total, I cg8, int D, int H, int W,
                                                    int C) {
   const I W2 = 2 * W, H2 = 2 * H, D2 = 2 * D;
@@ -392,9 +394,28 @@ __device__ __forceinline__ void trilinear_fwd_body(const T* __restrict__ x, int 
       frag_unpack(in[k], tt);
       for (int j = 0; j < 8; j++) acc[j] += wgt * tt[j];
     }
-    Frag8<T> f; frag_pack(f, acc);
-    frag_store<T>(y + (int64_t)ov * ldy + cg * 8, f, nv);
+    if constexpr (SPLIT) {
+      static_assert(sizeof(T) == 4, "split output: fp32 input");
+      bf16_t* p = (bf16_t*)y + (int64_t)ov * ldy + cg * 8;
+      v4u hi, lo;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const bf16_t h0 = f2bf(acc[2 * r]), h1 = f2bf(acc[2 * r + 1]);
+        const bf16_t l0 = f2bf(acc[2 * r] - bf2f(h0)), l1 = f2bf(acc[2 * r + 1] - bf2f(h1));
+        hi[r] = (unsigned)h0 | ((unsigned)h1 << 16); lo[r] = (unsigned)l0 | ((unsigned)l1 << 16);
+      }
+      *(v4u*)p = hi; *(v4u*)(p + ldy / 2) = lo;
+    } else {
+      Frag8<T> f; frag_pack(f, acc);
+      frag_store<T>(y + (int64_t)ov * ldy + cg * 8, f, nv);
+    }
   }
+}
+__global__ void k_trilinear_fwd_split(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, int N, int D, int H, int W, int C) {
+  const int cg8 = C >> 3;
+  const int64_t total = (int64_t)N * 8 * D * H * W * cg8;
+  if (total < (1ll << 31)) trilinear_fwd_body<float, unsigned, true>(x, ldx, y, ldy, (unsigned)total, (unsigned)cg8, D, H, W, C);
+  else trilinear_fwd_body<float, int64_t, true>(x, ldx, y, ldy, total, (int64_t)cg8, D, H, W, C);
 }
 // The same through LDS (round 4; 16-bit storage, C a multiple of 8 and <= 64: the 128^3 and 64^3 outputs of the C3D decoder).  One thread
 // per (output voxel, 8 channels) gathers its eight corners from global memory: 8 x the output bytes through the CU's load path (2.1 GB
@@ -473,6 +494,12 @@ __global__ void k_trilinear_bwd(const T* __restrict__ gy, int ldgy, float* __res
   }
 }
 extern "C" int dp_trilinear_up2_fwd(const void* x, int ldx, void* y, int ldy, int N, int D, int H, int W, int C, int dtype, void* stream) {
+  if (dtype == DP_X3) {        // fp32 rows in, bf16 [hi | lo] rows of ldy = 2 cp channels out (cp >= C, both multiples of 8)
+    if (C % 8 || ldy % 16 || ldy / 2 < C || ldx % 4 || (((uintptr_t)x | (uintptr_t)y) & 15)) DP_FAIL("trilinear_up2_fwd (DP_X3): C %% 8, ldy = 2 cp >= 2 C, 16-byte aligned rows");
+    const int64_t total = (int64_t)N * 8 * D * H * W * (C / 8);
+    hipLaunchKernelGGL(k_trilinear_fwd_split, dim3(grid_for(total, 256)), dim3(256), 0, STREAM, (const float*)x, ldx, (float*)y, ldy, N, D, H, W, C);
+    DP_CHECK_LAUNCH("trilinear_fwd_split"); return 0;
+  }
   static const int lds_on = [] { const char* e = getenv("DP_TRILINEAR_LDS"); return e ? atoi(e) : 1; }();
   if (lds_on && (dtype == DP_BF16 || dtype == DP_F16) && C % 8 == 0 && C <= 64 && ldx % 8 == 0 && ldy % 8 == 0 && W >= 16 && H >= 4 &&
       (((uintptr_t)x | (uintptr_t)y) & 15) == 0) {

@@ -1126,13 +1126,23 @@ def _split_conv_input(xa, ca, xb, cb, cp):
     while the very same tensor objects are alive and unmodified (weak references + version counters)."""
     import weakref
     key = (ca, cb, cp, xa.data_ptr(), xa._version, tuple(xa.shape), xa.stride(),
-           None if xb is None else (xb.data_ptr(), xb._version, tuple(xb.shape), xb.stride()), _stream())
+           None if xb is None else (xb.data_ptr(), xb._version, tuple(xb.shape), xb.stride()))
     ent = _SPLIT_LAST[0]
     if ent is not None and ent[0] == key and ent[1]() is xa and (xb is None or ent[2]() is xb):
         _SPLIT_LAST[0] = None             # (the pattern is exactly two consumers: do not keep half a gigabyte alive beyond the second)
-        return ent[3]
+        xs, ev, sh = ent[3], ent[4], ent[5]
+        if sh != _stream():
+            # the other branch runs on ANOTHER stream (config.set_branch_stream: the 3^3 branch beside the 7^3 one): wait for the split where
+            # it was made instead of making it twice -- round 6: with the stream in the key every level's input was split once per branch,
+            # 0.27 ms per 2 x 128^3 x 32-channel pair (tools/probes/x3_split_sites_probe.py)
+            cur = _current_stream_object(xs.device)
+            cur.wait_event(ev)
+            xs.record_stream(cur)
+        return xs
     xs = split_rows(xa, ca, xb, cb, cp, 2, 0b10)
-    _SPLIT_LAST[0] = (key, weakref.ref(xa), None if xb is None else weakref.ref(xb), xs)
+    ev = torch.cuda.Event()
+    ev.record(_current_stream_object(xs.device))
+    _SPLIT_LAST[0] = (key, weakref.ref(xa), None if xb is None else weakref.ref(xb), xs, ev, _stream())
     return xs
 
 
@@ -2376,7 +2386,26 @@ class TrilinearUp2(torch.autograd.Function):
         return gx
 
 
-def trilinear_up2(x):
+def trilinear_up2(x, x3_split_for=None):
+    """x3_split_for: the nn.Conv3d that is the ONLY consumer of the result.  In the fp32x3 mode, when no gradient flows through (the frozen C3D of
+    DOSE-PYFER, train_light_pyfer.py:85-88; inference) and that convolution takes the x3 path, the result is written directly as its bf16
+    [hi | lo] operand (shape [.., 2 C]; hand it to conv3d as is): the fp32 up-sampled tensor -- 1.07 GB at 2 x 128^3 x 32 channels -- and the
+    split pass over it do not exist (round 6: 0.25 ms of the fp32x3 step at the 128^3 level alone)."""
+    if x3_split_for is not None and x.dtype == torch.float32 and x.is_cuda and not (torch.is_grad_enabled() and x.requires_grad):
+        from . import config
+        c = x3_split_for
+        C = x.shape[-1]
+        if (config.x3() and C % 16 == 0 and c.weight.shape[1] == C and not (torch.is_grad_enabled() and c.weight.requires_grad) and
+                _x3_conv_shape_ok(2 * x.shape[3], C, c.weight.shape[0], c.kernel_size[0], c.stride[0], c.padding[0], c.dilation[0], _x3_min_w(c.weight))):
+            x = as_rows(x)
+            _, _, ld = rows_ld(x)
+            N, D, H, W = x.shape[:4]
+            y = torch.empty((N, 2 * D, 2 * H, 2 * W, 2 * C), dtype=torch.bfloat16, device=x.device)
+            _lib.call("dp_trilinear_up2_fwd", _p(x), ld, _p(y), 2 * C, N, D, H, W, C, DP_X3, _stream())
+            if len(_PRESPLIT_OUT) > 256:
+                _PRESPLIT_OUT.clear()
+            _PRESPLIT_OUT[y.data_ptr()] = True
+            return y
     return TrilinearUp2.apply(x)
 
 

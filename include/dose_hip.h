@@ -80,7 +80,9 @@ int dp_unpatchify(const void* gout, void* gx, int B, int S0, int S1, int S2, int
  * (column = ((a*2+b)*2+c)*C + co) -> dst NDHWC at (2d+a,2h+b,2w+c), pitch ldd.  unshuffle = inverse gather. */
 int dp_pixel_shuffle2(const void* src, void* dst, int N, int D, int H, int W, int C, int ldd, int dtype, void* stream);
 int dp_pixel_unshuffle2(const void* src, int lds, void* dst, int N, int D, int H, int W, int C, int dtype, void* stream);
-/* replaces: F.interpolate(scale_factor=2, mode='trilinear', align_corners=True) c3d.py:36 (+ its backward). */
+/* replaces: F.interpolate(scale_factor=2, mode='trilinear', align_corners=True) c3d.py:36 (+ its backward).
+ * dtype DP_X3 (forward only, fp32x3 mode): x is fp32, y receives the bf16 [hi | lo] operand of the x3 convolution that reads it -- hi at
+ * channel c, lo at channel c + ldy / 2 of rows of ldy = 2 cp bf16 elements -- instead of an fp32 tensor that a split pass would re-read. */
 int dp_trilinear_up2_fwd(const void* x, int ldx, void* y, int ldy, int N, int D, int H, int W, int C, int dtype, void* stream);
 int dp_trilinear_up2_bwd(const void* gy, int ldgy, float* gx_f32, int N, int D, int H, int W, int C, int dtype, void* stream);
 /* batched 2-D transpose: dst[b][c][r] = src[b][r][c]; two batch levels with independent strides. */

@@ -202,3 +202,85 @@ def test_nested_backward_does_not_reset_the_pass_arena():
     yr.backward(torch.ones_like(yr))
     assert rel_l2(gam.grad.cpu(), gr.grad) < 1e-5 and rel_l2(bet.grad.cpu(), br.grad) < 1e-5, "a stale arena must not leak into the next pass"
     del stale
+
+
+# ------------------------------------------------------------------------------------------------ fp32x3: producer-side splits (round 6)
+def test_x3_trilinear_writes_the_convolution_operand_directly():
+    """c3d.UpConv (c3d.py:25-38) in the fp32x3 mode without gradients (the frozen C3D of DOSE-PYFER): dp_trilinear_up2_fwd with DP_X3 writes the
+    bf16 [hi | lo] operand of the 3x3x3 convolution itself -- no fp32 up-sampled tensor, no split pass.  The halves are those of the same
+    fp32 accumulators, so the block's output is BIT-identical to the unfused path (forced by enabling gradients), and both match the float64
+    oracle at the x3 tolerance; dp_split_rows is not called on the fused path."""
+    import dose_prediction_amd
+    from dose_prediction_amd import ops
+    from dose_prediction_amd.blocks import UpConv
+    dev = _dev()
+    dose_prediction_amd.set_compute_dtype("fp32x3")
+    try:
+        torch.manual_seed(3)
+        up = UpConv(32, 16).to(dev)
+        x = rnd((2, 32, 5, 9, 16), 7)                                     # NCDHW
+        xh = x.permute(0, 2, 3, 4, 1).contiguous().to(dev)
+        calls = []
+        orig = ops.split_rows
+        ops.split_rows = lambda *a, **k: (calls.append(a[0].shape), orig(*a, **k))[1]
+        try:
+            with torch.no_grad():
+                y_fused = up(xh)
+            n_fused = len(calls)
+            y_plain = up(xh)                                              # gradients enabled + trainable weights: the fp32 tensor + split path
+            n_plain = len(calls) - n_fused
+        finally:
+            ops.split_rows = orig
+        assert n_fused == 0 and n_plain == 1, (n_fused, n_plain)
+        assert torch.equal(y_fused, y_plain.detach())
+        conv, norm = up.conv[0], up.conv[1]
+        u = torch.nn.functional.interpolate(x.double(), scale_factor=2, mode="trilinear", align_corners=True)
+        r = torch.nn.functional.conv3d(u, conv.weight.detach().double().cpu(), conv.bias.detach().double().cpu(), padding=1)
+        r = torch.relu(torch.nn.functional.instance_norm(r, weight=norm.weight.detach().double().cpu(), bias=norm.bias.detach().double().cpu(), eps=norm.eps))
+        got = y_fused.permute(0, 4, 1, 2, 3).double().cpu()
+        assert rel_err(got, r) < 1e-4, rel_err(got, r)
+    finally:
+        dose_prediction_amd.set_compute_dtype(torch.float32)
+
+
+def test_x3_branches_on_two_streams_share_one_input_split():
+    """conv_3_1 (blocks_MDUNet.py:132-157) in the fp32x3 mode with the 3x3x3 branch on its own stream (config.set_branch_stream): the virtual
+    concatenation both branches read is split ONCE -- the second consumer waits for the event of the split on the stream that made it --
+    and the block's output and gradients equal the single-stream run's bit for bit (deterministic reductions)."""
+    import dose_prediction_amd
+    from dose_prediction_amd import ops
+    from dose_prediction_amd.blocks import conv_3_1
+    dev = _dev()
+    dose_prediction_amd.set_compute_dtype("fp32x3")
+    cfg = dose_prediction_amd.config
+    prev = cfg.branch_stream()
+    try:
+        torch.manual_seed(5)
+        blk = conv_3_1(32, 16, "mish").to(dev).train()
+        a, b = rnd((1, 6, 20, 32, 16), 1).to(dev), rnd((1, 6, 20, 32, 16), 2).to(dev)
+        r = rnd((1, 6, 20, 32, 16), 3).to(dev)
+        res = {}
+        with cfg.deterministic_as(True):
+            for on in (True, False):
+                cfg.set_branch_stream(on)
+                calls = []
+                orig = ops.split_rows
+                ops.split_rows = lambda *x_, **k: (calls.append(x_[6] if len(x_) > 6 else None), orig(*x_, **k))[1]
+                try:
+                    blk.zero_grad(set_to_none=True)
+                    a_, b_ = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+                    y = blk((a_, b_))
+                    n_fwd = len(calls)
+                    y.backward(r)
+                    torch.cuda.synchronize()
+                finally:
+                    ops.split_rows = orig
+                res[on] = (y.detach().clone(), a_.grad.clone(), b_.grad.clone(), {k: p.grad.clone() for k, p in blk.named_parameters()}, n_fwd)
+        assert res[True][4] == res[False][4] == 1, "one forward split of the shared input, whichever stream made it"
+        for i in range(3):
+            assert torch.equal(res[True][i], res[False][i]), i
+        for k in res[True][3]:
+            assert torch.equal(res[True][3][k], res[False][3][k]), k
+    finally:
+        cfg.set_branch_stream(prev)
+        dose_prediction_amd.set_compute_dtype(torch.float32)

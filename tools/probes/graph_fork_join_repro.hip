@@ -94,12 +94,18 @@ int main(int argc, char** argv) {
   // pattern 99 (round 6, after rocgdb showed the crash to be UNBOUNDED RECURSION inside hip::Stream::EndCapture -- a cycle in the runtime's
   // "parallel capture streams" lists): a random event graph over four streams; `pairs` = number of record/wait edges, argv[4] (reuse) = seed.
   // Prints the edge list first, so that a crashing seed documents itself.
-  if (pattern == 99) {
+  // pattern 97 = pattern 99 with EVERY stream first joined to the capture by an event of the origin (0>1 0>2 0>3), then random edges: the candidate
+  // work-around (no stream ever joins the capture through a non-origin stream's event)
+  if (pattern == 99 || pattern == 97) {
     hipStream_t X; CK(hipStreamCreateWithFlags(&X, hipStreamNonBlocking));
     hipStream_t S[4] = {A, B, W, X}; bool cap[4] = {true, false, false, false};
     unsigned rng = 12345u + 7919u * (unsigned)reuse;
     auto rnd = [&](int n) { rng = rng * 1664525u + 1013904223u; return (int)((rng >> 16) % (unsigned)n); };
     printf("edges:");
+    if (pattern == 97) for (int k = 1; k < 4; k++) {
+      hipEvent_t e; CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      CK(hipEventRecord(e, A)); CK(hipStreamWaitEvent(S[k], e, 0)); cap[k] = true; launch(S[k], k & 3); printf(" 0>%d", k);
+    }
     for (int i = 0; i < pairs; i++) {
       int src; do { src = rnd(4); } while (!cap[src]);
       int dst; do { dst = rnd(4); } while (dst == src);
