@@ -18,6 +18,9 @@
 // Block = 4 waves side by side (32 positions each = two 16-position M tiles), 8 output rows, DT depth slices.  Slab layout,
 // swizzle, staging and the transposing epilogue are those of conv_tiled.hip.
 #include "common.h"
+#ifndef DP_CC16_BUF
+#define DP_CC16_BUF 1      // slab staging through buffer loads with block-constant offsets (round 6); 0: the round-2 form
+#endif
 #include <stdlib.h>
 
 #define STREAM ((hipStream_t)stream)
@@ -111,7 +114,8 @@ __global__ void __launch_bounds__(256, OCC) k_conv_cc16(const T* __restrict__ x,
   const int cin_in = g.x3 ? 32 * g.x3 : g.Cin;       // channels of the INPUT tensor (a DP_X3 launch reads [x_hi | x_lo])
   const bool fast = SWZ && ((g.x3 ? 2 * g.x3 : g.NCH) * 16 <= (g.x2 ? g.csplit + g.ldx2 : g.ldx)) && (g.ldx % 8 == 0) && (((uintptr_t)x & 15) == 0) &&
                     (!g.x2 || ((g.csplit % 16 == 0) && (g.ldx2 % 8 == 0) && (((uintptr_t)g.x2 & 15) == 0))) &&
-                    (int64_t)g.H * g.W * max(g.ldx, g.x2 ? g.ldx2 : 0) < (1ll << 30);
+                    (int64_t)g.H * g.W * max(g.ldx, g.x2 ? g.ldx2 : 0) < (1ll << 30) &&
+                    (int64_t)LR * g.W * max(g.ldx, g.x2 ? g.ldx2 : 0) < (1ll << 30);      // (a parked offset + LR row pitches stays above 2^31)
   const int st_half = tid & 1, st_lp0 = (tid >> 1) % LP, st_lr0 = (tid >> 1) / LP;
   // A operand: lane (r, q) = position r of the M tile, k-group q: q < 2 -> left tap of the pair, q >= 2 -> right tap (one voxel
   // further), q & 1 = which 8-channel half of the voxel
@@ -125,7 +129,54 @@ __global__ void __launch_bounds__(256, OCC) k_conv_cc16(const T* __restrict__ x,
     for (int ch = 0; ch < nstage; ch++) {
       lds_barrier();                               // every wave is done with the previous slab
       if (g.dbg & 1) {
-      } else if (fast) {
+      }
+#if DP_CC16_BUF
+      else if (fast) {
+        // Round 6: the slab as BUFFER loads with block-constant offsets.  A block owns one output tile for its whole life, so what a thread
+        // stages never moves: column lp = tid / 2 of the slab (8-channel half tid & 1), rows 0 .. LR-1, plus one piece of the LP - 128 extra
+        // columns.  Per piece that is ONE v_add (row pitch from an SGPR) and the load: rows above / below the volume are out of range of the
+        // PLANE's descriptor (unsigned wrap-around -> zeros from the hardware), a column outside the volume parks the thread's offset at
+        // 2^31.  The round-2 form (below, -DDP_CC16_BUF=0) spent ~18 VALU per piece on carry loops, four bounds compares, a 64-bit address and
+        // four v_cndmask -- in a phase of its own, which the knock-outs of profiles/r06_a_3x3x3_phase_counters.md show is NOT hidden behind the
+        // other blocks' sweeps.
+        const bool second = g.x2 && ch * CK >= g.csplit;
+        const T* xsrc = second ? (const T*)g.x2 : x;
+        const int ldsrc = second ? g.ldx2 : g.ldx, c0 = ch * CK - (second ? g.csplit : 0);
+        const T* xplane = xsrc + (((int64_t)n * g.D + z) * g.H) * (int64_t)g.W * ldsrc + c0;
+        const uint64_t pa = (uint64_t)(uintptr_t)xplane;
+        const unsigned plo = __builtin_amdgcn_readfirstlane((unsigned)pa), phi = __builtin_amdgcn_readfirstlane((unsigned)(pa >> 32));
+        const unsigned pbytes = __builtin_amdgcn_readfirstlane((unsigned)(g.H * g.W * ldsrc * 2 - c0 * 2));
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)(((uint64_t)phi << 32) | plo), 0, (int)pbytes, 0x00020000);
+        const unsigned rowb = (unsigned)(g.W * ldsrc * 2);
+        constexpr int EX = LP - 128;                               // extra columns beyond the 128 a thread pair owns
+        const int t2 = tid >> 1, iw = w0 - PAD + t2;
+        const unsigned vb = ((unsigned)iw < (unsigned)g.W) ? (unsigned)((((h0 - PAD) * g.W + iw) * ldsrc + st_half * 8) * 2) : 0x80000000u;
+        const int par0 = (t2 >> 3) & 1;
+        T* const dA = slab + t2 * CK + ((st_half ^ par0) * 8);        // even slab rows: + r * LP * CK (immediate)
+        T* const dB = slab + t2 * CK + ((st_half ^ par0 ^ 1) * 8);    // odd slab rows (LP / 8 is odd: the swizzle bit flips with the row)
+        static_assert(((LP >> 3) & 1) == 1, "row-parity form of the slab swizzle");
+        // the extra piece: e = tid < EX * LR * 2 -> (half e & 1, column 128 + (e >> 1) % EX, row (e >> 1) / EX)
+        const int e_half = tid & 1, e_col = 128 + (t2 % EX), e_row = t2 / EX, e_iw = w0 - PAD + e_col;
+        const bool e_on = tid < EX * LR * 2;
+        // (threads without an extra piece repeat their row-0 piece -- same value to the same address: no branch, no wait of its own)
+        const unsigned ve = !e_on ? vb : ((unsigned)e_iw < (unsigned)g.W) ? (unsigned)((((h0 - PAD + e_row) * g.W + e_iw) * ldsrc + e_half * 8) * 2) : 0x80000000u;
+        const int e_v = e_row * LP + e_col;
+        T* const dE = e_on ? slab + e_v * CK + ((e_half ^ ((e_v >> 3) & 1)) * 8) : dA;
+        constexpr int HALF = (LR + 1) / 2;
+        v4u bufa[HALF], bufb[LR - HALF + 1];
+#pragma unroll
+        for (int rr = 0; rr < HALF; rr++) bufa[rr] = __builtin_bit_cast(v4u, __builtin_amdgcn_raw_buffer_load_b128(rs, vb + (unsigned)rr * rowb, 0, 0));
+#pragma unroll
+        for (int rr = HALF; rr < LR; rr++) bufb[rr - HALF] = __builtin_bit_cast(v4u, __builtin_amdgcn_raw_buffer_load_b128(rs, vb + (unsigned)rr * rowb, 0, 0));
+        bufb[LR - HALF] = __builtin_bit_cast(v4u, __builtin_amdgcn_raw_buffer_load_b128(rs, ve, 0, 0));
+#pragma unroll
+        for (int rr = 0; rr < HALF; rr++) *(v4u*)(((rr & 1) ? dB : dA) + rr * LP * CK) = bufa[rr];
+#pragma unroll
+        for (int rr = HALF; rr < LR; rr++) *(v4u*)(((rr & 1) ? dB : dA) + rr * LP * CK) = bufb[rr - HALF];
+        *(v4u*)dE = bufb[LR - HALF];
+      }
+#else
+      else if (fast) {
         const bool second = g.x2 && ch * CK >= g.csplit;
         const T* xsrc = second ? (const T*)g.x2 : x;
         const int ldsrc = second ? g.ldx2 : g.ldx, c0 = ch * CK - (second ? g.csplit : 0);
@@ -148,7 +199,9 @@ __global__ void __launch_bounds__(256, OCC) k_conv_cc16(const T* __restrict__ x,
           for (int j = 0; j < SU; j++)
             if (vv[j] >= 0) *(v4u*)(slab + (int64_t)vv[j] * CK + (st_half ^ ((vv[j] >> 3) & 1)) * 8) = buf[j];
         }
-      } else {
+      }
+#endif
+      else {
         for (int p = tid; p < pieces; p += 256) {
           int half = p & 1, v = p >> 1, lp = v % LP, lr = v / LP;
           int ih = h0 - PAD + lr, iw = w0 - PAD + lp, c = ch * CK + half * 8;
@@ -418,7 +471,8 @@ __global__ void __launch_bounds__(256, OCC) k_conv_cc16w(const T* __restrict__ x
   const int cin_in = g.x3 ? 32 * g.x3 : g.Cin;
   const bool fast = SWZ && ((g.x3 ? 2 * g.x3 : g.NCH) * 16 <= (g.x2 ? g.csplit + g.ldx2 : g.ldx)) && (g.ldx % 8 == 0) && (((uintptr_t)x & 15) == 0) &&
                     (!g.x2 || ((g.csplit % 16 == 0) && (g.ldx2 % 8 == 0) && (((uintptr_t)g.x2 & 15) == 0))) &&
-                    (int64_t)g.H * g.W * max(g.ldx, g.x2 ? g.ldx2 : 0) < (1ll << 30);
+                    (int64_t)g.H * g.W * max(g.ldx, g.x2 ? g.ldx2 : 0) < (1ll << 30) &&
+                    (int64_t)LR * g.W * max(g.ldx, g.x2 ? g.ldx2 : 0) < (1ll << 30);
   const int st_half = tid & 1, st_lp0 = (tid >> 1) % LP, st_lr0 = (tid >> 1) / LP;
   const int hsel = q & 1;
   const int lane_off = r * 32 + q * 8;
@@ -433,7 +487,36 @@ __global__ void __launch_bounds__(256, OCC) k_conv_cc16w(const T* __restrict__ x
     for (int ch = 0; ch < nstage; ch++) {
       lds_barrier();
       if (g.dbg & 1) {
-      } else if (fast) {
+      }
+#if DP_CC16_BUF
+      else if (fast) {
+        // buffer loads with block-constant offsets, as in k_conv_cc16: the slab is 2 LP <= 256 pieces wide, so thread tid < 2 LP owns
+        // column tid / 2 (half tid & 1) in every row
+        const bool second = g.x2 && ch * CK >= g.csplit;
+        const T* xsrc = second ? (const T*)g.x2 : x;
+        const int ldsrc = second ? g.ldx2 : g.ldx, c0 = ch * CK - (second ? g.csplit : 0);
+        const T* xplane = xsrc + (((int64_t)n * g.D + z) * g.H) * (int64_t)g.W * ldsrc + c0;
+        const uint64_t pa = (uint64_t)(uintptr_t)xplane;
+        const unsigned plo = __builtin_amdgcn_readfirstlane((unsigned)pa), phi = __builtin_amdgcn_readfirstlane((unsigned)(pa >> 32));
+        const unsigned pbytes = __builtin_amdgcn_readfirstlane((unsigned)(g.H * g.W * ldsrc * 2 - c0 * 2));
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)(((uint64_t)phi << 32) | plo), 0, (int)pbytes, 0x00020000);
+        const unsigned rowb = (unsigned)(g.W * ldsrc * 2);
+        static_assert(2 * LP <= 256 && ((LP >> 3) & 1) == 1, "one column per thread; row-parity form of the slab swizzle");
+        if (tid < 2 * LP) {
+          const int t2 = tid >> 1, iw = w0 - PAD + t2;
+          const unsigned vb = ((unsigned)iw < (unsigned)g.W) ? (unsigned)((((h0 - PAD) * g.W + iw) * ldsrc + st_half * 8) * 2) : 0x80000000u;
+          const int par0 = (t2 >> 3) & 1;
+          T* const dA = slab + t2 * CK + ((st_half ^ par0) * 8);
+          T* const dB = slab + t2 * CK + ((st_half ^ par0 ^ 1) * 8);
+          v4u bufa[LR];
+#pragma unroll
+          for (int rr = 0; rr < LR; rr++) bufa[rr] = __builtin_bit_cast(v4u, __builtin_amdgcn_raw_buffer_load_b128(rs, vb + (unsigned)rr * rowb, 0, 0));
+#pragma unroll
+          for (int rr = 0; rr < LR; rr++) *(v4u*)(((rr & 1) ? dB : dA) + rr * LP * CK) = bufa[rr];
+        }
+      }
+#else
+      else if (fast) {
         const bool second = g.x2 && ch * CK >= g.csplit;
         const T* xsrc = second ? (const T*)g.x2 : x;
         const int ldsrc = second ? g.ldx2 : g.ldx, c0 = ch * CK - (second ? g.csplit : 0);
@@ -456,7 +539,9 @@ __global__ void __launch_bounds__(256, OCC) k_conv_cc16w(const T* __restrict__ x
           for (int j = 0; j < SU; j++)
             if (vv[j] >= 0) *(v4u*)(slab + (int64_t)vv[j] * CK + (st_half ^ ((vv[j] >> 3) & 1)) * 8) = buf[j];
         }
-      } else {
+      }
+#endif
+      else {
         for (int p = tid; p < pieces; p += 256) {
           int half = p & 1, v = p >> 1, lp = v % LP, lr = v / LP;
           int ih = h0 - PAD + lr, iw = w0 - PAD + lp, c = ch * CK + half * 8;
