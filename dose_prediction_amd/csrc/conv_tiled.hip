@@ -19,6 +19,9 @@
 #include <type_traits>
 #include <utility>
 
+#ifndef DP_TILED_TAB
+#define DP_TILED_TAB 1        // k_conv_tiled: slab staging from a per-block table of voxel indices + buffer loads (round 6); 0: the round-2 form
+#endif
 #ifndef STAGE_UNROLL
 #define STAGE_UNROLL 9
 #endif
@@ -196,6 +199,31 @@ __global__ void __launch_bounds__(256, (RW == 8 ? DP_TILED_MINB8 : DP_TILED_MINB
                     (int64_t)g.H * g.W * max(g.ldx, g.x2 ? g.ldx2 : 0) < (1ll << 30);
   const int lp_par = SWZ ? ((LP >> 3) & 1) : 0;
   const int st_half = tid & 1, st_lp0 = (tid >> 1) % LP, st_lr0 = (tid >> 1) / LP;
+#if DP_TILED_TAB
+  // Round 6: WHICH voxel each of a thread's slab pieces comes from never changes during the block's life (one tile, all kd, all chunks), so
+  // it is worked out once -- divisions, bounds and all -- into a table in LDS behind the slab: tab[j][tid] = voxel index inside the
+  // (n, depth) plane of piece j * 256 + tid, or H * W (the first voxel BEHIND the plane: out of range of the plane's buffer descriptor,
+  // which then returns zeros) for padding and for pieces that do not exist.  Staging a slab is then, per piece, one ds_read_b32, one
+  // v_mad_u32_u24 (voxel x row pitch: the two concat operands may differ in pitch), one buffer_load_dwordx4 and one ds_write_b128 at an
+  // immediate offset; the round-2 form spent ~20 VALU per piece on carries, bounds, a 64-bit address and the zero select.
+  constexpr int NJ = (LR * LP * 2 + 255) / 256;
+  unsigned* const tab = (unsigned*)(smem_raw + (size_t)LR * LP * CK * sizeof(T));
+  const bool fast_tab = fast && (int64_t)g.H * g.W < (1 << 24);
+  if (fast_tab) {
+    int lp = st_lp0, lr = st_lr0;
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+      const int ih = h0 - PAD + lr, iw = w0 - PAD + lp;
+      const bool ok = (j * 256 + tid < LR * LP * 2) && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W;
+      tab[j * 256 + tid] = ok ? (unsigned)(ih * g.W + iw) : (unsigned)(g.H * g.W);
+      lp += 128;
+#pragma unroll
+      for (int c_ = 0; c_ < (128 + LP - 1) / LP; c_++) if (lp >= LP) { lp -= LP; lr++; }
+    }
+  }
+  // (the table is read by the thread that wrote it: DS operations of one wave execute in order, no barrier)
+  unsigned char* const st_dst = smem_raw + (tid >> 1) * (CK * (int)sizeof(T)) + ((st_half ^ ((tid >> 4) & 1)) * 16);      // + j * 4096: piece j * 256 + tid
+#endif
 
   constexpr int RS = W16 ? 2 : 1, TS = NPAIR == 2 ? 2 : 1;        // slab rows per accumulator row / per kh tap (pair)
   constexpr int ROWS = RS * (RW - 1) + TS * (JH - 1) + 1;          // slab rows one wave sweeps per kw column
@@ -221,7 +249,33 @@ __global__ void __launch_bounds__(256, (RW == 8 ? DP_TILED_MINB8 : DP_TILED_MINB
       load_bk(wbase, 0, 0, b0);
       lds_barrier();                    // LDS-only: __syncthreads() would drain the weight loads just issued (vmcnt(0))
       if (g.dbg == 1 || g.dbg == 3 || g.dbg == 4) {
-      } else if (fast) {
+      }
+#if DP_TILED_TAB
+      else if (fast_tab) {
+        const bool second = g.x2 && ch * CK >= g.csplit;                    // block-uniform: which concat operand this chunk reads
+        const T* xsrc = second ? (const T*)g.x2 : x;
+        const int ldsrc = second ? g.ldx2 : g.ldx, c0 = ch * CK - (second ? g.csplit : 0);
+        const T* xplane = xsrc + (((int64_t)n * g.D + id) * g.H) * (int64_t)g.W * ldsrc + c0;
+        const uint64_t pa = (uint64_t)(uintptr_t)xplane;
+        const unsigned plo = __builtin_amdgcn_readfirstlane((unsigned)pa), phi = __builtin_amdgcn_readfirstlane((unsigned)(pa >> 32));
+        const unsigned pbytes = __builtin_amdgcn_readfirstlane((unsigned)(g.H * g.W * ldsrc * 2 - c0 * 2));
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)(((uint64_t)phi << 32) | plo), 0, (int)pbytes, 0x00020000);
+        const unsigned ldb = (unsigned)ldsrc * 2u, hoff = (unsigned)st_half * 16u;
+#pragma unroll
+        for (int j0 = 0; j0 < NJ; j0 += SU) {
+          v4u buf[SU];
+#pragma unroll
+          for (int j = 0; j < SU; j++)
+            if (j0 + j < NJ) buf[j] = __builtin_bit_cast(v4u, __builtin_amdgcn_raw_buffer_load_b128(rs, __umul24(tab[(j0 + j) * 256 + tid], ldb) + hoff, 0, 0));
+#pragma unroll
+          for (int j = 0; j < SU; j++)
+            if (j0 + j < NJ) {
+              if ((j0 + j + 1) * 256 <= LR * LP * 2 || (j0 + j) * 256 + tid < LR * LP * 2) *(v4u*)(st_dst + (j0 + j) * 4096) = buf[j];
+            }
+        }
+      }
+#endif
+      else if (fast && !DP_TILED_TAB) {          // (with the table: planes of >= 2^24 voxels take the guarded loop below)
         // straight-line staging: SU independent 16-byte loads are in flight before the first LDS store (a per-piece
         // load->store loop serialises on HBM/L2 latency and dominated the kernel); voxel coordinates advance incrementally
         // (256 threads = 128 voxels per step), no divisions in the loop.
@@ -526,6 +580,9 @@ __global__ void k_conv_split_finish(float* __restrict__ ws, const float* __restr
 template <typename T, int KS, int NPAIR, int RW, int NT, int TWP, typename TO = T, int WN = 1>
 static int launch_tiled(const void* x, const void* wq, const float* bias, void* y, float* ws, TiledGeom g, int ygrid, hipStream_t s) {
   size_t smem = (size_t)g.LR * g.LP * 16 * sizeof(T);
+#if DP_TILED_TAB
+  smem += (size_t)(((size_t)g.LR * g.LP * 2 + 255) / 256) * 256 * sizeof(unsigned);      // the staging table behind the slab
+#endif
   if (smem < 8 * 32 * 32 * sizeof(TO)) smem = 8 * 32 * 32 * sizeof(TO);     // the epilogue transposes through 2 patches per wave
   auto kern = k_conv_tiled<T, KS, NPAIR, RW, NT, TWP, TO, WN>;
   if (smem > 160 * 1024) { dp_set_error("conv3d_tiled: slab %zu B exceeds LDS", smem); return 1; }
