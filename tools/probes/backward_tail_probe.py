@@ -46,8 +46,13 @@ def main():
     blk = vit.blocks[len(vit.blocks) // 2]
     blk.norm1.weight.register_post_accumulate_grad_hook(lambda q: mark("vit_bwd_half"))
     pe = vit.patch_embedding
-    for q in pe._last:
-        q.register_post_accumulate_grad_hook(lambda q_: mark("vit_bwd_done_" + ("w" if q_.dim() > 1 else "b")))
+    lin = pe.patch_embeddings[1] if pe.pos_embed == "perceptron" else pe.patch_embeddings
+    lin.weight.register_post_accumulate_grad_hook(lambda q_: mark("vit_bwd_done"))
+    # the 128^3 block beside the transformer (ViTEncoder.skip1 = UnetResBlock: conv1 / conv3 are its first layers = last backward nodes)
+    enc = [m for m in net.modules() if type(m).__name__ == "ViTEncoder"][0]
+    names = dict(enc.skip1.named_parameters())
+    for n, q in names.items():
+        q.register_post_accumulate_grad_hook(lambda q_, n=n: mark("skip1." + n))
     rows = []
     for i in range(a.steps + 3):
         marks.clear()
