@@ -465,7 +465,7 @@ __global__ void __launch_bounds__(256) k_gemm_tn(const T* __restrict__ A, int64_
 // 128, lda / ldb multiples of 8, 16-byte aligned operands).  Tile ids are dealt problem-major, n-tile-major, m fastest.
 struct TnProblem { const void* A; const void* B; float* C; float* colsum; int64_t lda, ldb, ldc, M, N, K, tile0, tiles_m; };
 template <typename T>
-__global__ void __launch_bounds__(256) k_gemm_tn_grouped(const TnProblem* __restrict__ tab, int nprob, int64_t total_tiles) {
+__global__ void __launch_bounds__(256, 3) k_gemm_tn_grouped(const TnProblem* __restrict__ tab, int nprob, int64_t total_tiles) {
   __shared__ __attribute__((aligned(16))) T As[64 * 136];
   __shared__ __attribute__((aligned(16))) T Bs[64 * 136];
   // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, consecutive TILES share an operand panel (the row tiles
