@@ -14,6 +14,7 @@ from dose_prediction_amd import ops  # noqa: E402
 SHAPES = [
     ("proj  1024x768x768", 1024, 768, 768, 1, False), ("qkv   1024x2304x768", 1024, 2304, 768, 1, False),
     ("fc1   1024x3072x768", 1024, 3072, 768, 1, False), ("fc2   1024x768x3072", 1024, 768, 3072, 1, False),
+    ("qkv.dgrad 1024x768x2304", 1024, 768, 2304, 1, False), ("crop96 2304x768x768", 2304, 768, 768, 1, False), ("crop96 2304x768x3072", 2304, 768, 3072, 1, False),
     ("M256  256x768x768", 256, 768, 768, 1, False), ("M4096 4096x768x768", 4096, 768, 768, 1, False),
     ("dW    768x768x1024 f32", 768, 768, 1024, 1, True), ("dWfc  3072x768x1024 f32", 3072, 768, 1024, 1, True),
     ("QK^T  12x512x512x128", 512, 512, 128, 12, False), ("PV    12x512x128x512", 512, 128, 512, 12, False),
