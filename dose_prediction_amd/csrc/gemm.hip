@@ -464,8 +464,10 @@ __global__ void __launch_bounds__(256) k_gemm_tn(const T* __restrict__ A, int64_
 // pointers, lda, ldb, ldc, M, N, K, first tile id, tiles along M (| 1 << 32: 128 x 128 tiles instead of 64 x 64: M, N multiples of
 // 128, lda / ldb multiples of 8, 16-byte aligned operands).  Tile ids are dealt problem-major, n-tile-major, m fastest.
 struct TnProblem { const void* A; const void* B; float* C; float* colsum; int64_t lda, ldb, ldc, M, N, K, tile0, tiles_m; };
+// Three blocks per CU for the 16-bit types (round 6): a 128 x 128 tile is 16 K steps of one register-prefetched slab each, i.e. bound by the
+// round trip of its loads; at 172 VGPRs two blocks shared a CU, at 164 (no spills) three: 648 -> 399 us for the transformer's 41 problems.
 template <typename T>
-__global__ void __launch_bounds__(256, 3) k_gemm_tn_grouped(const TnProblem* __restrict__ tab, int nprob, int64_t total_tiles) {
+__global__ void __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) k_gemm_tn_grouped(const TnProblem* __restrict__ tab, int nprob, int64_t total_tiles) {
   __shared__ __attribute__((aligned(16))) T As[64 * 136];
   __shared__ __attribute__((aligned(16))) T Bs[64 * 136];
   // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, consecutive TILES share an operand panel (the row tiles
