@@ -610,7 +610,10 @@ def test_fused_adam_matches_torch(amsgrad):
     (1, 16, 16, 16, 16, 5, 11, 96, 3),       # (W >= 96, Cout <= 16: the wave-private 3^3 kernel k_conv_w3, odd depth, ragged rows, split in and out)
     (2, 16, 9, 16, 16, 2, 8, 128, 3),        # (... second operand padded to 16 channels)
     (1, 16, 16, 16, 16, 2, 9, 96, 7),        # (the 25-slot 7^3 sweep over a split input; W = 96: k_conv_cc16w)
-    (1, 16, 16, 16, 16, 3, 10, 192, 7), (2, 16, 9, 16, 16, 2, 8, 192, 3)])     # (two 96-position tiles, split in and out)
+    (1, 16, 16, 16, 16, 3, 10, 192, 7), (2, 16, 9, 16, 16, 2, 8, 192, 3),      # (two 96-position tiles, split in and out)
+    # the two operands with DIFFERENT row pitches (round 6: the slab staging multiplies a block-constant voxel index by the pitch of the operand
+    # it reads -- k_conv_tiled's table -- or forms its column offsets per operand -- k_conv_cc16)
+    (1, 32, 16, 16, 32, 2, 9, 40, 7), (1, 32, 16, 16, 16, 2, 9, 128, 3), (1, 16, 32, 32, 16, 3, 10, 128, 7), (2, 32, 9, 16, 64, 4, 12, 16, 3)])
 def test_conv3d_virtual_concat(cfg, dtype):
     """conv3d((a, b)) == conv3d(cat(a, b)) of the oracle, forward and every gradient (dp_conv3d_tiled2 / dp_conv3d_wgrad_tiled2;
     the last config is too narrow for the tiled kernels and must take the materialised-cat fallback)."""
